@@ -1,0 +1,211 @@
+/* include/pcreg.h -- C ABI of libpcreg_hip.so: the MI355X (gfx950) implementation of
+ * the PCReg correspondence-search + RANSAC rigid-alignment hot path.
+ *
+ * The reference (LCJebe/PCReg) is pure MATLAB and has no FFI layer; the boundary it
+ * exposes for this path is the set of MATLAB function signatures below.  Each entry
+ * point names the reference function it replaces (file:line in the reference tree);
+ * INTEGRATION.md shows the MEX binding a maintainer adds on the MATLAB side.
+ *
+ * Conventions (MATLAB's, so a MEX shim passes mxGetPr() pointers straight through):
+ *   - matrices are column-major with an explicit leading dimension `ld` (>= rows);
+ *     a point set is n x 3: x = p[i], y = p[i+ld], z = p[i+2*ld];
+ *   - T is a column-major 4x4 used as [p 1]*T (quickTF.m:5-7): rotation in
+ *     T(1:3,1:3), translation in T(4,1:3);
+ *   - indices that cross the boundary are 1-based, pairs are uint32 like matchFeatures';
+ *   - every function returns 0 on success or a PCREG_E_* code; pcreg_last_error()
+ *     gives the text.  "RANSAC found nothing" is NOT an error: it is reported through
+ *     *failed = 1 with T zeroed, mirroring ransac.m:77-89 (empty T, zeros).
+ *   - there is no CPU fallback: without a usable HIP device every compute entry
+ *     point returns PCREG_E_NODEVICE.
+ *
+ * Two tiers:
+ *   pcreg_*      host tier  -- pointers are HOST memory (what MEX hands over); the call
+ *                              stages to HBM, runs the kernels, copies results back.
+ *   pcreg_dev_*  device tier -- pointers are DEVICE memory and work is enqueued on the
+ *                              caller's HIP stream (passed as void*); nothing
+ *                              synchronises.  Used by resident pipelines, the
+ *                              multi-GPU host code and bench.py.
+ */
+#ifndef PCREG_H
+#define PCREG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCREG_OK            0
+#define PCREG_E_ARG         1   /* bad argument (null pointer, negative size, ld < n ...) */
+#define PCREG_E_HIP         2   /* a HIP runtime call failed                              */
+#define PCREG_E_NODEVICE    3   /* no usable gfx950 device                                */
+#define PCREG_E_WORKSPACE   4   /* caller's workspace too small (device tier)             */
+
+#define PCREG_METRIC_SAD 0
+#define PCREG_METRIC_SSD 1
+
+/* ransacCoef of ransac.m:7-12,23-34 (+ the build's sampler seed). */
+typedef struct pcreg_ransac_opts {
+    int32_t  minPtNum;     /* ransac.m:23; estimateTransform needs >= 3              */
+    int32_t  iterNum;      /* ransac.m:24                                            */
+    double   thDist;       /* ransac.m:26; compared with the SQUARED distance         */
+    double   thInlrRatio;  /* ransac.m:25; thInlr = round(thInlrRatio*ptNum), :28     */
+    int32_t  REFINE;       /* ransac.m:29                                            */
+    int32_t  VERBOSE;      /* ransac.m:30-34; printing is done by the host wrappers   */
+    uint64_t seed;         /* used only when sample_idx == NULL (built-in sampler)    */
+} pcreg_ransac_opts;
+
+/* `par` of getMatches.m:5-9,22,35,51-56 + matchFeatures' Prenormalized. */
+typedef struct pcreg_match_opts {
+    int32_t metric;          /* PCREG_METRIC_SAD | PCREG_METRIC_SSD   (par.Metric)     */
+    double  matchThreshold;  /* percent, par.MatchThreshold                            */
+    double  maxRatio;        /* par.MaxRatio                                           */
+    int32_t unique;          /* par.Unique                                             */
+    int32_t prenormalized;   /* matchFeatures 'Prenormalized' (getMatches passes 0)    */
+    int32_t unnormalize;     /* par.UNNORMALIZE, getMatches.m:22-26                    */
+    double  norm_factor;     /* par.norm_factor                                        */
+    int32_t change_metric;   /* par.CHANGE_METRIC, getMatches.m:35-37                  */
+    double  metric_factor;   /* par.metric_factor                                      */
+} pcreg_match_opts;
+
+/* ---- library ------------------------------------------------------------------- */
+const char* pcreg_last_error(void);
+const char* pcreg_version(void);
+int  pcreg_device_count(int* count);
+int  pcreg_set_device(int ordinal);          /* one process per GPU: call once per rank */
+int  pcreg_device_name(char* buf, int cap);  /* e.g. "gfx950:..."                       */
+
+/* ---- host tier ------------------------------------------------------------------ */
+
+/* estimateTransform.m:2  T = estimateTransform(pts1, pts2), [pts2,1]*T = [pts1,1].
+ * *empty = 1 reproduces the `T = []` return of estimateTransform.m:11-14. */
+int pcreg_estimate_transform(const double* pts1, const double* pts2, int n, int ld,
+                             double T[16], int* empty);
+
+/* getInliersRANSAC.m:46  d = calcDists(T, pts1, pts2): squared distances, length n. */
+int pcreg_calc_dists(const double T[16], const double* pts1, const double* pts2, int n, int ld,
+                     double* d);
+
+/* ransac.m:1  [T, inlierIdx, numSuccess, maxInliers, ratio] = ransac(pts1, pts2,
+ * ransacCoef, @estimateTransform, @calcDists).
+ * sample_idx: [iterNum][minPtNum] 1-based indices, hypothesis-major (pass the
+ * transpose of a MATLAB iterNum x minPtNum table, i.e. minPtNum x iterNum
+ * column-major), replacing `randperm(ptNum)(1:minPtNum)` of ransac.m:42-43; NULL
+ * selects the built-in counter-based sampler seeded by opts->seed.
+ * inlier_idx has capacity n (1-based, ascending); iter_inl / iter_inl_ref (optional,
+ * may be NULL, length iterNum) receive inlrNum / inlrNum_refined of ransac.m:36-37. */
+int pcreg_ransac(const double* pts1, const double* pts2, int n, int ld,
+                 const pcreg_ransac_opts* opts, const int32_t* sample_idx,
+                 double T[16], int32_t* inlier_idx, int* n_inliers, int* num_success,
+                 int* max_inliers, int* failed, int32_t* iter_inl, int32_t* iter_inl_ref);
+
+/* The same for B independent registrations in one launch (the parfor of
+ * completeExperimentFast.m:201-225).  Registration b owns rows
+ * [offsets[b], offsets[b+1]) of the concatenated pts1/pts2 (total = offsets[B]) and
+ * the sample table rows [b*iterNum, (b+1)*iterNum) (or seed + b).  Outputs are
+ * arrays of length B (T: 16*B); inlier_idx is concatenated with the same offsets. */
+int pcreg_ransac_batched(const double* pts1, const double* pts2, int total, int ld,
+                         const int32_t* offsets, int B, const pcreg_ransac_opts* opts,
+                         const int32_t* sample_idx, double* T, int32_t* inlier_idx,
+                         int32_t* n_inliers, int32_t* num_success, int32_t* max_inliers,
+                         int32_t* failed);
+
+/* fp32 3-D point search (the "KNN" of BASELINE.json's metric): for each query the two
+ * nearest model points, squared distance fmaf(dz,dz,fmaf(dy,dy,dx*dx)), ties to the
+ * lowest index.  idx [Q][2] 0-based (-1 when M < 2), dist [Q][2]. */
+int pcreg_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
+                          int32_t* idx, float* dist);
+
+/* matchFeatures' filter chain on raw fp32 points (Prenormalized, SSD, absolute
+ * threshold thr_abs on the squared distance, ratio test, optional Unique back-check).
+ * pairs: capacity Q x 2, ROW-major [k][0]=query, [k][1]=model, 1-based, ascending
+ * query.  *P receives the number of pairs. */
+int pcreg_match_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
+                           float thr_abs, float max_ratio, int unique,
+                           uint32_t* pairs, int* P);
+
+/* getMatches.m:51  matchFeatures(features1, features2, 'Method',..,'MatchThreshold',..,
+ * 'MaxRatio',..,'Metric',..,'Unique',..) on Q x D / M x D double features (exact
+ * search; 'Approximate' is answered exactly).  Only the matchFeatures fields of opts
+ * are used.  pairs as above; metric (optional) receives matchMetric. */
+int pcreg_match_features(const double* f1, int Q, int ld1, const double* f2, int M, int ld2, int D,
+                         const pcreg_match_opts* opts, uint32_t* pairs, double* metric, int* P);
+
+/* getMatches.m:1  matches = getMatches(descSurface, descModel, par): append the
+ * constant column (:22-26), element-wise power (:35-37), then matchFeatures (:51-56). */
+int pcreg_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M,
+                      int ldM, int D, const pcreg_match_opts* par, uint32_t* pairs, double* metric,
+                      int* P);
+
+/* AlignPoints_KNN.m:1  [pts_aligned, coeff_unambig, c] = AlignPoints_KNN(pts, C1, C2).
+ * aligned: n x 3 (ld n); coeff: column-major 3x3; c: 3. */
+int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2,
+                           double* aligned, double coeff[9], double c[3]);
+
+/* B supports in one launch (the per-keypoint loop of
+ * getSpacialHistogramDescriptors.m:64-145 calls the same LRF per support):
+ * support b owns rows [offsets[b], offsets[b+1]) of pts / aligned; coeff 9*B, c 3*B;
+ * status[b] = 0 ok, 1 = support too small (n < 2). */
+int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const int32_t* offsets,
+                                   int B, int C1, int C2, double* aligned, double* coeff,
+                                   double* c, int32_t* status);
+
+/* ---- device tier ------------------------------------------------------------------
+ * All pointers are device memory on the current device; `stream` is a hipStream_t.
+ * Workspaces are caller-owned device buffers; query the size first. */
+
+/* Two nearest model points per query for one model shard.  idx_base is added to the
+ * reported indices (global row of the shard's first point).  idx [Q][2] int32, dist
+ * [Q][2] float. */
+size_t pcreg_dev_knn2_points_f32_workspace(int Q, int M);
+int pcreg_dev_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
+                              int32_t idx_base, int32_t* idx, float* dist,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* Merge R candidate lists (e.g. the all-gathered per-shard results, laid out
+ * [R][Q][2]) into one top-2 per query, ordering by (dist, idx). */
+int pcreg_dev_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q,
+                             int32_t* idx, float* dist, void* stream);
+
+/* Threshold + ratio test on a merged top-2: cand_q/cand_m (capacity Q, 0-based,
+ * ascending query) and *n_cand (device int32). */
+int pcreg_dev_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total,
+                              float thr_abs, float max_ratio, int32_t* cand_q, int32_t* cand_m,
+                              int32_t* n_cand, void* stream);
+
+/* Unique back-check for the candidates whose model row lies in this shard
+ * [m_lo, m_lo+M): keep[k] = 1 if cand_q[k] is the first-best query of model row
+ * cand_m[k] over all Q queries, 0 if not, untouched if the row is in another shard.
+ * n_cand is read from device memory; capacity = Q. */
+size_t pcreg_dev_unique_points_f32_workspace(int Q);
+int pcreg_dev_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
+                                int32_t m_lo, const int32_t* cand_q, const int32_t* cand_m,
+                                const int32_t* n_cand, int32_t* keep,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* Compact the kept candidates into 1-based pairs (row-major [k][2]) and gather the
+ * matched coordinates as double n x 3 (ld = Q): pts1 = surface(query) rows, pts2 =
+ * model rows (completeExperimentFast.m:205-206).  m is the FULL model here (or any
+ * array indexable by the global model row). */
+int pcreg_dev_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm,
+                               const int32_t* cand_q, const int32_t* cand_m, const int32_t* keep,
+                               const int32_t* n_cand, uint32_t* pairs, double* pts1, double* pts2,
+                               int32_t* n_pairs, void* stream);
+
+/* Device-resident ransac: n is read from device memory (*n_dev <= n_cap), so the
+ * match stage can feed it without a host round trip.  Results land in `out`
+ * (pcreg_dev_ransac_result) and inlier_idx (capacity n_cap). */
+typedef struct pcreg_dev_ransac_result {
+    double  T[16];
+    int32_t n_inliers, num_success, max_inliers, failed, n, winner;
+} pcreg_dev_ransac_result;
+size_t pcreg_dev_ransac_workspace(int n_cap, int iterNum);
+int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                     const pcreg_ransac_opts* opts, const int32_t* sample_idx,
+                     pcreg_dev_ransac_result* out, int32_t* inlier_idx,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCREG_H */

@@ -1,0 +1,78 @@
+"""Loader of libpcreg_hip.so (the C ABI declared in include/pcreg.h).
+
+There is no CPU fallback: if the shared library has not been built, or no gfx950
+device is usable, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcreg_hip.so")
+
+PCREG_OK, PCREG_E_ARG, PCREG_E_HIP, PCREG_E_NODEVICE, PCREG_E_WORKSPACE = 0, 1, 2, 3, 4
+METRIC_SAD, METRIC_SSD = 0, 1
+
+
+class PcregError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpcreg_hip error {code}: {msg}")
+        self.code = code
+
+
+class RansacOpts(C.Structure):
+    """pcreg_ransac_opts (include/pcreg.h) == ransacCoef of ransac.m:7-12."""
+    _fields_ = [("minPtNum", C.c_int32), ("iterNum", C.c_int32), ("thDist", C.c_double),
+                ("thInlrRatio", C.c_double), ("REFINE", C.c_int32), ("VERBOSE", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class MatchOpts(C.Structure):
+    """pcreg_match_opts (include/pcreg.h) == `par` of getMatches.m."""
+    _fields_ = [("metric", C.c_int32), ("matchThreshold", C.c_double), ("maxRatio", C.c_double),
+                ("unique", C.c_int32), ("prenormalized", C.c_int32), ("unnormalize", C.c_int32),
+                ("norm_factor", C.c_double), ("change_metric", C.c_int32), ("metric_factor", C.c_double)]
+
+
+class DevRansacResult(C.Structure):
+    """pcreg_dev_ransac_result (include/pcreg.h)."""
+    _fields_ = [("T", C.c_double * 16), ("n_inliers", C.c_int32), ("num_success", C.c_int32),
+                ("max_inliers", C.c_int32), ("failed", C.c_int32), ("n", C.c_int32), ("winner", C.c_int32)]
+
+
+# every symbol include/pcreg.h declares (tests/test_abi.py checks the two lists agree)
+SYMBOLS = [
+    "pcreg_last_error", "pcreg_version", "pcreg_device_count", "pcreg_set_device", "pcreg_device_name",
+    "pcreg_estimate_transform", "pcreg_calc_dists", "pcreg_ransac", "pcreg_ransac_batched",
+    "pcreg_knn2_points_f32", "pcreg_match_points_f32", "pcreg_match_features", "pcreg_get_matches",
+    "pcreg_align_points_knn", "pcreg_align_points_knn_batched",
+    "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32",
+    "pcreg_dev_filter_top2_f32", "pcreg_dev_unique_points_f32_workspace", "pcreg_dev_unique_points_f32",
+    "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it was never built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C pcreg_amd/csrc` "
+                "(or __graft_entry__.build()).  pcreg_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.pcreg_last_error.restype = C.c_char_p
+        L.pcreg_version.restype = C.c_char_p
+        for name in ("pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_unique_points_f32_workspace",
+                     "pcreg_dev_ransac_workspace"):
+            getattr(L, name).restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != PCREG_OK:
+        raise PcregError(rc, lib().pcreg_last_error().decode(errors="replace"))

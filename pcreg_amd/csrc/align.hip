@@ -1,0 +1,236 @@
+// pcreg_amd/csrc/align.hip -- AlignPoints_KNN (KNN-PCA local reference frame), batched.
+//
+// AlignPoints_KNN.m:17-59, one workgroup per support region:
+//   :17     centroid                                   -> block reduction
+//   :20-26  keep the K = round(0.85 N) points nearest to the centroid.  The reference
+//           does a full stable sort; only the K-th order statistic is needed, so this
+//           kernel runs an 8-pass radix SELECT on the distance bit patterns held in LDS
+//           and resolves ties at the boundary by lowest index (= stable sort order)
+//   :30-34  pca(...,'Algorithm','eig')                 -> 3x3 covariance + Jacobi, then
+//           MathWorks' sign convention (largest-|.| entry of each column positive)
+//   :37-56  majority-sign disambiguation, y from det   -> block reduction of counts
+//   :59     pts * coeff_unambig                        -> one coalesced pass
+// The point set is read from HBM/L2 five times (centroid, distances, mean, covariance,
+// projection): 5 * 24 B per point in, 24 B out -- the HBM-bound member of the family.
+#include "common.hpp"
+#include <cfloat>
+
+namespace pcreg {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v, double* s_red) {
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ int block_sum_i(int v, int* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return t;
+}
+
+__device__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) V[r][c] = r == c ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= DBL_EPSILON * 1e-3 * dia) break;
+#define PCREG_JROT(P, Q)                                                                    \
+        if (A[P][Q] != 0.0) {                                                               \
+            double th = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);                              \
+            double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));                \
+            double c = 1.0 / sqrt(t * t + 1.0), s = c * t;                                  \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[k][P], b = A[k][Q]; A[k][P] = c*a - s*b; A[k][Q] = s*a + c*b; } \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[P][k], b = A[Q][k]; A[P][k] = c*a - s*b; A[Q][k] = s*a + c*b; } \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = V[k][P], b = V[k][Q]; V[k][P] = c*a - s*b; V[k][Q] = s*a + c*b; } \
+        }
+        PCREG_JROT(0, 1) PCREG_JROT(0, 2) PCREG_JROT(1, 2)
+#undef PCREG_JROT
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
+    const double* __restrict__ pts, int ld, const int32_t* __restrict__ offsets, int C1, int C2,
+    double* __restrict__ aligned, int ld_out, double* __restrict__ coeff_out, double* __restrict__ c_out,
+    int32_t* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sd[];    // n distances, later selection flags
+    __shared__ double s_red[4];
+    __shared__ int s_redi[4];
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_krem;
+    __shared__ double s_cu[9];       // coeff_unambig, row-major [r][col]
+    __shared__ double s_coeff[9];
+    __shared__ int s_base;
+
+    const int b = blockIdx.x;
+    const int off = offsets[b];
+    const int n = offsets[b + 1] - off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* px = pts + off; const double* py = px + (size_t)ld; const double* pz = py + (size_t)ld;
+    if (n < 2) { if (tid == 0) status[b] = 1; return; }
+
+    // --- 1) centroid (:17)
+    double sx = 0, sy = 0, sz = 0;
+    for (int i = tid; i < n; i += kBlock) { sx += px[i]; sy += py[i]; sz += pz[i]; }
+    const double cx = block_sum(sx, s_red) / n, cy = block_sum(sy, s_red) / n, cz = block_sum(sz, s_red) / n;
+
+    // --- 2) distances to the centroid (:22-23) and radix select of the K-th smallest
+    const int K = (int)floor(n * 0.85 + 0.5);                                   // :20-21
+    for (int i = tid; i < n; i += kBlock) {
+        double x = px[i] - cx, y = py[i] - cy, z = pz[i] - cz;
+        sd[i] = sqrt(x * x + y * y + z * z);
+    }
+    if (tid == 0) { s_prefix = 0ull; s_krem = K; }
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        s_hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        for (int i = tid; i < n; i += kBlock) {
+            unsigned long long key = (unsigned long long)__double_as_longlong(sd[i]);   // non-negative doubles order as integers
+            if ((key & himask) == prefix) atomicAdd(&s_hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int krem = s_krem, cum = 0, dg = 0;
+            for (; dg < 256; ++dg) { int h = (int)s_hist[dg]; if (cum + h >= krem) break; cum += h; }
+            s_krem = krem - cum;
+            s_prefix = prefix | ((unsigned long long)dg << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned long long vK = s_prefix;     // bit pattern of the K-th smallest distance
+    const int take_eq = s_krem;                 // how many of the ties at vK belong to the K nearest
+    // selection flags, ties by ascending index (stable sort order, :24)
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+        int i = i0 + tid;
+        unsigned long long key = i < n ? (unsigned long long)__double_as_longlong(sd[i]) : ~0ull;
+        bool eq = i < n && key == vK;
+        unsigned long long bal = __ballot(eq);
+        if (lane == 0) s_redi[wave] = __popcll(bal);
+        __syncthreads();
+        int rank = s_base;
+        for (int w = 0; w < wave; ++w) rank += s_redi[w];
+        rank += __popcll(bal & ((1ull << lane) - 1ull));
+        bool sel = i < n && (key < vK || (eq && rank < take_eq));
+        __syncthreads();
+        if (i < n) sd[i] = sel ? 1.0 : 0.0;
+        if (tid == 0) s_base += s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
+        __syncthreads();
+    }
+
+    // --- 3) pca of the K selected, centroid-relative points (:30-34)
+    double mx = 0, my = 0, mz = 0;
+    if (!C1) {
+        double ax = 0, ay = 0, az = 0;
+        for (int i = tid; i < n; i += kBlock) if (sd[i] != 0.0) { ax += px[i] - cx; ay += py[i] - cy; az += pz[i] - cz; }
+        mx = block_sum(ax, s_red) / K; my = block_sum(ay, s_red) / K; mz = block_sum(az, s_red) / K;
+    }
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < n; i += kBlock) if (sd[i] != 0.0) {
+        double x = (px[i] - cx) - mx, y = (py[i] - cy) - my, z = (pz[i] - cz) - mz;
+        cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z;
+    }
+    double dof = C1 ? (double)K : (double)(K - 1);
+    if (dof < 1.0) dof = 1.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cv[k] = block_sum(cv[k], s_red) / dof;
+    if (tid == 0) {
+        double A[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+        double V[3][3];
+        jacobi_eig3(A, V);
+        double ev[3] = {A[0][0], A[1][1], A[2][2]};
+        int ord[3] = {0, 1, 2};                                  // descending eigenvalue, stable
+        if (ev[ord[1]] > ev[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+        if (ev[ord[2]] > ev[ord[0]]) { int t = ord[0]; ord[0] = ord[2]; ord[2] = t; }
+        if (ev[ord[2]] > ev[ord[1]]) { int t = ord[1]; ord[1] = ord[2]; ord[2] = t; }
+        for (int col = 0; col < 3; ++col) {
+            double v0 = 0, v1 = 0, v2 = 0;
+            for (int k = 0; k < 3; ++k) if (ord[col] == k) { v0 = V[0][k]; v1 = V[1][k]; v2 = V[2][k]; }
+            double big = v0;                                     // largest-|.| entry positive (pca convention)
+            if (fabs(v1) > fabs(big)) big = v1;
+            if (fabs(v2) > fabs(big)) big = v2;
+            double sg = big < 0 ? -1.0 : 1.0;
+            s_coeff[0 * 3 + col] = sg * v0; s_coeff[1 * 3 + col] = sg * v1; s_coeff[2 * 3 + col] = sg * v2;
+        }
+    }
+    __syncthreads();
+    double co[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) co[k] = s_coeff[k];
+
+    // --- sign disambiguation (:37-56)
+    int posx = 0, posz = 0;
+    for (int i = tid; i < n; i += kBlock) {
+        if (C2) {
+            double x = px[i], y = py[i], z = pz[i];
+            posx += (x * co[0] + y * co[3] + z * co[6]) > 0;
+            posz += (x * co[2] + y * co[5] + z * co[8]) > 0;
+        } else if (sd[i] != 0.0) {
+            double x = (px[i] - cx) - mx, y = (py[i] - cy) - my, z = (pz[i] - cz) - mz;
+            posx += (x * co[0] + y * co[3] + z * co[6]) > 0;
+            posz += (x * co[2] + y * co[5] + z * co[8]) > 0;
+        }
+    }
+    posx = block_sum_i(posx, s_redi); posz = block_sum_i(posz, s_redi);
+    if (tid == 0) {
+        double xs = (2.0 * posx >= (double)n) ? 1.0 : -1.0;                    // :45,49 with k = N (:37)
+        double zs = (2.0 * posz >= (double)n) ? 1.0 : -1.0;                    // :46,50
+        double M[9];
+        for (int r = 0; r < 3; ++r) { M[r * 3] = co[r * 3] * xs; M[r * 3 + 1] = co[r * 3 + 1]; M[r * 3 + 2] = co[r * 3 + 2] * zs; }
+        double ys = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);   // :53
+        for (int r = 0; r < 3; ++r) { s_cu[r * 3] = co[r * 3] * xs; s_cu[r * 3 + 1] = co[r * 3 + 1] * ys; s_cu[r * 3 + 2] = co[r * 3 + 2] * zs; }   // :56
+        for (int r = 0; r < 3; ++r) for (int col = 0; col < 3; ++col) coeff_out[(size_t)b * 9 + r + 3 * col] = s_cu[r * 3 + col];
+        c_out[(size_t)b * 3] = cx; c_out[(size_t)b * 3 + 1] = cy; c_out[(size_t)b * 3 + 2] = cz;
+        status[b] = 0;
+    }
+    __syncthreads();
+    double cu[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cu[k] = s_cu[k];
+    double* ox = aligned + off; double* oy = ox + (size_t)ld_out; double* oz = oy + (size_t)ld_out;
+    for (int i = tid; i < n; i += kBlock) {                                    // :59
+        double x = px[i], y = py[i], z = pz[i];
+        ox[i] = x * cu[0] + y * cu[3] + z * cu[6];
+        oy[i] = x * cu[1] + y * cu[4] + z * cu[7];
+        oz[i] = x * cu[2] + y * cu[5] + z * cu[8];
+    }
+}
+
+}  // namespace
+
+int launch_align_points_knn(const double* pts, int ld, const int32_t* offsets_dev, int B, int max_n, int C1, int C2,
+                            double* aligned, int ld_out, double* coeff, double* c, int32_t* status, hipStream_t st) {
+    PCREG_ARG(B >= 0 && max_n >= 0);
+    if (B == 0) return PCREG_OK;
+    size_t lds = (size_t)(max_n > 0 ? max_n : 1) * sizeof(double);
+    if (lds > 60 * 1024) { set_error("AlignPoints_KNN support of %d points exceeds the LDS-resident limit (7680)", max_n); return PCREG_E_ARG; }
+    hipLaunchKernelGGL(align_points_knn_kernel, dim3(B), dim3(kBlock), lds, st, pts, ld, offsets_dev, C1, C2, aligned,
+                       ld_out, coeff, c, status);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+}  // namespace pcreg

@@ -1,0 +1,448 @@
+// pcreg_amd/csrc/api.hip -- the C ABI of libpcreg_hip.so (include/pcreg.h).
+//
+// Host tier: stage the caller's MATLAB-layout host arrays into HBM, enqueue the
+// kernels on the library stream, copy the results back.  Device tier: thin argument
+// checks around the launchers.  There is deliberately no CPU fallback anywhere in
+// this file: without a gfx950 device every compute entry point fails with
+// PCREG_E_NODEVICE.
+#include "common.hpp"
+#include <cstdarg>
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+namespace pcreg {
+
+static thread_local char g_err[512] = "no error";
+void set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+static std::mutex g_mu;
+static int g_device_ok = -1;          // -1 unknown, 0 ok, else error code
+static hipStream_t g_stream = nullptr;
+
+int ensure_device() {
+    if (g_device_ok == 0) return PCREG_OK;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libpcreg_hip has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return PCREG_E_NODEVICE;
+    }
+    int dev = 0;
+    PCREG_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PCREG_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libpcreg_hip is built for gfx950 only", dev, prop.gcnArchName);
+        return PCREG_E_NODEVICE;
+    }
+    if (!g_stream) PCREG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device_ok = 0;
+    return PCREG_OK;
+}
+
+int Scratch::get(int slot, size_t bytes, void** out) {
+    if (slot < 0 || slot >= kSlots) { set_error("scratch slot %d out of range", slot); return PCREG_E_ARG; }
+    if (bytes == 0) bytes = 256;
+    if (size[slot] < bytes) {
+        if (ptr[slot]) { PCREG_HIP(hipFree(ptr[slot])); ptr[slot] = nullptr; size[slot] = 0; }
+        size_t want = align_up(bytes + bytes / 4, 4096);       // grow geometrically
+        PCREG_HIP(hipMalloc(&ptr[slot], want));
+        size[slot] = want;
+    }
+    *out = ptr[slot];
+    return PCREG_OK;
+}
+void Scratch::release_all() {
+    for (int i = 0; i < kSlots; ++i) if (ptr[i]) { (void)hipFree(ptr[i]); ptr[i] = nullptr; size[i] = 0; }
+}
+Scratch& scratch() { static Scratch s; return s; }
+
+// copy an n x cols column-major host matrix (leading dimension ld) to a compact device
+// matrix (leading dimension n)
+template <typename T>
+static int upload_cols(const T* host, int n, int ld, int cols, T* dev, hipStream_t st) {
+    if (n <= 0 || cols <= 0) return PCREG_OK;
+    if (ld == n) { PCREG_HIP(hipMemcpyAsync(dev, host, sizeof(T) * (size_t)n * cols, hipMemcpyHostToDevice, st)); }
+    else PCREG_HIP(hipMemcpy2DAsync(dev, sizeof(T) * (size_t)n, host, sizeof(T) * (size_t)ld, sizeof(T) * (size_t)n, cols, hipMemcpyHostToDevice, st));
+    return PCREG_OK;
+}
+
+}  // namespace pcreg
+
+using namespace pcreg;
+
+#define GUARD()                                                     \
+    std::lock_guard<std::mutex> lock__(g_mu);                       \
+    do { int rc__ = ensure_device(); if (rc__) return rc__; } while (0)
+#define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+extern "C" {
+
+const char* pcreg_last_error(void) { return g_err; }
+const char* pcreg_version(void) { return "pcreg-hip 0.1 (gfx950)"; }
+
+int pcreg_device_count(int* count) {
+    PCREG_ARG(count != nullptr);
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); }
+    return PCREG_OK;
+}
+
+int pcreg_set_device(int ordinal) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device available"); (void)hipGetLastError(); return PCREG_E_NODEVICE; }
+    PCREG_ARG(ordinal >= 0 && ordinal < count);
+    scratch().release_all();
+    if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    g_device_ok = -1;
+    PCREG_HIP(hipSetDevice(ordinal));
+    return ensure_device();
+}
+
+int pcreg_device_name(char* buf, int cap) {
+    PCREG_ARG(buf != nullptr && cap > 0);
+    GUARD();
+    int dev = 0; PCREG_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop; PCREG_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, (size_t)cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return PCREG_OK;
+}
+
+// ------------------------------------------------------------------ host tier
+int pcreg_estimate_transform(const double* pts1, const double* pts2, int n, int ld, double T[16], int* empty) {
+    PCREG_ARG(pts1 && pts2 && T && empty && n >= 0 && ld >= n);
+    GUARD();
+    for (int k = 0; k < 16; ++k) T[k] = 0.0;
+    *empty = 1;
+    if (n < 3) return PCREG_OK;          // rank(pts1) < 3 -> [] (estimateTransform.m:11-14)
+    void *d1, *d2, *dT;
+    TRY(scratch().get(0, sizeof(double) * 3 * (size_t)n, &d1));
+    TRY(scratch().get(1, sizeof(double) * 3 * (size_t)n, &d2));
+    TRY(scratch().get(2, 256, &dT));
+    TRY(upload_cols(pts1, n, ld, 3, (double*)d1, g_stream));
+    TRY(upload_cols(pts2, n, ld, 3, (double*)d2, g_stream));
+    int32_t* dE = (int32_t*)((char*)dT + 128);
+    TRY(launch_estimate_transform((double*)d1, (double*)d2, n, n, (double*)dT, dE, g_stream));
+    int32_t e = 1;
+    PCREG_HIP(hipMemcpyAsync(T, dT, sizeof(double) * 16, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(&e, dE, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    *empty = e;
+    return PCREG_OK;
+}
+
+int pcreg_calc_dists(const double T[16], const double* pts1, const double* pts2, int n, int ld, double* d) {
+    PCREG_ARG(T && pts1 && pts2 && d && n >= 0 && ld >= n);
+    GUARD();
+    if (n == 0) return PCREG_OK;
+    void *d1, *d2, *dT, *dd;
+    TRY(scratch().get(0, sizeof(double) * 3 * (size_t)n, &d1));
+    TRY(scratch().get(1, sizeof(double) * 3 * (size_t)n, &d2));
+    TRY(scratch().get(2, 256, &dT));
+    TRY(scratch().get(3, sizeof(double) * (size_t)n, &dd));
+    TRY(upload_cols(pts1, n, ld, 3, (double*)d1, g_stream));
+    TRY(upload_cols(pts2, n, ld, 3, (double*)d2, g_stream));
+    PCREG_HIP(hipMemcpyAsync(dT, T, sizeof(double) * 16, hipMemcpyHostToDevice, g_stream));
+    TRY(launch_calc_dists((double*)dT, (double*)d1, (double*)d2, n, n, (double*)dd, g_stream));
+    PCREG_HIP(hipMemcpyAsync(d, dd, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    return PCREG_OK;
+}
+
+static int ransac_host(const double* pts1, const double* pts2, int total, int ld, const int32_t* offsets, int B,
+                       const pcreg_ransac_opts* o, const int32_t* sample_idx, double* T, int32_t* inlier_idx,
+                       int32_t* n_inliers, int32_t* num_success, int32_t* max_inliers, int32_t* failed,
+                       int32_t* iter_inl, int32_t* iter_inl_ref) {
+    PCREG_ARG(o->iterNum >= 1 && o->minPtNum >= 3);
+    PCREG_ARG(o->minPtNum == 3 || sample_idx != nullptr);
+    int max_n = 0;
+    for (int b = 0; b < B; ++b) { int nb = offsets[b + 1] - offsets[b]; PCREG_ARG(nb >= 0); if (nb > max_n) max_n = nb; }
+    PCREG_ARG(offsets[0] == 0 && offsets[B] == total);
+    size_t hyps = (size_t)o->iterNum * B;
+    size_t wsb = ransac_workspace_bytes(o->iterNum, B);
+    void *d1, *d2, *dOff, *dS = nullptr, *dOut, *dInl, *ws, *dI1 = nullptr, *dI2 = nullptr;
+    size_t tot = (size_t)(total > 0 ? total : 1);
+    TRY(scratch().get(0, sizeof(double) * 3 * tot, &d1));
+    TRY(scratch().get(1, sizeof(double) * 3 * tot, &d2));
+    TRY(scratch().get(2, sizeof(int32_t) * ((size_t)B + 1), &dOff));
+    TRY(scratch().get(3, sizeof(pcreg_dev_ransac_result) * (size_t)B, &dOut));
+    TRY(scratch().get(4, sizeof(int32_t) * tot, &dInl));
+    TRY(scratch().get(5, wsb, &ws));
+    if (sample_idx) {
+        TRY(scratch().get(6, sizeof(int32_t) * hyps * o->minPtNum, &dS));
+        PCREG_HIP(hipMemcpyAsync(dS, sample_idx, sizeof(int32_t) * hyps * o->minPtNum, hipMemcpyHostToDevice, g_stream));
+    }
+    if (iter_inl) TRY(scratch().get(7, sizeof(int32_t) * hyps, &dI1));
+    if (iter_inl_ref) TRY(scratch().get(8, sizeof(int32_t) * hyps, &dI2));
+    TRY(upload_cols(pts1, total, ld, 3, (double*)d1, g_stream));
+    TRY(upload_cols(pts2, total, ld, 3, (double*)d2, g_stream));
+    PCREG_HIP(hipMemcpyAsync(dOff, offsets, sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, g_stream));
+    TRY(launch_ransac((double*)d1, (double*)d2, total, (int32_t*)dOff, nullptr, max_n, B, *o, (int32_t*)dS,
+                      (pcreg_dev_ransac_result*)dOut, (int32_t*)dInl, (int32_t*)dI1, (int32_t*)dI2, ws, wsb, g_stream));
+    std::vector<pcreg_dev_ransac_result> res((size_t)B);
+    PCREG_HIP(hipMemcpyAsync(res.data(), dOut, sizeof(pcreg_dev_ransac_result) * (size_t)B, hipMemcpyDeviceToHost, g_stream));
+    if (total > 0) PCREG_HIP(hipMemcpyAsync(inlier_idx, dInl, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, g_stream));
+    if (iter_inl) PCREG_HIP(hipMemcpyAsync(iter_inl, dI1, sizeof(int32_t) * hyps, hipMemcpyDeviceToHost, g_stream));
+    if (iter_inl_ref) PCREG_HIP(hipMemcpyAsync(iter_inl_ref, dI2, sizeof(int32_t) * hyps, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    for (int b = 0; b < B; ++b) {
+        memcpy(T + 16 * (size_t)b, res[b].T, sizeof(double) * 16);
+        n_inliers[b] = res[b].n_inliers; num_success[b] = res[b].num_success;
+        max_inliers[b] = res[b].max_inliers; failed[b] = res[b].failed;
+    }
+    return PCREG_OK;
+}
+
+int pcreg_ransac(const double* pts1, const double* pts2, int n, int ld, const pcreg_ransac_opts* opts,
+                 const int32_t* sample_idx, double T[16], int32_t* inlier_idx, int* n_inliers, int* num_success,
+                 int* max_inliers, int* failed, int32_t* iter_inl, int32_t* iter_inl_ref) {
+    PCREG_ARG(pts1 && pts2 && opts && T && inlier_idx && n_inliers && num_success && max_inliers && failed);
+    PCREG_ARG(n >= 0 && ld >= n);
+    GUARD();
+    int32_t offsets[2] = {0, n};
+    int32_t ni = 0, ns = 0, mi = 0, fl = 1;
+    TRY(ransac_host(pts1, pts2, n, ld, offsets, 1, opts, sample_idx, T, inlier_idx, &ni, &ns, &mi, &fl, iter_inl, iter_inl_ref));
+    *n_inliers = ni; *num_success = ns; *max_inliers = mi; *failed = fl;
+    return PCREG_OK;
+}
+
+int pcreg_ransac_batched(const double* pts1, const double* pts2, int total, int ld, const int32_t* offsets, int B,
+                         const pcreg_ransac_opts* opts, const int32_t* sample_idx, double* T, int32_t* inlier_idx,
+                         int32_t* n_inliers, int32_t* num_success, int32_t* max_inliers, int32_t* failed) {
+    PCREG_ARG(pts1 && pts2 && offsets && opts && T && inlier_idx && n_inliers && num_success && max_inliers && failed);
+    PCREG_ARG(total >= 0 && ld >= total && B >= 1);
+    GUARD();
+    return ransac_host(pts1, pts2, total, ld, offsets, B, opts, sample_idx, T, inlier_idx, n_inliers, num_success,
+                       max_inliers, failed, nullptr, nullptr);
+}
+
+int pcreg_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t* idx, float* dist) {
+    PCREG_ARG(q && m && idx && dist && Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+    GUARD();
+    if (Q == 0) return PCREG_OK;
+    void *dq, *dm, *di, *dd, *ws;
+    size_t wsb = knn2_points_workspace_bytes(Q, M);
+    TRY(scratch().get(0, sizeof(float) * 3 * (size_t)Q, &dq));
+    TRY(scratch().get(1, sizeof(float) * 3 * (size_t)(M > 0 ? M : 1), &dm));
+    TRY(scratch().get(2, sizeof(int32_t) * 2 * (size_t)Q, &di));
+    TRY(scratch().get(3, sizeof(float) * 2 * (size_t)Q, &dd));
+    TRY(scratch().get(4, wsb, &ws));
+    TRY(upload_cols(q, Q, ldq, 3, (float*)dq, g_stream));
+    TRY(upload_cols(m, M, ldm, 3, (float*)dm, g_stream));
+    TRY(launch_knn2_points_f32((float*)dq, Q, Q, (float*)dm, M, M, 0, (int32_t*)di, (float*)dd, ws, wsb, g_stream));
+    PCREG_HIP(hipMemcpyAsync(idx, di, sizeof(int32_t) * 2 * (size_t)Q, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(dist, dd, sizeof(float) * 2 * (size_t)Q, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    return PCREG_OK;
+}
+
+int pcreg_match_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, float thr_abs,
+                           float max_ratio, int unique, uint32_t* pairs, int* P) {
+    PCREG_ARG(q && m && pairs && P && Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+    GUARD();
+    *P = 0;
+    if (Q == 0 || M == 0) return PCREG_OK;
+    void *dq, *dm, *di, *dd, *ws, *dcq, *dcm, *dkeep, *dcnt, *dpairs, *wsu;
+    size_t wsb = knn2_points_workspace_bytes(Q, M), wsu_b = unique_points_workspace_bytes(Q);
+    TRY(scratch().get(0, sizeof(float) * 3 * (size_t)Q, &dq));
+    TRY(scratch().get(1, sizeof(float) * 3 * (size_t)M, &dm));
+    TRY(scratch().get(2, sizeof(int32_t) * 2 * (size_t)Q, &di));
+    TRY(scratch().get(3, sizeof(float) * 2 * (size_t)Q, &dd));
+    TRY(scratch().get(4, wsb, &ws));
+    TRY(scratch().get(5, sizeof(int32_t) * (size_t)Q, &dcq));
+    TRY(scratch().get(6, sizeof(int32_t) * (size_t)Q, &dcm));
+    TRY(scratch().get(7, sizeof(int32_t) * (size_t)Q, &dkeep));
+    TRY(scratch().get(8, 256, &dcnt));
+    TRY(scratch().get(9, sizeof(uint32_t) * 2 * (size_t)Q, &dpairs));
+    TRY(scratch().get(10, wsu_b, &wsu));
+    int32_t* n_cand = (int32_t*)dcnt; int32_t* n_pairs = n_cand + 1;
+    TRY(upload_cols(q, Q, ldq, 3, (float*)dq, g_stream));
+    TRY(upload_cols(m, M, ldm, 3, (float*)dm, g_stream));
+    TRY(launch_knn2_points_f32((float*)dq, Q, Q, (float*)dm, M, M, 0, (int32_t*)di, (float*)dd, ws, wsb, g_stream));
+    TRY(launch_filter_top2_f32((int32_t*)di, (float*)dd, Q, M, thr_abs, max_ratio, (int32_t*)dcq, (int32_t*)dcm, n_cand, g_stream));
+    const int32_t* keep = nullptr;
+    if (unique) {
+        TRY(launch_unique_points_f32((float*)dq, Q, Q, (float*)dm, M, M, 0, (int32_t*)dcq, (int32_t*)dcm, n_cand,
+                                     (int32_t*)dkeep, wsu, wsu_b, g_stream));
+        keep = (int32_t*)dkeep;
+    }
+    TRY(launch_gather_pairs_f32((float*)dq, Q, Q, (float*)dm, M, (int32_t*)dcq, (int32_t*)dcm, keep, n_cand,
+                                (uint32_t*)dpairs, nullptr, nullptr, n_pairs, g_stream));
+    int32_t np = 0;
+    PCREG_HIP(hipMemcpyAsync(&np, n_pairs, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    if (np > 0) PCREG_HIP(hipMemcpy(pairs, dpairs, sizeof(uint32_t) * 2 * (size_t)np, hipMemcpyDeviceToHost));
+    *P = np;
+    return PCREG_OK;
+}
+
+static int match_host(const double* f1, int Q, int ld1, const double* f2, int M, int ld2, int D,
+                      const pcreg_match_opts* o, bool preprocess, uint32_t* pairs, double* metric, int* P) {
+    *P = 0;
+    if (Q == 0 || M == 0) return PCREG_OK;
+    const int Dp = D + ((preprocess && o->unnormalize) ? 1 : 0);
+    void *dS, *dM, *ws, *dpairs, *dmet, *dcnt, *rawS = nullptr, *rawM = nullptr, *pws = nullptr;
+    size_t wsb = match_features_workspace_bytes(Q, M, Dp);
+    TRY(scratch().get(0, sizeof(double) * (size_t)Q * Dp, &dS));
+    TRY(scratch().get(1, sizeof(double) * (size_t)M * Dp, &dM));
+    TRY(scratch().get(2, wsb, &ws));
+    TRY(scratch().get(3, sizeof(uint32_t) * 2 * (size_t)Q, &dpairs));
+    TRY(scratch().get(4, sizeof(double) * (size_t)Q, &dmet));
+    TRY(scratch().get(5, 256, &dcnt));
+    if (preprocess) {
+        TRY(scratch().get(6, sizeof(double) * (size_t)Q * D, &rawS));
+        TRY(scratch().get(7, sizeof(double) * (size_t)M * D, &rawM));
+        size_t pwb = sizeof(double) * ((size_t)Q + M + 1);
+        TRY(scratch().get(8, pwb, &pws));
+        TRY(upload_cols(f1, Q, ld1, D, (double*)rawS, g_stream));
+        TRY(upload_cols(f2, M, ld2, D, (double*)rawM, g_stream));
+        TRY(launch_preprocess((double*)rawS, Q, Q, (double*)rawM, M, M, D, *o, (double*)dS, (double*)dM, pws, pwb, g_stream));
+    } else {
+        TRY(upload_cols(f1, Q, ld1, D, (double*)dS, g_stream));
+        TRY(upload_cols(f2, M, ld2, D, (double*)dM, g_stream));
+    }
+    if (!o->prenormalized) {
+        TRY(launch_normalize_rows((double*)dS, Q, Q, Dp, g_stream));
+        TRY(launch_normalize_rows((double*)dM, M, M, Dp, g_stream));
+    }
+    TRY(launch_match_features((double*)dS, Q, Q, (double*)dM, M, M, Dp, *o, (uint32_t*)dpairs,
+                              metric ? (double*)dmet : nullptr, (int32_t*)dcnt, ws, wsb, g_stream));
+    int32_t np = 0;
+    PCREG_HIP(hipMemcpyAsync(&np, dcnt, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    if (np > 0) {
+        PCREG_HIP(hipMemcpy(pairs, dpairs, sizeof(uint32_t) * 2 * (size_t)np, hipMemcpyDeviceToHost));
+        if (metric) PCREG_HIP(hipMemcpy(metric, dmet, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost));
+    }
+    *P = np;
+    return PCREG_OK;
+}
+
+int pcreg_match_features(const double* f1, int Q, int ld1, const double* f2, int M, int ld2, int D,
+                         const pcreg_match_opts* opts, uint32_t* pairs, double* metric, int* P) {
+    PCREG_ARG(f1 && f2 && opts && pairs && P && Q >= 0 && M >= 0 && D >= 1 && ld1 >= Q && ld2 >= M);
+    PCREG_ARG(opts->metric == PCREG_METRIC_SAD || opts->metric == PCREG_METRIC_SSD);
+    GUARD();
+    return match_host(f1, Q, ld1, f2, M, ld2, D, opts, false, pairs, metric, P);
+}
+
+int pcreg_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M, int ldM, int D,
+                      const pcreg_match_opts* par, uint32_t* pairs, double* metric, int* P) {
+    PCREG_ARG(descSurface && descModel && par && pairs && P && Q >= 0 && M >= 0 && D >= 1 && ldS >= Q && ldM >= M);
+    PCREG_ARG(par->metric == PCREG_METRIC_SAD || par->metric == PCREG_METRIC_SSD);
+    GUARD();
+    return match_host(descSurface, Q, ldS, descModel, M, ldM, D, par, true, pairs, metric, P);
+}
+
+int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const int32_t* offsets, int B, int C1, int C2,
+                                   double* aligned, double* coeff, double* c, int32_t* status) {
+    PCREG_ARG(pts && offsets && aligned && coeff && c && status && total >= 0 && ld >= total && B >= 0);
+    GUARD();
+    if (B == 0) return PCREG_OK;
+    int max_n = 0;
+    for (int b = 0; b < B; ++b) { int nb = offsets[b + 1] - offsets[b]; PCREG_ARG(nb >= 0); if (nb > max_n) max_n = nb; }
+    PCREG_ARG(offsets[0] == 0 && offsets[B] == total);
+    size_t tot = (size_t)(total > 0 ? total : 1);
+    void *dp, *da, *doff, *dco, *dc, *dst;
+    TRY(scratch().get(0, sizeof(double) * 3 * tot, &dp));
+    TRY(scratch().get(1, sizeof(double) * 3 * tot, &da));
+    TRY(scratch().get(2, sizeof(int32_t) * ((size_t)B + 1), &doff));
+    TRY(scratch().get(3, sizeof(double) * 9 * (size_t)B, &dco));
+    TRY(scratch().get(4, sizeof(double) * 3 * (size_t)B, &dc));
+    TRY(scratch().get(5, sizeof(int32_t) * (size_t)B, &dst));
+    TRY(upload_cols(pts, total, ld, 3, (double*)dp, g_stream));
+    PCREG_HIP(hipMemcpyAsync(doff, offsets, sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, g_stream));
+    PCREG_HIP(hipMemsetAsync(dco, 0, sizeof(double) * 9 * (size_t)B, g_stream));
+    PCREG_HIP(hipMemsetAsync(dc, 0, sizeof(double) * 3 * (size_t)B, g_stream));
+    PCREG_HIP(hipMemsetAsync(da, 0, sizeof(double) * 3 * tot, g_stream));
+    TRY(launch_align_points_knn((double*)dp, total, (int32_t*)doff, B, max_n, C1, C2, (double*)da, total, (double*)dco,
+                                (double*)dc, (int32_t*)dst, g_stream));
+    if (total > 0) PCREG_HIP(hipMemcpyAsync(aligned, da, sizeof(double) * 3 * (size_t)total, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(coeff, dco, sizeof(double) * 9 * (size_t)B, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(c, dc, sizeof(double) * 3 * (size_t)B, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(status, dst, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    return PCREG_OK;
+}
+
+int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2, double* aligned, double coeff[9],
+                           double c[3]) {
+    PCREG_ARG(pts && aligned && coeff && c && n >= 2 && ld >= n);
+    int32_t offsets[2] = {0, n};
+    int32_t status = 0;
+    // compact the input so that "total == ld" holds for the batched entry point
+    if (ld != n) {
+        std::vector<double> tmp((size_t)n * 3);
+        for (int k = 0; k < 3; ++k) memcpy(tmp.data() + (size_t)k * n, pts + (size_t)k * ld, sizeof(double) * (size_t)n);
+        TRY(pcreg_align_points_knn_batched(tmp.data(), n, n, offsets, 1, C1, C2, aligned, coeff, c, &status));
+    } else {
+        TRY(pcreg_align_points_knn_batched(pts, n, n, offsets, 1, C1, C2, aligned, coeff, c, &status));
+    }
+    if (status != 0) { set_error("AlignPoints_KNN: support too small"); return PCREG_E_ARG; }
+    return PCREG_OK;
+}
+
+// ------------------------------------------------------------------ device tier
+size_t pcreg_dev_knn2_points_f32_workspace(int Q, int M) { return knn2_points_workspace_bytes(Q, M); }
+
+int pcreg_dev_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                              int32_t* idx, float* dist, void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(q && m && idx && dist && workspace);
+    GUARD();
+    return launch_knn2_points_f32(q, Q, ldq, m, M, ldm, idx_base, idx, dist, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pcreg_dev_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx, float* dist,
+                             void* stream) {
+    PCREG_ARG(idx_in && dist_in && idx && dist);
+    GUARD();
+    return launch_merge_top2_f32(idx_in, dist_in, R, Q, idx, dist, (hipStream_t)stream);
+}
+
+int pcreg_dev_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr_abs, float max_ratio,
+                              int32_t* cand_q, int32_t* cand_m, int32_t* n_cand, void* stream) {
+    PCREG_ARG(idx && dist && cand_q && cand_m && n_cand);
+    GUARD();
+    return launch_filter_top2_f32(idx, dist, Q, M_total, thr_abs, max_ratio, cand_q, cand_m, n_cand, (hipStream_t)stream);
+}
+
+size_t pcreg_dev_unique_points_f32_workspace(int Q) { return unique_points_workspace_bytes(Q); }
+
+int pcreg_dev_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t m_lo,
+                                const int32_t* cand_q, const int32_t* cand_m, const int32_t* n_cand, int32_t* keep,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(q && m && cand_q && cand_m && n_cand && keep && workspace);
+    GUARD();
+    return launch_unique_points_f32(q, Q, ldq, m, M, ldm, m_lo, cand_q, cand_m, n_cand, keep, workspace, workspace_bytes,
+                                    (hipStream_t)stream);
+}
+
+int pcreg_dev_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm, const int32_t* cand_q,
+                               const int32_t* cand_m, const int32_t* keep, const int32_t* n_cand, uint32_t* pairs,
+                               double* pts1, double* pts2, int32_t* n_pairs, void* stream) {
+    PCREG_ARG(q && m && cand_q && cand_m && n_cand && n_pairs);
+    GUARD();
+    return launch_gather_pairs_f32(q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand, pairs, pts1, pts2, n_pairs,
+                                   (hipStream_t)stream);
+}
+
+size_t pcreg_dev_ransac_workspace(int n_cap, int iterNum) { (void)n_cap; return ransac_workspace_bytes(iterNum, 1); }
+
+int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                     const pcreg_ransac_opts* opts, const int32_t* sample_idx, pcreg_dev_ransac_result* out,
+                     int32_t* inlier_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(pts1 && pts2 && opts && out && inlier_idx && workspace && n_cap >= 0 && ld >= n_cap);
+    GUARD();
+    return launch_ransac(pts1, pts2, ld, nullptr, n_dev, n_cap, 1, *opts, sample_idx, out, inlier_idx, nullptr, nullptr,
+                         workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

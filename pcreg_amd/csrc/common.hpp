@@ -1,0 +1,94 @@
+// pcreg_amd/csrc/common.hpp -- shared host-side helpers of libpcreg_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/pcreg.h"
+
+namespace pcreg {
+
+void set_error(const char* fmt, ...);
+int  ensure_device();   // PCREG_OK or PCREG_E_NODEVICE / PCREG_E_HIP
+
+#define PCREG_HIP(call)                                                                  \
+    do {                                                                                 \
+        hipError_t e__ = (call);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            ::pcreg::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+                               __FILE__, __LINE__);                                      \
+            return PCREG_E_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define PCREG_ARG(cond)                                                                  \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            ::pcreg::set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__);   \
+            return PCREG_E_ARG;                                                          \
+        }                                                                                \
+    } while (0)
+
+// Grow-only device scratch owned by the host tier (one per process; MEX calls arrive
+// on MATLAB's interpreter thread).  Slots keep independent
+// buffers alive across one call.
+struct Scratch {
+    static constexpr int kSlots = 24;
+    void*  ptr[kSlots]  = {};
+    size_t size[kSlots] = {};
+    int get(int slot, size_t bytes, void** out);
+    void release_all();
+};
+Scratch& scratch();
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- kernel launchers implemented in the .hip files (device pointers, async) --------
+struct RansacDims { int n_cap; int iters; int B; };
+
+size_t ransac_workspace_bytes(int iters, int B);
+int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* offsets /*B+1 dev or null*/,
+                  const int32_t* n_dev /*single registration: device n, or null*/, int n_cap, int B,
+                  const pcreg_ransac_opts& o, const int32_t* sample_idx_dev,
+                  pcreg_dev_ransac_result* out /*B*/, int32_t* inlier_idx, int32_t* iter_inl /*B*iters or null*/,
+                  int32_t* iter_inl_ref, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_estimate_transform(const double* p1, const double* p2, int n, int ld, double* T16_dev,
+                              int32_t* empty_dev, hipStream_t st);
+int launch_calc_dists(const double* T16_dev, const double* p1, const double* p2, int n, int ld,
+                      double* d, hipStream_t st);
+
+size_t knn2_points_workspace_bytes(int Q, int M);
+int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
+                           int32_t idx_base, int32_t* idx, float* dist, void* ws, size_t ws_bytes,
+                           hipStream_t st);
+int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx,
+                          float* dist, hipStream_t st);
+int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr,
+                           float ratio, int32_t* cand_q, int32_t* cand_m, int32_t* n_cand,
+                           hipStream_t st);
+size_t unique_points_workspace_bytes(int Q);
+int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
+                             int32_t m_lo, const int32_t* cand_q, const int32_t* cand_m,
+                             const int32_t* n_cand, int32_t* keep, void* ws, size_t ws_bytes,
+                             hipStream_t st);
+int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm,
+                            const int32_t* cand_q, const int32_t* cand_m, const int32_t* keep,
+                            const int32_t* n_cand, uint32_t* pairs, double* pts1, double* pts2,
+                            int32_t* n_pairs, hipStream_t st);
+
+// generic-D descriptor matching (fp64)
+size_t match_features_workspace_bytes(int Q, int M, int D);
+int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M, int ldM, int D,
+                      const pcreg_match_opts& o, double* outS, double* outM, void* ws, size_t ws_bytes,
+                      hipStream_t st);
+int launch_normalize_rows(double* f, int n, int ld, int D, hipStream_t st);
+int launch_match_features(const double* fS, int Q, int ldS, const double* fM, int M, int ldM, int D,
+                          const pcreg_match_opts& o, uint32_t* pairs, double* metric, int32_t* P_dev,
+                          void* ws, size_t ws_bytes, hipStream_t st);
+
+int launch_align_points_knn(const double* pts, int ld, const int32_t* offsets_dev, int B, int max_n,
+                            int C1, int C2, double* aligned, int ld_out, double* coeff, double* c,
+                            int32_t* status, hipStream_t st);
+
+}  // namespace pcreg

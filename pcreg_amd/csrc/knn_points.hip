@@ -1,0 +1,327 @@
+// pcreg_amd/csrc/knn_points.hip -- all-pairs 3-D correspondence search on gfx950, fp32.
+//
+// This is the "KNN" half of BASELINE.json's metric: for every surface (query) point the
+// two nearest model points, then matchFeatures' filter chain (threshold, ratio,
+// Unique) -- the role getMatches.m:51-56 plays in completeExperimentFast.m:134-149,
+// applied to raw 3-D points as in SURVEY.md section 8d (cfg 2/3).
+//
+// Kernel shape (CDNA4, wave64):
+//   * every lane owns QPT queries in registers together with their running top-2
+//     (distance + index), so the hot loop has no cross-lane traffic at all;
+//   * the model shard is split in S chunks (grid.y) so that >= ~2k workgroups fill the
+//     256 CUs; a chunk streams through LDS in tiles of float4 {x,y,z,-}; all lanes read
+//     the same LDS address (broadcast ds_read_b128), 4 model points per batch;
+//   * per batch and query: 6 VALU per pair (3 sub, 1 mul, 2 fma -- bit-identical to the
+//     oracle's fmaf chain), one v_min3/v_min tree and ONE compare against the lane's
+//     current 2nd-best; the index bookkeeping lives behind that rarely-taken branch;
+//   * per-chunk partial top-2 lists are merged by a second kernel ordering (dist, idx),
+//     the same kernel that merges the all-gathered per-GPU lists in the sharded setup.
+// Ties resolve to the lowest model index (MATLAB min / partial-sort behaviour).
+#include "common.hpp"
+#include "select.hpp"
+#include <cmath>
+
+namespace pcreg {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int QPT = 4;                       // queries per lane
+constexpr int kQTile = kBlock * QPT;         // queries per workgroup
+constexpr int kMTile = 1024;                 // model points per LDS tile (16 KiB)
+constexpr int UB = 4;                        // model points per batch
+
+struct Top2 { float d1, d2; int i1, i2; };
+
+__device__ __forceinline__ void top2_insert(Top2& t, float d, int j) {
+    // candidates arrive in ascending j inside a chunk, so strict '<' keeps the lowest index
+    if (d < t.d2) {
+        if (d < t.d1) { t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = j; }
+        else { t.d2 = d; t.i2 = j; }
+    }
+}
+__device__ __forceinline__ float sqd(float qx, float qy, float qz, const float4& m) {
+    float dx = qx - m.x, dy = qy - m.y, dz = qz - m.z;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+// grid = (query tiles, S model chunks).  part_* layout [S][Q][2].
+__global__ __launch_bounds__(kBlock) void knn2_points_kernel(
+    const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
+    int chunk, int idx_base, int32_t* __restrict__ part_idx, float* __restrict__ part_dist) {
+    __shared__ float4 tile[kMTile];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * kQTile;
+    const int s = blockIdx.y;
+    const int m_begin = s * chunk;
+    const int m_end = min(M, m_begin + chunk);
+
+    float qx[QPT], qy[QPT], qz[QPT];
+    Top2 best[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        int qi = q0 + r * kBlock + tid;
+        bool ok = qi < Q;
+        qx[r] = ok ? q[qi] : 0.0f;
+        qy[r] = ok ? q[qi + (size_t)ldq] : 0.0f;
+        qz[r] = ok ? q[qi + 2 * (size_t)ldq] : 0.0f;
+        best[r] = Top2{INFINITY, INFINITY, -1, -1};
+    }
+
+    for (int t0 = m_begin; t0 < m_end; t0 += kMTile) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kMTile / kBlock; ++k) {
+            int j = t0 + k * kBlock + tid;
+            float4 v;
+            if (j < m_end) { v.x = m[j]; v.y = m[j + (size_t)ldm]; v.z = m[j + 2 * (size_t)ldm]; v.w = 0.0f; }
+            else { v.x = v.y = v.z = INFINITY; v.w = 0.0f; }     // padding never beats anything
+            tile[k * kBlock + tid] = v;
+        }
+        __syncthreads();
+        const int cnt = min(kMTile, m_end - t0);
+        const int nb = (cnt + UB - 1) / UB * UB;
+        for (int jb = 0; jb < nb; jb += UB) {
+            float4 mp[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) mp[u] = tile[jb + u];
+#pragma unroll
+            for (int r = 0; r < QPT; ++r) {
+                float d[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) d[u] = sqd(qx[r], qy[r], qz[r], mp[u]);
+                float mn = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                if (mn < best[r].d2) {
+                    const int j0 = idx_base + t0 + jb;
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) top2_insert(best[r], d[u], j0 + u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        int qi = q0 + r * kBlock + tid;
+        if (qi < Q) {
+            size_t o = ((size_t)s * Q + qi) * 2;
+            part_idx[o] = best[r].i1; part_idx[o + 1] = best[r].i2;
+            part_dist[o] = best[r].d1; part_dist[o + 1] = best[r].d2;
+        }
+    }
+}
+
+// Unique back-check: for candidate k (model row j in this shard) find the first-best
+// query over all Q.  Same hot loop as the forward search with the roles swapped:
+// "queries" are the matched model points (gathered on the fly), the surface streams
+// through LDS.  Only the best index is needed.
+__global__ __launch_bounds__(kBlock) void unique_points_kernel(
+    const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm, int m_lo,
+    const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
+    int chunk, int32_t* __restrict__ part_idx, float* __restrict__ part_dist) {
+    __shared__ float4 tile[kMTile];
+    const int P = *n_cand;
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * kQTile;
+    if (k0 >= P) return;
+    const int s = blockIdx.y;
+    const int b_begin = s * chunk, b_end = min(Q, b_begin + chunk);
+    float px[QPT], py[QPT], pz[QPT], bd[QPT]; int bi[QPT];
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        int k = k0 + r * kBlock + tid;
+        int j = k < P ? cand_m[k] - m_lo : -1;
+        bool ok = j >= 0 && j < M;
+        px[r] = ok ? m[j] : 0.0f; py[r] = ok ? m[j + (size_t)ldm] : 0.0f; pz[r] = ok ? m[j + 2 * (size_t)ldm] : 0.0f;
+        bd[r] = INFINITY; bi[r] = -1;
+    }
+    for (int t0 = b_begin; t0 < b_end; t0 += kMTile) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kMTile / kBlock; ++k) {
+            int i = t0 + k * kBlock + tid;
+            float4 v;
+            if (i < b_end) { v.x = q[i]; v.y = q[i + (size_t)ldq]; v.z = q[i + 2 * (size_t)ldq]; v.w = 0.0f; }
+            else { v.x = v.y = v.z = INFINITY; v.w = 0.0f; }
+            tile[k * kBlock + tid] = v;
+        }
+        __syncthreads();
+        const int cnt = min(kMTile, b_end - t0);
+        const int nb = (cnt + UB - 1) / UB * UB;
+        for (int jb = 0; jb < nb; jb += UB) {
+            float4 mp[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) mp[u] = tile[jb + u];
+#pragma unroll
+            for (int r = 0; r < QPT; ++r) {
+                float d[UB];
+                // the score of (query i, model j) must be the bits the forward pass saw:
+                // dx = q - m, i.e. (surface - model)
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    float dx = mp[u].x - px[r], dy = mp[u].y - py[r], dz = mp[u].z - pz[r];
+                    d[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                }
+                float mn = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                if (mn < bd[r]) {
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) if (d[u] < bd[r]) { bd[r] = d[u]; bi[r] = t0 + jb + u; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        int k = k0 + r * kBlock + tid;
+        if (k < P) { size_t o = (size_t)s * Q + k; part_idx[o] = bi[r]; part_dist[o] = bd[r]; }
+    }
+}
+__global__ void unique_reduce_kernel(const int32_t* __restrict__ part_idx, const float* __restrict__ part_dist, int S,
+                                     int Q, int M, int m_lo, const int32_t* __restrict__ cand_q,
+                                     const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
+                                     int32_t* __restrict__ keep) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_cand) return;
+    int j = cand_m[k] - m_lo;
+    if (j < 0 || j >= M) return;                 // another shard's row
+    float bd = INFINITY; int bi = -1;
+    for (int s = 0; s < S; ++s) {                // chunks ascend in query index: strict '<' keeps the first
+        float d = part_dist[(size_t)s * Q + k]; int i = part_idx[(size_t)s * Q + k];
+        if (i >= 0 && d < bd) { bd = d; bi = i; }
+    }
+    keep[k] = (bi == cand_q[k]);
+}
+
+__global__ void gather_pairs_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
+                                    const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
+                                    const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
+                                    uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2,
+                                    int32_t* __restrict__ n_pairs) {
+    // single workgroup, ordered compaction (P <= Q is small: tens of thousands)
+    __shared__ int s_cnt[4];
+    __shared__ int s_base;
+    const int P = *n_cand;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < P; k0 += 256) {
+        int k = k0 + threadIdx.x;
+        bool kp = k < P && (keep == nullptr || keep[k] != 0);
+        unsigned long long b = __ballot(kp);
+        if (lane == 0) s_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wave; ++w) base += s_cnt[w];
+        if (kp) {
+            int o = base + __popcll(b & ((1ull << lane) - 1ull));
+            int qi = cand_q[k], mj = cand_m[k];
+            if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)mj + 1u; }
+            if (pts1) {
+                pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
+                pts2[o] = (double)m[mj]; pts2[o + (size_t)Q] = (double)m[mj + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[mj + 2 * (size_t)ldm];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_pairs = s_base;
+}
+
+// number of model chunks so that the grid has ~>= 8 workgroups per CU
+int pick_splits(int n_tiles, int M) {
+    int target = 2048;
+    int S = (target + n_tiles - 1) / n_tiles;
+    int maxS = (M + kMTile - 1) / kMTile;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    return S;
+}
+int chunk_of(int M, int S) {
+    int c = (M + S - 1) / S;
+    return (c + kMTile - 1) / kMTile * kMTile;       // whole LDS tiles
+}
+
+}  // namespace
+
+size_t knn2_points_workspace_bytes(int Q, int M) {
+    int n_tiles = (Q + kQTile - 1) / kQTile; if (n_tiles < 1) n_tiles = 1;
+    int S = pick_splits(n_tiles, M > 0 ? M : 1);
+    return 2 * align_up((size_t)S * (size_t)(Q > 0 ? Q : 1) * 2 * sizeof(float), 256);
+}
+
+int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                           int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
+    PCREG_ARG(Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+    if (Q == 0) return PCREG_OK;
+    size_t need = knn2_points_workspace_bytes(Q, M);
+    if (ws_bytes < need) { set_error("knn workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    int n_tiles = (Q + kQTile - 1) / kQTile;
+    int S = pick_splits(n_tiles, M > 0 ? M : 1);
+    int chunk = chunk_of(M > 0 ? M : 1, S);
+    S = M > 0 ? (M + chunk - 1) / chunk : 1;
+    int32_t* part_idx = (int32_t*)ws;
+    float* part_dist = (float*)((char*)ws + align_up((size_t)S * Q * 2 * sizeof(float), 256));
+    // need above was computed with the unrounded S (>= this S), so the split fits
+    hipLaunchKernelGGL(knn2_points_kernel, dim3(n_tiles, S), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, chunk,
+                       (int)idx_base, part_idx, part_dist);
+    PCREG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, idx, dist);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx, float* dist,
+                          hipStream_t st) {
+    PCREG_ARG(R >= 1 && Q >= 0);
+    if (Q == 0) return PCREG_OK;
+    hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, idx_in, dist_in, R, Q, idx, dist);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr, float ratio,
+                           int32_t* cand_q, int32_t* cand_m, int32_t* n_cand, hipStream_t st) {
+    PCREG_ARG(Q >= 0);
+    void* tmp = nullptr;   // flags [Q] + per-workgroup counters
+    int rc = scratch().get(20, ((size_t)Q + (Q + 255) / 256 + 1) * sizeof(int32_t), &tmp);
+    if (rc) return rc;
+    return run_filter_top2<float>(idx, dist, Q, M_total, thr, ratio, cand_q, cand_m, n_cand, (int32_t*)tmp, st);
+}
+
+size_t unique_points_workspace_bytes(int Q) {
+    int n_tiles = (Q + kQTile - 1) / kQTile; if (n_tiles < 1) n_tiles = 1;
+    int S = pick_splits(n_tiles, Q > 0 ? Q : 1);
+    return 2 * align_up((size_t)S * (size_t)(Q > 0 ? Q : 1) * sizeof(float), 256);
+}
+
+int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t m_lo,
+                             const int32_t* cand_q, const int32_t* cand_m, const int32_t* n_cand, int32_t* keep,
+                             void* ws, size_t ws_bytes, hipStream_t st) {
+    PCREG_ARG(Q >= 0 && M >= 0);
+    if (Q == 0) return PCREG_OK;
+    size_t need = unique_points_workspace_bytes(Q);
+    if (ws_bytes < need) { set_error("unique workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    int n_tiles = (Q + kQTile - 1) / kQTile;         // capacity: every query matched
+    int S = pick_splits(n_tiles, Q);
+    int chunk = chunk_of(Q, S);
+    S = (Q + chunk - 1) / chunk;
+    int32_t* part_idx = (int32_t*)ws;
+    float* part_dist = (float*)((char*)ws + align_up((size_t)S * Q * sizeof(float), 256));
+    hipLaunchKernelGGL(unique_points_kernel, dim3(n_tiles, S), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo,
+                       cand_q, cand_m, n_cand, chunk, part_idx, part_dist);
+    hipLaunchKernelGGL(unique_reduce_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, M,
+                       (int)m_lo, cand_q, cand_m, n_cand, keep);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm, const int32_t* cand_q,
+                            const int32_t* cand_m, const int32_t* keep, const int32_t* n_cand, uint32_t* pairs,
+                            double* pts1, double* pts2, int32_t* n_pairs, hipStream_t st) {
+    PCREG_ARG((pts1 == nullptr) == (pts2 == nullptr));
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3(1), dim3(256), 0, st, q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand,
+                       pairs, pts1, pts2, n_pairs);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+}  // namespace pcreg

@@ -1,0 +1,743 @@
+// pcreg_amd/csrc/ransac.hip -- RANSAC rigid alignment on gfx950 (MI355X), fp64.
+//
+// Replaces, behind the same semantics, the interpreted loop of the reference:
+//   ransac.m:40-66            hypothesis loop   -> ransac_hyp_kernel
+//   ransac.m:69-98            winner / outputs  -> ransac_select_kernel
+//   estimateTransform.m:8-71  SVD Procrustes    -> fit_3pt / fit_moments (per lane)
+//   getInliersRANSAC.m:46-54  calcDists         -> score_pass (canonical FMA order)
+//
+// Mapping to the hardware (CDNA4, wave64):
+//   * one wave owns `hpw` hypotheses.  The minimal-sample fits run one hypothesis PER
+//     LANE (the 3x3 Jacobi SVD is lane-parallel, no cross-lane traffic); scoring then
+//     walks the wave's hypotheses one pair at a time with ALL 64 lanes striding over
+//     the correspondences, the transform broadcast with v_readlane, inliers counted
+//     with v_cmp -> s_bcnt1 (ballot + popcount), i.e. "one hypothesis per wavefront".
+//   * correspondences (n x 6 doubles) are staged once per workgroup into LDS as six
+//     SoA columns (conflict-free ds_read_b64) when they fit, otherwise streamed from
+//     L2; two hypotheses share every point load.
+//   * the refit (estimateTransform on the inlier set) is a wave-reduced set of 27
+//     moments per passing hypothesis followed by a second lane-parallel SVD.
+// No data leaves the chip between the sample fit and the final inlier list.
+#include "common.hpp"
+#include <cfloat>
+
+namespace pcreg {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+constexpr int HB = 2;   // hypotheses sharing one pass over the points
+
+struct RansacArgs {
+    const double* p1; const double* p2; int ld;
+    const int32_t* offsets;     // B+1 (device) or null
+    const int32_t* n_dev;       // device n for the single-registration resident path, or null
+    int n_cap; int iters; int m;
+    double thDist; double ratio; int refine; unsigned long long seed;
+    const int32_t* sample_idx;  // [B*iters][m] 1-based or null
+    int hpw;                    // hypotheses per wave (<= 64)
+    double* TF;                 // [B*iters][12]
+    int32_t* cnt1; int32_t* cnt2; unsigned char* has;
+};
+
+// ---------------------------------------------------------------- lane utilities
+__device__ __forceinline__ double rdlane(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double ulp_at(double x) {   // MATLAB eps(x)
+    x = fabs(x);
+    return __longlong_as_double(__double_as_longlong(x) + 1) - x;
+}
+__device__ __forceinline__ int matlab_round_i(double x) {   // ransac.m:28
+    return (int)(x >= 0 ? floor(x + 0.5) : -floor(-x + 0.5));
+}
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull; unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------- 3x3 kernels (per lane)
+// One Hestenes rotation orthogonalising columns P,Q of W (stored W[col][row]).
+template <int P, int Q, bool WITH_V>
+__device__ __forceinline__ bool hrot(double (&W)[3][3], double (&V)[3][3]) {
+    double al = fma(W[P][2], W[P][2], fma(W[P][1], W[P][1], W[P][0] * W[P][0]));
+    double be = fma(W[Q][2], W[Q][2], fma(W[Q][1], W[Q][1], W[Q][0] * W[Q][0]));
+    double ga = fma(W[P][2], W[Q][2], fma(W[P][1], W[Q][1], W[P][0] * W[Q][0]));
+    bool doit = (ga != 0.0) && (fabs(ga) > DBL_EPSILON * sqrt(al * be));
+    if (doit) {
+        double zeta = (be - al) / (2.0 * ga);
+        double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+        double c = 1.0 / sqrt(fma(t, t, 1.0)), s = c * t;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double a = W[P][r], b = W[Q][r];
+            W[P][r] = c * a - s * b; W[Q][r] = s * a + c * b;
+        }
+        if (WITH_V) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double a = V[r][P], b = V[r][Q];
+                V[r][P] = c * a - s * b; V[r][Q] = s * a + c * b;
+            }
+        }
+    }
+    return doit;
+}
+template <bool WITH_V>
+__device__ __forceinline__ void hestenes3(double (&W)[3][3], double (&V)[3][3]) {
+    if (WITH_V) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) V[r][c] = (r == c) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool r0 = hrot<0, 1, WITH_V>(W, V);
+        bool r1 = hrot<0, 2, WITH_V>(W, V);
+        bool r2 = hrot<1, 2, WITH_V>(W, V);
+        if (!(r0 | r1 | r2)) break;
+    }
+}
+
+// rank(A) >= need for a raw 3x3 point matrix A[pt][coord] (estimateTransform.m:11).
+// Cheap certificates first (|det| and 2x2 minors bound the small singular values from
+// below); the exact MATLAB rule -- sigma > 3*eps(sigma_max) -- only when they fail.
+__device__ bool rank3x3_at_least(const double (&A)[3][3], int need) {
+    double fro2 = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) fro2 = fma(A[r][c], A[r][c], fro2);
+    double c0x = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+    double c0y = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    double c0z = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    if (need >= 3) {
+        double det = fma(A[0][0], c0x, fma(A[0][1], c0y, A[0][2] * c0z));
+        double fro = sqrt(fro2);
+        if (fabs(det) > 1e-12 * fro2 * fro) return true;       // sigma3 >= 2|det|/fro^2 >> tol
+    } else {
+        double c1x = A[0][1] * A[2][2] - A[0][2] * A[2][1];
+        double c1y = A[0][2] * A[2][0] - A[0][0] * A[2][2];
+        double c1z = A[0][0] * A[2][1] - A[0][1] * A[2][0];
+        double c2x = A[0][1] * A[1][2] - A[0][2] * A[1][1];
+        double c2y = A[0][2] * A[1][0] - A[0][0] * A[1][2];
+        double c2z = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+        double m2 = c0x*c0x + c0y*c0y + c0z*c0z + c1x*c1x + c1y*c1y + c1z*c1z + c2x*c2x + c2y*c2y + c2z*c2z;
+        if (m2 > 1e-24 * fro2 * fro2) return true;             // sigma2 >= sqrt(m2/3)/fro >> tol
+    }
+    double W[3][3], V[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) W[c][r] = A[r][c];
+    hestenes3<false>(W, V);
+    double s[3], smax = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        s[c] = sqrt(fma(W[c][2], W[c][2], fma(W[c][1], W[c][1], W[c][0] * W[c][0])));
+        smax = fmax(smax, s[c]);
+    }
+    double tol = 3.0 * ulp_at(smax);
+    int rk = (s[0] > tol) + (s[1] > tol) + (s[2] > tol);
+    return rk >= need;
+}
+
+// rank from a raw 3x3 Gram matrix G = A'A of an N x 3 point matrix (refit path).
+// g = {xx, xy, xz, yy, yz, zz}.
+__device__ bool rank_gram_at_least(const double (&g)[6], int N, int need) {
+    double tr = g[0] + g[3] + g[5];
+    if (!(tr > 0.0)) return false;
+    double m00 = g[3] * g[5] - g[4] * g[4], m11 = g[0] * g[5] - g[2] * g[2], m22 = g[0] * g[3] - g[1] * g[1];
+    if (need >= 3) {
+        double det = g[0] * m00 - g[1] * (g[1] * g[5] - g[4] * g[2]) + g[2] * (g[1] * g[4] - g[3] * g[2]);
+        if (det > 1e-10 * tr * tr * tr) return true;
+    } else {
+        if (m00 + m11 + m22 > 1e-10 * tr * tr) return true;
+    }
+    // exact-ish: Jacobi eigenvalues of G, sigma = sqrt(lambda)
+    double A[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off <= 1e-300 || off <= 1e-19 * tr) break;
+#define PCREG_JROT(P, Q)                                                                    \
+        if (A[P][Q] != 0.0) {                                                               \
+            double th = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);                              \
+            double t = copysign(1.0, th) / (fabs(th) + sqrt(fma(th, th, 1.0)));             \
+            double c = 1.0 / sqrt(fma(t, t, 1.0)), s = c * t;                               \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[k][P], b = A[k][Q]; A[k][P] = c*a - s*b; A[k][Q] = s*a + c*b; } \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[P][k], b = A[Q][k]; A[P][k] = c*a - s*b; A[Q][k] = s*a + c*b; } \
+        }
+        PCREG_JROT(0, 1) PCREG_JROT(0, 2) PCREG_JROT(1, 2)
+#undef PCREG_JROT
+    }
+    double s0 = sqrt(fmax(A[0][0], 0.0)), s1 = sqrt(fmax(A[1][1], 0.0)), s2 = sqrt(fmax(A[2][2], 0.0));
+    double smax = fmax(s0, fmax(s1, s2));
+    double tol = (double)(N > 3 ? N : 3) * ulp_at(smax);
+    return ((s0 > tol) + (s1 > tol) + (s2 > tol)) >= need;
+}
+
+// R = V*U' of H = U*S*V' (estimateTransform.m:60-62; no reflection fix), then
+// t = cd - R*cm (:63).  T12[j*4+k] = R(j,k), T12[j*4+3] = t(j).  Returns false when the
+// rotation is undefined (rank(H) <= 1) or not finite.
+__device__ bool polar_to_T(const double (&H)[3][3], const double (&cd)[3], const double (&cm)[3],
+                           double (&T)[12]) {
+    double W[3][3], V[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) W[c][r] = H[r][c];
+    hestenes3<true>(W, V);
+    double S[3], smax = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        S[c] = sqrt(fma(W[c][2], W[c][2], fma(W[c][1], W[c][1], W[c][0] * W[c][0])));
+        smax = fmax(smax, S[c]);
+    }
+    bool ok[3]; int nok = 0;
+    double U[3][3];   // U[row][col]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ok[c] = (S[c] > 1e-300) && (S[c] >= smax * 1e-12);
+        nok += ok[c];
+        double inv = 1.0 / S[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) U[r][c] = W[c][r] * inv;
+    }
+    if (nok < 2 || !(smax > 0.0)) return false;
+    if (nok == 2) {   // complete the missing column so that (u_m, u_a, u_b) is right-handed
+#define PCREG_CROSS(M, A_, B_)                                                   \
+        U[0][M] = U[1][A_] * U[2][B_] - U[2][A_] * U[1][B_];                     \
+        U[1][M] = U[2][A_] * U[0][B_] - U[0][A_] * U[2][B_];                     \
+        U[2][M] = U[0][A_] * U[1][B_] - U[1][A_] * U[0][B_];
+        if (!ok[0]) { PCREG_CROSS(0, 1, 2) } else if (!ok[1]) { PCREG_CROSS(1, 2, 0) } else { PCREG_CROSS(2, 0, 1) }
+#undef PCREG_CROSS
+    }
+    bool fin = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double r0 = fma(V[i][2], U[0][2], fma(V[i][1], U[0][1], V[i][0] * U[0][0]));
+        double r1 = fma(V[i][2], U[1][2], fma(V[i][1], U[1][1], V[i][0] * U[1][0]));
+        double r2 = fma(V[i][2], U[2][2], fma(V[i][1], U[2][1], V[i][0] * U[2][0]));
+        double t = cd[i] - fma(r2, cm[2], fma(r1, cm[1], r0 * cm[0]));
+        T[i * 4 + 0] = r0; T[i * 4 + 1] = r1; T[i * 4 + 2] = r2; T[i * 4 + 3] = t;
+        fin = fin && isfinite(r0) && isfinite(r1) && isfinite(r2) && isfinite(t);
+    }
+    return fin;
+}
+
+// estimateTransform for exactly three correspondences (estimateTransform.m:18-37 adds
+// the synthetic 4th point, then the common path :41-71).  A[pt][coord].
+__device__ bool fit_3pt(const double (&A1)[3][3], const double (&A2)[3][3], double (&T)[12]) {
+    if (!rank3x3_at_least(A1, 3) || !rank3x3_at_least(A2, 2)) return false;   // :11-14
+    double d[4][3], m[4][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const double (&P)[3][3] = s == 0 ? A1 : A2;
+        double (&O)[4][3] = s == 0 ? d : m;
+        double cen[3], a[3], b[3], e[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cen[c] = (P[0][c] + P[1][c] + P[2][c]) / 3.0;                      // :20-21
+            a[c] = P[2][c] - P[1][c]; b[c] = P[2][c] - P[0][c];
+        }
+        double nx = a[1] * b[2] - a[2] * b[1], ny = a[2] * b[0] - a[0] * b[2], nz = a[0] * b[1] - a[1] * b[0]; // :24-25
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                                          // :28-29
+            const int j = (i + 2) % 3;
+            double dx = P[i][0] - P[j][0], dy = P[i][1] - P[j][1], dz = P[i][2] - P[j][2];
+            e[i] = sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        double l = fmax(fmin(e[0], e[1]), fmin(fmax(e[0], e[1]), e[2]));     // median
+        double nn = sqrt(nx * nx + ny * ny + nz * nz);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) O[i][c] = P[i][c];
+        O[3][0] = cen[0] + (nx / nn) * l; O[3][1] = cen[1] + (ny / nn) * l; O[3][2] = cen[2] + (nz / nn) * l;   // :32-36
+    }
+    double cd[3], cm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                                              // :46-47
+        cd[c] = (((d[0][c] + d[1][c]) + d[2][c]) + d[3][c]) / 4.0;
+        cm[c] = (((m[0][c] + m[1][c]) + m[2][c]) + m[3][c]) / 4.0;
+    }
+    double H[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                                          // :55-58
+            double acc = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma(m[k][i] - cm[i], d[k][j] - cd[j], acc);
+            H[i][j] = acc;
+        }
+    return polar_to_T(H, cd, cm, T);
+}
+
+// Moments of a correspondence set, taken about a fixed origin (o1,o2) so that the
+// centring of estimateTransform.m:55-58 does not cancel digits:
+//   mom[0..2]  = sum(d')      mom[3..5] = sum(m')            (d' = p1-o1, m' = p2-o2)
+//   mom[6..14] = sum(m'_i d'_j), row-major i,j
+//   mom[15..20]= raw Gram of p1 (xx,xy,xz,yy,yz,zz), mom[21..26] = raw Gram of p2.
+__device__ __forceinline__ void mom_accumulate(double (&mom)[27], const double (&p)[6],
+                                               const double (&o)[6]) {
+    double d0 = p[0] - o[0], d1 = p[1] - o[1], d2 = p[2] - o[2];
+    double m0 = p[3] - o[3], m1 = p[4] - o[4], m2 = p[5] - o[5];
+    mom[0] += d0; mom[1] += d1; mom[2] += d2; mom[3] += m0; mom[4] += m1; mom[5] += m2;
+    mom[6]  = fma(m0, d0, mom[6]);  mom[7]  = fma(m0, d1, mom[7]);  mom[8]  = fma(m0, d2, mom[8]);
+    mom[9]  = fma(m1, d0, mom[9]);  mom[10] = fma(m1, d1, mom[10]); mom[11] = fma(m1, d2, mom[11]);
+    mom[12] = fma(m2, d0, mom[12]); mom[13] = fma(m2, d1, mom[13]); mom[14] = fma(m2, d2, mom[14]);
+    mom[15] = fma(p[0], p[0], mom[15]); mom[16] = fma(p[0], p[1], mom[16]); mom[17] = fma(p[0], p[2], mom[17]);
+    mom[18] = fma(p[1], p[1], mom[18]); mom[19] = fma(p[1], p[2], mom[19]); mom[20] = fma(p[2], p[2], mom[20]);
+    mom[21] = fma(p[3], p[3], mom[21]); mom[22] = fma(p[3], p[4], mom[22]); mom[23] = fma(p[3], p[5], mom[23]);
+    mom[24] = fma(p[4], p[4], mom[24]); mom[25] = fma(p[4], p[5], mom[25]); mom[26] = fma(p[5], p[5], mom[26]);
+}
+
+// estimateTransform for N > 3 correspondences given their moments.
+__device__ bool fit_moments(int N, const double (&mom)[27], const double (&o)[6], double (&T)[12]) {
+    if (N < 4) return false;
+    double g1[6] = {mom[15], mom[16], mom[17], mom[18], mom[19], mom[20]};
+    double g2[6] = {mom[21], mom[22], mom[23], mom[24], mom[25], mom[26]};
+    if (!rank_gram_at_least(g1, N, 3) || !rank_gram_at_least(g2, N, 2)) return false;   // :11-14
+    double inv = 1.0 / (double)N;
+    double cdp[3] = {mom[0] * inv, mom[1] * inv, mom[2] * inv};
+    double cmp_[3] = {mom[3] * inv, mom[4] * inv, mom[5] * inv};
+    double H[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) H[i][j] = mom[6 + i * 3 + j] - (double)N * cmp_[i] * cdp[j];
+    double cd[3] = {cdp[0] + o[0], cdp[1] + o[1], cdp[2] + o[2]};
+    double cm[3] = {cmp_[0] + o[3], cmp_[1] + o[4], cmp_[2] + o[5]};
+    return polar_to_T(H, cd, cm, T);
+}
+
+// ---------------------------------------------------------------- point access
+template <bool LDS_PTS>
+struct Pts {
+    const double* g1; const double* g2; int ld; const double* s; int n;
+    __device__ __forceinline__ void load(int i, double (&p)[6]) const {
+        if (LDS_PTS) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) p[c] = s[c * n + i];
+        } else {
+            p[0] = g1[i]; p[1] = g1[i + (size_t)ld]; p[2] = g1[i + 2 * (size_t)ld];
+            p[3] = g2[i]; p[4] = g2[i + (size_t)ld]; p[5] = g2[i + 2 * (size_t)ld];
+        }
+    }
+};
+
+// calcDists (getInliersRANSAC.m:50-53) in the canonical FMA order shared with the oracle.
+__device__ __forceinline__ double sqdist(const double (&p)[6], const double (&T)[12]) {
+    double tx = fma(p[3], T[0], fma(p[4], T[1], fma(p[5], T[2],  T[3])));
+    double ty = fma(p[3], T[4], fma(p[4], T[5], fma(p[5], T[6],  T[7])));
+    double tz = fma(p[3], T[8], fma(p[4], T[9], fma(p[5], T[10], T[11])));
+    double dx = p[0] - tx, dy = p[1] - ty, dz = p[2] - tz;
+    return fma(dz, dz, fma(dy, dy, dx * dx));
+}
+
+template <bool LDS_PTS>
+__device__ __forceinline__ void score_pass(const Pts<LDS_PTS>& P, int n, int lane,
+                                           const double (&T)[HB][12], double th, int (&cnt)[HB]) {
+#pragma unroll
+    for (int b = 0; b < HB; ++b) cnt[b] = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        int i = i0 + lane;
+        bool act = i < n;
+        double p[6];
+        P.load(act ? i : n - 1, p);
+#pragma unroll
+        for (int b = 0; b < HB; ++b) {
+            double d = sqdist(p, T[b]);
+            cnt[b] += __popcll(__ballot(act && d < th));
+        }
+    }
+}
+
+__device__ __forceinline__ void bcast_T(const double (&Tl)[12], int h, double (&T)[12]) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = rdlane(Tl[k], h);
+}
+
+// sample indices of hypothesis p (0-based out).  Built-in sampler = oracle's sample_table.
+__device__ __forceinline__ void sample3(const RansacArgs& a, int b, int p, int n, int (&s)[3]) {
+    if (a.sample_idx) {
+        const int32_t* t = a.sample_idx + ((size_t)b * a.iters + p) * 3;
+        s[0] = t[0] - 1; s[1] = t[1] - 1; s[2] = t[2] - 1;
+    } else {
+        unsigned long long seed = a.seed + (unsigned long long)b;
+        unsigned r[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            unsigned long long h = splitmix64(seed ^ splitmix64((unsigned long long)p * 16ull + j));
+            r[j] = (unsigned)(((h >> 32) * (unsigned long long)(unsigned)(n - j)) >> 32);
+        }
+        unsigned i0 = r[0], i1 = r[1];
+        if (i1 >= i0) ++i1;
+        unsigned lo = min(i0, i1), hi = max(i0, i1), i2 = r[2];
+        if (i2 >= lo) ++i2;
+        if (i2 >= hi) ++i2;
+        s[0] = (int)i0; s[1] = (int)i1; s[2] = (int)i2;
+    }
+    // out-of-range tables must not fault the GPU: clamp (documented in pcreg.h)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s[j] = min(max(s[j], 0), n - 1);
+}
+
+// ---------------------------------------------------------------- hypothesis kernel
+template <bool LDS_PTS>
+__global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sp[];
+    const int b = blockIdx.y;
+    const int off = a.offsets ? a.offsets[b] : 0;
+    int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
+    n = min(n, a.n_cap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t hyp0 = (size_t)b * a.iters;
+    const int wbase = (blockIdx.x * kWavesPerBlock + wave) * a.hpw;   // first hypothesis of this wave
+    const double* g1 = a.p1 + off; const double* g2 = a.p2 + off;
+
+    if (LDS_PTS) {
+        for (int i = threadIdx.x; i < n; i += kBlock) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { sp[c * n + i] = g1[i + (size_t)c * a.ld]; sp[(3 + c) * n + i] = g2[i + (size_t)c * a.ld]; }
+        }
+        __syncthreads();
+    }
+    if (wbase >= a.iters) return;
+    const int nh = min(a.hpw, a.iters - wbase);
+    const int p = wbase + lane;
+    const bool mine = lane < nh;
+    Pts<LDS_PTS> P{g1, g2, a.ld, sp, n};
+    const int thInlr = matlab_round_i(a.ratio * (double)n);                   // ransac.m:28
+
+    if (n < a.m || n < 3) {   // randperm(ptNum)(1:minPtNum) would throw; report nothing found
+        if (mine) { a.cnt1[hyp0 + p] = 0; a.cnt2[hyp0 + p] = 0; a.has[hyp0 + p] = 0; }
+        return;
+    }
+    double o[6];
+    P.load(0, o);   // fixed origin for the refit moments
+
+    // ---- phase 0: minimal-sample fit, one hypothesis per lane (ransac.m:42-45)
+    double T1[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T1[k] = 0.0;
+    bool v1 = false;
+    if (mine) {
+        if (a.m == 3) {
+            int s[3]; sample3(a, b, p, n, s);
+            double A1[3][3], A2[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double q[6]; P.load(s[j], q);
+                A1[j][0] = q[0]; A1[j][1] = q[1]; A1[j][2] = q[2];
+                A2[j][0] = q[3]; A2[j][1] = q[4]; A2[j][2] = q[5];
+            }
+            v1 = fit_3pt(A1, A2, T1);
+        } else {   // minPtNum > 3: general estimateTransform path on the sample
+            double mom[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+            const int32_t* t = a.sample_idx + ((size_t)hyp0 + p) * a.m;
+            double os[6];
+            for (int j = 0; j < a.m; ++j) {
+                int idx = min(max(t[j] - 1, 0), n - 1);
+                double q[6]; P.load(idx, q);
+                if (j == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) os[c] = q[c];
+                }
+                mom_accumulate(mom, q, os);
+            }
+            v1 = fit_moments(a.m, mom, os, T1);
+        }
+    }
+
+    // ---- phase 1: score every sample fit (ransac.m:48-50)
+    int c1 = 0, c2 = 0;
+    for (int h = 0; h < nh; h += HB) {
+        double T[HB][12]; int cnt[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) bcast_T(T1, min(h + k, nh - 1), T[k]);
+        score_pass<LDS_PTS>(P, n, lane, T, a.thDist, cnt);
+#pragma unroll
+        for (int k = 0; k < HB; ++k) if (lane == h + k) c1 = cnt[k];
+    }
+    if (!v1) c1 = 0;   // empty transform: scores 0 (deviation documented in DESIGN.md)
+    const bool pass1 = mine && v1 && c1 >= thInlr;                              // ransac.m:53
+
+    if (!a.refine) {                                                            // ransac.m:62-64
+        if (mine) {
+            a.cnt1[hyp0 + p] = c1; a.cnt2[hyp0 + p] = 0; a.has[hyp0 + p] = pass1;
+            if (pass1) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) a.TF[(hyp0 + p) * 12 + k] = T1[k];
+            }
+        }
+        return;
+    }
+
+    // ---- phase 2: moments of each passing hypothesis' inlier set (ransac.m:55)
+    double mom[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+    unsigned long long mask = __ballot(pass1);
+    while (mask) {
+        const int h = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        double T[12]; bcast_T(T1, h, T);
+        double acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            int i = i0 + lane;
+            bool act = i < n;
+            double q[6]; P.load(act ? i : n - 1, q);
+            if (act && sqdist(q, T) < a.thDist) mom_accumulate(acc, q, o);
+        }
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            double tot = wave_sum(acc[k]);
+            if (lane == h) mom[k] = tot;
+        }
+    }
+
+    // ---- phase 3: refit, one hypothesis per lane (estimateTransform on the inliers)
+    double T2[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T2[k] = 0.0;
+    bool v2 = false;
+    if (pass1) v2 = fit_moments(c1, mom, o, T2);
+
+    // ---- phase 4: rescore the refined transforms (ransac.m:56-58)
+    mask = __ballot(v2);
+    while (mask) {
+        int hs[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) {
+            hs[k] = mask ? __builtin_ctzll(mask) : hs[k > 0 ? k - 1 : 0];
+            if (mask) mask &= mask - 1;
+        }
+        double T[HB][12]; int cnt[HB];
+#pragma unroll
+        for (int k = 0; k < HB; ++k) bcast_T(T2, hs[k], T[k]);
+        score_pass<LDS_PTS>(P, n, lane, T, a.thDist, cnt);
+#pragma unroll
+        for (int k = 0; k < HB; ++k) if (lane == hs[k]) c2 = cnt[k];
+    }
+    if (mine) {
+        const bool keep = v2 && c2 >= thInlr;                                   // ransac.m:59-61
+        a.cnt1[hyp0 + p] = c1; a.cnt2[hyp0 + p] = v2 ? c2 : 0; a.has[hyp0 + p] = keep;
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) a.TF[(hyp0 + p) * 12 + k] = T2[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- winner + outputs
+// ransac.m:69-98.  One workgroup per registration.
+__global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcreg_dev_ransac_result* out,
+                                                               int32_t* inlier_idx) {
+    __shared__ unsigned long long s_key[kWavesPerBlock];
+    __shared__ int s_cnt[kWavesPerBlock];
+    __shared__ double s_T[12];
+    __shared__ int s_base;
+    const int b = blockIdx.x;
+    const int off = a.offsets ? a.offsets[b] : 0;
+    int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
+    n = min(n, a.n_cap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t hyp0 = (size_t)b * a.iters;
+    const int32_t* cc = a.refine ? a.cnt2 + hyp0 : a.cnt1 + hyp0;               // :69-73
+    const int thInlr = matlab_round_i(a.ratio * (double)n);
+    // first index of the maximum: max over (count << 32 | ~index)
+    unsigned long long key = 0; int ns = 0;
+    for (int p = threadIdx.x; p < a.iters; p += kBlock) {
+        unsigned long long k = ((unsigned long long)(unsigned)cc[p] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+        key = k > key ? k : key;
+        ns += cc[p] >= thInlr;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+        ns += __shfl_xor(ns, o);
+    }
+    if (lane == 0) { s_key[wave] = key; s_cnt[wave] = ns; }
+    __syncthreads();
+    key = s_key[0]; ns = s_cnt[0];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) { key = s_key[w] > key ? s_key[w] : key; ns += s_cnt[w]; }
+    const int winner = a.iters > 0 ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
+    const int maxInl = (int)(key >> 32);
+    const bool failed = !(a.iters > 0 && a.has[hyp0 + winner]);                 // :75-89
+    pcreg_dev_ransac_result* r = out + b;
+    if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : a.TF[(hyp0 + winner) * 12 + threadIdx.x];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    if (threadIdx.x < 16) {   // column-major 4x4: T(k,j) = R(j,k), T(4,j) = t(j)
+        int k = threadIdx.x & 3, j = threadIdx.x >> 2;
+        double v = 0.0;
+        if (!failed) v = (j < 3) ? s_T[j * 4 + k] : (k == 3 ? 1.0 : 0.0);
+        r->T[k + 4 * j] = v;
+    }
+    if (threadIdx.x == 0) {
+        r->failed = failed; r->num_success = failed ? 0 : ns; r->max_inliers = failed ? 0 : maxInl;
+        r->n = n; r->winner = winner;
+    }
+    if (failed) { if (threadIdx.x == 0) r->n_inliers = 0; return; }
+    // inlierIdx = find(dist < thDist), ascending, 1-based (:92)
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = s_T[k];
+    Pts<false> P{a.p1 + off, a.p2 + off, a.ld, nullptr, n};
+    __shared__ int s_wcnt[kWavesPerBlock];
+    int32_t* dst = inlier_idx + off;
+    for (int i0 = 0; i0 < n; i0 += kBlock) {
+        int i = i0 + threadIdx.x;
+        bool act = i < n;
+        double q[6]; P.load(act ? i : n - 1, q);
+        bool in = act && sqdist(q, T) < a.thDist;
+        unsigned long long bal = __ballot(in);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+        if (in) dst[base + __popcll(bal & ((1ull << lane) - 1ull))] = i + 1;
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) r->n_inliers = s_base;
+}
+
+// ---------------------------------------------------------------- single-fit kernels
+// estimateTransform.m as a stand-alone call (host API / tests): one wave.
+__global__ __launch_bounds__(64) void estimate_transform_kernel(const double* p1, const double* p2, int n,
+                                                                int ld, double* T16, int32_t* empty) {
+    const int lane = threadIdx.x;
+    Pts<false> P{p1, p2, ld, nullptr, n};
+    double T[12]; bool ok = false;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = 0.0;
+    if (n == 3) {
+        double A1[3][3], A2[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double q[6]; P.load(j, q);
+            A1[j][0] = q[0]; A1[j][1] = q[1]; A1[j][2] = q[2];
+            A2[j][0] = q[3]; A2[j][1] = q[4]; A2[j][2] = q[5];
+        }
+        ok = fit_3pt(A1, A2, T);
+    } else if (n > 3) {
+        double o[6]; P.load(0, o);
+        double acc[27], mom[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+        for (int i = lane; i < n; i += 64) { double q[6]; P.load(i, q); mom_accumulate(acc, q, o); }
+#pragma unroll
+        for (int k = 0; k < 27; ++k) mom[k] = wave_sum(acc[k]);
+        ok = fit_moments(n, mom, o, T);
+    }
+    if (lane < 16) {
+        int k = lane & 3, j = lane >> 2;
+        double v = 0.0;
+        if (ok) {
+            double tv = 0.0;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) if (e == j * 4 + k) tv = T[e];
+            v = (j < 3) ? tv : (k == 3 ? 1.0 : 0.0);
+        }
+        T16[k + 4 * j] = v;
+    }
+    if (lane == 0) *empty = ok ? 0 : 1;
+}
+
+__global__ void calc_dists_kernel(const double* T16, const double* p1, const double* p2, int n, int ld, double* d) {
+    double T[12];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) T[j * 4 + k] = T16[k + 4 * j];
+    Pts<false> P{p1, p2, ld, nullptr, n};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double q[6]; P.load(i, q);
+        d[i] = sqdist(q, T);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- launchers
+size_t ransac_workspace_bytes(int iters, int B) {
+    size_t h = (size_t)iters * (size_t)B;
+    return align_up(h * 12 * sizeof(double), 256) + 2 * align_up(h * sizeof(int32_t), 256) + align_up(h, 256);
+}
+
+int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
+                  int n_cap, int B, const pcreg_ransac_opts& o, const int32_t* sample_idx_dev,
+                  pcreg_dev_ransac_result* out, int32_t* inlier_idx, int32_t* iter_inl, int32_t* iter_inl_ref,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+    PCREG_ARG(o.iterNum >= 1 && o.minPtNum >= 3 && B >= 1 && n_cap >= 0);
+    PCREG_ARG(o.minPtNum == 3 || sample_idx_dev != nullptr);   // built-in sampler draws triples
+    size_t need = ransac_workspace_bytes(o.iterNum, B);
+    if (ws_bytes < need) { set_error("ransac workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    size_t h = (size_t)o.iterNum * (size_t)B;
+    char* w = (char*)ws;
+    RansacArgs a{};
+    a.p1 = p1; a.p2 = p2; a.ld = ld; a.offsets = offsets; a.n_dev = n_dev; a.n_cap = n_cap;
+    a.iters = o.iterNum; a.m = o.minPtNum; a.thDist = o.thDist; a.ratio = o.thInlrRatio;
+    a.refine = o.REFINE != 0; a.seed = o.seed; a.sample_idx = sample_idx_dev;
+    a.TF = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
+    a.cnt1 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
+    a.cnt2 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
+    a.has = (unsigned char*)w;
+    // hypotheses per wave: fill the chip first (>= ~2 waves per SIMD), then grow towards
+    // 64 so that the lane-parallel fits run with full lanes.
+    long long total = (long long)o.iterNum * B;
+    int hpw = 64;
+    while (hpw > 8 && total / hpw < 256LL * 4 * 2) hpw >>= 1;
+    a.hpw = hpw;
+    int per_block = hpw * kWavesPerBlock;
+    dim3 grid((o.iterNum + per_block - 1) / per_block, B);
+    size_t lds = (size_t)n_cap * 6 * sizeof(double);
+    if (n_cap > 0 && lds <= 64 * 1024) {
+        hipLaunchKernelGGL(ransac_hyp_kernel<true>, grid, dim3(kBlock), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(ransac_hyp_kernel<false>, grid, dim3(kBlock), 0, st, a);
+    }
+    PCREG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ransac_select_kernel, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx);
+    PCREG_HIP(hipGetLastError());
+    if (iter_inl) PCREG_HIP(hipMemcpyAsync(iter_inl, a.cnt1, h * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    if (iter_inl_ref) PCREG_HIP(hipMemcpyAsync(iter_inl_ref, a.cnt2, h * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return PCREG_OK;
+}
+
+int launch_estimate_transform(const double* p1, const double* p2, int n, int ld, double* T16_dev,
+                              int32_t* empty_dev, hipStream_t st) {
+    hipLaunchKernelGGL(estimate_transform_kernel, dim3(1), dim3(64), 0, st, p1, p2, n, ld, T16_dev, empty_dev);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_calc_dists(const double* T16_dev, const double* p1, const double* p2, int n, int ld, double* d,
+                      hipStream_t st) {
+    if (n <= 0) return PCREG_OK;
+    int blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(calc_dists_kernel, dim3(blocks), dim3(256), 0, st, T16_dev, p1, p2, n, ld, d);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+}  // namespace pcreg

@@ -1,0 +1,122 @@
+// pcreg_amd/csrc/select.hpp -- matchFeatures' post-search filters as device templates
+// shared by the fp32 point search and the fp64 descriptor search:
+//   threshold (removeWeakMatches), ratio test (removeAmbiguousMatches), and the
+//   order-preserving compaction that keeps pairs ascending in the query index
+//   (matchFeatures' output order; getMatches.m:51-56).
+#pragma once
+#include "common.hpp"
+
+namespace pcreg {
+
+template <typename T>
+struct Top2T { T d1, d2; int i1, i2; };
+
+template <typename T>
+__device__ __forceinline__ bool lex_lt_t(T da, int ia, T db, int ib) {
+    return da < db || (da == db && (unsigned)ia < (unsigned)ib);
+}
+// insert ordering by (dist, idx); -1 = empty slot; duplicates of an index are ignored
+template <typename T>
+__device__ __forceinline__ void top2_insert_lex_t(Top2T<T>& t, T d, int j) {
+    if (j < 0 || j == t.i1 || j == t.i2) return;
+    if (lex_lt_t(d, j, t.d2, t.i2)) {
+        if (lex_lt_t(d, j, t.d1, t.i1)) { t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = j; }
+        else { t.d2 = d; t.i2 = j; }
+    }
+}
+
+// Merge R lists [R][Q][2] -> [Q][2].
+template <typename T>
+__global__ void merge_top2_kernel_t(const int32_t* __restrict__ idx_in, const T* __restrict__ dist_in, int R, int Q,
+                                    int32_t* __restrict__ idx, T* __restrict__ dist) {
+    int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= Q) return;
+    Top2T<T> t{(T)INFINITY, (T)INFINITY, -1, -1};
+    for (int r = 0; r < R; ++r) {
+        size_t o = ((size_t)r * Q + qi) * 2;
+        top2_insert_lex_t(t, dist_in[o], idx_in[o]);
+        top2_insert_lex_t(t, dist_in[o + 1], idx_in[o + 1]);
+    }
+    idx[(size_t)qi * 2] = t.i1; idx[(size_t)qi * 2 + 1] = t.i2;
+    dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
+}
+
+template <typename T>
+__global__ void filter_flag_kernel_t(const int32_t* __restrict__ idx, const T* __restrict__ dist, int Q, int M_total,
+                                     T thr, T ratio, int32_t* __restrict__ flag, int32_t* __restrict__ block_cnt) {
+    int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (qi < Q) {
+        T d1 = dist[(size_t)qi * 2], d2 = dist[(size_t)qi * 2 + 1];
+        int i1 = idx[(size_t)qi * 2];
+        keep = i1 >= 0 && d1 <= thr;
+        if (keep && M_total > 1) {
+            T t1 = d1, t2 = d2;
+            if (t2 < (T)1e-6) { t1 = (T)1; t2 = (T)1; }
+            keep = (t1 / t2) <= ratio;
+        }
+        flag[qi] = keep;
+    }
+    __shared__ int s_cnt[4];
+    unsigned long long b = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// exclusive scan of per-workgroup counts by one workgroup; *total = sum
+static __global__ void scan_blocks_kernel(int32_t* __restrict__ block_cnt, int nblocks, int32_t* __restrict__ total) {
+    __shared__ int s[256];
+    int carry = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 256) {
+        int i = b0 + threadIdx.x;
+        int v = i < nblocks ? block_cnt[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) block_cnt[i] = carry + s[threadIdx.x] - v;
+        int tot = s[255];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+static __global__ void filter_scatter_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ flag, int Q,
+                                             const int32_t* __restrict__ block_off, int32_t* __restrict__ cand_q,
+                                             int32_t* __restrict__ cand_m) {
+    int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = qi < Q && flag[qi];
+    __shared__ int s_cnt[4];
+    unsigned long long b = __ballot(keep);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[wave] = __popcll(b);
+    __syncthreads();
+    int base = block_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += s_cnt[w];
+    if (keep) {
+        int o = base + __popcll(b & ((1ull << lane) - 1ull));
+        cand_q[o] = qi; cand_m[o] = idx[(size_t)qi * 2];
+    }
+}
+
+// threshold + ratio + ordered compaction; tmp must hold (Q + ceil(Q/256)) int32
+template <typename T>
+int run_filter_top2(const int32_t* idx, const T* dist, int Q, int M_total, T thr, T ratio, int32_t* cand_q,
+                    int32_t* cand_m, int32_t* n_cand, int32_t* tmp, hipStream_t st) {
+    if (Q == 0) { PCREG_HIP(hipMemsetAsync(n_cand, 0, sizeof(int32_t), st)); return PCREG_OK; }
+    int nb = (Q + 255) / 256;
+    int32_t* flag = tmp; int32_t* bc = tmp + Q;
+    hipLaunchKernelGGL(filter_flag_kernel_t<T>, dim3(nb), dim3(256), 0, st, idx, dist, Q, M_total, thr, ratio, flag, bc);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_cand);
+    hipLaunchKernelGGL(filter_scatter_kernel, dim3(nb), dim3(256), 0, st, idx, flag, Q, bc, cand_q, cand_m);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+}  // namespace pcreg

@@ -1,0 +1,49 @@
+"""AlignPoints_KNN on the GPU vs the oracle (floating point: tolerance 1e-9 absolute on
+coordinates of O(100), stated here; sign decisions must agree exactly)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def _support(n, seed):
+    rng = np.random.default_rng(seed)
+    A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    return (rng.normal(size=(n, 3)) * np.array([3.0, 1.5, 0.4])) @ A + rng.uniform(-50, 50, 3)
+
+
+@pytest.mark.parametrize("n", [2, 3, 20, 500, 777, 6000])
+@pytest.mark.parametrize("C1,C2", [(False, False), (True, False), (False, True), (True, True)])
+def test_align_points_knn(n, C1, C2, oracle_c):
+    import pcreg_amd as pc
+    X = _support(n, n)
+    al, co, c = pc.AlignPoints_KNN(X, C1, C2)
+    ral, rco, rc = oracle_c.AlignPoints_KNN(X, C1, C2)
+    assert np.abs(c.ravel() - rc).max() < TOL
+    assert np.abs(co - rco).max() < TOL
+    assert np.abs(al - ral).max() < TOL
+
+
+def test_align_points_knn_ties_and_varargin(oracle_c):
+    import pcreg_amd as pc
+    rng = np.random.default_rng(1)
+    X = rng.integers(-3, 4, (400, 3)).astype(float)         # many equal distances at the K-th boundary
+    al, co, c = pc.AlignPoints_KNN(X)
+    ral, rco, rc = oracle_c.AlignPoints_KNN(X)
+    assert np.abs(co - rco).max() < TOL and np.abs(al - ral).max() < TOL
+    # a single flag is ignored, like AlignPoints_KNN.m:8-14
+    al1, co1, _ = pc.AlignPoints_KNN(X, True)
+    assert np.array_equal(co1, co)
+
+
+def test_align_points_knn_batched(oracle_c):
+    import pcreg_amd as pc
+    sups = [_support(n, 50 + n) for n in (500, 1, 1400, 6000, 33)]
+    al, co, c, status = pc.AlignPoints_KNN_batched(sups)
+    assert list(status) == [0, 1, 0, 0, 0]
+    for b, X in enumerate(sups):
+        if status[b]:
+            continue
+        ral, rco, rc = oracle_c.AlignPoints_KNN(X)
+        assert np.abs(co[b] - rco).max() < TOL and np.abs(al[b] - ral).max() < TOL and np.abs(c[b] - rc).max() < TOL

@@ -1,0 +1,92 @@
+"""HIP correspondence search vs the oracle through the C ABI: index sets bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _clouds(Q, M, seed, box=(100.0, 56.0, 99.0)):
+    rng = np.random.default_rng(seed)
+    model = (rng.uniform(0, 1, (M, 3)) * np.array(box)).astype(np.float32)
+    pick = rng.choice(M, min(Q, M), replace=Q > M)
+    surf = (model[pick] + rng.normal(0, 0.05, (len(pick), 3))).astype(np.float32)
+    if Q > len(pick):
+        surf = np.vstack([surf, (rng.uniform(0, 1, (Q - len(pick), 3)) * np.array(box)).astype(np.float32)])
+    return surf, model
+
+
+@pytest.mark.parametrize("Q,M", [(1, 1), (5, 2), (100, 1), (1000, 3000), (1025, 4097), (4096, 20000), (3000, 70001)])
+def test_knn2_points_bit_exact(Q, M, oracle_c):
+    import pcreg_amd as pc
+    q, m = _clouds(Q, M, Q + M)
+    idx, dist = pc.knn2_points(q, m)
+    ridx, rdist = oracle_c.knn2_points_f32(q, m)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)        # same bits (fmaf chain)
+
+
+def test_knn2_points_ties_lowest_index(oracle_c):
+    import pcreg_amd as pc
+    rng = np.random.default_rng(0)
+    m = rng.integers(0, 4, (5000, 3)).astype(np.float32)     # massive duplication -> ties everywhere
+    q = rng.integers(0, 4, (300, 3)).astype(np.float32)
+    idx, dist = pc.knn2_points(q, m)
+    ridx, rdist = oracle_c.knn2_points_f32(q, m)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)
+
+
+@pytest.mark.parametrize("Q,M,unique", [(2000, 9000, True), (2000, 9000, False), (5000, 1500, True)])
+def test_match_points_pairs(Q, M, unique, oracle_c):
+    import pcreg_amd as pc
+    q, m = _clouds(Q, M, 17 + Q)
+    pairs = pc.match_points(q, m, 0.5, 0.8, unique)
+    ref = oracle_c.match_points_f32(q, m, 0.5, 0.8, unique)
+    np.testing.assert_array_equal(pairs, ref)
+    assert pairs.dtype == np.uint32 and (np.diff(pairs[:, 0].astype(np.int64)) > 0).all()
+
+
+def _descs(Q, M, D, seed):
+    rng = np.random.default_rng(seed)
+    dM = rng.poisson(3.0, (M, D)).astype(np.float64)
+    dS = rng.poisson(3.0, (Q, D)).astype(np.float64)
+    k = min(Q, M) // 2
+    dS[:k] = dM[rng.choice(M, k, replace=False)] + rng.poisson(0.2, (k, D))
+    return dS, dM
+
+
+PAR = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate",
+           MatchThreshold=10, MaxRatio=0.99, Metric="SAD", Unique=True, VERBOSE=0)
+"""completeExperimentFast.m:75-87."""
+
+
+@pytest.mark.parametrize("Q,M,D", [(60, 200, 40), (300, 1000, 980), (130, 70, 17), (129, 65, 16), (1, 5, 8)])
+@pytest.mark.parametrize("metric", ["SAD", "SSD"])
+def test_get_matches(Q, M, D, metric, oracle_c):
+    import pcreg_amd as pc
+    dS, dM = _descs(Q, M, D, Q * 7 + D)
+    par = dict(PAR, Metric=metric)
+    got = pc.getMatches(dS, dM, par)
+    ref = oracle_c.getMatches(dS, dM, par)
+    np.testing.assert_array_equal(got, ref)
+    assert got.dtype == np.uint32
+
+
+def test_match_features_metric_and_options(oracle_c):
+    import pcreg_amd as pc
+    dS, dM = _descs(200, 500, 64, 3)
+    for kw in (dict(Metric="SSD", MatchThreshold=1.0, MaxRatio=0.6, Unique=False),
+               dict(Metric="SAD", MatchThreshold=10.0, MaxRatio=0.9, Unique=True),
+               dict(Metric="SSD", MatchThreshold=100.0, MaxRatio=1.0, Unique=False, Prenormalized=True)):
+        pairs, met = pc.matchFeatures(dS, dM, **kw)
+        rp, rm = oracle_c.matchFeatures(dS, dM, kw)
+        np.testing.assert_array_equal(pairs, rp)
+        np.testing.assert_allclose(met, rm, rtol=0, atol=1e-14)
+
+
+def test_get_matches_empty_and_verbose(capsys):
+    import pcreg_amd as pc
+    dS, dM = _descs(10, 20, 12, 1)
+    out = pc.getMatches(dS[:0], dM, dict(PAR, VERBOSE=1))
+    assert out.shape == (0, 2)
+    assert "Calculated matches in" in capsys.readouterr().out                 # getMatches.m:58

@@ -1,0 +1,191 @@
+"""HIP RANSAC path vs the oracle, through the C ABI (pcreg_amd.api -> libpcreg_hip.so).
+
+Bar: inlier index sets, per-iteration inlier counts, numSuccess and maxInliers
+bit-exact; T within 1e-5 Frobenius (BASELINE.json north_star) -- in practice ~1e-12.
+"""
+import numpy as np
+import pytest
+
+from conftest import rigid_case
+
+pytestmark = pytest.mark.gpu
+
+T_TOL = 1e-5      # Frobenius tolerance stated by BASELINE.json:north_star
+
+
+def _cmp(res_gpu, ref, n):
+    T, inl, ns, mi, ratio, it1, it2 = res_gpu
+    assert not ref["failed"]
+    np.testing.assert_array_equal(it1, ref["inlrNum"])
+    np.testing.assert_array_equal(it2, ref["inlrNum_refined"])
+    assert ns == ref["numSuccess"] and mi == ref["maxInliers"]
+    np.testing.assert_array_equal(inl.astype(np.int64), ref["inlierIdx"])
+    assert np.linalg.norm(T - ref["T"]) < T_TOL
+    assert len(inl) == mi                                  # ransac.m invariant (:58,70,92)
+    assert ratio == pytest.approx(100.0 * mi / n)
+
+
+def test_estimate_transform_kat():
+    """testTransformEstimation.m:2-14 -- known answer [R 0; t 1]."""
+    import pcreg_amd as pc
+    from oracle import pcreg_oracle as o
+    pts = np.array([[1, 5, 7], [4, 9, 3], [9, 3, 4], [1, 2, 4]], float)
+    R = o.eul2rotm([0.1, 0.2, 0.3]); t = np.array([1.0, 2.0, 3.0])
+    pts_tf = pts @ R + t
+    Texp = np.eye(4); Texp[:3, :3] = R; Texp[3, :3] = t
+    assert np.abs(pc.estimateTransform(pts_tf, pts) - Texp).max() < 1e-12
+    assert np.abs(pc.estimateTransform(pts_tf[:3], pts[:3]) - Texp).max() < 1e-12      # 4th-point path
+    assert np.abs(pc.estimateTransform(pts, pts_tf) - pc.invertTF(Texp)).max() < 1e-12
+    # rank-deficient -> [] (estimateTransform.m:11-14)
+    flat = pts.copy(); flat[:, 2] = 0.0
+    assert pc.estimateTransform(flat, pts).size == 0
+    assert pc.estimateTransform(pts[:2], pts[:2]).size == 0
+
+
+@pytest.mark.parametrize("n", [3, 4, 7, 64, 65, 500])
+def test_estimate_transform_vs_oracle(n, oracle_c):
+    import pcreg_amd as pc
+    p1, p2, _ = rigid_case(n, 100 + n, noise=0.5, outlier_frac=0.0)
+    T = pc.estimateTransform(p1, p2)
+    Tref = oracle_c.estimateTransform(p1, p2)
+    assert np.abs(T - Tref).max() < 1e-10
+
+
+def test_calc_dists_bit_exact(oracle_c):
+    import pcreg_amd as pc
+    p1, p2, T = rigid_case(1000, 5)
+    np.testing.assert_array_equal(pc.calcDists(T, p1, p2), oracle_c.calcDists(T, p1, p2))
+
+
+@pytest.mark.parametrize("n,iters,refine", [(1000, 2000, True), (1000, 2000, False), (200, 3000, True),
+                                            (1500, 1000, True), (5000, 600, True), (37, 500, True)])
+def test_ransac_builtin_sampler(n, iters, refine, oracle_c):
+    import pcreg_amd as pc
+    p1, p2, Ttrue = rigid_case(n, n + iters)
+    coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=refine, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=9)
+    res = pc.ransac(p1, p2, coef, pc.estimateTransform, pc.calcDists, seed=9, return_iter_counts=True)
+    _cmp(res, ref, n)
+    if refine:      # a 3-point fit alone is noise-limited
+        assert np.linalg.norm(res[0] - Ttrue) < 0.1
+
+
+def test_ransac_sample_table(oracle_c):
+    """Host-provided index table (the MATLAB randperm stand-in, ransac.m:42-43)."""
+    import pcreg_amd as pc
+    n, iters = 800, 1500
+    p1, p2, _ = rigid_case(n, 77)
+    rng = np.random.default_rng(3)
+    table = np.stack([rng.permutation(n)[:3] + 1 for _ in range(iters)]).astype(np.int32)
+    coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, sample_idx=table)
+    res = pc.ransac(p1, p2, coef, sample_idx=table, return_iter_counts=True)
+    _cmp(res, ref, n)
+
+
+def test_ransac_min_pt_num_4(oracle_c):
+    import pcreg_amd as pc
+    n, iters = 600, 800
+    p1, p2, _ = rigid_case(n, 78)
+    rng = np.random.default_rng(4)
+    table = np.stack([rng.permutation(n)[:4] + 1 for _ in range(iters)]).astype(np.int32)
+    coef = dict(minPtNum=4, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, sample_idx=table)
+    res = pc.ransac(p1, p2, coef, sample_idx=table, return_iter_counts=True)
+    _cmp(res, ref, n)
+
+
+def test_testRANSAC_script(oracle_c, capsys):
+    """testRANSAC.m:13-58 + getInliersRANSAC.m:17-42 on a teapot-sized stand-in cloud
+    (teapot.ply ships with MATLAB, not with the reference): T must come back as T_back."""
+    import pcreg_amd as pc
+    from oracle import pcreg_oracle as o
+    rng = np.random.default_rng(1)
+    pts = rng.uniform([-3, -2, 0], [3, 2, 3], (1000, 3))
+    R = o.eul2rotm([1.5, -1.2, 0.8]); t = np.array([1.0, 2.0, 3.0])            # :13-17
+    T_true2 = np.eye(4); T_true2[:3, :3] = R; T_true2[3, :3] = t               # :27-29
+    T_back = np.eye(4); T_back[:3, :3] = R.T; T_back[3, :3] = -t @ R.T         # :40-42
+    pts_tf2 = pc.quickTF(pts, T_true2)
+    assert np.abs(pc.quickTF(pts_tf2, T_back) - pts).max() < 1e-12             # error3 ~ 0 (:45-48)
+    loc1M = pts + np.random.default_rng(2).normal(0, 0.1, pts.shape)           # :52-57
+    loc1S = pts_tf2                                                            # :58
+    ws = pc.getInliersRANSAC(loc1M, loc1S, seed=3)
+    out = capsys.readouterr().out
+    assert "RANSAC succeeded" in out and "Inliers" in out                      # ransac.m:100 format
+    ref = oracle_c.ransac(loc1M, loc1S, dict(o.GETINLIERS_COEFF), seed=3)
+    np.testing.assert_array_equal(ws["inlierPtIdx"].astype(np.int64), ref["inlierIdx"])
+    assert np.linalg.norm(ws["T"] - ref["T"]) < T_TOL
+    assert np.linalg.norm(ws["T"] - T_back) < 0.05                             # noise-limited
+    assert len(ws["inlierPtIdx"]) >= 990
+
+
+def test_debugRANSAC_script():
+    """debugRANSAC.m:2-54 -- N = 3 exact correspondences: every hypothesis is the exact transform."""
+    import pcreg_amd as pc
+    from oracle import pcreg_oracle as o
+    rng = np.random.default_rng(11)
+    pts = rng.normal(size=(3, 3))
+    R = o.eul2rotm(rng.uniform(0, 2 * np.pi, 3), "XYZ"); t = rng.normal(size=3)
+    T = np.eye(4); T[:3, :3] = R; T[3, :3] = t
+    pts_tf = pc.quickTF(pts, T)
+    coef = dict(minPtNum=3, iterNum=1000, thDist=0.1, thInlrRatio=0.5, REFINE=True, VERBOSE=0)
+    T_est, inl, ns, mi, ratio = pc.ransac(pts, pts_tf, coef, pc.estimateTransform, pc.calcDists)
+    # REFINE calls estimateTransform on the 3 inliers again -> same answer
+    assert np.linalg.norm(T @ T_est - np.eye(4)) < 1e-10                       # est_error (:38)
+    assert ns == 1000 and mi == 3 and list(inl) == [1, 2, 3]
+
+
+def test_ransac_failure_is_empty(capsys):
+    """ransac.m:77-89 -- nothing found: T = [], inlierIdx = [], zeros; the message is printed."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(5)
+    p1 = rng.uniform(0, 100, (300, 3)); p2 = rng.uniform(0, 100, (300, 3))
+    coef = dict(minPtNum=3, iterNum=500, thDist=1e-3, thInlrRatio=0.5, REFINE=True, VERBOSE=1)
+    T, inl, ns, mi, ratio = pc.ransac(p1, p2, coef)
+    assert T.size == 0 and inl.size == 0 and ns == 0 and mi == 0 and ratio == 0.0
+    assert "RANSAC could not find an appropriate transformation" in capsys.readouterr().out
+
+
+def test_ransac_degenerate_inputs(oracle_c):
+    """Duplicate rows / collinear samples: rank-deficient hypotheses score 0 on both sides."""
+    import pcreg_amd as pc
+    p1, p2, _ = rigid_case(300, 21, outlier_frac=0.2)
+    p1[10:40] = p1[10]                 # 30 identical surface points
+    p2[50:60] = p2[50] + np.arange(10)[:, None] * np.array([1.0, 2.0, 3.0])   # collinear model points
+    coef = dict(minPtNum=3, iterNum=4000, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=2)
+    res = pc.ransac(p1, p2, coef, seed=2, return_iter_counts=True)
+    _cmp(res, ref, 300)
+
+
+def test_ransac_batched(oracle_c):
+    import pcreg_amd as pc
+    sizes = [170, 333, 1000, 64, 2000]
+    cases = [rigid_case(n, 300 + i) for i, n in enumerate(sizes)]
+    coef = dict(minPtNum=3, iterNum=1000, thDist=0.05, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    out = pc.ransac_batched([c[0] for c in cases], [c[1] for c in cases], coef, seed=40)
+    for b, (p1, p2, _) in enumerate(cases):
+        ref = oracle_c.ransac(p1, p2, coef, seed=40 + b)
+        T, inl, ns, mi, _ = out[b]
+        np.testing.assert_array_equal(inl.astype(np.int64), ref["inlierIdx"])
+        assert ns == ref["numSuccess"] and mi == ref["maxInliers"]
+        assert np.linalg.norm(T - ref["T"]) < T_TOL
+
+
+def test_generic_handles_run_on_host():
+    """Any other handle pair takes the reference's generic loop (ransac.m:14-19 protocol)."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 10, (200, 1)); y = 2 * x + 1 + rng.normal(0, 0.01, x.shape)
+    y[::5] += rng.uniform(-5, 5, y[::5].shape)
+
+    def fit(a, b):
+        A = np.hstack([a, np.ones_like(a)])
+        return np.linalg.lstsq(A, b, rcond=None)[0]
+
+    def dist(f, a, b):
+        return np.abs(np.hstack([a, np.ones_like(a)]) @ f - b)[:, 0]
+
+    coef = dict(minPtNum=2, iterNum=50, thDist=0.05, thInlrRatio=0.5, REFINE=True, VERBOSE=0)
+    f, inl, ns, mi, _ = pc.ransac(x, y, coef, fit, dist, seed=1)
+    assert abs(f[0, 0] - 2) < 0.01 and abs(f[1, 0] - 1) < 0.05 and mi >= 150
