@@ -495,6 +495,31 @@ __global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
         const int h = __builtin_ctzll(mask);
         mask &= mask - 1;
         double T[12]; bcast_T(T1, h, T);
+        const int ch = __builtin_amdgcn_readlane(c1, h);
+        if (ch == 3) {
+            // exactly three inliers: the refit is estimateTransform's N == 3 branch
+            // (estimateTransform.m:18-37); hand the three points to lane h in mom[0..17]
+            int k = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                int i = i0 + lane;
+                bool act = i < n;
+                double q[6]; P.load(act ? i : n - 1, q);
+                unsigned long long bal = __ballot(act && sqdist(q, T) < a.thDist);
+                while (bal) {
+                    const int L = __builtin_ctzll(bal);
+                    bal &= bal - 1;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double v = rdlane(q[c], L);
+                        if (lane == h) {
+                            if (k == 0) mom[c] = v; else if (k == 1) mom[6 + c] = v; else if (k == 2) mom[12 + c] = v;
+                        }
+                    }
+                    ++k;
+                }
+            }
+            continue;
+        }
         double acc[27];
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc[k] = 0.0;
@@ -516,7 +541,18 @@ __global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) T2[k] = 0.0;
     bool v2 = false;
-    if (pass1) v2 = fit_moments(c1, mom, o, T2);
+    if (pass1) {
+        if (c1 == 3) {
+            double A1[3][3], A2[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { A1[j][c] = mom[j * 6 + c]; A2[j][c] = mom[j * 6 + 3 + c]; }
+            v2 = fit_3pt(A1, A2, T2);
+        } else {
+            v2 = fit_moments(c1, mom, o, T2);
+        }
+    }
 
     // ---- phase 4: rescore the refined transforms (ransac.m:56-58)
     mask = __ballot(v2);

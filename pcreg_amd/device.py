@@ -84,26 +84,39 @@ class RegistrationPipeline:
         self.ws_ransac = None
 
     # -- search --------------------------------------------------------------------
-    def search(self, q_soa: torch.Tensor, model_soa: torch.Tensor):
-        """Top-2 of every query over the whole (possibly sharded) model -> self.idx/self.distm."""
+    def search_local(self, q_soa: torch.Tensor, model_soa: torch.Tensor):
+        """Top-2 of every query over THIS rank's model shard (the dominant kernel)."""
         L = lib()
         Q, M = self.Q, self.M_local
         check(L.pcreg_dev_knn2_points_f32(_p(q_soa), Q, q_soa.shape[1], _p(model_soa), M, model_soa.shape[1],
                                           C.c_int32(self.m_lo), _p(self.idx_local), _p(self.dist_local),
                                           _p(self.ws_knn), C.c_size_t(self.ws_knn.numel()), _stream()))
+
+    def merge_ranks(self):
+        """The search's only collective: all_gather of the per-rank lists, then the merge kernel."""
         if self.world == 1:
             self.idx, self.distm = self.idx_local, self.dist_local
             return
         self.dist.all_gather_into_tensor(self.idx_all, self.idx_local, group=self.group)
         self.dist.all_gather_into_tensor(self.dist_all, self.dist_local, group=self.group)
-        check(L.pcreg_dev_merge_top2_f32(_p(self.idx_all), _p(self.dist_all), self.world, Q, _p(self.idx),
-                                         _p(self.distm), _stream()))
+        check(lib().pcreg_dev_merge_top2_f32(_p(self.idx_all), _p(self.dist_all), self.world, self.Q, _p(self.idx),
+                                             _p(self.distm), _stream()))
+
+    def search(self, q_soa: torch.Tensor, model_soa: torch.Tensor):
+        """Top-2 of every query over the whole (possibly sharded) model -> self.idx / self.distm."""
+        self.search_local(q_soa, model_soa)
+        self.merge_ranks()
 
     def match(self, q_soa: torch.Tensor, model_soa: torch.Tensor, thr_abs: float, max_ratio: float,
               unique: bool = True) -> MatchResult:
+        self.search_local(q_soa, model_soa)
+        return self.match_after_search(q_soa, model_soa, thr_abs, max_ratio, unique)
+
+    def match_after_search(self, q_soa: torch.Tensor, model_soa: torch.Tensor, thr_abs: float, max_ratio: float,
+                           unique: bool = True) -> MatchResult:
         L = lib()
         Q, M = self.Q, self.M_local
-        self.search(q_soa, model_soa)
+        self.merge_ranks()
         check(L.pcreg_dev_filter_top2_f32(_p(self.idx), _p(self.distm), Q, self.M_total, C.c_float(thr_abs),
                                           C.c_float(max_ratio), _p(self.cand_q), _p(self.cand_m), _p(self.n_cand),
                                           _stream()))
