@@ -63,6 +63,13 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C pcreg_amd/csrc` "
                 "(or __graft_entry__.build()).  pcreg_amd has no CPU fallback.")
+        # Load torch (the process's device-memory / RCCL plumbing) BEFORE the library: the
+        # torch wheel bundles its own HIP runtime, and on this image the runtime that is
+        # loaded second only sees the GPU when torch's was loaded first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.pcreg_last_error.restype = C.c_char_p
         L.pcreg_version.restype = C.c_char_p

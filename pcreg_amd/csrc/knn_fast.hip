@@ -1,0 +1,428 @@
+// pcreg_amd/csrc/knn_fast.hip -- certified fast path of the fp32 3-D point search.
+//
+// Same contract as knn2_points_kernel (knn_points.hip): for every query the two nearest
+// model points under d = fmaf(dz,dz, fmaf(dy,dy, dx*dx)), dx = q - m, ties to the lowest
+// index -- the bits the oracle produces.  The direct form costs 6 VALU per pair; this path
+// gets the same answer from ~3.6 VALU per pair:
+//
+//  1. prep      model -> float4 {x-c, y-c, z-c, |m-c|^2} about the bounding-box centre c
+//               (one streaming pass, 12 B in / 16 B out per point) and the radii R_m.
+//  2. candidates  s(q,m) = |m~|^2 - 2 q~.m~  (= |q~-m~|^2 - |q~|^2): THREE fma per pair.
+//               Every lane owns QPT queries with a sorted top-4 of s in registers; model
+//               tiles stream through LDS (16-B loads, broadcast ds_read_b128); one
+//               v_min tree + ONE compare per batch of 8 pairs guards the insertion code.
+//               The model is split in chunks over grid.y; all chunks of a query share one
+//               monotone threshold word in HBM (relaxed atomicMin of the ordered-uint image
+//               of the lane's 4th-best): it only prunes, results never depend on who
+//               published what first.
+//  3. finalize  one wave per query: exact fmaf-chain distances for the few union candidates
+//               that can still be in the top-2, wave-shuffle (dist,idx) top-2 reduction,
+//               and the CERTIFICATE: every point not in a candidate list has s >= G (the
+//               final threshold word), hence exact d >= G + |q~|^2 - E with the rounding
+//               bound E below; if that is > the exact 2nd-best the answer is proven.
+//  4. fallback  queries that fail the certificate (~0.2 % on the benchmark cloud, all of
+//               them when coordinates are so large that E swamps the spacing) are redone
+//               exactly: one workgroup per query when few, the tiled exact kernel when many.
+//
+// Rounding bound (u = 2^-24, R_m = max|m~|, r = |q~|), derived in DESIGN.md section 5:
+//   E = u*(3 R_m^2 + 3.03 (R_m^2 + 2 r R_m) + 4.04 (r + R_m)^2) + 16 u (d2 + |G + r^2|)
+#include "common.hpp"
+#include "select.hpp"
+#include <cmath>
+#include <cstdlib>
+
+namespace pcreg {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int KC = 4;                        // candidates kept per query and chunk
+constexpr int kMTile = 1024;                 // model points per LDS tile (16 KiB)
+
+struct Prep { float cx, cy, cz, rm2; };      // centre and max |m~|^2, produced on device
+
+__device__ __forceinline__ unsigned f2ord(float f) {       // order-preserving float -> uint
+    unsigned b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// ---- 1a. bounding box of model + queries (two-stage, deterministic) -----------------
+__global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __restrict__ m, int M, int ldm,
+                                                              const float* __restrict__ q, int Q, int ldq,
+                                                              float* __restrict__ part /*[grid][6]*/) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < M + Q; i += gridDim.x * kBlock) {
+        const float* p = i < M ? m + i : q + (i - M);
+        size_t ld = i < M ? (size_t)ldm : (size_t)ldq;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { float v = p[c * ld]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+    }
+    __shared__ float s[kBlock / 64][6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s[threadIdx.x >> 6][c] = lo[c]; s[threadIdx.x >> 6][3 + c] = hi[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+__global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, Prep* __restrict__ prep,
+                                  unsigned* __restrict__ rm2_bits) {
+    if (threadIdx.x == 0) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int b = 0; b < nparts; ++b)
+            for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
+        prep->cx = 0.5f * lo[0] + 0.5f * hi[0]; prep->cy = 0.5f * lo[1] + 0.5f * hi[1]; prep->cz = 0.5f * lo[2] + 0.5f * hi[2];
+        prep->rm2 = 0.0f;
+        *rm2_bits = 0u;
+    }
+}
+// ---- 1b. model -> {m~, |m~|^2}; R_m^2 by atomicMax on the (non-negative) float bits ----
+__global__ __launch_bounds__(kBlock) void prep_model_kernel(const float* __restrict__ m, int M, int ldm,
+                                                            const Prep* __restrict__ prep, float4* __restrict__ out,
+                                                            unsigned* __restrict__ rm2_bits) {
+    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
+    float mx = 0.0f;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
+        float x = m[i] - cx, y = m[i + (size_t)ldm] - cy, z = m[i + 2 * (size_t)ldm] - cz;
+        float w = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+        out[i] = make_float4(x, y, z, w);
+        mx = fmaxf(mx, w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(rm2_bits, __float_as_uint(mx));     // max is order-independent
+}
+
+// ---- 2. candidate generation -------------------------------------------------------------
+struct Cand { float s[KC]; int i[KC]; };
+
+__device__ __forceinline__ void cand_insert(Cand& c, float s, int j) {
+    // keep c.s ascending; strict '<' so that, within a lane, earlier (lower) indices win ties
+    if (s < c.s[3]) {
+        if (s < c.s[1]) {
+            c.s[3] = c.s[2]; c.i[3] = c.i[2];
+            c.s[2] = c.s[1]; c.i[2] = c.i[1];
+            if (s < c.s[0]) { c.s[1] = c.s[0]; c.i[1] = c.i[0]; c.s[0] = s; c.i[0] = j; }
+            else { c.s[1] = s; c.i[1] = j; }
+        } else {
+            if (s < c.s[2]) { c.s[3] = c.s[2]; c.i[3] = c.i[2]; c.s[2] = s; c.i[2] = j; }
+            else { c.s[3] = s; c.i[3] = j; }
+        }
+    }
+}
+
+template <int QPT_, int UB_, bool DRY = false>
+__global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
+    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk,
+    const Prep* __restrict__ prep, unsigned* __restrict__ gthr /*[Q] ordered-uint thresholds*/,
+    int32_t* __restrict__ part_idx /*[S][Q][KC]*/, float* __restrict__ part_s) {
+    __shared__ float4 tile[kMTile];
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * (kBlock * QPT_);
+    const int sidx = blockIdx.y;
+    const int m_begin = sidx * chunk, m_end = min(M, m_begin + chunk);
+    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
+
+    float ax[QPT_], ay[QPT_], az[QPT_], thr[QPT_];
+    unsigned gseen[QPT_];
+    Cand cand[QPT_];
+#pragma unroll
+    for (int r = 0; r < QPT_; ++r) {
+        int qi = q0 + r * kBlock + tid;
+        bool ok = qi < Q;
+        float x = ok ? q[qi] - cx : 0.0f, y = ok ? q[qi + (size_t)ldq] - cy : 0.0f, z = ok ? q[qi + 2 * (size_t)ldq] - cz : 0.0f;
+        ax[r] = -2.0f * x; ay[r] = -2.0f * y; az[r] = -2.0f * z;                 // exact scaling
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { cand[r].s[k] = INFINITY; cand[r].i[k] = -1; }
+        thr[r] = INFINITY; gseen[r] = 0xFFFFFFFFu;
+    }
+
+    for (int t0 = m_begin; t0 < m_end; t0 += kMTile) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kMTile / kBlock; ++k) {
+            int j = t0 + k * kBlock + tid;
+            tile[k * kBlock + tid] = j < m_end ? mp[j] : make_float4(0.0f, 0.0f, 0.0f, INFINITY);   // s = +inf: never a candidate
+        }
+        // pick up what the other chunks of these queries have already proven
+#pragma unroll
+        for (int r = 0; r < QPT_; ++r) {
+            int qi = q0 + r * kBlock + tid;
+            if (qi < Q) {
+                unsigned g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gseen[r] = g;
+                thr[r] = fminf(cand[r].s[3], ord2f(g));
+            }
+        }
+        __syncthreads();
+        const int cnt = min(kMTile, m_end - t0);
+        const int nb = (cnt + UB_ - 1) / UB_ * UB_;
+        for (int jb = 0; jb < nb; jb += UB_) {
+            float4 p[UB_];
+#pragma unroll
+            for (int u = 0; u < UB_; ++u) p[u] = tile[jb + u];
+#pragma unroll
+            for (int r = 0; r < QPT_; ++r) {
+                float s[UB_];
+#pragma unroll
+                for (int u = 0; u < UB_; ++u)
+                    s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, p[u].w)));
+                float mn = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+                if (UB_ == 8) mn = fminf(mn, fminf(fminf(s[4 % UB_], s[5 % UB_]), fminf(s[6 % UB_], s[7 % UB_])));
+                if (DRY) { asm volatile("" :: "v"(mn)); }   // timing-only build: hot loop without insertions
+                else if (mn < thr[r]) {
+                    const int j0 = t0 + jb;
+#pragma unroll
+                    for (int u = 0; u < UB_; ++u) if (s[u] < thr[r]) cand_insert(cand[r], s[u], j0 + u);
+                    thr[r] = fminf(thr[r], cand[r].s[3]);
+                }
+            }
+        }
+        // publish a tighter bound (relaxed: a late or lost update only costs pruning)
+#pragma unroll
+        for (int r = 0; r < QPT_; ++r) {
+            int qi = q0 + r * kBlock + tid;
+            if (qi < Q && cand[r].s[3] < INFINITY) {
+                unsigned k = f2ord(cand[r].s[3]);
+                if (k < gseen[r]) { atomicMin(&gthr[qi], k); gseen[r] = k; }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QPT_; ++r) {
+        int qi = q0 + r * kBlock + tid;
+        if (qi < Q) {
+            size_t o = ((size_t)sidx * Q + qi) * KC;
+            *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[r].i[0], cand[r].i[1], cand[r].i[2], cand[r].i[3]);
+            *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[r].s[0], cand[r].s[1], cand[r].s[2], cand[r].s[3]);
+        }
+    }
+}
+
+// ---- 3. exact re-rank + certificate: one wave per query ------------------------------------
+__device__ __forceinline__ bool lex_lt_f(float da, int ia, float db, int ib) {
+    return da < db || (da == db && (unsigned)ia < (unsigned)ib);
+}
+__global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
+    const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
+    const Prep* __restrict__ prep, const unsigned* __restrict__ rm2_bits, const unsigned* __restrict__ gthr,
+    const int32_t* __restrict__ part_idx, const float* __restrict__ part_s, int S, int idx_base,
+    int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (qi >= Q) return;
+    const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
+    const int total = S * KC;
+    // pass 1: the two smallest approximate scores of the union (values only)
+    float a1 = INFINITY, a2 = INFINITY;
+    for (int e = lane; e < total; e += 64) {
+        size_t o = ((size_t)(e / KC) * Q + qi) * KC + (e % KC);
+        if (part_idx[o] >= 0) { float s = part_s[o]; if (s < a2) { if (s < a1) { a2 = a1; a1 = s; } else a2 = s; } }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float b1 = __shfl_xor(a1, o), b2 = __shfl_xor(a2, o);
+        float n1 = fminf(a1, b1);
+        float n2 = fminf(fmaxf(a1, b1), fminf(a2, b2));
+        a1 = n1; a2 = n2;
+    }
+    // rounding bound (double arithmetic on the fp32 quantities the candidate kernel used)
+    const double u = 5.9604644775390625e-08;                     // 2^-24
+    const float cxf = prep->cx, cyf = prep->cy, czf = prep->cz;
+    const float tx = qx - cxf, ty = qy - cyf, tz = qz - czf;       // the same q~ the candidate kernel formed
+    const double r2 = (double)tx * tx + (double)ty * ty + (double)tz * tz;
+    const double r = sqrt(r2);
+    const double Rm2 = (double)__uint_as_float(*rm2_bits), Rm = sqrt(Rm2);
+    const double Eab = u * (3.0 * Rm2 + 3.03 * (Rm2 + 2.0 * r * Rm) + 4.04 * (r + Rm) * (r + Rm));
+    // pass 2: exact distances of every candidate that can still reach the top-2
+    const float cut = (float)((double)a2 + 2.0 * Eab + 16.0 * u * fabs((double)a2 + r2));
+    const float cut_up = nextafterf(cut, INFINITY);              // float rounding of the cut must not exclude anything
+    float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+    for (int e = lane; e < total; e += 64) {
+        size_t o = ((size_t)(e / KC) * Q + qi) * KC + (e % KC);
+        int j = part_idx[o];
+        if (j >= 0 && (part_s[o] <= cut_up || !(a2 < INFINITY))) {
+            float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (lex_lt_f(d, j, d2, i2)) {
+                if (lex_lt_f(d, j, d1, i1)) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; }
+            }
+        }
+    }
+    // wave-shuffle top-2 reduction ordered by (dist, idx); empty slots are (+inf, -1 -> max uint)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+        int j1 = __shfl_xor(i1, o), j2 = __shfl_xor(i2, o);
+        // merge two sorted pairs
+        bool first_mine = lex_lt_f(d1, i1, e1, j1);
+        float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1;
+        float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;      // my next
+        float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1 : j2;      // other's next
+        bool sec_mine = lex_lt_f(x2, y2, x3, y3);
+        d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
+    }
+    // certificate
+    const float G = ord2f(gthr[qi]);
+    bool ok;
+    if (M <= 2) ok = (i1 >= 0) && (M < 2 || i2 >= 0);          // nothing outside the lists when M <= KC (handled below too)
+    else if (!(G < INFINITY)) ok = true;                         // no chunk ever filled its list: every point is a candidate
+    else {
+        double lower = (double)G + r2;
+        double E = Eab + 16.0 * u * ((double)d2 + fabs(lower));
+        ok = (i2 >= 0) && (lower - E > (double)d2);
+    }
+    if (lane == 0) {
+        if (ok) {
+            idx[(size_t)qi * 2] = i1 >= 0 ? i1 + idx_base : -1; idx[(size_t)qi * 2 + 1] = i2 >= 0 ? i2 + idx_base : -1;
+            dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2;
+        } else {
+            int slot = atomicAdd(n_flag, 1);
+            flag_list[slot] = qi;
+        }
+    }
+}
+
+// ---- 4a. exact fallback, few queries: one workgroup per flagged query ------------------
+__global__ __launch_bounds__(kBlock) void knn_fallback_block_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ m, int M, int ldm, int idx_base,
+    const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag, int max_active,
+    int32_t* __restrict__ idx, float* __restrict__ dist) {
+    const int nf = *n_flag;
+    if (nf > max_active) return;                                 // the tiled kernel handles big lists
+    __shared__ float sd[kBlock / 64][2];
+    __shared__ int si[kBlock / 64][2];
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int qi = flag_list[f];
+        const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
+        float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+        for (int j = threadIdx.x; j < M; j += kBlock) {           // ascending j per thread: strict '<' keeps ties low
+            float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (d < d2) { if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; } }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+            int j1 = __shfl_xor(i1, o), j2 = __shfl_xor(i2, o);
+            bool first_mine = lex_lt_f(d1, i1, e1, j1);
+            float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1;
+            float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;
+            float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1 : j2;
+            bool sec_mine = lex_lt_f(x2, y2, x3, y3);
+            d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sd[w][0] = d1; sd[w][1] = d2; si[w][0] = i1; si[w][1] = i2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Top2T<float> t{INFINITY, INFINITY, -1, -1};
+            for (int k = 0; k < kBlock / 64; ++k) { top2_insert_lex_t(t, sd[k][0], si[k][0]); top2_insert_lex_t(t, sd[k][1], si[k][1]); }
+            idx[(size_t)qi * 2] = t.i1 >= 0 ? t.i1 + idx_base : -1; idx[(size_t)qi * 2 + 1] = t.i2 >= 0 ? t.i2 + idx_base : -1;
+            dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
+        }
+        __syncthreads();
+    }
+}
+
+int pick_splits_fast(int n_tiles, int M, int target) {
+    int S = (target + n_tiles - 1) / n_tiles;
+    int maxS = (M + kMTile - 1) / kMTile;
+    if (S > maxS) S = maxS;
+    return S < 1 ? 1 : S;
+}
+
+}  // namespace
+
+// tiled exact kernel on a query list (implemented in knn_points.hip)
+int launch_knn2_points_exact_list(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                                  const int32_t* qlist, const int32_t* n_list, int min_active, int32_t* idx,
+                                  float* dist, void* ws, size_t ws_bytes, hipStream_t st);
+size_t knn2_points_exact_workspace_bytes(int Q, int M);
+
+// workspace layout: Prep | rm2 bits | n_flag | bbox partials | gthr [Q] | flag_list [Q] | model float4 [M]
+//                   | part_idx [S][Q][KC] | part_s | exact-kernel workspace (fallback)
+static size_t fast_fixed_bytes(int Q, int M, int S) {
+    size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1);
+    return 256 + 256 + 256 + align_up(512 * 6 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
+           align_up(mm * 16, 256) + 2 * align_up((size_t)S * q * KC * 4, 256);
+}
+static constexpr int kFastTarget = 1024;      // workgroups the candidate grid aims for
+static constexpr int kFastQPT = 4;
+
+size_t knn2_points_fast_workspace_bytes(int Q, int M) {
+    int n_tiles = (Q + kBlock * 2 - 1) / (kBlock * 2); if (n_tiles < 1) n_tiles = 1;    // covers QPT 2..8
+    int S = pick_splits_fast(n_tiles, M > 0 ? M : 1, 8192);
+    return fast_fixed_bytes(Q, M, S) + knn2_points_exact_workspace_bytes(Q, M);
+}
+
+int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                                int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
+    PCREG_ARG(Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+    if (Q == 0) return PCREG_OK;
+    size_t need = knn2_points_fast_workspace_bytes(Q, M);
+    if (ws_bytes < need) { set_error("knn (fast) workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    static const int target = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : kFastTarget;
+    static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 0;
+    const int qpt = variant == 12 ? 8 : (variant == 13 ? 2 : kFastQPT);
+    int n_tiles = (Q + kBlock * qpt - 1) / (kBlock * qpt);
+    int S = pick_splits_fast(n_tiles, M > 0 ? M : 1, target);
+    int chunk = (((M > 0 ? M : 1) + S - 1) / S + kMTile - 1) / kMTile * kMTile;
+    S = M > 0 ? (M + chunk - 1) / chunk : 1;
+    size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1);
+    char* w = (char*)ws;
+    Prep* prep = (Prep*)w;                 w += 256;
+    unsigned* rm2 = (unsigned*)w;          w += 256;
+    int32_t* n_flag = (int32_t*)w;         w += 256;
+    float* bpart = (float*)w;              w += align_up(512 * 6 * sizeof(float), 256);
+    unsigned* gthr = (unsigned*)w;         w += align_up(qq * 4, 256);
+    int32_t* flag_list = (int32_t*)w;      w += align_up(qq * 4, 256);
+    float4* mp = (float4*)w;               w += align_up(mm * 16, 256);
+    int32_t* part_idx = (int32_t*)w;       w += align_up((size_t)S * qq * KC * 4, 256);
+    float* part_s = (float*)w;             w += align_up((size_t)S * qq * KC * 4, 256);
+    void* ews = w;
+    size_t ews_bytes = ws_bytes - (size_t)(w - (char*)ws);
+
+    int nb = (M + Q + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, prep, rm2);
+    PCREG_HIP(hipMemsetAsync(gthr, 0xFF, qq * 4, st));            // +inf in the ordered-uint image
+    PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
+    if (M > 0) {
+        int pb = (M + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
+        hipLaunchKernelGGL(prep_model_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, prep, mp, rm2);
+    }
+    dim3 grid(n_tiles, S);
+#define PCREG_CAND_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn_candidates_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, mp, M, chunk, prep, gthr, part_idx, part_s)
+    switch (variant) {
+        case 11: PCREG_CAND_LAUNCH(4, 4); break;
+        case 19: hipLaunchKernelGGL((knn_candidates_kernel<4, 8, true>), grid, dim3(kBlock), 0, st, q, Q, ldq, mp, M, chunk, prep, gthr, part_idx, part_s); break;
+        case 12: PCREG_CAND_LAUNCH(8, 8); break;
+        case 13: PCREG_CAND_LAUNCH(2, 8); break;
+        default: PCREG_CAND_LAUNCH(4, 8); break;
+    }
+#undef PCREG_CAND_LAUNCH
+    PCREG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
+                       part_idx, part_s, S, (int)idx_base, idx, dist, flag_list, n_flag);
+    PCREG_HIP(hipGetLastError());
+    // fallbacks (both launched; each decides from the device-side count which one works)
+    const int kFew = 1024;
+    hipLaunchKernelGGL(knn_fallback_block_kernel, dim3(kFew), dim3(kBlock), 0, st, q, ldq, m, M, ldm, (int)idx_base,
+                       flag_list, n_flag, kFew, idx, dist);
+    PCREG_HIP(hipGetLastError());
+    return launch_knn2_points_exact_list(q, Q, ldq, m, M, ldm, idx_base, flag_list, n_flag, kFew, idx, dist, ews, ews_bytes, st);
+}
+
+}  // namespace pcreg

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "select.hpp"
 #include <cmath>
+#include <cstdlib>
 
 namespace pcreg {
 namespace {
@@ -45,22 +46,29 @@ __device__ __forceinline__ float sqd(float qx, float qy, float qz, const float4&
 }
 
 // grid = (query tiles, S model chunks).  part_* layout [S][Q][2].
+template <int QPT_, int UB_>
 __global__ __launch_bounds__(kBlock) void knn2_points_kernel(
     const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
-    int chunk, int idx_base, int32_t* __restrict__ part_idx, float* __restrict__ part_dist) {
+    int chunk, int idx_base, int32_t* __restrict__ part_idx, float* __restrict__ part_dist,
+    const int32_t* __restrict__ qlist, const int32_t* __restrict__ n_list, int min_active) {
     __shared__ float4 tile[kMTile];
     const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * kQTile;
+    const int q0 = blockIdx.x * (kBlock * QPT_);
     const int s = blockIdx.y;
+    // optional query list (exact re-run of the queries the fast path could not certify):
+    // slot k of this launch is query qlist[k]; partials stay indexed by slot
+    int Qe = Q;
+    if (qlist) { Qe = *n_list; if (Qe <= min_active || q0 >= Qe) return; }
     const int m_begin = s * chunk;
     const int m_end = min(M, m_begin + chunk);
 
-    float qx[QPT], qy[QPT], qz[QPT];
-    Top2 best[QPT];
+    float qx[QPT_], qy[QPT_], qz[QPT_];
+    Top2 best[QPT_];
 #pragma unroll
-    for (int r = 0; r < QPT; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        bool ok = qi < Q;
+    for (int r = 0; r < QPT_; ++r) {
+        int slot = q0 + r * kBlock + tid;
+        bool ok = slot < Qe;
+        int qi = ok ? (qlist ? qlist[slot] : slot) : 0;
         qx[r] = ok ? q[qi] : 0.0f;
         qy[r] = ok ? q[qi + (size_t)ldq] : 0.0f;
         qz[r] = ok ? q[qi + 2 * (size_t)ldq] : 0.0f;
@@ -79,33 +87,53 @@ __global__ __launch_bounds__(kBlock) void knn2_points_kernel(
         }
         __syncthreads();
         const int cnt = min(kMTile, m_end - t0);
-        const int nb = (cnt + UB - 1) / UB * UB;
-        for (int jb = 0; jb < nb; jb += UB) {
-            float4 mp[UB];
+        const int nb = (cnt + UB_ - 1) / UB_ * UB_;
+        for (int jb = 0; jb < nb; jb += UB_) {
+            float4 mp[UB_];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) mp[u] = tile[jb + u];
+            for (int u = 0; u < UB_; ++u) mp[u] = tile[jb + u];
 #pragma unroll
-            for (int r = 0; r < QPT; ++r) {
-                float d[UB];
+            for (int r = 0; r < QPT_; ++r) {
+                float d[UB_];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) d[u] = sqd(qx[r], qy[r], qz[r], mp[u]);
+                for (int u = 0; u < UB_; ++u) d[u] = sqd(qx[r], qy[r], qz[r], mp[u]);
                 float mn = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                if (UB_ == 8) mn = fminf(mn, fminf(fminf(d[4 % UB_], d[5 % UB_]), fminf(d[6 % UB_], d[7 % UB_])));
                 if (mn < best[r].d2) {
                     const int j0 = idx_base + t0 + jb;
 #pragma unroll
-                    for (int u = 0; u < UB; ++u) top2_insert(best[r], d[u], j0 + u);
+                    for (int u = 0; u < UB_; ++u) top2_insert(best[r], d[u], j0 + u);
                 }
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < QPT; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        if (qi < Q) {
-            size_t o = ((size_t)s * Q + qi) * 2;
+    for (int r = 0; r < QPT_; ++r) {
+        int slot = q0 + r * kBlock + tid;
+        if (slot < Qe) {
+            size_t o = ((size_t)s * Q + slot) * 2;
             part_idx[o] = best[r].i1; part_idx[o + 1] = best[r].i2;
             part_dist[o] = best[r].d1; part_dist[o + 1] = best[r].d2;
         }
+    }
+}
+
+// merge of the per-chunk partials of a query-list launch, scattered to the listed queries
+__global__ void merge_top2_list_kernel(const int32_t* __restrict__ part_idx, const float* __restrict__ part_dist, int S,
+                                       int Qcap, const int32_t* __restrict__ qlist, const int32_t* __restrict__ n_list,
+                                       int min_active, int32_t* __restrict__ idx, float* __restrict__ dist) {
+    const int n = *n_list;
+    if (n <= min_active) return;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        Top2T<float> t{INFINITY, INFINITY, -1, -1};
+        for (int r = 0; r < S; ++r) {
+            size_t o = ((size_t)r * Qcap + slot) * 2;
+            top2_insert_lex_t(t, part_dist[o], part_idx[o]);
+            top2_insert_lex_t(t, part_dist[o + 1], part_idx[o + 1]);
+        }
+        int qi = qlist[slot];
+        idx[(size_t)qi * 2] = t.i1; idx[(size_t)qi * 2 + 1] = t.i2;
+        dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
     }
 }
 
@@ -227,8 +255,7 @@ __global__ void gather_pairs_kernel(const float* __restrict__ q, int Q, int ldq,
 }
 
 // number of model chunks so that the grid has ~>= 8 workgroups per CU
-int pick_splits(int n_tiles, int M) {
-    int target = 2048;
+int pick_splits(int n_tiles, int M, int target = 2048) {
     int S = (target + n_tiles - 1) / n_tiles;
     int maxS = (M + kMTile - 1) / kMTile;
     if (S > maxS) S = maxS;
@@ -242,31 +269,72 @@ int chunk_of(int M, int S) {
 
 }  // namespace
 
-size_t knn2_points_workspace_bytes(int Q, int M) {
-    int n_tiles = (Q + kQTile - 1) / kQTile; if (n_tiles < 1) n_tiles = 1;
-    int S = pick_splits(n_tiles, M > 0 ? M : 1);
+size_t knn2_points_exact_workspace_bytes(int Q, int M) {
+    // sized for the most-split configuration any tuning variant can pick
+    int n_tiles = (Q + kBlock * 8 - 1) / (kBlock * 8); if (n_tiles < 1) n_tiles = 1;
+    int S = pick_splits(n_tiles, M > 0 ? M : 1, 8192);
     return 2 * align_up((size_t)S * (size_t)(Q > 0 ? Q : 1) * 2 * sizeof(float), 256);
 }
 
-int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+size_t knn2_points_exact_workspace_bytes(int Q, int M);
+size_t knn2_points_fast_workspace_bytes(int Q, int M);
+int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                                int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st);
+
+static int knn2_exact_impl(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                           const int32_t* qlist, const int32_t* n_list, int min_active,
                            int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
     PCREG_ARG(Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
     if (Q == 0) return PCREG_OK;
-    size_t need = knn2_points_workspace_bytes(Q, M);
+    size_t need = knn2_points_exact_workspace_bytes(Q, M);
     if (ws_bytes < need) { set_error("knn workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
-    int n_tiles = (Q + kQTile - 1) / kQTile;
-    int S = pick_splits(n_tiles, M > 0 ? M : 1);
+    static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 0;
+    static const int target = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : 2048;
+    const int qpt = (variant == 2) ? 8 : (variant == 3 ? 2 : 4);
+    int n_tiles = (Q + kBlock * qpt - 1) / (kBlock * qpt);
+    int S = pick_splits(n_tiles, M > 0 ? M : 1, target);
     int chunk = chunk_of(M > 0 ? M : 1, S);
     S = M > 0 ? (M + chunk - 1) / chunk : 1;
     int32_t* part_idx = (int32_t*)ws;
     float* part_dist = (float*)((char*)ws + align_up((size_t)S * Q * 2 * sizeof(float), 256));
-    // need above was computed with the unrounded S (>= this S), so the split fits
-    hipLaunchKernelGGL(knn2_points_kernel, dim3(n_tiles, S), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, chunk,
-                       (int)idx_base, part_idx, part_dist);
+    dim3 grid(n_tiles, S);
+#define PCREG_KNN_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn2_points_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, chunk, (int)idx_base, part_idx, part_dist, qlist, n_list, min_active)
+    switch (variant) {
+        case 1: PCREG_KNN_LAUNCH(4, 8); break;
+        case 2: PCREG_KNN_LAUNCH(8, 4); break;
+        case 3: PCREG_KNN_LAUNCH(2, 8); break;
+        default: PCREG_KNN_LAUNCH(4, 4); break;
+    }
+#undef PCREG_KNN_LAUNCH
     PCREG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, idx, dist);
+    if (qlist)
+        hipLaunchKernelGGL(merge_top2_list_kernel, dim3(64), dim3(256), 0, st, part_idx, part_dist, S, Q, qlist, n_list, min_active, idx, dist);
+    else
+        hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, idx, dist);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
+}
+
+int launch_knn2_points_exact_list(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                                  const int32_t* qlist, const int32_t* n_list, int min_active, int32_t* idx,
+                                  float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
+    return knn2_exact_impl(q, Q, ldq, m, M, ldm, idx_base, qlist, n_list, min_active, idx, dist, ws, ws_bytes, st);
+}
+
+// PCREG_KNN_EXACT=1 forces the direct-form kernel (tuning / A-B runs); the default is the
+// certified fast path of knn_fast.hip, which returns the same bits.
+static bool use_exact_only() { static const bool v = getenv("PCREG_KNN_EXACT") && atoi(getenv("PCREG_KNN_EXACT")) != 0; return v; }
+
+size_t knn2_points_workspace_bytes(int Q, int M) {
+    size_t a = knn2_points_exact_workspace_bytes(Q, M), b = knn2_points_fast_workspace_bytes(Q, M);
+    return a > b ? a : b;
+}
+
+int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                           int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (use_exact_only())
+        return knn2_exact_impl(q, Q, ldq, m, M, ldm, idx_base, nullptr, nullptr, 0, idx, dist, ws, ws_bytes, st);
+    return launch_knn2_points_fast_f32(q, Q, ldq, m, M, ldm, idx_base, idx, dist, ws, ws_bytes, st);
 }
 
 int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx, float* dist,
