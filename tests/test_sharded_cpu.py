@@ -1,0 +1,131 @@
+"""The N > 1 path on CPU: world_size-2 gloo run of pcreg_amd.sharded.ShardedMatcher with
+the ORACLE standing in for the kernels (tests may use the oracle; the product may not).
+Checks that the all_gather + merge, MAX-reduced Unique flags and SUM-assembled
+coordinates give exactly what one process gets on the unsharded model."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class OracleOps:
+    """ShardedMatcher `ops` implemented with the oracle on CPU tensors (test double)."""
+
+    def __init__(self, Q):
+        self.Q = Q
+        self.device = torch.device("cpu")
+
+    @staticmethod
+    def _np(t):
+        return t.numpy()
+
+    def local_top2(self, q, model, m_lo):
+        from oracle import c_oracle
+        idx, d = c_oracle.knn2_points_f32(q.numpy().T, model.numpy().T)
+        idx = np.where(idx >= 0, idx + m_lo, -1).astype(np.int32)
+        return torch.from_numpy(idx), torch.from_numpy(d)
+
+    def merge_top2(self, idx_all, dist_all):
+        ia, da = idx_all.numpy(), dist_all.numpy()
+        R, Q, _ = ia.shape
+        oi = np.full((Q, 2), -1, np.int32); od = np.full((Q, 2), np.inf, np.float32)
+        for qi in range(Q):
+            c = [(float(da[r, qi, k]), int(ia[r, qi, k])) for r in range(R) for k in range(2) if ia[r, qi, k] >= 0]
+            c.sort()
+            for k, (d, i) in enumerate(c[:2]):
+                oi[qi, k], od[qi, k] = i, d
+        return torch.from_numpy(oi), torch.from_numpy(od)
+
+    def filter_top2(self, idx, d, M_total, thr, ratio):
+        i, dd = idx.numpy(), d.numpy()
+        keep = (i[:, 0] >= 0) & (dd[:, 0] <= np.float32(thr))
+        if M_total > 1:
+            z = dd[:, 1] < np.float32(1e-6)
+            t1 = np.where(z, np.float32(1), dd[:, 0]); t2 = np.where(z, np.float32(1), dd[:, 1])
+            keep &= (t1 / t2).astype(np.float32) <= np.float32(ratio)
+        qi = np.nonzero(keep)[0].astype(np.int32)
+        cq = np.zeros(self.Q, np.int32); cm = np.zeros(self.Q, np.int32)
+        cq[:len(qi)] = qi; cm[:len(qi)] = i[qi, 0]
+        return torch.from_numpy(cq), torch.from_numpy(cm), torch.tensor([len(qi)], dtype=torch.int32)
+
+    def unique_local(self, q, model, m_lo, cand_q, cand_m, n_cand):
+        from oracle import c_oracle
+        n = int(n_cand)
+        keep = np.zeros(self.Q, np.int32)
+        cm, cq = cand_m.numpy()[:n], cand_q.numpy()[:n]
+        M = model.shape[1]
+        loc = np.nonzero((cm >= m_lo) & (cm < m_lo + M))[0]
+        if len(loc):
+            back, _ = c_oracle.knn2_points_f32(model.numpy().T[cm[loc] - m_lo], q.numpy().T)
+            keep[loc] = (back[:, 0] == cq[loc]).astype(np.int32)
+        return torch.from_numpy(keep)
+
+    def gather_pairs(self, q, table, dense, cand_q, cand_m, keep, n_cand):
+        n = int(n_cand)
+        cq, cm = cand_q.numpy()[:n], cand_m.numpy()[:n]
+        k = np.ones(n, bool) if keep is None else keep.numpy()[:n].astype(bool)
+        sel = np.nonzero(k)[0]
+        pairs = np.zeros((self.Q, 2), np.int32); p1 = np.zeros((3, self.Q)); p2 = np.zeros((3, self.Q))
+        pairs[:len(sel), 0] = cq[sel] + 1; pairs[:len(sel), 1] = cm[sel] + 1
+        p1[:, :len(sel)] = q.numpy()[:, cq[sel]].astype(np.float64)
+        col = sel if dense else cm[sel]
+        p2[:, :len(sel)] = table.numpy()[:, col].astype(np.float64)
+        return torch.from_numpy(pairs), torch.from_numpy(p1), torch.from_numpy(p2), torch.tensor([len(sel)], dtype=torch.int32)
+
+
+def _data():
+    rng = np.random.default_rng(0)
+    model = (rng.random((4000, 3)) * [100, 56, 99]).astype(np.float32)
+    pick = rng.choice(4000, 900, replace=False)
+    surf = (model[pick] + rng.normal(0, 0.4, (900, 3))).astype(np.float32)
+    return model, surf
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcreg_amd.sharded import ShardedMatcher
+    model, surf = _data()
+    M_local = len(model) // world
+    m_lo = rank * M_local
+    shard = torch.from_numpy(np.ascontiguousarray(model[m_lo:m_lo + M_local].T))
+    q = torch.from_numpy(np.ascontiguousarray(surf.T))
+    sm = ShardedMatcher(OracleOps(len(surf)), len(surf), M_local, m_lo, len(model))
+    pairs, p1, p2, n = sm.match(q, shard, 0.5, 0.8, unique=True)
+    n = int(n)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), pairs=pairs.numpy()[:n], p1=p1.numpy()[:, :n], p2=p2.numpy()[:, :n],
+             idx=sm.idx.numpy(), dist=sm.dist.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_match_equals_unsharded_world2(tmp_path):
+    from oracle import c_oracle
+    c_oracle.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    model, surf = _data()
+    ref_pairs = c_oracle.match_points_f32(surf, model, 0.5, 0.8, True)
+    ref_idx, ref_dist = c_oracle.knn2_points_f32(surf, model)
+    for r in range(2):
+        z = np.load(tmp_path / f"r{r}.npz")
+        np.testing.assert_array_equal(z["idx"], ref_idx)                      # merged global top-2 on every rank
+        np.testing.assert_array_equal(z["dist"], ref_dist)
+        np.testing.assert_array_equal(z["pairs"].astype(np.uint32), ref_pairs)
+        np.testing.assert_array_equal(z["p1"].T, surf[ref_pairs[:, 0] - 1].astype(np.float64))
+        np.testing.assert_array_equal(z["p2"].T, model[ref_pairs[:, 1] - 1].astype(np.float64))
+    assert len(ref_pairs) > 100
+
+
+def test_world1_is_a_no_op_protocol():
+    from pcreg_amd.sharded import ShardedMatcher
+    from oracle import c_oracle
+    model, surf = _data()
+    sm = ShardedMatcher(OracleOps(len(surf)), len(surf), len(model), 0, len(model))
+    pairs, p1, p2, n = sm.match(torch.from_numpy(np.ascontiguousarray(surf.T)), torch.from_numpy(np.ascontiguousarray(model.T)), 0.5, 0.8, True)
+    np.testing.assert_array_equal(pairs.numpy()[:int(n)].astype(np.uint32), c_oracle.match_points_f32(surf, model, 0.5, 0.8, True))
