@@ -1,0 +1,126 @@
+// mex/pcreg_mex.cpp -- the MATLAB binding of libpcreg_hip.so (include/pcreg.h).
+//
+// One gateway, string-dispatched:   out = pcreg_mex('<command>', args...)
+//   'estimateTransform', pts1, pts2                      -> T (4x4 or [])
+//   'calcDists', T, pts1, pts2                           -> d (n x 1)
+//   'ransac', pts1, pts2, coef, sample_idx|[], seed      -> T, inlierIdx, numSuccess, maxInliers, failed
+//   'getMatches', descSurface, descModel, par            -> matches (P x 2 uint32)
+//   'AlignPoints_KNN', pts, C1, C2                       -> pts_aligned, coeff_unambig, c
+// The shim only unpacks mxArrays: MATLAB's column-major doubles go straight through
+// (ld = number of rows).  It never throws with C++ objects alive:
+// errors are collected as codes and raised by one mexErrMsgIdAndTxt at the very end.
+//
+// Build (on a machine with MATLAB; neither the build container nor the GPU box has one):
+//   mex -I../include mex/pcreg_mex.cpp -L../pcreg_amd -lpcreg_hip -output matlab/pcreg_mex
+// This file is compile-gated on mex.h and is NOT part of libpcreg_hip.so.
+#if __has_include("mex.h")
+#include "mex.h"
+#include <cstring>
+#include <string>
+#include "../include/pcreg.h"
+
+static double field(const mxArray* s, const char* name, double dflt, bool* missing = nullptr) {
+    const mxArray* f = mxIsStruct(s) ? mxGetField(s, 0, name) : nullptr;
+    if (!f) { if (missing) *missing = true; return dflt; }
+    if (mxIsChar(f)) return dflt;
+    return mxGetScalar(f);
+}
+static bool field_is(const mxArray* s, const char* name, const char* value) {
+    const mxArray* f = mxIsStruct(s) ? mxGetField(s, 0, name) : nullptr;
+    if (!f || !mxIsChar(f)) return false;
+    char buf[64]; mxGetString(f, buf, sizeof buf);
+    return strcmp(buf, value) == 0;
+}
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+    if (nrhs < 1 || !mxIsChar(prhs[0])) { mexErrMsgIdAndTxt("pcreg:usage", "pcreg_mex('<command>', ...)"); return; }
+    char cmd[64]; mxGetString(prhs[0], cmd, sizeof cmd);
+    int rc = PCREG_OK;
+    const char* usage = nullptr;
+
+    if (!strcmp(cmd, "estimateTransform")) {
+        if (nrhs != 3) usage = "estimateTransform: pts1, pts2";
+        else {
+            int n = (int)mxGetM(prhs[1]);
+            double T[16]; int empty = 1;
+            rc = pcreg_estimate_transform(mxGetPr(prhs[1]), mxGetPr(prhs[2]), n, n, T, &empty);
+            if (rc == PCREG_OK) {
+                plhs[0] = empty ? mxCreateDoubleMatrix(0, 0, mxREAL) : mxCreateDoubleMatrix(4, 4, mxREAL);
+                if (!empty) memcpy(mxGetPr(plhs[0]), T, sizeof T);
+            }
+        }
+    } else if (!strcmp(cmd, "calcDists")) {
+        if (nrhs != 4) usage = "calcDists: T, pts1, pts2";
+        else {
+            int n = (int)mxGetM(prhs[2]);
+            plhs[0] = mxCreateDoubleMatrix(n, 1, mxREAL);
+            rc = pcreg_calc_dists(mxGetPr(prhs[1]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), n, n, mxGetPr(plhs[0]));
+        }
+    } else if (!strcmp(cmd, "ransac")) {
+        if (nrhs < 4) usage = "ransac: pts1, pts2, coef[, sample_idx, seed]";
+        else {
+            const mxArray* c = prhs[3];
+            pcreg_ransac_opts o;
+            o.minPtNum = (int)field(c, "minPtNum", 3); o.iterNum = (int)field(c, "iterNum", 1000);
+            o.thDist = field(c, "thDist", 0.5); o.thInlrRatio = field(c, "thInlrRatio", 0.1);
+            o.REFINE = (int)field(c, "REFINE", 1); o.VERBOSE = (int)field(c, "VERBOSE", 1);
+            o.seed = nrhs > 5 ? (uint64_t)mxGetScalar(prhs[5]) : 0;
+            int n = (int)mxGetM(prhs[1]);
+            // sample_idx: int32 minPtNum x iterNum (each COLUMN one hypothesis) or []
+            const int32_t* si = (nrhs > 4 && !mxIsEmpty(prhs[4]) && mxIsInt32(prhs[4])) ? (const int32_t*)mxGetData(prhs[4]) : nullptr;
+            mxArray* inl = mxCreateNumericMatrix(n > 0 ? n : 1, 1, mxINT32_CLASS, mxREAL);
+            double T[16]; int ni = 0, ns = 0, mi = 0, fl = 1;
+            rc = pcreg_ransac(mxGetPr(prhs[1]), mxGetPr(prhs[2]), n, n, &o, si, T, (int32_t*)mxGetData(inl), &ni, &ns, &mi, &fl, nullptr, nullptr);
+            if (rc == PCREG_OK) {
+                plhs[0] = fl ? mxCreateDoubleMatrix(0, 0, mxREAL) : mxCreateDoubleMatrix(4, 4, mxREAL);
+                if (!fl) memcpy(mxGetPr(plhs[0]), T, sizeof T);
+                if (nlhs > 1) {                         // inlierIdx as a double column, like find()
+                    plhs[1] = mxCreateDoubleMatrix(fl ? 0 : ni, fl ? 0 : 1, mxREAL);
+                    const int32_t* src = (const int32_t*)mxGetData(inl);
+                    for (int k = 0; k < (fl ? 0 : ni); ++k) mxGetPr(plhs[1])[k] = (double)src[k];
+                }
+                if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(ns);
+                if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(mi);
+                if (nlhs > 4) plhs[4] = mxCreateDoubleScalar(fl);
+            }
+            mxDestroyArray(inl);
+        }
+    } else if (!strcmp(cmd, "getMatches")) {
+        if (nrhs != 4) usage = "getMatches: descSurface, descModel, par";
+        else {
+            const mxArray* p = prhs[3];
+            pcreg_match_opts o;
+            o.metric = field_is(p, "Metric", "SAD") ? PCREG_METRIC_SAD : PCREG_METRIC_SSD;
+            o.matchThreshold = field(p, "MatchThreshold", 1.0); o.maxRatio = field(p, "MaxRatio", 0.6);
+            o.unique = (int)field(p, "Unique", 0); o.prenormalized = 0;
+            o.unnormalize = (int)field(p, "UNNORMALIZE", 0); o.norm_factor = field(p, "norm_factor", 0.0);
+            o.change_metric = (int)field(p, "CHANGE_METRIC", 0); o.metric_factor = field(p, "metric_factor", 1.0);
+            int Q = (int)mxGetM(prhs[1]), M = (int)mxGetM(prhs[2]), D = (int)mxGetN(prhs[1]);
+            mxArray* buf = mxCreateNumericMatrix(2, Q > 0 ? Q : 1, mxUINT32_CLASS, mxREAL);   // row-major pairs = 2 x Q column-major
+            int P = 0;
+            rc = pcreg_get_matches(mxGetPr(prhs[1]), Q, Q, mxGetPr(prhs[2]), M, M, D, &o, (uint32_t*)mxGetData(buf), nullptr, &P);
+            if (rc == PCREG_OK) {
+                plhs[0] = mxCreateNumericMatrix(P, 2, mxUINT32_CLASS, mxREAL);
+                const uint32_t* src = (const uint32_t*)mxGetData(buf); uint32_t* dst = (uint32_t*)mxGetData(plhs[0]);
+                for (int k = 0; k < P; ++k) { dst[k] = src[2 * k]; dst[k + P] = src[2 * k + 1]; }
+            }
+            mxDestroyArray(buf);
+        }
+    } else if (!strcmp(cmd, "AlignPoints_KNN")) {
+        if (nrhs != 4) usage = "AlignPoints_KNN: pts, C1, C2";
+        else {
+            int n = (int)mxGetM(prhs[1]);
+            plhs[0] = mxCreateDoubleMatrix(n, 3, mxREAL);
+            mxArray* co = mxCreateDoubleMatrix(3, 3, mxREAL); mxArray* c = mxCreateDoubleMatrix(1, 3, mxREAL);
+            rc = pcreg_align_points_knn(mxGetPr(prhs[1]), n, n, (int)mxGetScalar(prhs[2]), (int)mxGetScalar(prhs[3]),
+                                        mxGetPr(plhs[0]), mxGetPr(co), mxGetPr(c));
+            if (nlhs > 1) plhs[1] = co; else mxDestroyArray(co);
+            if (nlhs > 2) plhs[2] = c; else mxDestroyArray(c);
+        }
+    } else {
+        usage = "unknown command";
+    }
+    if (usage) mexErrMsgIdAndTxt("pcreg:usage", "%s", usage);
+    if (rc != PCREG_OK) mexErrMsgIdAndTxt("pcreg:hip", "%s", pcreg_last_error());
+}
+#endif  // __has_include("mex.h")
