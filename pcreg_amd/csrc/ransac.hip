@@ -20,6 +20,7 @@
 // No data leaves the chip between the sample fit and the final inlier list.
 #include "common.hpp"
 #include <cfloat>
+#include <cstdlib>
 
 namespace pcreg {
 namespace {
@@ -580,6 +581,242 @@ __global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- hypothesis kernel, large n
+// When the correspondences do not fit LDS, a per-wave sweep streams n x 48 B from L2 for
+// every hypothesis pair and the kernel is L2-bandwidth bound (measured: 31 GB per
+// registration at n = 32.5k).  Here an 8-wave workgroup marches over the points TOGETHER:
+// a tile of kTile points is staged once in LDS (six SoA fp64 columns) and every wave scores
+// its own hypothesis pair against it, so L2 traffic drops 8x and the sweeps run at LDS
+// speed.  All waves execute the same sequence of sweeps (score, refit moments, rescore);
+// block-wide votes (__syncthreads_or) decide which sweeps are needed at all.
+constexpr int kTW = 8;                  // waves per workgroup (2 per SIMD: 256 VGPRs each)
+constexpr int kTBlock = kTW * 64;
+constexpr int kTile = kTBlock;          // points per LDS tile: one per thread (2 x 24 KiB, double-buffered)
+
+// One pass of the whole workgroup over the correspondences through LDS tiles, software
+// pipelined: the loads of tile t+1 are issued before tile t is scored and land in the other
+// LDS buffer afterwards (one barrier per tile, L2 latency hidden behind the arithmetic).
+// A macro pair rather than a lambda-taking template: captured-by-reference accumulators
+// ended up in scratch.
+#define PCREG_TILE_SWEEP_BEGIN                                                              \
+    {                                                                                       \
+        const int nt_ = (n + kTile - 1) / kTile;                                            \
+        double pf_[6];                                                                      \
+        {                                                                                   \
+            const int gi_ = threadIdx.x; const bool ok_ = gi_ < n;                          \
+            _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                              \
+                pf_[c_] = ok_ ? g1[gi_ + (size_t)c_ * a.ld] : 0.0;                          \
+                pf_[3 + c_] = ok_ ? g2[gi_ + (size_t)c_ * a.ld] : 0.0;                      \
+            }                                                                               \
+            _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) sp[c_ * kTile + threadIdx.x] = pf_[c_]; \
+        }                                                                                   \
+        __syncthreads();                                                                    \
+        for (int t_ = 0; t_ < nt_; ++t_) {                                                  \
+            const bool more_ = t_ + 1 < nt_;                                                \
+            if (more_) {                                                                    \
+                const int gi_ = (t_ + 1) * kTile + threadIdx.x; const bool ok_ = gi_ < n;   \
+                _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                          \
+                    pf_[c_] = ok_ ? g1[gi_ + (size_t)c_ * a.ld] : 0.0;                      \
+                    pf_[3 + c_] = ok_ ? g2[gi_ + (size_t)c_ * a.ld] : 0.0;                  \
+                }                                                                           \
+            }                                                                               \
+            const double* buf_ = sp + (t_ & 1) * 6 * kTile;                                 \
+            const int cnt_ = min(kTile, n - t_ * kTile);                                    \
+            for (int i0_ = 0; i0_ < cnt_; i0_ += 128) {   /* two 64-point slots per trip: 12 LDS reads in flight */ \
+                double qq_[2][6];                                                           \
+                _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                            \
+                    _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) qq_[u_][c_] = buf_[c_ * kTile + i0_ + u_ * 64 + lane]; \
+                _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                          \
+                    const bool act = i0_ + u_ * 64 + lane < cnt_;                           \
+                    double q[6];                                                            \
+                    _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) q[c_] = qq_[u_][c_];
+#define PCREG_TILE_SWEEP_END                                                                \
+                }                                                                           \
+            }                                                                               \
+            if (more_) {                                                                    \
+                double* nb_ = sp + ((t_ + 1) & 1) * 6 * kTile;                              \
+                _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) nb_[c_ * kTile + threadIdx.x] = pf_[c_]; \
+            }                                                                               \
+            __syncthreads();                                                                \
+        }                                                                                   \
+    }
+
+__global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a) {
+    __shared__ __attribute__((aligned(16))) double sp[2 * 6 * kTile];
+    __shared__ double s_mom[kTW][HB][27];    // refit moments (or the 3 inlier points) of the wave's current hypotheses
+    const int b = blockIdx.y;
+    const int off = a.offsets ? a.offsets[b] : 0;
+    int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
+    n = min(n, a.n_cap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t hyp0 = (size_t)b * a.iters;
+    const int wbase = (blockIdx.x * kTW + wave) * a.hpw;
+    const double* g1 = a.p1 + off; const double* g2 = a.p2 + off;
+    const int nh = max(0, min(a.hpw, a.iters - wbase));      // 0: this wave only helps with the tiles
+    const int p = wbase + lane;
+    const bool mine = lane < nh;
+    Pts<false> P{g1, g2, a.ld, nullptr, n};
+    const int thInlr = matlab_round_i(a.ratio * (double)n);
+
+    if (n < a.m || n < 3) {
+        if (mine) { a.cnt1[hyp0 + p] = 0; a.cnt2[hyp0 + p] = 0; a.has[hyp0 + p] = 0; }
+        return;
+    }
+    double o[6];
+    P.load(0, o);
+
+    // ---- phase 0: sample fits, one hypothesis per lane
+    double T1[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T1[k] = 0.0;
+    bool v1 = false;
+    if (mine) {
+        if (a.m == 3) {
+            int s[3]; sample3(a, b, p, n, s);
+            double A1[3][3], A2[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double q[6]; P.load(s[j], q);
+                A1[j][0] = q[0]; A1[j][1] = q[1]; A1[j][2] = q[2];
+                A2[j][0] = q[3]; A2[j][1] = q[4]; A2[j][2] = q[5];
+            }
+            v1 = fit_3pt(A1, A2, T1);
+        } else {
+            double mom[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+            const int32_t* t = a.sample_idx + ((size_t)hyp0 + p) * a.m;
+            double os[6];
+            for (int j = 0; j < a.m; ++j) {
+                int idx = min(max(t[j] - 1, 0), n - 1);
+                double q[6]; P.load(idx, q);
+                if (j == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) os[c] = q[c];
+                }
+                mom_accumulate(mom, q, os);
+            }
+            v1 = fit_moments(a.m, mom, os, T1);
+        }
+    }
+
+    int c1 = 0, c2 = 0;
+    double T2[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T2[k] = 0.0;
+    bool v2 = false, pass1 = false;
+    const double th = a.thDist;
+
+    for (int h0 = 0; h0 < a.hpw; h0 += HB) {            // rounds: every wave, same trip count
+        // ---- phase 1: score the sample fits of this round
+        {
+            double T[HB][12]; int cnt[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) { bcast_T(T1, min(h0 + k, 63), T[k]); cnt[k] = 0; }
+            PCREG_TILE_SWEEP_BEGIN
+#pragma unroll
+                for (int k = 0; k < HB; ++k) cnt[k] += __popcll(__ballot((sqdist(q, T[k]) < th) & act));
+            PCREG_TILE_SWEEP_END
+#pragma unroll
+            for (int k = 0; k < HB; ++k) if (lane == h0 + k) c1 = cnt[k];
+        }
+        if (!v1) c1 = 0;
+        {
+            const bool in_round = mine && lane >= h0 && lane < h0 + HB;
+            if (in_round) pass1 = v1 && c1 >= thInlr;
+        }
+        if (!a.refine) continue;
+
+        // ---- phase 2+3: refit moments, one passing hypothesis of every wave per sweep;
+        //      the 27 sums (or the three inlier points) go through s_mom to the owning lane
+#pragma unroll 1
+        for (int k = 0; k < HB; ++k) {
+            const int h = h0 + k;
+            const bool want = __builtin_amdgcn_readlane((int)(pass1 && (lane == h)), min(h, 63)) != 0 && h < nh;
+            if (!__syncthreads_or(want)) continue;          // nobody in the workgroup needs this sweep
+            double T[12]; bcast_T(T1, min(h, 63), T);
+            const int ch = __builtin_amdgcn_readlane(c1, min(h, 63));
+            double acc[27];
+#pragma unroll
+            for (int e = 0; e < 27; ++e) acc[e] = 0.0;
+            int k3 = 0;
+            PCREG_TILE_SWEEP_BEGIN
+                const bool in = (sqdist(q, T) < th) & act & want;
+                if (in) mom_accumulate(acc, q, o);
+                if (ch == 3) {                  // estimateTransform's N == 3 branch needs the points themselves
+                    unsigned long long bal = __ballot(in);
+                    const int r3 = k3 + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (in && r3 < 3) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) s_mom[wave][k][r3 * 6 + c] = q[c];
+                    }
+                    k3 += __popcll(bal);
+                }
+            PCREG_TILE_SWEEP_END
+            if (want && ch != 3) {
+#pragma unroll
+                for (int e = 0; e < 27; ++e) {
+                    double tot = wave_sum(acc[e]);
+                    if (lane == 0) s_mom[wave][k][e] = tot;
+                }
+            }
+        }
+        // s_mom was written by this wave only (after the sweep's last barrier)
+        __builtin_amdgcn_wave_barrier();
+        {
+            const bool in_round = mine && lane >= h0 && lane < h0 + HB;
+            if (in_round && pass1) {         // both hypotheses of the round refit side by side
+                double mom[27];
+#pragma unroll
+                for (int e = 0; e < 27; ++e) mom[e] = s_mom[wave][lane - h0][e];
+                if (c1 == 3) {
+                    double A1[3][3], A2[3][3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { A1[j][c] = mom[j * 6 + c]; A2[j][c] = mom[j * 6 + 3 + c]; }
+                    v2 = fit_3pt(A1, A2, T2);
+                } else {
+                    v2 = fit_moments(c1, mom, o, T2);
+                }
+            }
+        }
+        // ---- phase 4: rescore the refined transforms of this round
+        {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < HB; ++k) any |= (__builtin_amdgcn_readlane((int)v2, min(h0 + k, 63)) != 0) && (h0 + k < nh);
+            if (__syncthreads_or(any)) {
+                double T[HB][12]; int cnt[HB];
+#pragma unroll
+                for (int k = 0; k < HB; ++k) { bcast_T(T2, min(h0 + k, 63), T[k]); cnt[k] = 0; }
+                PCREG_TILE_SWEEP_BEGIN
+#pragma unroll
+                    for (int k = 0; k < HB; ++k) cnt[k] += __popcll(__ballot((sqdist(q, T[k]) < th) & act));
+                PCREG_TILE_SWEEP_END
+#pragma unroll
+                for (int k = 0; k < HB; ++k) if (lane == h0 + k) c2 = cnt[k];
+            }
+        }
+    }
+    if (mine) {
+        if (!a.refine) {
+            a.cnt1[hyp0 + p] = c1; a.cnt2[hyp0 + p] = 0; a.has[hyp0 + p] = pass1;
+            if (pass1) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) a.TF[(hyp0 + p) * 12 + k] = T1[k];
+            }
+        } else {
+            const bool keep = v2 && c2 >= thInlr;
+            a.cnt1[hyp0 + p] = c1; a.cnt2[hyp0 + p] = v2 ? c2 : 0; a.has[hyp0 + p] = keep;
+            if (keep) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) a.TF[(hyp0 + p) * 12 + k] = T2[k];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- winner + outputs
 // ransac.m:69-98.  One workgroup per registration.
 __global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcreg_dev_ransac_result* out,
@@ -738,19 +975,25 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
     a.cnt1 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.cnt2 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.has = (unsigned char*)w;
-    // hypotheses per wave: fill the chip first (>= ~2 waves per SIMD), then grow towards
-    // 64 so that the lane-parallel fits run with full lanes.
     long long total = (long long)o.iterNum * B;
-    int hpw = 64;
-    while (hpw > 8 && total / hpw < 256LL * 4 * 2) hpw >>= 1;
-    a.hpw = hpw;
-    int per_block = hpw * kWavesPerBlock;
-    dim3 grid((o.iterNum + per_block - 1) / per_block, B);
     size_t lds = (size_t)n_cap * 6 * sizeof(double);
     if (n_cap > 0 && lds <= 64 * 1024) {
+        // small sets: correspondences resident in LDS; hypotheses per wave: fill the chip
+        // first (>= ~2 waves per SIMD), then grow towards 64 so the lane-parallel fits run full
+        int hpw = 64;
+        while (hpw > 8 && total / hpw < 256LL * 4 * 2) hpw >>= 1;
+        a.hpw = hpw;
+        int per_block = hpw * kWavesPerBlock;
+        dim3 grid((o.iterNum + per_block - 1) / per_block, B);
         hipLaunchKernelGGL(ransac_hyp_kernel<true>, grid, dim3(kBlock), lds, st, a);
     } else {
-        hipLaunchKernelGGL(ransac_hyp_kernel<false>, grid, dim3(kBlock), 0, st, a);
+        // large sets: 8-wave workgroups share LDS tiles of the correspondences
+        int hpw = 16;
+        while (hpw > HB && total / ((long long)hpw * kTW) < 512) hpw >>= 1;
+        a.hpw = hpw;
+        int per_block = hpw * kTW;
+        dim3 grid((o.iterNum + per_block - 1) / per_block, B);
+        hipLaunchKernelGGL(ransac_hyp_tiled_kernel, grid, dim3(kTBlock), 0, st, a);
     }
     PCREG_HIP(hipGetLastError());
     hipLaunchKernelGGL(ransac_select_kernel, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx);

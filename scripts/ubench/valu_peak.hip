@@ -37,7 +37,23 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
     for (int i = 0; i < 8; ++i) s += p[i].x + p[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+__global__ __launch_bounds__(256) void kd(double* out, int iters, double a, double b) {
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = threadIdx.x * 0.001 + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = __builtin_fma(x[i], a, b);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 int main() {
+    { double* dd; hipMalloc(&dd, 8192 * 256 * 8); hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int blocks : {1024, 2048, 4096}) { float ms = 0; for (int rep = 0; rep < 3; ++rep) { hipEventRecord(e0); kd<<<blocks, 256>>>(dd, 20000, 1.0001, 0.5); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); }
+        double ops = (double)blocks * 256 * 20000 * 8.0; printf("fp64 fma blocks %d: %.3f ms, %.2f T lane-instr/s, %.1f TFLOP/s\n", blocks, ms, ops / ms / 1e9, 2 * ops / ms / 1e9); } }
     float* d; hipMalloc(&d, 8192 * 256 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
