@@ -28,25 +28,12 @@
 //   E = u*(3 R_m^2 + 3.03 (R_m^2 + 2 r R_m) + 4.04 (r + R_m)^2) + 16 u (d2 + |G + r^2|)
 #include "common.hpp"
 #include "select.hpp"
+#include "knn_fast_common.hpp"
 #include <cmath>
 #include <cstdlib>
 
 namespace pcreg {
 namespace {
-
-constexpr int kBlock = 256;
-constexpr int KC = 4;                        // candidates kept per query and chunk
-constexpr int kMTile = 1024;                 // model points per LDS tile (16 KiB)
-
-struct Prep { float cx, cy, cz, rm2; };      // centre and max |m~|^2, produced on device
-
-__device__ __forceinline__ unsigned f2ord(float f) {       // order-preserving float -> uint
-    unsigned b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
-}
 
 // ---- 1a. bounding box of model + queries (two-stage, deterministic) -----------------
 __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __restrict__ m, int M, int ldm,
@@ -102,24 +89,6 @@ __global__ __launch_bounds__(kBlock) void prep_model_kernel(const float* __restr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) atomicMax(rm2_bits, __float_as_uint(mx));     // max is order-independent
-}
-
-// ---- 2. candidate generation -------------------------------------------------------------
-struct Cand { float s[KC]; int i[KC]; };
-
-__device__ __forceinline__ void cand_insert(Cand& c, float s, int j) {
-    // keep c.s ascending; strict '<' so that, within a lane, earlier (lower) indices win ties
-    if (s < c.s[3]) {
-        if (s < c.s[1]) {
-            c.s[3] = c.s[2]; c.i[3] = c.i[2];
-            c.s[2] = c.s[1]; c.i[2] = c.i[1];
-            if (s < c.s[0]) { c.s[1] = c.s[0]; c.i[1] = c.i[0]; c.s[0] = s; c.i[0] = j; }
-            else { c.s[1] = s; c.i[1] = j; }
-        } else {
-            if (s < c.s[2]) { c.s[3] = c.s[2]; c.i[3] = c.i[2]; c.s[2] = s; c.i[2] = j; }
-            else { c.s[3] = s; c.i[3] = j; }
-        }
-    }
 }
 
 template <int QPT_, int UB_, bool DRY = false>
@@ -217,17 +186,17 @@ __device__ __forceinline__ bool lex_lt_f(float da, int ia, float db, int ib) {
 __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
     const Prep* __restrict__ prep, const unsigned* __restrict__ rm2_bits, const unsigned* __restrict__ gthr,
-    const int32_t* __restrict__ part_idx, const float* __restrict__ part_s, int S, int idx_base,
+    const int32_t* __restrict__ part_idx, const float* __restrict__ part_s, int S, int kc, int idx_base,
     int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (qi >= Q) return;
     const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
-    const int total = S * KC;
+    const int total = S * kc;      // kc candidates per (chunk, query): 4 (VALU path) or 16 (MFMA path)
     // pass 1: the two smallest approximate scores of the union (values only)
     float a1 = INFINITY, a2 = INFINITY;
     for (int e = lane; e < total; e += 64) {
-        size_t o = ((size_t)(e / KC) * Q + qi) * KC + (e % KC);
+        size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc);
         if (part_idx[o] >= 0) { float s = part_s[o]; if (s < a2) { if (s < a1) { a2 = a1; a1 = s; } else a2 = s; } }
     }
 #pragma unroll
@@ -250,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const float cut_up = nextafterf(cut, INFINITY);              // float rounding of the cut must not exclude anything
     float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
     for (int e = lane; e < total; e += 64) {
-        size_t o = ((size_t)(e / KC) * Q + qi) * KC + (e % KC);
+        size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc);
         int j = part_idx[o];
         if (j >= 0 && (part_s[o] <= cut_up || !(a2 < INFINITY))) {
             float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
@@ -345,42 +314,47 @@ int pick_splits_fast(int n_tiles, int M, int target) {
 
 }  // namespace
 
+// MFMA formulation of the candidate kernel (knn_mfma.hip, built with its own flags)
+int launch_knn_candidates_mfma(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
+                               unsigned* rm2, float* mtiles, int n_tiles, int tiles_per_chunk, int q_blocks, int S,
+                               unsigned* gthr, int32_t* part_idx, float* part_s, bool dry, hipStream_t st);
+
 // tiled exact kernel on a query list (implemented in knn_points.hip)
 int launch_knn2_points_exact_list(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
                                   const int32_t* qlist, const int32_t* n_list, int min_active, int32_t* idx,
                                   float* dist, void* ws, size_t ws_bytes, hipStream_t st);
 size_t knn2_points_exact_workspace_bytes(int Q, int M);
 
-// workspace layout: Prep | rm2 bits | n_flag | bbox partials | gthr [Q] | flag_list [Q] | model float4 [M]
-//                   | part_idx [S][Q][KC] | part_s | exact-kernel workspace (fallback)
-static size_t fast_fixed_bytes(int Q, int M, int S) {
-    size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1);
+// workspace layout: Prep | rm2 bits | n_flag | bbox partials | gthr [Q] | flag_list [Q]
+//                   | prepared model (16 B/point, padded to whole 16-point tiles)
+//                   | part_idx [S][Q][kc] | part_s | exact-kernel workspace (fallback)
+static constexpr int kPartCap = 40;           // upper bound of S * kc / 16 any variant may use (x16 entries per query)
+static size_t fast_fixed_bytes(int Q, int M) {
+    size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + 16;
     return 256 + 256 + 256 + align_up(512 * 6 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
-           align_up(mm * 16, 256) + 2 * align_up((size_t)S * q * KC * 4, 256);
+           align_up(mm * 16, 256) + 2 * align_up((size_t)kPartCap * 16 * q * 4, 256);
 }
-static constexpr int kFastTarget = 1024;      // workgroups the candidate grid aims for
-static constexpr int kFastQPT = 4;
 
 size_t knn2_points_fast_workspace_bytes(int Q, int M) {
-    int n_tiles = (Q + kBlock * 2 - 1) / (kBlock * 2); if (n_tiles < 1) n_tiles = 1;    // covers QPT 2..8
-    int S = pick_splits_fast(n_tiles, M > 0 ? M : 1, 8192);
-    return fast_fixed_bytes(Q, M, S) + knn2_points_exact_workspace_bytes(Q, M);
+    return fast_fixed_bytes(Q, M) + knn2_points_exact_workspace_bytes(Q, M);
 }
 
+// PCREG_KNN_VARIANT: 0 (default) VALU candidates QPT4/UB8; 11 QPT4/UB4; 12 QPT8/UB8; 13 QPT2/UB8; 19 VALU
+//                    timing-only (no insertions); 5 MFMA candidates; 9 MFMA timing-only.
+//                    The fp32 MFMA shares the SIMD's fp32 datapath with the VALU (measured: 32.5 -> 49 cycles per
+//                    MFMA once three VALU ops sit between issues, scripts/ubench/mfma_f32.hip), so the MFMA
+//                    formulation is slower than the 3-FMA VALU form here and is kept for reference only.
+//                    PCREG_KNN_BLOCKS: grid target.
 int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
                                 int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
     PCREG_ARG(Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
     if (Q == 0) return PCREG_OK;
     size_t need = knn2_points_fast_workspace_bytes(Q, M);
     if (ws_bytes < need) { set_error("knn (fast) workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
-    static const int target = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : kFastTarget;
+    static const int target_env = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : 0;
     static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 0;
-    const int qpt = variant == 12 ? 8 : (variant == 13 ? 2 : kFastQPT);
-    int n_tiles = (Q + kBlock * qpt - 1) / (kBlock * qpt);
-    int S = pick_splits_fast(n_tiles, M > 0 ? M : 1, target);
-    int chunk = (((M > 0 ? M : 1) + S - 1) / S + kMTile - 1) / kMTile * kMTile;
-    S = M > 0 ? (M + chunk - 1) / chunk : 1;
-    size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1);
+    const bool use_mfma = variant >= 5 && variant < 10;
+    size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1) + 16;
     char* w = (char*)ws;
     Prep* prep = (Prep*)w;                 w += 256;
     unsigned* rm2 = (unsigned*)w;          w += 256;
@@ -388,9 +362,9 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     float* bpart = (float*)w;              w += align_up(512 * 6 * sizeof(float), 256);
     unsigned* gthr = (unsigned*)w;         w += align_up(qq * 4, 256);
     int32_t* flag_list = (int32_t*)w;      w += align_up(qq * 4, 256);
-    float4* mp = (float4*)w;               w += align_up(mm * 16, 256);
-    int32_t* part_idx = (int32_t*)w;       w += align_up((size_t)S * qq * KC * 4, 256);
-    float* part_s = (float*)w;             w += align_up((size_t)S * qq * KC * 4, 256);
+    void* mprep = w;                       w += align_up(mm * 16, 256);
+    int32_t* part_idx = (int32_t*)w;       w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
+    float* part_s = (float*)w;             w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
     void* ews = w;
     size_t ews_bytes = ws_bytes - (size_t)(w - (char*)ws);
 
@@ -399,23 +373,50 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, prep, rm2);
     PCREG_HIP(hipMemsetAsync(gthr, 0xFF, qq * 4, st));            // +inf in the ordered-uint image
     PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
-    if (M > 0) {
-        int pb = (M + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
-        hipLaunchKernelGGL(prep_model_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, prep, mp, rm2);
-    }
-    dim3 grid(n_tiles, S);
-#define PCREG_CAND_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn_candidates_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, mp, M, chunk, prep, gthr, part_idx, part_s)
-    switch (variant) {
-        case 11: PCREG_CAND_LAUNCH(4, 4); break;
-        case 19: hipLaunchKernelGGL((knn_candidates_kernel<4, 8, true>), grid, dim3(kBlock), 0, st, q, Q, ldq, mp, M, chunk, prep, gthr, part_idx, part_s); break;
-        case 12: PCREG_CAND_LAUNCH(8, 8); break;
-        case 13: PCREG_CAND_LAUNCH(2, 8); break;
-        default: PCREG_CAND_LAUNCH(4, 8); break;
-    }
+    int S = 1, kc = KC;
+    if (use_mfma) {
+        constexpr int NQ = 8;                    // must match knn_mfma.hip
+        const int n_tiles = (M + 15) / 16;
+        const int q_blocks = (Q + (kBlock / 64) * NQ * 16 - 1) / ((kBlock / 64) * NQ * 16);
+        // whole rounds of resident workgroups (4 per CU at <= 128 VGPRs): avoid a ragged last round
+        const int target = target_env > 0 ? target_env : 2048;
+        S = target / q_blocks; if (S < 1) S = 1;
+        if (S > kPartCap) S = kPartCap;
+        if (S > n_tiles) S = n_tiles > 0 ? n_tiles : 1;
+        int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
+        S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
+        kc = 16;
+        PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * qq * 16 * 4, st));     // -1: empty slots (M == 0, padding)
+        if (M > 0) {
+            int rc = launch_knn_candidates_mfma(q, Q, ldq, m, M, ldm, prep, rm2, (float*)mprep, n_tiles, tiles_per_chunk,
+                                                q_blocks, S, gthr, part_idx, part_s, variant == 9, st);
+            if (rc) return rc;
+        }
+    } else {
+        const int qpt = variant == 12 ? 8 : (variant == 13 ? 2 : 4);
+        int n_qt = (Q + kBlock * qpt - 1) / (kBlock * qpt);
+        S = pick_splits_fast(n_qt, M > 0 ? M : 1, target_env > 0 ? target_env : 4096);
+        if (S > kPartCap * 4) S = kPartCap * 4;
+        int chunk = (((M > 0 ? M : 1) + S - 1) / S + kMTile - 1) / kMTile * kMTile;
+        S = M > 0 ? (M + chunk - 1) / chunk : 1;
+        if (M > 0) {
+            int pb = (M + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
+            hipLaunchKernelGGL(prep_model_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, prep, (float4*)mprep, rm2);
+        }
+        dim3 grid(n_qt, S);
+#define PCREG_CAND_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn_candidates_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s)
+        switch (variant) {
+            case 11: PCREG_CAND_LAUNCH(4, 4); break;
+            case 12: PCREG_CAND_LAUNCH(8, 8); break;
+            case 13: PCREG_CAND_LAUNCH(2, 8); break;
+            case 19: hipLaunchKernelGGL((knn_candidates_kernel<4, 8, true>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
+            default: PCREG_CAND_LAUNCH(4, 8); break;
+        }
 #undef PCREG_CAND_LAUNCH
+    }
     PCREG_HIP(hipGetLastError());
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
-                       part_idx, part_s, S, (int)idx_base, idx, dist, flag_list, n_flag);
+                       part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag);
     PCREG_HIP(hipGetLastError());
     // fallbacks (both launched; each decides from the device-side count which one works)
     const int kFew = 1024;

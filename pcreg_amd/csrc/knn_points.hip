@@ -218,40 +218,43 @@ __global__ void unique_reduce_kernel(const int32_t* __restrict__ part_idx, const
     keep[k] = (bi == cand_q[k]);
 }
 
-__global__ void gather_pairs_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
-                                    const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
-                                    const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
-                                    uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2,
-                                    int32_t* __restrict__ n_pairs) {
-    // single workgroup, ordered compaction (P <= Q is small: tens of thousands)
-    __shared__ int s_cnt[4];
-    __shared__ int s_base;
+// Ordered compaction of the kept candidates (three small launches: per-workgroup counts,
+// exclusive scan, scatter) into 1-based pairs and, optionally, the matched coordinates.
+__global__ void gather_count_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
+                                    int32_t* __restrict__ block_cnt) {
     const int P = *n_cand;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_base = 0;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool kp = k < P && (keep == nullptr || keep[k] != 0);
+    __shared__ int s_cnt[4];
+    unsigned long long b = __ballot(kp);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(b);
     __syncthreads();
-    for (int k0 = 0; k0 < P; k0 += 256) {
-        int k = k0 + threadIdx.x;
-        bool kp = k < P && (keep == nullptr || keep[k] != 0);
-        unsigned long long b = __ballot(kp);
-        if (lane == 0) s_cnt[wave] = __popcll(b);
-        __syncthreads();
-        int base = s_base;
-        for (int w = 0; w < wave; ++w) base += s_cnt[w];
-        if (kp) {
-            int o = base + __popcll(b & ((1ull << lane) - 1ull));
-            int qi = cand_q[k], mj = cand_m[k];
-            if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)mj + 1u; }
-            if (pts1) {
-                pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
-                pts2[o] = (double)m[mj]; pts2[o + (size_t)Q] = (double)m[mj + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[mj + 2 * (size_t)ldm];
-            }
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+__global__ void gather_scatter_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
+                                      const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
+                                      const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
+                                      const int32_t* __restrict__ block_off, uint32_t* __restrict__ pairs,
+                                      double* __restrict__ pts1, double* __restrict__ pts2) {
+    const int P = *n_cand;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool kp = k < P && (keep == nullptr || keep[k] != 0);
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long b = __ballot(kp);
+    if (lane == 0) s_cnt[wave] = __popcll(b);
+    __syncthreads();
+    int base = block_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += s_cnt[w];
+    if (kp) {
+        int o = base + __popcll(b & ((1ull << lane) - 1ull));
+        int qi = cand_q[k], mj = cand_m[k];
+        if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)mj + 1u; }
+        if (pts1) {
+            pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
+            pts2[o] = (double)m[mj]; pts2[o + (size_t)Q] = (double)m[mj + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[mj + 2 * (size_t)ldm];
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        __syncthreads();
     }
-    if (threadIdx.x == 0) *n_pairs = s_base;
 }
 
 // number of model chunks so that the grid has ~>= 8 workgroups per CU
@@ -386,8 +389,16 @@ int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int 
                             const int32_t* cand_m, const int32_t* keep, const int32_t* n_cand, uint32_t* pairs,
                             double* pts1, double* pts2, int32_t* n_pairs, hipStream_t st) {
     PCREG_ARG((pts1 == nullptr) == (pts2 == nullptr));
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3(1), dim3(256), 0, st, q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand,
-                       pairs, pts1, pts2, n_pairs);
+    if (Q <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
+    const int nb = (Q + 255) / 256;                   // capacity launch: the kernels read the real count
+    void* tmp = nullptr;
+    int rc = scratch().get(21, ((size_t)nb + 1) * sizeof(int32_t), &tmp);
+    if (rc) return rc;
+    int32_t* bc = (int32_t*)tmp;
+    hipLaunchKernelGGL(gather_count_kernel, dim3(nb), dim3(256), 0, st, keep, n_cand, bc);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_pairs);
+    hipLaunchKernelGGL(gather_scatter_kernel, dim3(nb), dim3(256), 0, st, q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand,
+                       bc, pairs, pts1, pts2);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
