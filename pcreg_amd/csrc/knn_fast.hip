@@ -80,7 +80,9 @@ __global__ __launch_bounds__(kBlock) void prep_model_kernel(const float* __restr
                                                             unsigned* __restrict__ rm2_bits) {
     const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
     float mx = 0.0f;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
+    const int Mpad = (M + kMTile - 1) / kMTile * kMTile;   // whole LDS tiles; padding has w = +inf, never a candidate
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < Mpad; i += gridDim.x * kBlock) {
+        if (i >= M) { out[i] = make_float4(0.0f, 0.0f, 0.0f, INFINITY); continue; }
         float x = m[i] - cx, y = m[i + (size_t)ldm] - cy, z = m[i + 2 * (size_t)ldm] - cz;
         float w = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
         out[i] = make_float4(x, y, z, w);
@@ -93,14 +95,14 @@ __global__ __launch_bounds__(kBlock) void prep_model_kernel(const float* __restr
 
 template <int QPT_, int UB_, bool DRY = false>
 __global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
-    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk,
+    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk, int chunk_stride,
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr /*[Q] ordered-uint thresholds*/,
     int32_t* __restrict__ part_idx /*[S][Q][KC]*/, float* __restrict__ part_s) {
     __shared__ float4 tile[kMTile];
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x * (kBlock * QPT_);
     const int sidx = blockIdx.y;
-    const int m_begin = sidx * chunk, m_end = min(M, m_begin + chunk);
+    const int m_begin = min(M, sidx * chunk_stride), m_end = min(M, m_begin + chunk);
     const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
 
     float ax[QPT_], ay[QPT_], az[QPT_], thr[QPT_];
@@ -171,7 +173,189 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
 #pragma unroll
     for (int r = 0; r < QPT_; ++r) {
         int qi = q0 + r * kBlock + tid;
+        if (qi < Q && part_idx != nullptr) {          // the seeding pass only publishes thresholds
+            size_t o = ((size_t)sidx * Q + qi) * KC;
+            *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[r].i[0], cand[r].i[1], cand[r].i[2], cand[r].i[3]);
+            *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[r].s[0], cand[r].s[1], cand[r].s[2], cand[r].s[3]);
+        }
+    }
+}
+
+// ---- 2a'. the same kernel with LDS-DMA double buffering ------------------------------------
+// Tile t+1 is copied global -> LDS by `global_load_lds_dwordx4` (no VGPR staging: each wave
+// instruction lands 64 x 16 B contiguously) into the other buffer while tile t is scored;
+// one barrier per tile instead of two and the L2 latency disappears behind the arithmetic.
+// The prepared model is padded with w = +inf to a whole number of tiles, so no tail code.
+template <int QPT_, int UB_>
+__global__ __launch_bounds__(kBlock) void knn_candidates_dma_kernel(
+    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk, int chunk_stride,
+    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx, float* __restrict__ part_s) {
+    __shared__ __attribute__((aligned(16))) float4 tile[2][kMTile];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * (kBlock * QPT_);
+    const int sidx = blockIdx.y;
+    const int m_begin = min(M, sidx * chunk_stride), m_end = min(M, m_begin + chunk);
+    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
+
+    float ax[QPT_], ay[QPT_], az[QPT_], thr[QPT_];
+    unsigned gseen[QPT_];
+    Cand cand[QPT_];
+#pragma unroll
+    for (int r = 0; r < QPT_; ++r) {
+        int qi = q0 + r * kBlock + tid;
+        bool ok = qi < Q;
+        float x = ok ? q[qi] - cx : 0.0f, y = ok ? q[qi + (size_t)ldq] - cy : 0.0f, z = ok ? q[qi + 2 * (size_t)ldq] - cz : 0.0f;
+        ax[r] = -2.0f * x; ay[r] = -2.0f * y; az[r] = -2.0f * z;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { cand[r].s[k] = INFINITY; cand[r].i[k] = -1; }
+        thr[r] = INFINITY; gseen[r] = 0xFFFFFFFFu;
+    }
+    // wave w copies the 1-KiB segments w, w+4, w+8, w+12 of a 16-KiB tile
+    auto dma_tile = [&](int t0, int buf) {
+#pragma unroll
+        for (int k = 0; k < kMTile / kBlock; ++k) {
+            const int seg = k * (kBlock / 64) + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mp + t0 + seg * 64 + lane),
+                                             (__attribute__((address_space(3))) void*)(&tile[buf][seg * 64]), 16, 0, 0);
+        }
+    };
+    const int ntile = (m_end - m_begin + kMTile - 1) / kMTile;
+    if (ntile > 0) dma_tile(m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int t0 = m_begin + t * kMTile;
+        if (t + 1 < ntile) dma_tile(t0 + kMTile, (t + 1) & 1);
+#pragma unroll
+        for (int r = 0; r < QPT_; ++r) {
+            int qi = q0 + r * kBlock + tid;
+            if (qi < Q) {
+                if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
+                unsigned g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gseen[r] = g;
+                thr[r] = fminf(cand[r].s[3], ord2f(g));
+            }
+        }
+        const float4* cur = tile[t & 1];
+        const int cnt = min(kMTile, m_end - t0);
+        const int nb = (cnt + UB_ - 1) / UB_ * UB_;
+        for (int jb = 0; jb < nb; jb += UB_) {
+            float4 p[UB_];
+#pragma unroll
+            for (int u = 0; u < UB_; ++u) p[u] = cur[jb + u];
+#pragma unroll
+            for (int r = 0; r < QPT_; ++r) {
+                float s[UB_];
+#pragma unroll
+                for (int u = 0; u < UB_; ++u)
+                    s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, p[u].w)));
+                float mn = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+                if (UB_ == 8) mn = fminf(mn, fminf(fminf(s[4 % UB_], s[5 % UB_]), fminf(s[6 % UB_], s[7 % UB_])));
+                if (mn < thr[r]) {
+                    const int j0 = t0 + jb;
+#pragma unroll
+                    for (int u = 0; u < UB_; ++u) if (s[u] < thr[r] && j0 + u < m_end) cand_insert(cand[r], s[u], j0 + u);
+                    thr[r] = fminf(thr[r], cand[r].s[3]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < QPT_; ++r) {
+        int qi = q0 + r * kBlock + tid;
         if (qi < Q) {
+            if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
+            if (part_idx != nullptr) {
+                size_t o = ((size_t)sidx * Q + qi) * KC;
+                *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[r].i[0], cand[r].i[1], cand[r].i[2], cand[r].i[3]);
+                *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[r].s[0], cand[r].s[1], cand[r].s[2], cand[r].s[3]);
+            }
+        }
+    }
+}
+
+// ---- 2c. candidate generation with the model in SCALAR registers ------------------------
+// The model point of a batch is the same for every lane, so it does not need LDS (or VGPRs)
+// at all: the prepared float4 stream is read with s_load_dwordx8 through the scalar cache and
+// used as the SGPR operand of the FMAs (one SGPR per VOP3 on gfx9: |m~|^2 goes through one
+// v_mov per point, shared by the lane's QPT queries).  No LDS, no barriers, ~35 fewer VGPRs
+// than the LDS-tiled kernel -> more waves per SIMD.  The next batch is requested before the
+// current one is consumed (scalar loads return out of order; one s_waitcnt per batch).
+template <int QPT_>
+__global__ __launch_bounds__(kBlock) void knn_candidates_sgpr_kernel(
+    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk,
+    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx, float* __restrict__ part_s) {
+    constexpr int UB = 8;
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * (kBlock * QPT_);
+    const int sidx = blockIdx.y;
+    const int m_begin = min(M, sidx * chunk), m_end = min(M, m_begin + chunk);
+    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
+
+    float ax[QPT_], ay[QPT_], az[QPT_], thr[QPT_];
+    unsigned gseen[QPT_];
+    Cand cand[QPT_];
+#pragma unroll
+    for (int r = 0; r < QPT_; ++r) {
+        int qi = q0 + r * kBlock + tid;
+        bool ok = qi < Q;
+        float x = ok ? q[qi] - cx : 0.0f, y = ok ? q[qi + (size_t)ldq] - cy : 0.0f, z = ok ? q[qi + 2 * (size_t)ldq] - cz : 0.0f;
+        ax[r] = -2.0f * x; ay[r] = -2.0f * y; az[r] = -2.0f * z;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { cand[r].s[k] = INFINITY; cand[r].i[k] = -1; }
+        thr[r] = INFINITY; gseen[r] = 0xFFFFFFFFu;
+    }
+    // the prepared array is padded to a multiple of 16 points with w = +inf, so whole batches
+    // can be read past m_end without a tail loop (a padded point is never a candidate)
+    const int nb = (m_end - m_begin + UB - 1) / UB;
+    float4 pn[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) pn[u] = mp[m_begin + u];
+    for (int b = 0; b < nb; ++b) {
+        const int j0 = m_begin + b * UB;
+        float4 p[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) p[u] = pn[u];
+        if (b + 1 < nb) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) pn[u] = mp[j0 + UB + u];
+        }
+        if ((b & 127) == 0) {      // every 1024 points: exchange thresholds with the other chunks
+#pragma unroll
+            for (int r = 0; r < QPT_; ++r) {
+                int qi = q0 + r * kBlock + tid;
+                if (qi < Q) {
+                    if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
+                    unsigned g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gseen[r] = g;
+                    thr[r] = fminf(cand[r].s[3], ord2f(g));
+                }
+            }
+        }
+        float w[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) w[u] = (j0 + u < m_end) ? p[u].w : INFINITY;
+#pragma unroll
+        for (int r = 0; r < QPT_; ++r) {
+            float s[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, w[u])));
+            float mn = fminf(fminf(fminf(s[0], s[1]), fminf(s[2], s[3])), fminf(fminf(s[4], s[5]), fminf(s[6], s[7])));
+            if (mn < thr[r]) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) if (s[u] < thr[r]) cand_insert(cand[r], s[u], j0 + u);
+                thr[r] = fminf(thr[r], cand[r].s[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QPT_; ++r) {
+        int qi = q0 + r * kBlock + tid;
+        if (qi < Q) {
+            if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
             size_t o = ((size_t)sidx * Q + qi) * KC;
             *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[r].i[0], cand[r].i[1], cand[r].i[2], cand[r].i[3]);
             *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[r].s[0], cand[r].s[1], cand[r].s[2], cand[r].s[3]);
@@ -330,7 +514,7 @@ size_t knn2_points_exact_workspace_bytes(int Q, int M);
 //                   | part_idx [S][Q][kc] | part_s | exact-kernel workspace (fallback)
 static constexpr int kPartCap = 40;           // upper bound of S * kc / 16 any variant may use (x16 entries per query)
 static size_t fast_fixed_bytes(int Q, int M) {
-    size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + 16;
+    size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
     return 256 + 256 + 256 + align_up(512 * 6 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
            align_up(mm * 16, 256) + 2 * align_up((size_t)kPartCap * 16 * q * 4, 256);
 }
@@ -354,7 +538,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     static const int target_env = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : 0;
     static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 0;
     const bool use_mfma = variant >= 5 && variant < 10;
-    size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1) + 16;
+    size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
     char* w = (char*)ws;
     Prep* prep = (Prep*)w;                 w += 256;
     unsigned* rm2 = (unsigned*)w;          w += 256;
@@ -393,23 +577,40 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
             if (rc) return rc;
         }
     } else {
-        const int qpt = variant == 12 ? 8 : (variant == 13 ? 2 : 4);
+        const int qpt = (variant == 12 || variant == 21) ? 8 : ((variant == 13 || variant == 22) ? 2 : ((variant == 15 || variant == 16 || variant == 32) ? 3 : 4));
         int n_qt = (Q + kBlock * qpt - 1) / (kBlock * qpt);
         S = pick_splits_fast(n_qt, M > 0 ? M : 1, target_env > 0 ? target_env : 4096);
         if (S > kPartCap * 4) S = kPartCap * 4;
         int chunk = (((M > 0 ? M : 1) + S - 1) / S + kMTile - 1) / kMTile * kMTile;
         S = M > 0 ? (M + chunk - 1) / chunk : 1;
         if (M > 0) {
-            int pb = (M + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
+            int pb = (M + kMTile + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
             hipLaunchKernelGGL(prep_model_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, prep, (float4*)mprep, rm2);
         }
+        // seeding pass: 8 slices of 256 points spread over the shard give every query a first
+        // threshold (~0.2 % of the pairs), so the main grid's workgroups do not all start from
+        // +inf and pay the insertion path on their whole first tile.  A skipped point always
+        // has s >= the word it was compared with, so the certificate is unaffected.
+        if (M >= 64 * 1024 && variant != 14 && variant < 20) {
+            const int seeds = 8, slen = 256;
+            hipLaunchKernelGGL((knn_candidates_kernel<4, 8>), dim3((Q + kBlock * 4 - 1) / (kBlock * 4), seeds), dim3(kBlock), 0, st,
+                               q, Q, ldq, (const float4*)mprep, M, slen, M / seeds, prep, gthr, (int32_t*)nullptr, (float*)nullptr);
+        }
         dim3 grid(n_qt, S);
-#define PCREG_CAND_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn_candidates_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s)
+#define PCREG_CAND_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn_candidates_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s)
         switch (variant) {
+            case 20: hipLaunchKernelGGL((knn_candidates_sgpr_kernel<4>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
+            case 21: hipLaunchKernelGGL((knn_candidates_sgpr_kernel<8>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
+            case 22: hipLaunchKernelGGL((knn_candidates_sgpr_kernel<2>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
+            case 30: hipLaunchKernelGGL((knn_candidates_dma_kernel<4, 8>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
+            case 31: hipLaunchKernelGGL((knn_candidates_dma_kernel<4, 4>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
+            case 32: hipLaunchKernelGGL((knn_candidates_dma_kernel<3, 4>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
+            case 15: PCREG_CAND_LAUNCH(3, 4); break;
+            case 16: PCREG_CAND_LAUNCH(3, 8); break;
             case 11: PCREG_CAND_LAUNCH(4, 4); break;
             case 12: PCREG_CAND_LAUNCH(8, 8); break;
             case 13: PCREG_CAND_LAUNCH(2, 8); break;
-            case 19: hipLaunchKernelGGL((knn_candidates_kernel<4, 8, true>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
+            case 19: hipLaunchKernelGGL((knn_candidates_kernel<4, 8, true>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
             default: PCREG_CAND_LAUNCH(4, 8); break;
         }
 #undef PCREG_CAND_LAUNCH
