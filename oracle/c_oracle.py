@@ -162,6 +162,31 @@ def getMatches(descSurface, descModel, par: dict, nthreads=0):
     return pairs[:P].copy()
 
 
+class DescOpts(C.Structure):
+    _fields_ = [("min_pts", C.c_int32), ("max_pts", C.c_int32), ("R", C.c_double), ("thVar", C.c_double * 2),
+                ("k", C.c_double), ("ALIGN_POINTS", C.c_int32)]
+
+
+def desc_opts(options: dict) -> DescOpts:
+    k = options["k"]
+    kf = 1.0 if (k == "all" or k == 1) else float(k)
+    mx = options["max_pts"]
+    mx = 2**31 - 1 if (mx == float("inf") or mx > 2**31 - 1) else int(mx)
+    return DescOpts(int(options["min_pts"]), mx, float(options["R"]), (C.c_double * 2)(*[float(v) for v in options["thVar"]]),
+                    kf, int(bool(options["ALIGN_POINTS"])))
+
+
+def getSpacialHistogramDescriptors(pts, sample_pts, options: dict, nthreads=0):
+    p, k = _f(pts), _f(sample_pts)
+    P, S = p.shape[0], k.shape[0]
+    feat = np.zeros((max(S, 1), 3)); desc = np.zeros((max(S, 1), 980))
+    o = desc_opts(options)
+    lib().orc_spatial_histogram_descriptors.restype = C.c_int
+    V = lib().orc_spatial_histogram_descriptors(_p(p), C.c_int(P), C.c_int(P), _p(k), C.c_int(S), C.c_int(S), C.byref(o),
+                                                _p(feat), _p(desc), C.c_int(nthreads))
+    return feat[:V].copy(), desc[:V].copy()
+
+
 def AlignPoints_KNN(pts, C1=False, C2=False):
     p = _f(pts)
     n = p.shape[0]

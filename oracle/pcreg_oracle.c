@@ -11,6 +11,8 @@
  *   orc_match_features       getMatches.m:51-56 -> MathWorks matchFeatures (documented
  *                            semantics; closed source, un-vendored: PARITY UNPINNED)
  *   orc_align_points_knn     AlignPoints_KNN.m:8-59 -> MathWorks pca (PARITY UNPINNED)
+ *   orc_spatial_histogram_descriptors  getSpacialHistogramDescriptors.m:18-179,
+ *                            getLocalPoints.m:8-35, histcn.m:94-131
  *
  * Pinning: MATLAB cannot run here.  This file is pinned (tests/test_oracle_kat.py)
  * against the known answers in the reference's own test scripts
@@ -551,4 +553,119 @@ int orc_align_points_knn(const double* pts, int n, int ld, int C1, int C2,
     }
     for (int r = 0; r < 3; ++r) for (int col = 0; col < 3; ++col) coeff_out[r + 3*col] = cu[r*3+col];
     return 0;
+}
+
+/* ------------------------------------------- getSpacialHistogramDescriptors (cfg 4) */
+#define ORC_NR 10
+#define ORC_NT 7
+#define ORC_NP 14
+static int hist_loc(double x, const double* e, int ne) {   /* histcounts bin, 1-based, 0 = outside / NaN */
+    if (!(x >= e[0]) || !(x <= e[ne - 1])) return 0;
+    if (x == e[ne - 1]) return ne - 1;
+    int k = 1; while (k < ne && x >= e[k]) ++k;            /* e[k-1] <= x < e[k] */
+    return k;
+}
+static int desc_one(const double* pts, int P, int ld, const double c[3], const orc_desc_opts* o,
+                    const double* rb, const double* tb, const double* pb, double* out /*980*/) {
+    const double R = o->R;
+    /* getLocalPoints.m:8-35: open box, then dists < R, min <= n <= max; points relative to c */
+    int cap = 1024, n = 0;
+    double* L = (double*)malloc(sizeof(double) * 3 * cap);
+    for (int i = 0; i < P; ++i) {
+        double x = pts[i], y = pts[i + (size_t)ld], z = pts[i + 2*(size_t)ld];
+        if (!(x > c[0] - R && x < c[0] + R && y > c[1] - R && y < c[1] + R && z > c[2] - R && z < c[2] + R)) continue;
+        double dx = x - c[0], dy = y - c[1], dz = z - c[2];
+        if (!(sqrt(dx*dx + dy*dy + dz*dz) < R)) continue;
+        if (n == cap) { cap *= 2; L = (double*)realloc(L, sizeof(double) * 3 * cap); }
+        L[3*n] = dx; L[3*n+1] = dy; L[3*n+2] = dz; ++n;
+    }
+    int ok = 0;
+    if (n >= 1 && n >= o->min_pts && n <= o->max_pts) {
+        int k = n;
+        if (!(o->k >= 1.0)) {                                                 /* :75-84 */
+            k = orc_matlab_round(n * o->k);
+            double cen[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) { double s = 0; for (int i = 0; i < n; ++i) s += L[3*i+a]; cen[a] = s / n; }
+            di_t* ord = (di_t*)malloc(sizeof(di_t) * (size_t)n);
+            for (int i = 0; i < n; ++i) { double x = L[3*i]-cen[0], y = L[3*i+1]-cen[1], z = L[3*i+2]-cen[2]; ord[i].d = sqrt(x*x+y*y+z*z); ord[i].i = i; }
+            qsort(ord, (size_t)n, sizeof(di_t), cmp_di);
+            double* S = (double*)malloc(sizeof(double) * 3 * (size_t)n);
+            for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) S[3*i+a] = L[3*ord[i].i+a];
+            memcpy(L, S, sizeof(double) * 3 * (size_t)n); free(S); free(ord);
+        }
+        if (k >= 2) {
+            double mu[3], C[9], V[9];                                         /* pca(pts_k,'eig'), :91 */
+            for (int a = 0; a < 3; ++a) { double s = 0; for (int i = 0; i < k; ++i) s += L[3*i+a]; mu[a] = s / k; }
+            for (int a = 0; a < 3; ++a) for (int b = a; b < 3; ++b) {
+                double s = 0; for (int i = 0; i < k; ++i) s += (L[3*i+a]-mu[a]) * (L[3*i+b]-mu[b]);
+                C[a*3+b] = C[b*3+a] = s / (double)(k - 1);
+            }
+            jacobi_eig3(C, V);
+            int od[3] = {0, 1, 2};
+            for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b) if (C[od[b]*3+od[b]] > C[od[a]*3+od[a]]) { int t = od[a]; od[a] = od[b]; od[b] = t; }
+            double var[3] = { C[od[0]*3+od[0]], C[od[1]*3+od[1]], C[od[2]*3+od[2]] };
+            if (!(var[0] / var[1] < o->thVar[0]) && !(var[1] / var[2] < o->thVar[1])) {   /* :118-121 */
+                double co[9];
+                for (int col = 0; col < 3; ++col) {
+                    int src = od[col], mi = 0;
+                    for (int r = 1; r < 3; ++r) if (fabs(V[r*3+src]) > fabs(V[mi*3+src])) mi = r;
+                    double sg = V[mi*3+src] < 0 ? -1.0 : 1.0;
+                    for (int r = 0; r < 3; ++r) co[r*3+col] = sg * V[r*3+src];
+                }
+                double cu[9] = {1,0,0, 0,1,0, 0,0,1};
+                if (o->ALIGN_POINTS) {                                        /* :128-145, vote over k rows */
+                    int px = 0, pz = 0;
+                    for (int i = 0; i < k; ++i) {
+                        double x = L[3*i]-mu[0], y = L[3*i+1]-mu[1], z = L[3*i+2]-mu[2];
+                        px += (x*co[0] + y*co[3] + z*co[6]) > 0; pz += (x*co[2] + y*co[5] + z*co[8]) > 0;
+                    }
+                    double xs = (2.0*px >= (double)k) ? 1.0 : -1.0, zs = (2.0*pz >= (double)k) ? 1.0 : -1.0;
+                    double M[9]; for (int r = 0; r < 3; ++r) { M[r*3] = co[r*3]*xs; M[r*3+1] = co[r*3+1]; M[r*3+2] = co[r*3+2]*zs; }
+                    double ys = M[0]*(M[4]*M[8]-M[5]*M[7]) - M[1]*(M[3]*M[8]-M[5]*M[6]) + M[2]*(M[3]*M[7]-M[4]*M[6]);
+                    for (int r = 0; r < 3; ++r) { cu[r*3] = co[r*3]*xs; cu[r*3+1] = co[r*3+1]*ys; cu[r*3+2] = co[r*3+2]*zs; }
+                }
+                for (int b = 0; b < ORC_NR*ORC_NT*ORC_NP; ++b) out[b] = 0.0;
+                for (int i = 0; i < n; ++i) {                                 /* :150-171 */
+                    double x0 = L[3*i], y0 = L[3*i+1], z0 = L[3*i+2], x = x0, y = y0, z = z0;
+                    if (o->ALIGN_POINTS) { x = x0*cu[0] + y0*cu[3] + z0*cu[6]; y = x0*cu[1] + y0*cu[4] + z0*cu[7]; z = x0*cu[2] + y0*cu[5] + z0*cu[8]; }
+                    double r = sqrt(x*x + y*y + z*z), th = acos(z / r), ph = atan2(y, y);
+                    int lr = hist_loc(r, rb, ORC_NR+1), lt = hist_loc(th, tb, ORC_NT+1), lp = hist_loc(ph, pb, ORC_NP+1);
+                    if (lr > 0 && lt > 0 && lp > 0) out[(lr-1) + ORC_NR*(lt-1) + ORC_NR*ORC_NT*(lp-1)] += 1.0;
+                }
+                ok = 1;
+            }
+        }
+    }
+    free(L);
+    return ok;
+}
+
+int orc_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk,
+                                      const orc_desc_opts* o, double* feat, double* desc, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    const int ND = ORC_NR*ORC_NT*ORC_NP;
+    double rb[ORC_NR+1], tb[ORC_NT+1], pb[ORC_NP+1];
+    const double r3 = o->R * o->R * o->R, pi = 3.14159265358979323846;
+    for (int k = 0; k <= ORC_NR; ++k) rb[k] = cbrt(k * (r3 / ORC_NR));
+    for (int k = 0; k <= ORC_NT; ++k) tb[k] = k * (pi / ORC_NT);
+    for (int k = 0; k <= ORC_NP; ++k) pb[k] = -pi + k * (2 * pi / ORC_NP);
+    char* valid = (char*)calloc((size_t)(S > 0 ? S : 1), 1);
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)ND * (size_t)(S > 0 ? S : 1));
+    #pragma omp parallel for schedule(dynamic, 4)
+    for (int s = 0; s < S; ++s) {
+        double c[3] = { kp[s], kp[s + (size_t)ldk], kp[s + 2*(size_t)ldk] };
+        valid[s] = (char)desc_one(pts, P, ld, c, o, rb, tb, pb, tmp + (size_t)s * ND);
+    }
+    int V = 0;
+    for (int s = 0; s < S; ++s) if (valid[s]) {                               /* :177-179 */
+        for (int a = 0; a < 3; ++a) feat[3*(size_t)V + a] = kp[s + (size_t)a*ldk];
+        memcpy(desc + (size_t)V * ND, tmp + (size_t)s * ND, sizeof(double) * ND);
+        ++V;
+    }
+    free(valid); free(tmp);
+    return V;
 }

@@ -68,6 +68,18 @@ int  orc_match_features(const double* fS, int Q, int ldS, const double* fM, int 
 int  orc_get_matches(const double* dS, int Q, int ldS, const double* dM, int M, int ldM, int D,
                      const orc_match_opts* o, uint32_t* pairs, double* metric, int nthreads);
 
+typedef struct {
+    int32_t min_pts;      /* options.min_pts                                             */
+    int32_t max_pts;      /* options.max_pts (INT32_MAX for inf)                         */
+    double  R;            /* options.R                                                   */
+    double  thVar[2];     /* options.thVar                                               */
+    double  k;            /* options.k: fraction in (0,1); 1 (or 'all' -> 1) = all points */
+    int32_t ALIGN_POINTS; /* options.ALIGN_POINTS                                        */
+} orc_desc_opts;
+/* getSpacialHistogramDescriptors: feat [V][3] and desc [V][980] ROW-major, returns V. */
+int  orc_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk,
+                                       const orc_desc_opts* o, double* feat, double* desc, int nthreads);
+
 int  orc_align_points_knn(const double* pts, int n, int ld, int C1, int C2,
                           double* aligned /* n x 3, ld n */, double coeff[9] /* col-major */,
                           double c[3]);

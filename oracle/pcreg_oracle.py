@@ -46,6 +46,7 @@ __all__ = [
     "ransac", "getInliersRANSAC", "quickTF", "invertTF", "sample_table",
     "matchFeatures", "getMatches", "preprocess_descriptors", "pca_eig",
     "AlignPoints_KNN", "getLocalPoints", "knn2_points_f32", "match_points_f32",
+    "histogram_edges", "histcounts_loc", "getSpacialHistogramDescriptors",
 ]
 
 
@@ -455,6 +456,84 @@ def getLocalPoints(pts, R, c, min_points, max_points):
     if k.sum() < min_points or k.sum() > max_points:            # :31
         return None, None
     return rel[k], d[k]
+
+
+# ------------------------------------------------- getSpacialHistogramDescriptors (cfg 4)
+NUM_R, NUM_THETA, NUM_PHI = 10, 7, 14          # getSpacialHistogramDescriptors.m:38-40
+
+
+def histogram_edges(R: float):
+    """Bin edges of getSpacialHistogramDescriptors.m:155-158 as a + k*step (the colon
+    operator's rounding of the interior edges is not reproducible here; only points
+    lying exactly on an edge could tell the difference)."""
+    r3 = float(R) ** 3
+    r_bins = np.cbrt(np.array([k * (r3 / NUM_R) for k in range(NUM_R + 1)]))            # nthroot(0:R^3/10:R^3, 3)
+    theta_bins = np.array([k * (math.pi / NUM_THETA) for k in range(NUM_THETA + 1)])     # 0:pi/7:pi
+    phi_bins = np.array([-math.pi + k * (2 * math.pi / NUM_PHI) for k in range(NUM_PHI + 1)])   # -pi:2pi/14:pi
+    return r_bins, theta_bins, phi_bins
+
+
+def histcounts_loc(x: np.ndarray, edges: np.ndarray) -> np.ndarray:
+    """Bin index (1-based, 0 = outside/NaN) as MATLAB histcounts returns it to histcn.m:108:
+    edges(k) <= x < edges(k+1), the last bin also contains x == edges(end)."""
+    x = np.asarray(x, dtype=np.float64)
+    loc = np.searchsorted(edges, x, side="right")
+    loc = np.where(x == edges[-1], len(edges) - 1, loc)
+    bad = np.isnan(x) | (x < edges[0]) | (x > edges[-1])
+    return np.where(bad, 0, loc).astype(np.int64)
+
+
+def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
+    """getSpacialHistogramDescriptors.m:18-179 (+ histcn.m:94-131) -> (feat V x 3, desc V x 980).
+
+    Restated quirks: the LRF sign vote uses k = K rows (:125,129-130); phi = atan2(y, y)
+    (:152); NORMALIZE and LOCAL_PCA are hard-wired off (:31-32); points with r == 0 give
+    NaN angles and are dropped by histcn.  Deviation: a support whose K nearest points are
+    fewer than 2 is skipped (the reference would index an empty `variances`)."""
+    pts = np.asarray(pts, dtype=np.float64)
+    sample_pts = np.asarray(sample_pts, dtype=np.float64)
+    min_pts, max_pts = options["min_pts"], options["max_pts"]                   # :18-19
+    R, thVar, K, ALIGN = float(options["R"]), options["thVar"], options["k"], bool(options["ALIGN_POINTS"])
+    r_bins, theta_bins, phi_bins = histogram_edges(R)
+    feat, desc = [], []
+    for c in sample_pts:                                                        # :48-54 and :64-174 fused
+        pts_local, _ = getLocalPoints(pts, R, c, min_pts, max_pts)              # :50, :68
+        if pts_local is None or pts_local.shape[0] == 0:
+            continue
+        n = pts_local.shape[0]                                                  # :71
+        if K == "all" or K == 1:                                                # :75-76
+            k = n
+        else:
+            k = matlab_round(n * K)                                             # :78
+            centroid = pts_local.mean(axis=0)                                   # :80
+            d = np.sqrt(np.sum((pts_local - centroid) ** 2, axis=1))            # :81
+            pts_local = pts_local[np.argsort(d, kind="stable")]                 # :82-83
+        if k < 2:
+            continue
+        pts_k = pts_local[:k]                                                   # :85
+        coeff, pts_lrf, variances = pca_eig(pts_k)                              # :91
+        if variances[0] / variances[1] < thVar[0] or variances[1] / variances[2] < thVar[1]:   # :118-121
+            continue
+        kk = pts_lrf.shape[0]                                                   # :125
+        if ALIGN:                                                               # :128-145
+            x_sign = 1.0 if np.sum(pts_lrf[:, 0] > 0) >= kk / 2 else -1.0
+            z_sign = 1.0 if np.sum(pts_lrf[:, 2] > 0) >= kk / 2 else -1.0
+            y_sign = float(np.linalg.det(coeff * np.array([x_sign, 1.0, z_sign])))
+            pts_local = pts_local @ (coeff * np.array([x_sign, y_sign, z_sign]))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            r = np.sqrt(np.sum(pts_local * pts_local, axis=1))                  # :150
+            theta = np.arccos(pts_local[:, 2] / r)                              # :151
+            phi = np.arctan2(pts_local[:, 1], pts_local[:, 1])                  # :152 (sic)
+        lr, lt, lp = histcounts_loc(r, r_bins), histcounts_loc(theta, theta_bins), histcounts_loc(phi, phi_bins)
+        ok = (lr > 0) & (lt > 0) & (lp > 0)                                     # histcn.m:126
+        counts = np.zeros(NUM_R * NUM_THETA * NUM_PHI)
+        flat = (lr[ok] - 1) + NUM_R * (lt[ok] - 1) + NUM_R * NUM_THETA * (lp[ok] - 1)   # column-major reshape (:164)
+        np.add.at(counts, flat, 1.0)
+        desc.append(counts)                                                     # :171
+        feat.append(c)                                                          # :172
+    if not feat:
+        return np.zeros((0, 3)), np.zeros((0, NUM_R * NUM_THETA * NUM_PHI))
+    return np.array(feat), np.array(desc)
 
 
 # --------------------------------------------- fp32 point KNN (the bench's D=3 search)
