@@ -150,6 +150,27 @@ int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const i
                                    int B, int C1, int C2, double* aligned, double* coeff,
                                    double* c, int32_t* status);
 
+/* `options` of getSpacialHistogramDescriptors.m:18-27 (completeExperimentFast.m:299-304). */
+typedef struct pcreg_desc_opts {
+    int32_t min_pts;       /* options.min_pts                                            */
+    int32_t max_pts;       /* options.max_pts (INT32_MAX for inf)                        */
+    double  R;             /* options.R: support radius                                  */
+    double  thVar[2];      /* options.thVar: eigenvalue-ratio rejection thresholds       */
+    double  k;             /* options.k: fraction of nearest points used for the LRF;
+                              >= 1 means 'all'                                           */
+    int32_t ALIGN_POINTS;  /* options.ALIGN_POINTS                                       */
+} pcreg_desc_opts;
+#define PCREG_DESC_LEN 980   /* NUM_R*NUM_THETA*NUM_PHI = 10*7*14, getSpacialHistogramDescriptors.m:38-40 */
+
+/* getSpacialHistogramDescriptors.m:2  [feat, desc] = getSpacialHistogramDescriptors(pts,
+ * sample_pts, options) (with getLocalPoints.m and histcn.m folded in).  pts: P x 3,
+ * sample_pts: S x 3 (column-major).  Outputs are ROW-major with capacity S rows:
+ * feat [V][3], desc [V][980] (counts, r fastest / then theta / then phi, i.e. MATLAB's
+ * reshape(counts,[],1)); *V = number of surviving keypoints, in input order.
+ * The O(S*P) brute-force radius search of the reference is replaced by a uniform grid. */
+int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                        const pcreg_desc_opts* options, double* feat, double* desc, int* V);
+
 /* ---- device tier ------------------------------------------------------------------
  * All pointers are device memory on the current device; `stream` is a hipStream_t.
  * Workspaces are caller-owned device buffers; query the size first. */

@@ -79,6 +79,19 @@ def main():
             al, co, c = o.AlignPoints_KNN(X, bool(C1), bool(C2))
             out[f"aligned_{C1}{C2}"] = al; out[f"coeff_{C1}{C2}"] = co; out[f"c_{C1}{C2}"] = c
     np.savez_compressed(os.path.join(OUT, "align_points_knn.npz"), pts=X, **out)
+    # --- getSpacialHistogramDescriptors (ridge-like strips so supports pass the variance test)
+    per = 2000
+    strips = []
+    for s in range(8):
+        x = rng.uniform(0, 60, per); y = 6 * s + rng.uniform(-1.2, 1.2, per); z = 10 + 0.1 * x * np.sin(s) + rng.normal(0, 0.25, per)
+        strips.append(np.column_stack([x, y, z]))
+    cloud = np.vstack(strips)
+    kp = np.column_stack([rng.uniform(5, 55, 40), 6 * rng.integers(0, 8, 40) + rng.uniform(-1.5, 1.5, 40), rng.uniform(9, 16, 40)])
+    opt = dict(min_pts=60, max_pts=6000, R=3.5, thVar=[3, 1.5], k=0.85, ALIGN_POINTS=True)
+    f, d = o.getSpacialHistogramDescriptors(cloud, kp, opt)
+    f2, d2 = o.getSpacialHistogramDescriptors(cloud, kp, dict(opt, ALIGN_POINTS=False))
+    np.savez_compressed(os.path.join(OUT, "descriptors.npz"), pts=cloud, sample_pts=kp, feat=f, desc=d.astype(np.uint16),
+                        feat_noalign=f2, desc_noalign=d2.astype(np.uint16))
     print("wrote", sorted(os.listdir(OUT)))
 
 

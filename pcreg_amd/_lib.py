@@ -35,6 +35,12 @@ class MatchOpts(C.Structure):
                 ("norm_factor", C.c_double), ("change_metric", C.c_int32), ("metric_factor", C.c_double)]
 
 
+class DescOpts(C.Structure):
+    """pcreg_desc_opts (include/pcreg.h) == `options` of getSpacialHistogramDescriptors.m."""
+    _fields_ = [("min_pts", C.c_int32), ("max_pts", C.c_int32), ("R", C.c_double), ("thVar", C.c_double * 2),
+                ("k", C.c_double), ("ALIGN_POINTS", C.c_int32)]
+
+
 class DevRansacResult(C.Structure):
     """pcreg_dev_ransac_result (include/pcreg.h)."""
     _fields_ = [("T", C.c_double * 16), ("n_inliers", C.c_int32), ("num_success", C.c_int32),
@@ -46,7 +52,7 @@ SYMBOLS = [
     "pcreg_last_error", "pcreg_version", "pcreg_device_count", "pcreg_set_device", "pcreg_device_name",
     "pcreg_estimate_transform", "pcreg_calc_dists", "pcreg_ransac", "pcreg_ransac_batched",
     "pcreg_knn2_points_f32", "pcreg_match_points_f32", "pcreg_match_features", "pcreg_get_matches",
-    "pcreg_align_points_knn", "pcreg_align_points_knn_batched",
+    "pcreg_align_points_knn", "pcreg_align_points_knn_batched", "pcreg_spatial_histogram_descriptors",
     "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32",
     "pcreg_dev_filter_top2_f32", "pcreg_dev_unique_points_f32_workspace", "pcreg_dev_unique_points_f32",
     "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",

@@ -20,7 +20,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MatchOpts, RansacOpts, check, lib
+from ._lib import DescOpts, MatchOpts, RansacOpts, check, lib
 
 EMPTY = np.zeros((0, 0))
 """MATLAB's ``[]`` (what estimateTransform / ransac return on failure)."""
@@ -363,6 +363,35 @@ def AlignPoints_KNN_batched(pts_list, C1: bool = False, C2: bool = False):
                                                _ptr(coeff, C.c_double), _ptr(c, C.c_double), _ptr(status, C.c_int32)))
     al = [np.ascontiguousarray(aligned[offsets[b]:offsets[b + 1]]) for b in range(B)]
     return al, coeff.reshape(B, 3, 3).transpose(0, 2, 1).copy(), c.reshape(B, 3), status
+
+
+# ------------------------------------------------------- getSpacialHistogramDescriptors
+def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
+    """[feat, desc] = getSpacialHistogramDescriptors(pts, sample_pts, options)
+    (getSpacialHistogramDescriptors.m:2-183): feat V x 3 keypoint locations, desc V x 980
+    spherical count histograms of the surviving keypoints, in input order."""
+    for k in ("min_pts", "max_pts", "R", "thVar", "k", "ALIGN_POINTS"):        # :18-23
+        if k not in options:
+            raise KeyError(f"options.{k} is required (getSpacialHistogramDescriptors.m:18-23)")
+    import time
+    t0 = time.time()
+    p, s = _pts3(pts, "pts"), _pts3(sample_pts, "sample_pts")
+    P, S = p.shape[0], s.shape[0]
+    kk = options["k"]
+    kf = 1.0 if (isinstance(kk, str) and kk == "all") or kk == 1 else float(kk)      # :75
+    mx = options["max_pts"]
+    mx = 2**31 - 1 if (mx == float("inf") or mx > 2**31 - 1) else int(mx)
+    o = DescOpts(int(options["min_pts"]), mx, float(options["R"]), (C.c_double * 2)(*[float(v) for v in options["thVar"]]),
+                 kf, int(bool(options["ALIGN_POINTS"])))
+    feat = np.zeros((max(S, 1), 3))
+    desc = np.zeros((max(S, 1), 980))
+    V = C.c_int(0)
+    check(lib().pcreg_spatial_histogram_descriptors(_ptr(p, C.c_double), C.c_int(P), C.c_int(P), _ptr(s, C.c_double),
+                                                    C.c_int(S), C.c_int(S), C.byref(o), _ptr(feat, C.c_double),
+                                                    _ptr(desc, C.c_double), C.byref(V)))
+    if options.get("VERBOSE", 1):
+        print("Calculated descriptors in %0.1f seconds..." % (time.time() - t0))       # :181
+    return feat[:V.value].copy(), desc[:V.value].copy()
 
 
 # ----------------------------------------------------------------- transform helpers

@@ -390,6 +390,36 @@ int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2, dou
     return PCREG_OK;
 }
 
+int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                        const pcreg_desc_opts* options, double* feat, double* desc, int* V) {
+    PCREG_ARG(pts && sample_pts && options && feat && desc && V && P >= 0 && S >= 0 && ld >= P && lds >= S);
+    GUARD();
+    *V = 0;
+    if (P == 0 || S == 0) return PCREG_OK;
+    void *dp, *dk, *dfeat, *ddesc, *dcnt, *ws;
+    size_t wsb = descriptors_workspace_bytes(P, S);
+    TRY(scratch().get(0, sizeof(double) * 3 * (size_t)P, &dp));
+    TRY(scratch().get(1, sizeof(double) * 3 * (size_t)S, &dk));
+    TRY(scratch().get(2, sizeof(double) * 3 * (size_t)S, &dfeat));
+    TRY(scratch().get(3, sizeof(double) * PCREG_DESC_LEN * (size_t)S, &ddesc));
+    TRY(scratch().get(4, 256, &dcnt));
+    TRY(scratch().get(5, wsb, &ws));
+    int32_t* dV = (int32_t*)dcnt; int32_t* dErr = dV + 1;
+    TRY(upload_cols(pts, P, ld, 3, (double*)dp, g_stream));
+    TRY(upload_cols(sample_pts, S, lds, 3, (double*)dk, g_stream));
+    TRY(launch_descriptors((double*)dp, P, P, (double*)dk, S, S, *options, (double*)dfeat, (double*)ddesc, dV, dErr, ws, wsb, g_stream));
+    int32_t hv[2] = {0, 0};
+    PCREG_HIP(hipMemcpyAsync(hv, dcnt, sizeof hv, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    if (hv[1] != 0) { set_error("a support holds %d points: more than the %d an LDS-resident support may have (lower max_pts)", hv[1], 8191); return PCREG_E_ARG; }
+    if (hv[0] > 0) {
+        PCREG_HIP(hipMemcpy(feat, dfeat, sizeof(double) * 3 * (size_t)hv[0], hipMemcpyDeviceToHost));
+        PCREG_HIP(hipMemcpy(desc, ddesc, sizeof(double) * PCREG_DESC_LEN * (size_t)hv[0], hipMemcpyDeviceToHost));
+    }
+    *V = hv[0];
+    return PCREG_OK;
+}
+
 // ------------------------------------------------------------------ device tier
 size_t pcreg_dev_knn2_points_f32_workspace(int Q, int M) { return knn2_points_workspace_bytes(Q, M); }
 

@@ -91,4 +91,11 @@ int launch_align_points_knn(const double* pts, int ld, const int32_t* offsets_de
                             int C1, int C2, double* aligned, int ld_out, double* coeff, double* c,
                             int32_t* status, hipStream_t st);
 
+
+// spatial-histogram descriptors (cfg 4)
+size_t descriptors_workspace_bytes(int P, int S);
+int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o,
+                       double* feat, double* desc, int32_t* V_dev, int32_t* err_dev, void* ws, size_t ws_bytes,
+                       hipStream_t st);
+
 }  // namespace pcreg

@@ -1,0 +1,542 @@
+// pcreg_amd/csrc/descriptors.hip -- getSpacialHistogramDescriptors on gfx950, fp64.
+//
+//   getLocalPoints.m:8-35                 radius search (brute force O(S*P) in the reference,
+//                                         called twice per keypoint)  -> uniform grid + 27 cells
+//   getSpacialHistogramDescriptors.m:75-145  KNN-PCA local reference frame (the inlined twin of
+//                                         AlignPoints_KNN: sort key = distance to the LOCAL
+//                                         centroid, sign vote over the K kept rows)
+//   :118-121                              eigenvalue-ratio rejection
+//   :150-171 + histcn.m:94-131            spherical 10 x 7 x 14 count histogram (phi = atan2(y,y))
+//   :177-179                              drop rejected keypoints, keep input order
+//
+// Pipeline (all resident):
+//   grid_*       deterministic counting sort of the cloud into cells of edge >= R: per-tile
+//                private count rows (no contended atomics), a (cell, tile) exclusive scan, and a
+//                scatter whose in-tile rank comes from an LDS bitonic sort of (cell, index)
+//                keys -> inside a cell points stay in ascending original index, every run the same.
+//   desc_kernel  one workgroup per keypoint: gather the <= 27 cells (coalesced runs), keep
+//                |p-c| < R in LDS (index + distance-to-centroid), radix-select the K nearest to the
+//                local centroid (ties by original index = stable sort), 3x3 covariance + Jacobi,
+//                sign vote, rotate, bin into an LDS histogram (ds_add_u32), one coalesced row store.
+//   compact      order-preserving compaction of the surviving rows into feat / desc (double).
+// The dominant traffic is the 980-count row per keypoint: HBM-write-bound.
+#include "common.hpp"
+#include "select.hpp"
+#include <cfloat>
+#include <cmath>
+
+namespace pcreg {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kSortTile = 2048;            // points per counting-sort tile
+constexpr int kMaxCells = 1 << 16;
+constexpr int NR = 10, NT = 7, NP = 14, ND = NR * NT * NP;
+
+struct Grid {
+    double ox, oy, oz, inv;                // origin and 1 / cell edge
+    int nx, ny, nz, ncells;
+};
+struct Edges { double r[NR + 1], t[NT + 1], p[NP + 1]; };
+
+__device__ __forceinline__ int cell_coord(double v, double o, double inv, int n) {
+    int c = (int)floor((v - o) * inv);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+__device__ __forceinline__ int cell_of(const Grid& g, double x, double y, double z) {
+    return (cell_coord(z, g.oz, g.inv, g.nz) * g.ny + cell_coord(y, g.oy, g.inv, g.ny)) * g.nx + cell_coord(x, g.ox, g.inv, g.nx);
+}
+
+// ---- grid: bounding box -> cell size ------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void bbox_partial_d_kernel(const double* __restrict__ p, int P, int ld,
+                                                                double* __restrict__ part) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < P; i += gridDim.x * kBlock) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { double v = p[i + (size_t)c * ld]; lo[c] = fmin(lo[c], v); hi[c] = fmax(hi[c], v); }
+    }
+    __shared__ double s[kBlock / 64][6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fmin(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmax(hi[c], __shfl_xor(hi[c], o)); }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { s[threadIdx.x >> 6][c] = lo[c]; s[threadIdx.x >> 6][3 + c] = hi[c]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = s[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) v = threadIdx.x < 3 ? fmin(v, s[w][threadIdx.x]) : fmax(v, s[w][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+__global__ void grid_setup_kernel(const double* __restrict__ part, int nparts, double R, Grid* __restrict__ g) {
+    if (threadIdx.x != 0) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = 0; b < nparts; ++b)
+        for (int c = 0; c < 3; ++c) { lo[c] = fmin(lo[c], part[b * 6 + c]); hi[c] = fmax(hi[c], part[b * 6 + 3 + c]); }
+    if (!(hi[0] >= lo[0])) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = 0; }
+    double cell = R;                       // >= R so that a sphere touches at most 3 cells per axis
+    for (;;) {
+        double nx = floor((hi[0] - lo[0]) / cell) + 1, ny = floor((hi[1] - lo[1]) / cell) + 1, nz = floor((hi[2] - lo[2]) / cell) + 1;
+        if (nx * ny * nz <= (double)kMaxCells) { g->nx = (int)nx; g->ny = (int)ny; g->nz = (int)nz; break; }
+        cell *= 1.26;                      // ~ halve the cell count
+    }
+    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2]; g->inv = 1.0 / cell;
+    g->ncells = g->nx * g->ny * g->nz;
+}
+
+// ---- grid: deterministic counting sort ------------------------------------------------------
+// counts[tile][cell] (row private to the tile's workgroup: atomics without cross-block races)
+__global__ __launch_bounds__(kBlock) void grid_count_kernel(const double* __restrict__ p, int P, int ld,
+                                                            const Grid* __restrict__ gp, int32_t* __restrict__ cell_id,
+                                                            int32_t* __restrict__ counts) {
+    const Grid g = *gp;
+    const int t0 = blockIdx.x * kSortTile;
+    int32_t* row = counts + (size_t)blockIdx.x * kMaxCells;
+    for (int i = t0 + threadIdx.x; i < min(P, t0 + kSortTile); i += kBlock) {
+        int c = cell_of(g, p[i], p[i + (size_t)ld], p[i + 2 * (size_t)ld]);
+        cell_id[i] = c;
+        atomicAdd(&row[c], 1);             // integer adds commute: the row is order-independent
+    }
+}
+// per cell: prefix over tiles (in place) and the cell total
+__global__ void grid_cell_prefix_kernel(int32_t* __restrict__ counts, int ntiles, const Grid* __restrict__ gp,
+                                        int32_t* __restrict__ cell_total) {
+    const int nc = gp->ncells;
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) { if (c < kMaxCells + 1) cell_total[c] = 0; return; }
+    int run = 0;
+    for (int t = 0; t < ntiles; ++t) { int v = counts[(size_t)t * kMaxCells + c]; counts[(size_t)t * kMaxCells + c] = run; run += v; }
+    cell_total[c] = run;
+}
+// exclusive scan of cell totals -> cell_start[0..kMaxCells] (one workgroup)
+__global__ void grid_cell_scan_kernel(const int32_t* __restrict__ cell_total, int32_t* __restrict__ cell_start) {
+    __shared__ int s[256];
+    int carry = 0;
+    for (int b0 = 0; b0 < kMaxCells; b0 += 256) {
+        int i = b0 + threadIdx.x;
+        int v = cell_total[i];
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        cell_start[i] = carry + s[threadIdx.x] - v;
+        int tot = s[255];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) cell_start[kMaxCells] = carry;
+}
+// scatter: in-tile rank from a bitonic sort of (cell << 32 | index) keys
+__global__ __launch_bounds__(kBlock) void grid_scatter_kernel(const double* __restrict__ p, int P, int ld,
+                                                              const int32_t* __restrict__ cell_id,
+                                                              const int32_t* __restrict__ counts /*prefix over tiles*/,
+                                                              const int32_t* __restrict__ cell_start,
+                                                              int32_t* __restrict__ sorted_idx, double* __restrict__ sx,
+                                                              double* __restrict__ sy, double* __restrict__ sz) {
+    __shared__ unsigned long long key[kSortTile];
+    __shared__ int run_start[kSortTile];
+    const int t0 = blockIdx.x * kSortTile;
+    const int cnt = min(kSortTile, P - t0);
+    for (int i = threadIdx.x; i < kSortTile; i += kBlock)
+        key[i] = i < cnt ? (((unsigned long long)(unsigned)cell_id[t0 + i] << 32) | (unsigned)(t0 + i)) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= kSortTile; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < kSortTile; i += kBlock) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    unsigned long long a = key[i], b = key[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // start of each run of equal cells (max-scan of run heads)
+    for (int i = threadIdx.x; i < kSortTile; i += kBlock)
+        run_start[i] = (i == 0 || (key[i] >> 32) != (key[i - 1] >> 32)) ? i : 0;
+    __syncthreads();
+    for (int o = 1; o < kSortTile; o <<= 1) {
+        int v[kSortTile / kBlock];
+#pragma unroll
+        for (int r = 0; r < kSortTile / kBlock; ++r) { int i = r * kBlock + threadIdx.x; v[r] = i >= o ? max(run_start[i], run_start[i - o]) : run_start[i]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kSortTile / kBlock; ++r) run_start[r * kBlock + threadIdx.x] = v[r];
+        __syncthreads();
+    }
+    const int32_t* row = counts + (size_t)blockIdx.x * kMaxCells;
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        unsigned long long kk = key[i];
+        int c = (int)(kk >> 32), idx = (int)(kk & 0xFFFFFFFFull);
+        int dst = cell_start[c] + row[c] + (i - run_start[i]);
+        sorted_idx[dst] = idx;
+        sx[dst] = p[idx]; sy[dst] = p[idx + (size_t)ld]; sz[dst] = p[idx + 2 * (size_t)ld];
+    }
+}
+
+// ---- per-keypoint descriptor ------------------------------------------------------------------
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double bsum(double v, double* s_red) {
+    v = wsum(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    __syncthreads();
+    return t;
+}
+__device__ __forceinline__ int bsum_i(int v, int* s_red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    return t;
+}
+__device__ void jacobi3(double (&A)[3][3], double (&V)[3][3]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) V[r][c] = r == c ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-300 || off <= DBL_EPSILON * 1e-3 * dia) break;
+#define PCREG_JROT(P_, Q_)                                                                  \
+        if (A[P_][Q_] != 0.0) {                                                             \
+            double th = (A[Q_][Q_] - A[P_][P_]) / (2.0 * A[P_][Q_]);                        \
+            double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));                \
+            double c = 1.0 / sqrt(t * t + 1.0), s = c * t;                                  \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[k][P_], b = A[k][Q_]; A[k][P_] = c*a - s*b; A[k][Q_] = s*a + c*b; } \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[P_][k], b = A[Q_][k]; A[P_][k] = c*a - s*b; A[Q_][k] = s*a + c*b; } \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = V[k][P_], b = V[k][Q_]; V[k][P_] = c*a - s*b; V[k][Q_] = s*a + c*b; } \
+        }
+        PCREG_JROT(0, 1) PCREG_JROT(0, 2) PCREG_JROT(1, 2)
+#undef PCREG_JROT
+    }
+}
+// histcounts bin (histcn.m:108): e[k-1] <= x < e[k], last bin closed, 0 = outside / NaN
+template <int NE>
+__device__ __forceinline__ int hist_loc(double x, const double (&e)[NE]) {
+    if (!(x >= e[0]) || !(x <= e[NE - 1])) return 0;
+    if (x == e[NE - 1]) return NE - 1;
+    int k = 1;
+#pragma unroll
+    for (int j = 1; j < NE - 1; ++j) k += (x >= e[j]);
+    return k;
+}
+
+__global__ __launch_bounds__(kBlock) void desc_kernel(
+    const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ sz,
+    const int32_t* __restrict__ sorted_idx, const int32_t* __restrict__ cell_start, const Grid* __restrict__ gp,
+    const double* __restrict__ kp, int S, int ldk, pcreg_desc_opts o, Edges ed, int cap,
+    uint32_t* __restrict__ rows /*[S][ND]*/, int32_t* __restrict__ valid, int32_t* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* sd = reinterpret_cast<double*>(smem);                       // [cap] distance to the local centroid, then flags
+    int* lpos = reinterpret_cast<int*>(smem + (size_t)cap * sizeof(double));   // [cap] position in the sorted arrays
+    __shared__ double s_red[4];
+    __shared__ int s_redi[4];
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_cnt[ND];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_krem, s_base, s_ok;
+    __shared__ double s_m[9];
+
+    const Grid g = *gp;
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double cx = kp[s], cy = kp[s + (size_t)ldk], cz = kp[s + 2 * (size_t)ldk];
+    const double R = o.R;
+    if (tid == 0) { s_base = 0; valid[s] = 0; }
+    for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
+    __syncthreads();
+
+    // ---- getLocalPoints: |p - c| < R (strict), from the <= 27 cells around c ----
+    const int kx = cell_coord(cx, g.ox, g.inv, g.nx), ky = cell_coord(cy, g.oy, g.inv, g.ny), kz = cell_coord(cz, g.oz, g.inv, g.nz);
+    // a keypoint outside the cloud's box by more than one cell has no neighbours: the clamped
+    // cell is then farther than R along that axis and the distance test rejects everything
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
+        const int zz = kz + dz, yy = ky + dy;
+        if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+        const int x0 = max(kx - 1, 0), x1 = min(kx + 1, g.nx - 1);
+        const int c0 = (zz * g.ny + yy) * g.nx + x0, c1 = (zz * g.ny + yy) * g.nx + x1;
+        const int b = cell_start[c0], e = cell_start[c1 + 1];         // x-adjacent cells are contiguous
+        for (int j0 = b; j0 < e; j0 += kBlock) {
+            const int j = j0 + tid;
+            bool in = false;
+            if (j < e) {
+                double x = sx[j] - cx, y = sy[j] - cy, z = sz[j] - cz;
+                in = sqrt(x * x + y * y + z * z) < R;                   // getLocalPoints.m:23-25
+            }
+            unsigned long long bal = __ballot(in);
+            if (lane == 0) s_redi[wave] = __popcll(bal);
+            __syncthreads();
+            int pos = s_base;
+            for (int w = 0; w < wave; ++w) pos += s_redi[w];
+            pos += __popcll(bal & ((1ull << lane) - 1ull));
+            if (in && pos < cap) lpos[pos] = j;
+            __syncthreads();
+            if (tid == 0) s_base += s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
+            __syncthreads();
+        }
+    }
+    const int n = s_base;
+    if (n < 1 || n < o.min_pts || n > o.max_pts) return;                   // getLocalPoints.m:17,31
+    if (n > cap) { if (tid == 0) atomicMax(err, n); return; }              // support larger than the LDS list
+
+    // ---- K nearest to the local centroid (:75-85) ----
+    const bool all = o.k >= 1.0;
+    const int K = all ? n : (int)floor(n * o.k + 0.5);
+    if (K < 2) return;
+    double ax = 0, ay = 0, az = 0;
+    for (int i = tid; i < n; i += kBlock) { int j = lpos[i]; ax += sx[j] - cx; ay += sy[j] - cy; az += sz[j] - cz; }
+    const double gx = bsum(ax, s_red) / n, gy = bsum(ay, s_red) / n, gz = bsum(az, s_red) / n;
+    if (!all) {
+        for (int i = tid; i < n; i += kBlock) {
+            int j = lpos[i];
+            double x = (sx[j] - cx) - gx, y = (sy[j] - cy) - gy, z = (sz[j] - cz) - gz;
+            sd[i] = sqrt(x * x + y * y + z * z);
+        }
+        if (tid == 0) { s_prefix = 0ull; s_krem = K; }
+        __syncthreads();
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            s_hist[tid] = 0u;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+            for (int i = tid; i < n; i += kBlock) {
+                unsigned long long key = (unsigned long long)__double_as_longlong(sd[i]);
+                if ((key & himask) == prefix) atomicAdd(&s_hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int krem = s_krem, cum = 0, dg = 0;
+                for (; dg < 256; ++dg) { int h = (int)s_hist[dg]; if (cum + h >= krem) break; cum += h; }
+                s_krem = krem - cum;
+                s_prefix = prefix | ((unsigned long long)dg << shift);
+            }
+            __syncthreads();
+        }
+        const unsigned long long vK = s_prefix;
+        const int take_eq = s_krem;
+        // ties at the K-th distance: the stable sort keeps the lowest ORIGINAL indices
+        int n_eq_local = 0;
+        for (int i = tid; i < n; i += kBlock) n_eq_local += ((unsigned long long)__double_as_longlong(sd[i]) == vK);
+        const int n_eq = bsum_i(n_eq_local, s_redi);
+        unsigned selmask = 0u;                       // bit r: element tid + r*256 (cap <= 8191 -> r < 32)
+        for (int i = tid, r = 0; i < n; i += kBlock, ++r) {
+            unsigned long long key = (unsigned long long)__double_as_longlong(sd[i]);
+            bool sel = key < vK;
+            if (key == vK) {
+                if (n_eq == take_eq) sel = true;
+                else {
+                    const int me = sorted_idx[lpos[i]];
+                    int rank = 0;
+                    for (int t = 0; t < n; ++t)
+                        if ((unsigned long long)__double_as_longlong(sd[t]) == vK && sorted_idx[lpos[t]] < me) ++rank;
+                    sel = rank < take_eq;
+                }
+            }
+            selmask |= (sel ? 1u : 0u) << r;
+        }
+        __syncthreads();                             // every thread is done reading lpos / sd
+        for (int i = tid, r = 0; i < n; i += kBlock, ++r) if ((selmask >> r) & 1u) lpos[i] |= 0x40000000;
+        __syncthreads();
+    }
+#define PCREG_SEL(i) (all || (lpos[i] & 0x40000000))
+#define PCREG_POS(i) (lpos[i] & 0x3FFFFFFF)
+
+    // ---- pca(pts_k, 'eig') (:91) ----
+    double mx = 0, my = 0, mz = 0;
+    {
+        double bx = 0, by = 0, bz = 0;
+        for (int i = tid; i < n; i += kBlock) if (PCREG_SEL(i)) { int j = PCREG_POS(i); bx += sx[j] - cx; by += sy[j] - cy; bz += sz[j] - cz; }
+        mx = bsum(bx, s_red) / K; my = bsum(by, s_red) / K; mz = bsum(bz, s_red) / K;
+    }
+    double cv[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < n; i += kBlock) if (PCREG_SEL(i)) {
+        int j = PCREG_POS(i);
+        double x = (sx[j] - cx) - mx, y = (sy[j] - cy) - my, z = (sz[j] - cz) - mz;
+        cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cv[k] = bsum(cv[k], s_red) / (double)(K - 1);
+    if (tid == 0) {
+        double A[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
+        double V[3][3];
+        jacobi3(A, V);
+        double ev[3] = {A[0][0], A[1][1], A[2][2]};
+        int od[3] = {0, 1, 2};
+        if (ev[od[1]] > ev[od[0]]) { int t = od[0]; od[0] = od[1]; od[1] = t; }
+        if (ev[od[2]] > ev[od[0]]) { int t = od[0]; od[0] = od[2]; od[2] = t; }
+        if (ev[od[2]] > ev[od[1]]) { int t = od[1]; od[1] = od[2]; od[2] = t; }
+        double v0 = ev[od[0]], v1 = ev[od[1]], v2 = ev[od[2]];
+        s_ok = !((v0 / v1 < o.thVar[0]) || (v1 / v2 < o.thVar[1]));        // :118-121
+        for (int col = 0; col < 3; ++col) {
+            double a0 = 0, a1 = 0, a2 = 0;
+            for (int k = 0; k < 3; ++k) if (od[col] == k) { a0 = V[0][k]; a1 = V[1][k]; a2 = V[2][k]; }
+            double big = a0;
+            if (fabs(a1) > fabs(big)) big = a1;
+            if (fabs(a2) > fabs(big)) big = a2;
+            double sg = big < 0 ? -1.0 : 1.0;
+            s_m[0 * 3 + col] = sg * a0; s_m[1 * 3 + col] = sg * a1; s_m[2 * 3 + col] = sg * a2;
+        }
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    double cu[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cu[k] = s_m[k];
+    if (o.ALIGN_POINTS) {                                                   // :128-145, vote over the K rows
+        int px = 0, pz = 0;
+        for (int i = tid; i < n; i += kBlock) if (PCREG_SEL(i)) {
+            int j = PCREG_POS(i);
+            double x = (sx[j] - cx) - mx, y = (sy[j] - cy) - my, z = (sz[j] - cz) - mz;
+            px += (x * cu[0] + y * cu[3] + z * cu[6]) > 0;
+            pz += (x * cu[2] + y * cu[5] + z * cu[8]) > 0;
+        }
+        px = bsum_i(px, s_redi); pz = bsum_i(pz, s_redi);
+        double xs = (2.0 * px >= (double)K) ? 1.0 : -1.0, zs = (2.0 * pz >= (double)K) ? 1.0 : -1.0;
+        double M[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { M[r * 3] = cu[r * 3] * xs; M[r * 3 + 1] = cu[r * 3 + 1]; M[r * 3 + 2] = cu[r * 3 + 2] * zs; }
+        double ys = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cu[r * 3] = cu[r * 3] * xs; cu[r * 3 + 1] = cu[r * 3 + 1] * ys; cu[r * 3 + 2] = cu[r * 3 + 2] * zs; }
+    }
+    // ---- spherical histogram over ALL local points (:150-171, histcn.m:108-131) ----
+    for (int i = tid; i < n; i += kBlock) {
+        int j = PCREG_POS(i);
+        double x0 = sx[j] - cx, y0 = sy[j] - cy, z0 = sz[j] - cz, x = x0, y = y0, z = z0;
+        if (o.ALIGN_POINTS) { x = x0 * cu[0] + y0 * cu[3] + z0 * cu[6]; y = x0 * cu[1] + y0 * cu[4] + z0 * cu[7]; z = x0 * cu[2] + y0 * cu[5] + z0 * cu[8]; }
+        double r = sqrt(x * x + y * y + z * z), th = acos(z / r), ph = atan2(y, y);
+        int lr = hist_loc<NR + 1>(r, ed.r), lt = hist_loc<NT + 1>(th, ed.t), lp = hist_loc<NP + 1>(ph, ed.p);
+        if (lr > 0 && lt > 0 && lp > 0) atomicAdd(&s_cnt[(lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1)], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = rows + (size_t)s * ND;
+    for (int i = tid; i < ND; i += kBlock) row[i] = s_cnt[i];
+    if (tid == 0) valid[s] = 1;
+#undef PCREG_SEL
+#undef PCREG_POS
+}
+
+// ---- compaction of the surviving rows (:177-179) ----------------------------------------------
+__global__ void desc_count_kernel(const int32_t* __restrict__ valid, int S, int32_t* __restrict__ block_cnt) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool kp = s < S && valid[s] != 0;
+    __shared__ int s_c[4];
+    unsigned long long b = __ballot(kp);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+__global__ void desc_slot_kernel(const int32_t* __restrict__ valid, int S, const int32_t* __restrict__ block_off,
+                                 int32_t* __restrict__ slot) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool kp = s < S && valid[s] != 0;
+    __shared__ int s_c[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long b = __ballot(kp);
+    if (lane == 0) s_c[wave] = __popcll(b);
+    __syncthreads();
+    int base = block_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += s_c[w];
+    if (s < S) slot[s] = kp ? base + __popcll(b & ((1ull << lane) - 1ull)) : -1;
+}
+__global__ __launch_bounds__(kBlock) void desc_emit_kernel(const uint32_t* __restrict__ rows, const int32_t* __restrict__ slot,
+                                                           const double* __restrict__ kp, int S, int ldk,
+                                                           double* __restrict__ feat, double* __restrict__ desc) {
+    const int s = blockIdx.x;
+    const int v = slot[s];
+    if (v < 0) return;
+    const uint32_t* row = rows + (size_t)s * ND;
+    double* out = desc + (size_t)v * ND;
+    for (int i = threadIdx.x; i < ND; i += kBlock) out[i] = (double)row[i];
+    if (threadIdx.x < 3) feat[(size_t)v * 3 + threadIdx.x] = kp[s + (size_t)threadIdx.x * ldk];
+}
+
+}  // namespace
+
+// workspace: Grid | bbox partials | cell_total | cell_start | cell_id [P] | counts [tiles][kMaxCells]
+//            | sorted_idx [P] | sx sy sz [P] | rows u32 [S][980] | valid [S] | slot [S] | block counters
+size_t descriptors_workspace_bytes(int P, int S) {
+    size_t p = (size_t)(P > 0 ? P : 1), s = (size_t)(S > 0 ? S : 1);
+    size_t tiles = (p + kSortTile - 1) / kSortTile;
+    return 256 + align_up(512 * 6 * 8, 256) + 2 * align_up(((size_t)kMaxCells + 1) * 4, 256) + align_up(p * 4, 256) +
+           align_up(tiles * kMaxCells * 4, 256) + align_up(p * 4, 256) + 3 * align_up(p * 8, 256) +
+           align_up(s * ND * 4, 256) + 2 * align_up(s * 4, 256) + align_up((s / 256 + 2) * 4, 256);
+}
+
+int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o,
+                       double* feat, double* desc, int32_t* V_dev, int32_t* err_dev, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
+    PCREG_ARG(P >= 0 && S >= 0 && o.R > 0 && o.k > 0 && o.min_pts >= 0);
+    PCREG_HIP(hipMemsetAsync(V_dev, 0, sizeof(int32_t), st));
+    PCREG_HIP(hipMemsetAsync(err_dev, 0, sizeof(int32_t), st));
+    if (S == 0 || P == 0) return PCREG_OK;
+    size_t need = descriptors_workspace_bytes(P, S);
+    if (ws_bytes < need) { set_error("descriptor workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    size_t p = (size_t)P, s = (size_t)S;
+    const int tiles = (P + kSortTile - 1) / kSortTile;
+    char* w = (char*)ws;
+    Grid* grid = (Grid*)w;                  w += 256;
+    double* bpart = (double*)w;             w += align_up(512 * 6 * 8, 256);
+    int32_t* cell_total = (int32_t*)w;      w += align_up(((size_t)kMaxCells + 1) * 4, 256);
+    int32_t* cell_start = (int32_t*)w;      w += align_up(((size_t)kMaxCells + 1) * 4, 256);
+    int32_t* cell_id = (int32_t*)w;         w += align_up(p * 4, 256);
+    int32_t* counts = (int32_t*)w;          w += align_up((size_t)tiles * kMaxCells * 4, 256);
+    int32_t* sorted_idx = (int32_t*)w;      w += align_up(p * 4, 256);
+    double* sx = (double*)w;                w += align_up(p * 8, 256);
+    double* sy = (double*)w;                w += align_up(p * 8, 256);
+    double* sz = (double*)w;                w += align_up(p * 8, 256);
+    uint32_t* rows = (uint32_t*)w;          w += align_up(s * ND * 4, 256);
+    int32_t* valid = (int32_t*)w;           w += align_up(s * 4, 256);
+    int32_t* slot = (int32_t*)w;            w += align_up(s * 4, 256);
+    int32_t* bcnt = (int32_t*)w;
+
+    int nb = (P + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(bbox_partial_d_kernel, dim3(nb), dim3(kBlock), 0, st, pts, P, ld, bpart);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, st, bpart, nb, o.R, grid);
+    PCREG_HIP(hipMemsetAsync(counts, 0, (size_t)tiles * kMaxCells * 4, st));
+    hipLaunchKernelGGL(grid_count_kernel, dim3(tiles), dim3(kBlock), 0, st, pts, P, ld, grid, cell_id, counts);
+    hipLaunchKernelGGL(grid_cell_prefix_kernel, dim3((kMaxCells + 1 + 255) / 256), dim3(256), 0, st, counts, tiles, grid, cell_total);
+    hipLaunchKernelGGL(grid_cell_scan_kernel, dim3(1), dim3(256), 0, st, cell_total, cell_start);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(tiles), dim3(kBlock), 0, st, pts, P, ld, cell_id, counts, cell_start,
+                       sorted_idx, sx, sy, sz);
+    PCREG_HIP(hipGetLastError());
+
+    Edges ed;
+    const double r3 = o.R * o.R * o.R, pi = 3.14159265358979323846;
+    for (int k = 0; k <= NR; ++k) ed.r[k] = cbrt(k * (r3 / NR));                 // nthroot(0:R^3/10:R^3, 3)
+    for (int k = 0; k <= NT; ++k) ed.t[k] = k * (pi / NT);                       // 0:pi/7:pi
+    for (int k = 0; k <= NP; ++k) ed.p[k] = -pi + k * (2 * pi / NP);             // -pi:2*pi/14:pi
+    int cap = o.max_pts < 8190 ? o.max_pts + 1 : 8191;
+    if (cap < 64) cap = 64;
+    size_t lds = (size_t)cap * (sizeof(double) + sizeof(int));
+    PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(desc_kernel, dim3(S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, S, ldk, o,
+                       ed, cap, rows, valid, err_dev);
+    PCREG_HIP(hipGetLastError());
+    const int nbs = (S + 255) / 256;
+    hipLaunchKernelGGL(desc_count_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bcnt, nbs, V_dev);
+    hipLaunchKernelGGL(desc_slot_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt, slot);
+    hipLaunchKernelGGL(desc_emit_kernel, dim3(S), dim3(kBlock), 0, st, rows, slot, kp, S, ldk, feat, desc);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+}  // namespace pcreg

@@ -45,6 +45,27 @@ def test_oracle_reproduces_the_rest(oracle_c):
             assert np.abs(al - z[f"aligned_{C1}{C2}"]).max() < 1e-9 and np.abs(co - z[f"coeff_{C1}{C2}"]).max() < 1e-11
 
 
+DOPT = dict(min_pts=60, max_pts=6000, R=3.5, thVar=[3, 1.5], k=0.85, ALIGN_POINTS=True, VERBOSE=0)
+
+
+def test_oracle_reproduces_descriptors(oracle_c):
+    z = np.load(os.path.join(G, "descriptors.npz"))
+    f, d = oracle_c.getSpacialHistogramDescriptors(z["pts"], z["sample_pts"], DOPT)
+    np.testing.assert_array_equal(f, z["feat"]); np.testing.assert_array_equal(d, z["desc"].astype(np.float64))
+    f, d = oracle_c.getSpacialHistogramDescriptors(z["pts"], z["sample_pts"], dict(DOPT, ALIGN_POINTS=False))
+    np.testing.assert_array_equal(f, z["feat_noalign"]); np.testing.assert_array_equal(d, z["desc_noalign"].astype(np.float64))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_descriptors():
+    import pcreg_amd as pc
+    z = np.load(os.path.join(G, "descriptors.npz"))
+    f, d = pc.getSpacialHistogramDescriptors(z["pts"], z["sample_pts"], DOPT)
+    np.testing.assert_array_equal(f, z["feat"]); np.testing.assert_array_equal(d, z["desc"].astype(np.float64))
+    f, d = pc.getSpacialHistogramDescriptors(z["pts"], z["sample_pts"], dict(DOPT, ALIGN_POINTS=False))
+    np.testing.assert_array_equal(f, z["feat_noalign"]); np.testing.assert_array_equal(d, z["desc_noalign"].astype(np.float64))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ransac_a", "ransac_b"])
 def test_hip_reproduces_ransac(name):

@@ -201,3 +201,43 @@ def test_knn2_points_numpy_vs_c(oracle_py, oracle_c):
     np.testing.assert_array_equal(oracle_py.match_points_f32(q, m, 0.5, 0.8), oracle_c.match_points_f32(q, m, 0.5, 0.8))
     i3, d3 = oracle_c.knn2_points_f32(q, m[:1])
     assert (i3[:, 1] == -1).all() and np.isinf(d3[:, 1]).all()
+
+
+def _strips(P, seed, ns=8):
+    rng = np.random.default_rng(seed)
+    per = P // ns
+    out = []
+    for s in range(ns):
+        x = rng.uniform(0, 60, per); y = 6 * s + rng.uniform(-1.2, 1.2, per); z = 10 + 0.1 * x * np.sin(s) + rng.normal(0, 0.25, per)
+        out.append(np.column_stack([x, y, z]))
+    return np.vstack(out)
+
+
+def test_histcounts_semantics(oracle_py):
+    """histcn.m:108 -> histcounts: left-closed bins, last bin right-closed, outside / NaN -> 0."""
+    e = np.array([0.0, 1.0, 2.0, 3.0])
+    x = np.array([-0.1, 0.0, 0.5, 1.0, 2.999, 3.0, 3.0001, np.nan])
+    assert oracle_py.histcounts_loc(x, e).tolist() == [0, 1, 1, 2, 3, 3, 0, 0]
+    r, t, p = oracle_py.histogram_edges(3.5)
+    assert len(r) == 11 and len(t) == 8 and len(p) == 15
+    assert np.allclose(r ** 3, np.linspace(0, 3.5 ** 3, 11)) and np.isclose(t[-1], np.pi) and np.isclose(p[0], -np.pi)
+    # phi = atan2(y, y) only ever takes three values (getSpacialHistogramDescriptors.m:152)
+    assert oracle_py.histcounts_loc(np.array([np.pi / 4, -3 * np.pi / 4]), p).tolist() == [9, 2]
+
+
+def test_descriptors_numpy_vs_c(oracle_py, oracle_c):
+    pts = _strips(16000, 0)
+    rng = np.random.default_rng(1)
+    kp = np.column_stack([rng.uniform(5, 55, 60), 6 * rng.integers(0, 8, 60) + rng.uniform(-1.5, 1.5, 60), rng.uniform(9, 16, 60)])
+    for align in (True, False):
+        for k in (0.85, "all"):
+            opt = dict(min_pts=60, max_pts=6000, R=3.5, thVar=[3, 1.5], k=k, ALIGN_POINTS=align)
+            f1, d1 = oracle_py.getSpacialHistogramDescriptors(pts, kp, opt)
+            f2, d2 = oracle_c.getSpacialHistogramDescriptors(pts, kp, opt)
+            assert len(f1) > 5 and np.array_equal(f1, f2) and np.array_equal(d1, d2)
+            # every local point lands in exactly one bin unless r == 0: row sums = support sizes
+            n_local = [int(np.sum(np.linalg.norm(pts - c, axis=1) < 3.5)) for c in f1]
+            assert d1.sum(axis=1).tolist() == n_local
+            # only 2 of the 14 phi slabs can be populated (y > 0 -> pi/4, y < 0 -> -3pi/4)
+            slabs = d1.reshape(len(d1), 14, 7, 10).sum(axis=(2, 3))
+            assert (np.count_nonzero(slabs, axis=1) <= 2).all()
