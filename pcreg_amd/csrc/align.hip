@@ -4,7 +4,7 @@
 //   :17     centroid                                   -> block reduction
 //   :20-26  keep the K = round(0.85 N) points nearest to the centroid.  The reference
 //           does a full stable sort; only the K-th order statistic is needed, so this
-//           kernel runs an 8-pass radix SELECT on the distance bit patterns held in LDS
+//           kernel runs a bisection SELECT on the distance bit patterns held in LDS (select_kth.hpp)
 //           and resolves ties at the boundary by lowest index (= stable sort order)
 //   :30-34  pca(...,'Algorithm','eig')                 -> 3x3 covariance + Jacobi, then
 //           MathWorks' sign convention (largest-|.| entry of each column positive)
@@ -13,6 +13,7 @@
 // The point set is read from HBM/L2 five times (centroid, distances, mean, covariance,
 // projection): 5 * 24 B per point in, 24 B out -- the HBM-bound member of the family.
 #include "common.hpp"
+#include "select_kth.hpp"
 #include <cfloat>
 
 namespace pcreg {
@@ -73,9 +74,7 @@ __global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
     extern __shared__ __attribute__((aligned(16))) double sd[];    // n distances, later selection flags
     __shared__ double s_red[4];
     __shared__ int s_redi[4];
-    __shared__ unsigned s_hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ int s_krem;
+    __shared__ unsigned long long s_u64[8];
     __shared__ double s_cu[9];       // coeff_unambig, row-major [r][col]
     __shared__ double s_coeff[9];
     __shared__ int s_base;
@@ -98,29 +97,10 @@ __global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
         double x = px[i] - cx, y = py[i] - cy, z = pz[i] - cz;
         sd[i] = sqrt(x * x + y * y + z * z);
     }
-    if (tid == 0) { s_prefix = 0ull; s_krem = K; }
     __syncthreads();
-    for (int pass = 0; pass < 8; ++pass) {
-        const int shift = 56 - 8 * pass;
-        s_hist[tid] = 0u;
-        __syncthreads();
-        const unsigned long long prefix = s_prefix;
-        const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-        for (int i = tid; i < n; i += kBlock) {
-            unsigned long long key = (unsigned long long)__double_as_longlong(sd[i]);   // non-negative doubles order as integers
-            if ((key & himask) == prefix) atomicAdd(&s_hist[(unsigned)(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int krem = s_krem, cum = 0, dg = 0;
-            for (; dg < 256; ++dg) { int h = (int)s_hist[dg]; if (cum + h >= krem) break; cum += h; }
-            s_krem = krem - cum;
-            s_prefix = prefix | ((unsigned long long)dg << shift);
-        }
-        __syncthreads();
-    }
-    const unsigned long long vK = s_prefix;     // bit pattern of the K-th smallest distance
-    const int take_eq = s_krem;                 // how many of the ties at vK belong to the K nearest
+    int n_less = 0;
+    const unsigned long long vK = block_select_kth(sd, n, K, s_u64, s_redi, &n_less);   // bit pattern of the K-th smallest distance
+    const int take_eq = K - n_less;              // how many of the ties at vK belong to the K nearest
     // selection flags, ties by ascending index (stable sort order, :24)
     if (tid == 0) s_base = 0;
     __syncthreads();

@@ -15,13 +15,14 @@
 //                scatter whose in-tile rank comes from an LDS bitonic sort of (cell, index)
 //                keys -> inside a cell points stay in ascending original index, every run the same.
 //   desc_kernel  one workgroup per keypoint: gather the <= 27 cells (coalesced runs), keep
-//                |p-c| < R in LDS (index + distance-to-centroid), radix-select the K nearest to the
+//                |p-c| < R in LDS (index + distance-to-centroid), bisection-select the K nearest to the
 //                local centroid (ties by original index = stable sort), 3x3 covariance + Jacobi,
 //                sign vote, rotate, bin into an LDS histogram (ds_add_u32), one coalesced row store.
 //   compact      order-preserving compaction of the surviving rows into feat / desc (double).
 // The dominant traffic is the 980-count row per keypoint: HBM-write-bound.
 #include "common.hpp"
 #include "select.hpp"
+#include "select_kth.hpp"
 #include <cfloat>
 #include <cmath>
 
@@ -247,10 +248,9 @@ __global__ __launch_bounds__(kBlock) void desc_kernel(
     int* lpos = reinterpret_cast<int*>(smem + (size_t)cap * sizeof(double));   // [cap] position in the sorted arrays
     __shared__ double s_red[4];
     __shared__ int s_redi[4];
-    __shared__ unsigned s_hist[256];
     __shared__ unsigned s_cnt[ND];
-    __shared__ unsigned long long s_prefix;
-    __shared__ int s_krem, s_base, s_ok;
+    __shared__ unsigned long long s_u64[8];
+    __shared__ int s_base, s_ok;
     __shared__ double s_m[9];
 
     const Grid g = *gp;
@@ -308,29 +308,10 @@ __global__ __launch_bounds__(kBlock) void desc_kernel(
             double x = (sx[j] - cx) - gx, y = (sy[j] - cy) - gy, z = (sz[j] - cz) - gz;
             sd[i] = sqrt(x * x + y * y + z * z);
         }
-        if (tid == 0) { s_prefix = 0ull; s_krem = K; }
         __syncthreads();
-        for (int pass = 0; pass < 8; ++pass) {
-            const int shift = 56 - 8 * pass;
-            s_hist[tid] = 0u;
-            __syncthreads();
-            const unsigned long long prefix = s_prefix;
-            const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-            for (int i = tid; i < n; i += kBlock) {
-                unsigned long long key = (unsigned long long)__double_as_longlong(sd[i]);
-                if ((key & himask) == prefix) atomicAdd(&s_hist[(unsigned)(key >> shift) & 255u], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int krem = s_krem, cum = 0, dg = 0;
-                for (; dg < 256; ++dg) { int h = (int)s_hist[dg]; if (cum + h >= krem) break; cum += h; }
-                s_krem = krem - cum;
-                s_prefix = prefix | ((unsigned long long)dg << shift);
-            }
-            __syncthreads();
-        }
-        const unsigned long long vK = s_prefix;
-        const int take_eq = s_krem;
+        int n_less = 0;
+        const unsigned long long vK = block_select_kth(sd, n, K, s_u64, s_redi, &n_less);
+        const int take_eq = K - n_less;
         // ties at the K-th distance: the stable sort keeps the lowest ORIGINAL indices
         int n_eq_local = 0;
         for (int i = tid; i < n; i += kBlock) n_eq_local += ((unsigned long long)__double_as_longlong(sd[i]) == vK);
