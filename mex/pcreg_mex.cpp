@@ -6,6 +6,7 @@
 //   'ransac', pts1, pts2, coef, sample_idx|[], seed      -> T, inlierIdx, numSuccess, maxInliers, failed
 //   'getMatches', descSurface, descModel, par            -> matches (P x 2 uint32)
 //   'AlignPoints_KNN', pts, C1, C2                       -> pts_aligned, coeff_unambig, c
+//   'getSpacialHistogramDescriptors', pts, sample_pts, options -> feat (V x 3), desc (V x 980)
 // The shim only unpacks mxArrays: MATLAB's column-major doubles go straight through
 // (ld = number of rows).  It never throws with C++ objects alive:
 // errors are collected as codes and raised by one mexErrMsgIdAndTxt at the very end.
@@ -116,6 +117,33 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                                         mxGetPr(plhs[0]), mxGetPr(co), mxGetPr(c));
             if (nlhs > 1) plhs[1] = co; else mxDestroyArray(co);
             if (nlhs > 2) plhs[2] = c; else mxDestroyArray(c);
+        }
+    } else if (!strcmp(cmd, "getSpacialHistogramDescriptors")) {
+        if (nrhs != 4) usage = "getSpacialHistogramDescriptors: pts, sample_pts, options";
+        else {
+            const mxArray* p = prhs[3];
+            pcreg_desc_opts o;
+            double mx = field(p, "max_pts", 6000);
+            o.min_pts = (int)field(p, "min_pts", 500); o.max_pts = mx > 2147483647.0 ? 2147483647 : (int)mx;
+            o.R = field(p, "R", 3.5); o.ALIGN_POINTS = (int)field(p, "ALIGN_POINTS", 1);
+            const mxArray* tv = mxGetField(p, 0, "thVar");
+            o.thVar[0] = tv ? mxGetPr(tv)[0] : 3.0; o.thVar[1] = tv ? mxGetPr(tv)[1] : 1.5;
+            const mxArray* kk = mxGetField(p, 0, "k");
+            o.k = (!kk || mxIsChar(kk)) ? 1.0 : mxGetScalar(kk);           // 'all' -> 1
+            int P = (int)mxGetM(prhs[1]), S = (int)mxGetM(prhs[2]);
+            mxArray* f = mxCreateDoubleMatrix(3, S > 0 ? S : 1, mxREAL);     // row-major V x 3 == 3 x V column-major
+            mxArray* d = mxCreateDoubleMatrix(PCREG_DESC_LEN, S > 0 ? S : 1, mxREAL);
+            int V = 0;
+            rc = pcreg_spatial_histogram_descriptors(mxGetPr(prhs[1]), P, P, mxGetPr(prhs[2]), S, S, &o, mxGetPr(f), mxGetPr(d), &V);
+            if (rc == PCREG_OK) {      // transpose into MATLAB's V x 3 / V x 980
+                plhs[0] = mxCreateDoubleMatrix(V, 3, mxREAL);
+                for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) mxGetPr(plhs[0])[v + (size_t)c * V] = mxGetPr(f)[c + 3 * (size_t)v];
+                if (nlhs > 1) {
+                    plhs[1] = mxCreateDoubleMatrix(V, PCREG_DESC_LEN, mxREAL);
+                    for (int v = 0; v < V; ++v) for (int c = 0; c < PCREG_DESC_LEN; ++c) mxGetPr(plhs[1])[v + (size_t)c * V] = mxGetPr(d)[c + PCREG_DESC_LEN * (size_t)v];
+                }
+            }
+            mxDestroyArray(f); mxDestroyArray(d);
         }
     } else {
         usage = "unknown command";
