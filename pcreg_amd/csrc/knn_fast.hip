@@ -149,8 +149,17 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
 #pragma unroll
                 for (int u = 0; u < UB_; ++u)
                     s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, p[u].w)));
-                float mn = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
-                if (UB_ == 8) mn = fminf(mn, fminf(fminf(s[4 % UB_], s[5 % UB_]), fminf(s[6 % UB_], s[7 % UB_])));
+                // min/max/compare issue at HALF the FMA rate on gfx950 (scripts/ubench/op_rates.hip):
+                // fold three values per v_min3 -> 4 selection ops per 8 scores instead of 7
+                float mn;
+                if (UB_ == 8) {
+                    float m1 = fminf(fminf(s[0], s[1]), s[2]);
+                    float m2 = fminf(fminf(s[3 % UB_], s[4 % UB_]), s[5 % UB_]);
+                    float m3 = fminf(fminf(s[6 % UB_], s[7 % UB_]), m1);
+                    mn = fminf(m2, m3);
+                } else {
+                    mn = fminf(fminf(fminf(s[0], s[1]), s[2]), s[3]);
+                }
                 if (DRY) { asm volatile("" :: "v"(mn)); }   // timing-only build: hot loop without insertions
                 else if (mn < thr[r]) {
                     const int j0 = t0 + jb;
@@ -249,8 +258,17 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_dma_kernel(
 #pragma unroll
                 for (int u = 0; u < UB_; ++u)
                     s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, p[u].w)));
-                float mn = fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
-                if (UB_ == 8) mn = fminf(mn, fminf(fminf(s[4 % UB_], s[5 % UB_]), fminf(s[6 % UB_], s[7 % UB_])));
+                // min/max/compare issue at HALF the FMA rate on gfx950 (scripts/ubench/op_rates.hip):
+                // fold three values per v_min3 -> 4 selection ops per 8 scores instead of 7
+                float mn;
+                if (UB_ == 8) {
+                    float m1 = fminf(fminf(s[0], s[1]), s[2]);
+                    float m2 = fminf(fminf(s[3 % UB_], s[4 % UB_]), s[5 % UB_]);
+                    float m3 = fminf(fminf(s[6 % UB_], s[7 % UB_]), m1);
+                    mn = fminf(m2, m3);
+                } else {
+                    mn = fminf(fminf(fminf(s[0], s[1]), s[2]), s[3]);
+                }
                 if (mn < thr[r]) {
                     const int j0 = t0 + jb;
 #pragma unroll

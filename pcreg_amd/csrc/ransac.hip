@@ -368,6 +368,11 @@ __device__ __forceinline__ void bcast_T(const double (&Tl)[12], int h, double (&
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = rdlane(Tl[k], h);
 }
+// A VOP3 may read one SGPR: with the whole transform in SGPRs every fma(x, R, t) needs a
+// v_mov_b64 for t first.  Keeping the three translations in VGPRs removes 3 moves per point.
+__device__ __forceinline__ void pin_translation_vgpr(double (&T)[12]) {
+    asm volatile("" : "+v"(T[3]), "+v"(T[7]), "+v"(T[11]));
+}
 
 // sample indices of hypothesis p (0-based out).  Built-in sampler = oracle's sample_table.
 __device__ __forceinline__ void sample3(const RansacArgs& a, int b, int p, int n, int (&s)[3]) {
@@ -591,7 +596,8 @@ __global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
 // block-wide votes (__syncthreads_or) decide which sweeps are needed at all.
 constexpr int kTW = 8;                  // waves per workgroup (2 per SIMD: 256 VGPRs each)
 constexpr int kTBlock = kTW * 64;
-constexpr int kTile = kTBlock;          // points per LDS tile: one per thread (2 x 24 KiB, double-buffered)
+constexpr int kPPT = 2;                 // points per thread and tile
+constexpr int kTile = kTBlock * kPPT;   // points per LDS tile (2 x 48 KiB, double-buffered)
 
 // One pass of the whole workgroup over the correspondences through LDS tiles, software
 // pipelined: the loads of tile t+1 are issued before tile t is scored and land in the other
@@ -601,23 +607,25 @@ constexpr int kTile = kTBlock;          // points per LDS tile: one per thread (
 #define PCREG_TILE_SWEEP_BEGIN                                                              \
     {                                                                                       \
         const int nt_ = (n + kTile - 1) / kTile;                                            \
-        double pf_[6];                                                                      \
-        {                                                                                   \
-            const int gi_ = threadIdx.x; const bool ok_ = gi_ < n;                          \
+        double pf_[kPPT][6];                                                                \
+        _Pragma("unroll") for (int v_ = 0; v_ < kPPT; ++v_) {                               \
+            const int gi_ = v_ * kTBlock + threadIdx.x; const bool ok_ = gi_ < n;           \
             _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                              \
-                pf_[c_] = ok_ ? g1[gi_ + (size_t)c_ * a.ld] : 0.0;                          \
-                pf_[3 + c_] = ok_ ? g2[gi_ + (size_t)c_ * a.ld] : 0.0;                      \
+                pf_[v_][c_] = ok_ ? g1[gi_ + (size_t)c_ * a.ld] : 0.0;                      \
+                pf_[v_][3 + c_] = ok_ ? g2[gi_ + (size_t)c_ * a.ld] : 0.0;                  \
             }                                                                               \
-            _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) sp[c_ * kTile + threadIdx.x] = pf_[c_]; \
+            _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) sp[c_ * kTile + gi_] = pf_[v_][c_]; \
         }                                                                                   \
         __syncthreads();                                                                    \
         for (int t_ = 0; t_ < nt_; ++t_) {                                                  \
             const bool more_ = t_ + 1 < nt_;                                                \
             if (more_) {                                                                    \
-                const int gi_ = (t_ + 1) * kTile + threadIdx.x; const bool ok_ = gi_ < n;   \
-                _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                          \
-                    pf_[c_] = ok_ ? g1[gi_ + (size_t)c_ * a.ld] : 0.0;                      \
-                    pf_[3 + c_] = ok_ ? g2[gi_ + (size_t)c_ * a.ld] : 0.0;                  \
+                _Pragma("unroll") for (int v_ = 0; v_ < kPPT; ++v_) {                       \
+                    const int gi_ = (t_ + 1) * kTile + v_ * kTBlock + threadIdx.x; const bool ok_ = gi_ < n; \
+                    _Pragma("unroll") for (int c_ = 0; c_ < 3; ++c_) {                      \
+                        pf_[v_][c_] = ok_ ? g1[gi_ + (size_t)c_ * a.ld] : 0.0;              \
+                        pf_[v_][3 + c_] = ok_ ? g2[gi_ + (size_t)c_ * a.ld] : 0.0;          \
+                    }                                                                       \
                 }                                                                           \
             }                                                                               \
             const double* buf_ = sp + (t_ & 1) * 6 * kTile;                                 \
@@ -635,7 +643,8 @@ constexpr int kTile = kTBlock;          // points per LDS tile: one per thread (
             }                                                                               \
             if (more_) {                                                                    \
                 double* nb_ = sp + ((t_ + 1) & 1) * 6 * kTile;                              \
-                _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) nb_[c_ * kTile + threadIdx.x] = pf_[c_]; \
+                _Pragma("unroll") for (int v_ = 0; v_ < kPPT; ++v_)                         \
+                    _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) nb_[c_ * kTile + v_ * kTBlock + threadIdx.x] = pf_[v_][c_]; \
             }                                                                               \
             __syncthreads();                                                                \
         }                                                                                   \
@@ -712,10 +721,10 @@ __global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a)
         {
             double T[HB][12]; int cnt[HB];
 #pragma unroll
-            for (int k = 0; k < HB; ++k) { bcast_T(T1, min(h0 + k, 63), T[k]); cnt[k] = 0; }
+            for (int k = 0; k < HB; ++k) { bcast_T(T1, min(h0 + k, 63), T[k]); pin_translation_vgpr(T[k]); cnt[k] = 0; }
             PCREG_TILE_SWEEP_BEGIN
 #pragma unroll
-                for (int k = 0; k < HB; ++k) cnt[k] += __popcll(__ballot((sqdist(q, T[k]) < th) & act));
+                for (int k = 0; k < HB; ++k) if (h0 + k < a.hpw) cnt[k] += __popcll(__ballot((sqdist(q, T[k]) < th) & act));
             PCREG_TILE_SWEEP_END
 #pragma unroll
             for (int k = 0; k < HB; ++k) if (lane == h0 + k) c1 = cnt[k];
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a)
             const int h = h0 + k;
             const bool want = __builtin_amdgcn_readlane((int)(pass1 && (lane == h)), min(h, 63)) != 0 && h < nh;
             if (!__syncthreads_or(want)) continue;          // nobody in the workgroup needs this sweep
-            double T[12]; bcast_T(T1, min(h, 63), T);
+            double T[12]; bcast_T(T1, min(h, 63), T); pin_translation_vgpr(T);
             const int ch = __builtin_amdgcn_readlane(c1, min(h, 63));
             double acc[27];
 #pragma unroll
@@ -789,10 +798,10 @@ __global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a)
             if (__syncthreads_or(any)) {
                 double T[HB][12]; int cnt[HB];
 #pragma unroll
-                for (int k = 0; k < HB; ++k) { bcast_T(T2, min(h0 + k, 63), T[k]); cnt[k] = 0; }
+                for (int k = 0; k < HB; ++k) { bcast_T(T2, min(h0 + k, 63), T[k]); pin_translation_vgpr(T[k]); cnt[k] = 0; }
                 PCREG_TILE_SWEEP_BEGIN
 #pragma unroll
-                    for (int k = 0; k < HB; ++k) cnt[k] += __popcll(__ballot((sqdist(q, T[k]) < th) & act));
+                    for (int k = 0; k < HB; ++k) if (h0 + k < a.hpw) cnt[k] += __popcll(__ballot((sqdist(q, T[k]) < th) & act));
                 PCREG_TILE_SWEEP_END
 #pragma unroll
                 for (int k = 0; k < HB; ++k) if (lane == h0 + k) c2 = cnt[k];
@@ -988,8 +997,12 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
         hipLaunchKernelGGL(ransac_hyp_kernel<true>, grid, dim3(kBlock), lds, st, a);
     } else {
         // large sets: 8-wave workgroups share LDS tiles of the correspondences
-        int hpw = 16;
-        while (hpw > HB && total / ((long long)hpw * kTW) < 512) hpw >>= 1;
+        // one workgroup per CU is resident (<= 256 VGPRs x 8 waves); give every wave just enough
+        // hypotheses that ~250 workgroups cover the job in a single round (a second, ragged
+        // round of workgroups costs a full sweep sequence for a fraction of the CUs)
+        int hpw = (int)((total + 250LL * kTW - 1) / (250LL * kTW));
+        if (hpw < 1) hpw = 1;
+        if (hpw > 16) hpw = 16;
         a.hpw = hpw;
         int per_block = hpw * kTW;
         dim3 grid((o.iterNum + per_block - 1) / per_block, B);
