@@ -99,13 +99,19 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr /*[Q] ordered-uint thresholds*/,
     int32_t* __restrict__ part_idx /*[S][Q][KC]*/, float* __restrict__ part_s) {
     __shared__ float4 tile[kMTile];
+    // Query coefficients live in LDS and are re-read once per tile as 128-bit tuples {az, ax, ay, -}:
+    // a ds_read_b128 result is an aligned VGPR quad, and with this component order no coefficient
+    // shares a VGPR bank (register number mod 4) with the model component it multiplies -- an fma
+    // whose src0 sits in the bank of another VGPR source issues at half rate on gfx950
+    // (scripts/ubench/vgpr_bank.hip).
+    __shared__ float4 qcoef[QPT_][kBlock];
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x * (kBlock * QPT_);
     const int sidx = blockIdx.y;
     const int m_begin = min(M, sidx * chunk_stride), m_end = min(M, m_begin + chunk);
     const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
 
-    float ax[QPT_], ay[QPT_], az[QPT_], thr[QPT_];
+    float thr[QPT_];
     unsigned gseen[QPT_];
     Cand cand[QPT_];
 #pragma unroll
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
         int qi = q0 + r * kBlock + tid;
         bool ok = qi < Q;
         float x = ok ? q[qi] - cx : 0.0f, y = ok ? q[qi + (size_t)ldq] - cy : 0.0f, z = ok ? q[qi + 2 * (size_t)ldq] - cz : 0.0f;
-        ax[r] = -2.0f * x; ay[r] = -2.0f * y; az[r] = -2.0f * z;                 // exact scaling
+        qcoef[r][tid] = make_float4(-2.0f * z, -2.0f * x, -2.0f * y, 0.0f);       // exact scaling
 #pragma unroll
         for (int k = 0; k < KC; ++k) { cand[r].s[k] = INFINITY; cand[r].i[k] = -1; }
         thr[r] = INFINITY; gseen[r] = 0xFFFFFFFFu;
@@ -137,6 +143,9 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
             }
         }
         __syncthreads();
+        float4 qc[QPT_];
+#pragma unroll
+        for (int r = 0; r < QPT_; ++r) qc[r] = qcoef[r][tid];
         const int cnt = min(kMTile, m_end - t0);
         const int nb = (cnt + UB_ - 1) / UB_ * UB_;
         for (int jb = 0; jb < nb; jb += UB_) {
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
                 float s[UB_];
 #pragma unroll
                 for (int u = 0; u < UB_; ++u)
-                    s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, p[u].w)));
+                    s[u] = __builtin_fmaf(qc[r].y, p[u].x, __builtin_fmaf(qc[r].z, p[u].y, __builtin_fmaf(qc[r].x, p[u].z, p[u].w)));
                 // min/max/compare issue at HALF the FMA rate on gfx950 (scripts/ubench/op_rates.hip):
                 // fold three values per v_min3 -> 4 selection ops per 8 scores instead of 7
                 float mn;
