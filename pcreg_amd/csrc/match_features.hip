@@ -253,6 +253,17 @@ size_t score_tmp_bytes(int nA, int nB) {
 
 }  // namespace
 
+// the certified u16 fast path (match_sad16.hip)
+size_t sad16_workspace_bytes(int nA, int nB, int D);
+int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, int ldb, int D,
+                   int32_t* idx, double* dist, void* ws, size_t ws_bytes, hipStream_t st);
+
+// SAD runs on the certified u16 path unless PCREG_MATCH_EXACT=1 (identical results either way)
+static bool use_sad16(int metric) {
+    const char* e = getenv("PCREG_MATCH_EXACT");
+    return metric == PCREG_METRIC_SAD && !(e && atoi(e) != 0);
+}
+
 // workspace layout of launch_match_features (all sizes for capacity Q):
 //   idx [Q][2] i32 | dist [Q][2] f64 | cand_q [Q] | cand_m [Q] | keep [Q] | n_cand | filter tmp
 //   | back_idx [Q][2] | back_dist [Q][2] | gathered rows [Q x D] | score partials
@@ -265,7 +276,9 @@ size_t match_features_workspace_bytes(int Q, int M, int D) {
     b += align_up(q * 2 * sizeof(int32_t), 256) + align_up(q * 2 * sizeof(double), 256);
     b += align_up(q * (size_t)(D > 0 ? D : 1) * sizeof(double), 256);
     size_t t1 = score_tmp_bytes(Q, M), t2 = score_tmp_bytes(Q, Q);
-    b += t1 > t2 ? t1 : t2;
+    size_t t3 = sad16_workspace_bytes(Q, M > Q ? M : Q, D);
+    t1 = t1 > t2 ? t1 : t2;
+    b += t1 > t3 ? t1 : t3;
     return b;
 }
 
@@ -317,8 +330,11 @@ int launch_match_features(const double* fS, int Q, int ldS, const double* fM, in
     double* back_dist = (double*)w;    w += align_up(q * 2 * sizeof(double), 256);
     double* rows = (double*)w;         w += align_up(q * (size_t)D * sizeof(double), 256);
     void* stmp = w;
+    const size_t stmp_bytes = ws_bytes - (size_t)(w - (char*)ws);
+    const bool fast = use_sad16(o.metric);
 
-    int rc = run_score_top2(fS, Q, ldS, fM, M, ldM, D, o.metric, idx, dist, stmp, st);
+    int rc = fast ? run_sad16_top2(fS, Q, ldS, fM, M, ldM, D, idx, dist, stmp, stmp_bytes, st)
+                  : run_score_top2(fS, Q, ldS, fM, M, ldM, D, o.metric, idx, dist, stmp, st);
     if (rc) return rc;
     double maxval = o.metric == PCREG_METRIC_SSD ? 4.0 : 2.0 * sqrt((double)D);   // percentToLevel
     double thr = (o.matchThreshold * 0.01) * maxval;
@@ -333,7 +349,8 @@ int launch_match_features(const double* fS, int Q, int ldS, const double* fM, in
         if (P_host > 0) {
             hipLaunchKernelGGL(gather_rows_kernel, dim3(1024), dim3(256), 0, st, fM, ldM, D, cand_m, n_cand, Q, rows);
             PCREG_HIP(hipGetLastError());
-            rc = run_score_top2(rows, P_host, Q, fS, Q, ldS, D, o.metric, back_idx, back_dist, stmp, st);
+            rc = fast ? run_sad16_top2(rows, P_host, Q, fS, Q, ldS, D, back_idx, back_dist, stmp, stmp_bytes, st)
+                      : run_score_top2(rows, P_host, Q, fS, Q, ldS, D, o.metric, back_idx, back_dist, stmp, st);
             if (rc) return rc;
             hipLaunchKernelGGL(unique_flag_kernel, dim3((P_host + 255) / 256), dim3(256), 0, st, back_idx, cand_q, n_cand, keep);
         }

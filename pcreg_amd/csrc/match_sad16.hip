@@ -1,0 +1,395 @@
+// pcreg_amd/csrc/match_sad16.hip -- certified fast path of the SAD descriptor search.
+//
+// getMatches.m:51-56 with Metric = 'SAD' (every PCReg driver: completeExperimentFast.m:84) is an
+// all-pairs sum of absolute differences over D = 981 features.  In fp64 that is two DP-rate VALU
+// ops per element.  gfx950 has V_SAD_U16: one instruction adds |a.lo-b.lo| + |a.hi-b.hi| to an
+// accumulator, i.e. TWO elements per (half-rate) issue slot -- 4.3x the element rate of the fp64
+// loop (scripts/ubench/op_rates.hip).  So:
+//
+//   1. quantise   both (already L2-normalised) matrices to u16 on one common range, two features
+//                 per dword, K-major like the input ([feature pair][row]: coalesced along rows);
+//   2. candidates the same 128 x 64 register-tiled all-pairs kernel as the exact one, on dwords:
+//                 32 v_sad_u16 per lane and feature pair; per lane and query a sorted top-4
+//                 (integer score, index); the 16 lanes sharing a query merge through LDS;
+//   3. finalize   one wave per query: candidates that can still be in the top-2 are re-scored
+//                 EXACTLY in fp64 with the oracle's accumulation order (s += |a-b|, ascending
+//                 feature index, one lane per candidate), wave-shuffle (dist, idx) top-2, and the
+//                 certificate: every row outside the lists has integer score >= G, so its true
+//                 distance is >= (G - D - 1) / scale; if that exceeds the exact 2nd-best the
+//                 answer is proven identical to the exhaustive fp64 search;
+//   4. fallback   unproven queries are redone by the exact fp64 kernel.
+// Quantisation error: |f - (fmin + u/scale)| <= 0.5/scale per value => each |a-b| moves by at
+// most 1/scale => |SAD - SADq/scale| <= D/scale.
+#include "common.hpp"
+#include "select.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <cstdio>
+#include <algorithm>
+
+namespace pcreg {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int TQ = 8, TM = 4;
+constexpr int BQ = 16 * TQ, BM = 16 * TM;     // 128 x 64 tile
+constexpr int DK2 = 32;                        // feature PAIRS per LDS slab
+constexpr int KC = 4;
+constexpr int kMaxSplit = 16;                  // S * KC <= 64: one candidate per lane in the finalize wave
+
+struct Range { double fmin, scale, inv_scale; };
+
+// ---- range (two-stage, deterministic) --------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const double* __restrict__ A, int nA, int lda,
+                                                                const double* __restrict__ B, int nB, int ldb, int D,
+                                                                double* __restrict__ part) {
+    double lo = INFINITY, hi = -INFINITY;
+    const size_t eA = (size_t)nA * D, eB = (size_t)nB * D;
+    for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < eA + eB; e += (size_t)gridDim.x * kBlock) {
+        double v;
+        if (e < eA) v = A[e % nA + (e / nA) * (size_t)lda];
+        else { size_t f = e - eA; v = B[f % nB + (f / nB) * (size_t)ldb]; }
+        lo = fmin(lo, v); hi = fmax(hi, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+    __shared__ double s[8];
+    if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = lo; s[4 + (threadIdx.x >> 6)] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = fmin(fmin(s[0], s[1]), fmin(s[2], s[3]));
+        part[blockIdx.x * 2 + 1] = fmax(fmax(s[4], s[5]), fmax(s[6], s[7]));
+    }
+}
+__global__ void range_final_kernel(const double* __restrict__ part, int nparts, Range* __restrict__ r) {
+    if (threadIdx.x != 0) return;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int b = 0; b < nparts; ++b) { lo = fmin(lo, part[2 * b]); hi = fmax(hi, part[2 * b + 1]); }
+    if (!(hi > lo)) hi = lo + 1.0;                 // constant (or empty) input: any scale works
+    r->fmin = lo; r->scale = 65535.0 / (hi - lo); r->inv_scale = (hi - lo) / 65535.0;
+}
+// f (n x D, ld) -> packed u16 pairs [D2p][ldq]; D2p = D2 rounded up to DK2, ldq = n rounded up to BQ;
+// padding is zero, so the tile loads of the candidates kernel need no bounds checks.
+__global__ __launch_bounds__(kBlock) void quantize_pack_kernel(const double* __restrict__ f, int n, int ld, int D, int D2p, int ldq,
+                                                               const Range* __restrict__ rp, uint32_t* __restrict__ out) {
+    const double f0 = rp->fmin, scale = rp->scale;
+    size_t total = (size_t)ldq * D2p;
+    for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
+        int kk = (int)(e / ldq), i = (int)(e % ldq);
+        unsigned q[2] = {0u, 0u};
+        if (i < n) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int d = 2 * kk + h;
+                double u = d < D ? rint((f[i + (size_t)d * ld] - f0) * scale) : 0.0;
+                q[h] = (unsigned)fmin(fmax(u, 0.0), 65535.0);
+            }
+        }
+        out[e] = q[0] | (q[1] << 16);
+    }
+}
+
+// ---- candidates ------------------------------------------------------------------------------------
+struct CandU { unsigned s[KC]; int i[KC]; };
+__device__ __forceinline__ void candu_insert(CandU& c, unsigned s, int j) {   // ascending j inside a lane: strict '<'
+    if (s < c.s[3]) {
+        if (s < c.s[1]) {
+            c.s[3] = c.s[2]; c.i[3] = c.i[2]; c.s[2] = c.s[1]; c.i[2] = c.i[1];
+            if (s < c.s[0]) { c.s[1] = c.s[0]; c.i[1] = c.i[0]; c.s[0] = s; c.i[0] = j; } else { c.s[1] = s; c.i[1] = j; }
+        } else {
+            if (s < c.s[2]) { c.s[3] = c.s[2]; c.i[3] = c.i[2]; c.s[2] = s; c.i[2] = j; } else { c.s[3] = s; c.i[3] = j; }
+        }
+    }
+}
+__device__ __forceinline__ bool lexu_lt(unsigned sa, int ia, unsigned sb, int ib) { return sa < sb || (sa == sb && (unsigned)ia < (unsigned)ib); }
+__device__ __forceinline__ void candu_insert_lex(CandU& c, unsigned s, int j) {
+    if (j < 0) return;
+    int pos = KC;
+#pragma unroll
+    for (int k = KC - 1; k >= 0; --k) if (lexu_lt(s, j, c.s[k], c.i[k])) pos = k;
+    if (pos == KC) return;
+#pragma unroll
+    for (int k = KC - 1; k > 0; --k) if (k > pos) { c.s[k] = c.s[k - 1]; c.i[k] = c.i[k - 1]; }
+#pragma unroll
+    for (int k = 0; k < KC; ++k) if (k == pos) { c.s[k] = s; c.i[k] = j; }
+}
+
+// grid = (ceil(nA/BQ), S).  part_* layout [S][nA][KC].  Empty slots: idx -1, score 0xFFFFFFFF.
+// Aq / Bq are the padded layouts of quantize_pack_kernel (lda / ldb multiples of BQ, D2p of DK2).
+__global__ __launch_bounds__(kBlock) void sad16_candidates_kernel(const uint32_t* __restrict__ Aq, int nA, int lda,
+                                                                  const uint32_t* __restrict__ Bq, int nB, int ldb, int D2p, int chunk,
+                                                                  int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s) {
+    // slabs (24 KiB) and the final merge cells (32 KiB) share one buffer
+    __shared__ __attribute__((aligned(16))) uint32_t smem[64 * 16 * 8];
+    uint32_t* As = smem; uint32_t* Bs = smem + DK2 * BQ; uint32_t* cells = smem;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int q0 = blockIdx.x * BQ, sidx = blockIdx.y;
+    const int b_begin = sidx * chunk, b_end = min(nB, b_begin + chunk);
+    CandU best[TQ];
+#pragma unroll
+    for (int r = 0; r < TQ; ++r)
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { best[r].s[k] = 0xFFFFFFFFu; best[r].i[k] = -1; }
+
+    for (int m0 = b_begin; m0 < b_end; m0 += BM) {
+        unsigned acc[TQ][TM];
+#pragma unroll
+        for (int r = 0; r < TQ; ++r)
+#pragma unroll
+            for (int c = 0; c < TM; ++c) acc[r][c] = 0u;
+        for (int d0 = 0; d0 < D2p; d0 += DK2) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < DK2 * BQ / 4 / kBlock; ++k) {       // 4 x uint4 per thread
+                int e = k * kBlock + tid, r4 = e % (BQ / 4), dd = e / (BQ / 4);
+                *(uint4*)(As + dd * BQ + r4 * 4) = *(const uint4*)(Aq + (size_t)(d0 + dd) * lda + q0 + r4 * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < DK2 * BM / 4 / kBlock; ++k) {       // 2 x uint4 per thread
+                int e = k * kBlock + tid, r4 = e % (BM / 4), dd = e / (BM / 4);
+                *(uint4*)(Bs + dd * BM + r4 * 4) = *(const uint4*)(Bq + (size_t)(d0 + dd) * ldb + m0 + r4 * 4);
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int dd = 0; dd < DK2; ++dd) {
+                unsigned a[TQ], b[TM];
+#pragma unroll
+                for (int r = 0; r < TQ; ++r) a[r] = As[dd * BQ + tx * TQ + r];
+#pragma unroll
+                for (int c = 0; c < TM; ++c) b[c] = Bs[dd * BM + ty * TM + c];
+#pragma unroll
+                for (int r = 0; r < TQ; ++r)
+#pragma unroll
+                    for (int c = 0; c < TM; ++c) acc[r][c] = __builtin_amdgcn_sad_u16(a[r], b[c], acc[r][c]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            unsigned mn = min(min(acc[r][0], acc[r][1]), min(acc[r][2], acc[r][3]));
+            if (mn < best[r].s[3]) {
+#pragma unroll
+                for (int c = 0; c < TM; ++c) {
+                    int j = m0 + ty * TM + c;
+                    if (j < b_end) candu_insert(best[r], acc[r][c], j);
+                }
+            }
+        }
+    }
+    // merge the 16 ty-lists of every query (two halves of 64 queries)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < TQ; ++r) {
+            int ql = tx * TQ + r;
+            if ((ql >> 6) == half) {
+                uint32_t* cell = cells + ((ql & 63) * 16 + ty) * 8;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { cell[k] = best[r].s[k]; cell[4 + k] = (uint32_t)best[r].i[k]; }
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int qi = q0 + half * 64 + tid;
+            if (qi < nA) {
+                CandU t;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { t.s[k] = 0xFFFFFFFFu; t.i[k] = -1; }
+                for (int y = 0; y < 16; ++y) {
+                    const uint32_t* cell = cells + (tid * 16 + y) * 8;
+#pragma unroll
+                    for (int k = 0; k < KC; ++k) candu_insert_lex(t, cell[k], (int)cell[4 + k]);
+                }
+                size_t o = ((size_t)sidx * nA + qi) * KC;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { part_idx[o + k] = t.i[k]; part_s[o + k] = t.s[k]; }
+            }
+        }
+    }
+}
+
+// ---- exact re-rank + certificate: one wave per query, one lane per candidate ----------------------
+__device__ __forceinline__ bool lexd_lt(double da, int ia, double db, int ib) { return da < db || (da == db && (unsigned)ia < (unsigned)ib); }
+
+__global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __restrict__ A, int nA, int lda,
+                                                                const double* __restrict__ B, int nB, int ldb, int D,
+                                                                const Range* __restrict__ rp, const int32_t* __restrict__ part_idx,
+                                                                const uint32_t* __restrict__ part_s, int S,
+                                                                int32_t* __restrict__ idx, double* __restrict__ dist,
+                                                                int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (qi >= nA) return;
+    const int total = S * KC;                              // <= 64
+    int j = -1; unsigned sq = 0xFFFFFFFFu;
+    if (lane < total) { size_t o = ((size_t)(lane / KC) * nA + qi) * KC + (lane % KC); j = part_idx[o]; sq = part_s[o]; }
+    // the two smallest integer scores of the union, and G = the smallest "4th-best of a chunk"
+    unsigned a1 = sq, a2 = 0xFFFFFFFFu;
+    unsigned g = (lane < total && (lane % KC) == KC - 1 && j >= 0) ? sq : 0xFFFFFFFFu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned b1 = __shfl_xor(a1, o), b2 = __shfl_xor(a2, o);
+        unsigned n1 = min(a1, b1), n2 = min(max(a1, b1), min(a2, b2));
+        a1 = n1; a2 = n2;
+        g = min(g, (unsigned)__shfl_xor((int)g, o));
+    }
+    const unsigned slack = 2u * (unsigned)(D + 1) + 2u;
+    const bool need = j >= 0 && (a2 == 0xFFFFFFFFu || sq <= a2 + slack || a2 > 0xFFFFFFFFu - slack);
+    double d = INFINITY;
+    if (need) {                                            // exact SAD, the oracle's accumulation order
+        const double* a = A + qi; const double* b = B + j;
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s += fabs(a[(size_t)k * lda] - b[(size_t)k * ldb]);
+        d = s;
+    }
+    int jd = need ? j : -1;
+    double d1 = d, d2 = INFINITY; int i1 = jd, i2 = -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+        int k1 = __shfl_xor(i1, o), k2 = __shfl_xor(i2, o);
+        // empty slots carry (inf, -1): (unsigned)-1 orders last
+        bool fm = lexd_lt(d1, i1, e1, k1);
+        double w1 = fm ? d1 : e1; int x1 = fm ? i1 : k1;
+        double m2 = fm ? d2 : d1; int y2 = fm ? i2 : i1;
+        double o2 = fm ? e1 : e2; int z2 = fm ? k1 : k2;
+        bool sm = lexd_lt(m2, y2, o2, z2);
+        d1 = w1; i1 = x1; d2 = sm ? m2 : o2; i2 = sm ? y2 : z2;
+    }
+    bool ok;
+    if (g == 0xFFFFFFFFu) ok = true;                      // no chunk filled its list: every row is a candidate
+    else {
+        double lower = ((double)g - (double)(D + 1)) * rp->inv_scale;
+        ok = (i2 >= 0) && (lower * (1.0 - 1e-12) > d2);
+    }
+    if (force_unproven) ok = false;                        // test hook: exercise the fallback
+    if (lane == 0) {
+        if (ok) { idx[(size_t)qi * 2] = i1; idx[(size_t)qi * 2 + 1] = i2; dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2; }
+        else { int slot = atomicAdd(n_flag, 1); flag_list[slot] = qi; }
+    }
+}
+
+// ---- fallback: unproven queries, exhaustively, exact ---------------------------------------------
+// grid (nf, SC): block = one unproven query x one slice of B; the query row sits in LDS, each thread
+// owns rows j = begin + tid + 256 t and accumulates in the oracle's order; B is read coalesced.
+constexpr int kFbSlices = 64;
+__global__ __launch_bounds__(kBlock) void sad_exact_rows_kernel(const double* __restrict__ A, int lda,
+                                                                const double* __restrict__ B, int nB, int ldb, int D,
+                                                                const int32_t* __restrict__ list, int nf, int slice,
+                                                                int32_t* __restrict__ part_idx, double* __restrict__ part_dist) {
+    extern __shared__ double s_a[];                           // D doubles
+    __shared__ double s_d[4][2]; __shared__ int s_i[4][2];
+    const int k = blockIdx.x, qi = list[k];
+    for (int d = threadIdx.x; d < D; d += kBlock) s_a[d] = A[qi + (size_t)d * lda];
+    __syncthreads();
+    const int begin = blockIdx.y * slice, end = min(nB, begin + slice);
+    double d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+    for (int j = begin + threadIdx.x; j < end; j += kBlock) {
+        const double* b = B + j;
+        double s = 0.0;
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) s += fabs(s_a[d] - b[(size_t)d * ldb]);
+        if (s < d1) { d2 = d1; i2 = i1; d1 = s; i1 = j; } else if (s < d2) { d2 = s; i2 = j; }   // ascending j: strict
+    }
+    auto merge = [&](double e1, int k1, double e2, int k2) {
+        bool fm = lexd_lt(d1, i1, e1, k1);
+        double w1 = fm ? d1 : e1; int x1 = fm ? i1 : k1;
+        double m2 = fm ? d2 : d1; int y2 = fm ? i2 : i1;
+        double o2 = fm ? e1 : e2; int z2 = fm ? k1 : k2;
+        bool sm = lexd_lt(m2, y2, o2, z2);
+        d1 = w1; i1 = x1; d2 = sm ? m2 : o2; i2 = sm ? y2 : z2;
+    };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) merge(__shfl_xor(d1, o), __shfl_xor(i1, o), __shfl_xor(d2, o), __shfl_xor(i2, o));
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_d[wv][0] = d1; s_d[wv][1] = d2; s_i[wv][0] = i1; s_i[wv][1] = i2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) merge(s_d[w][0], s_i[w][0], s_d[w][1], s_i[w][1]);
+        size_t o = ((size_t)blockIdx.y * nf + k) * 2;        // [slice][nf][2]: merge_top2_kernel_t layout
+        part_idx[o] = i1; part_idx[o + 1] = i2; part_dist[o] = d1; part_dist[o + 1] = d2;
+    }
+}
+__global__ void scatter_flagged_kernel(const int32_t* __restrict__ list, int nf, const int32_t* __restrict__ fi,
+                                       const double* __restrict__ fd, int32_t* __restrict__ idx, double* __restrict__ dist) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nf) return;
+    int qi = list[k];
+    idx[(size_t)qi * 2] = fi[(size_t)k * 2]; idx[(size_t)qi * 2 + 1] = fi[(size_t)k * 2 + 1];
+    dist[(size_t)qi * 2] = fd[(size_t)k * 2]; dist[(size_t)qi * 2 + 1] = fd[(size_t)k * 2 + 1];
+}
+
+}  // namespace
+
+// workspace: Range | n_flag | minmax partials | Aq | Bq | part_idx | part_s | flag_list
+//            | fallback: fi | fd | slice partials [kFbSlices][nA][2] (i32, f64)
+size_t sad16_workspace_bytes(int nA, int nB, int D) {
+    size_t a = (size_t)(nA > 0 ? nA : 1), b = (size_t)(nB > 0 ? nB : 1);
+    size_t D2p = align_up((size_t)(D + 1) / 2, DK2);
+    return 256 + 256 + align_up(1024 * 2 * 8, 256) + D2p * align_up(a, BQ) * 4 + D2p * align_up(b, BQ) * 4 +
+           2 * align_up((size_t)kMaxSplit * a * KC * 4, 256) + align_up(a * 4, 256) +
+           align_up(a * 2 * 4, 256) + align_up(a * 2 * 8, 256) +
+           align_up((size_t)kFbSlices * a * 2 * 4, 256) + align_up((size_t)kFbSlices * a * 2 * 8, 256);
+}
+
+// Top-2 of every row of A against all rows of B under SAD: indices and fp64 distances identical to
+// the exhaustive fp64 search (launch_score_top2_exact).  One host sync (the unproven-query count).
+int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, int ldb, int D,
+                   int32_t* idx, double* dist, void* ws, size_t ws_bytes, hipStream_t st) {
+    PCREG_ARG(nA >= 1 && nB >= 1 && D >= 1);
+    size_t need = sad16_workspace_bytes(nA, nB, D);
+    if (ws_bytes < need) { set_error("sad16 workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    const int D2p = (int)align_up((size_t)(D + 1) / 2, DK2);
+    const int ldqa = (int)align_up((size_t)nA, BQ), ldqb = (int)align_up((size_t)nB, BQ);
+    size_t a = (size_t)nA, b = (size_t)nB;
+    char* w = (char*)ws;
+    Range* range = (Range*)w;               w += 256;
+    int32_t* n_flag = (int32_t*)w;          w += 256;
+    double* mpart = (double*)w;             w += align_up(1024 * 2 * 8, 256);
+    uint32_t* Aq = (uint32_t*)w;            w += (size_t)D2p * ldqa * 4;
+    uint32_t* Bq = (uint32_t*)w;            w += (size_t)D2p * ldqb * 4;
+    int32_t* part_idx = (int32_t*)w;        w += align_up((size_t)kMaxSplit * a * KC * 4, 256);
+    uint32_t* part_s = (uint32_t*)w;        w += align_up((size_t)kMaxSplit * a * KC * 4, 256);
+    int32_t* flag_list = (int32_t*)w;       w += align_up(a * 4, 256);
+    int32_t* fi = (int32_t*)w;              w += align_up(a * 2 * 4, 256);
+    double* fd = (double*)w;                w += align_up(a * 2 * 8, 256);
+    int32_t* fpi = (int32_t*)w;             w += align_up((size_t)kFbSlices * a * 2 * 4, 256);
+    double* fpd = (double*)w;
+
+    PCREG_ARG(lda >= nA && ldb >= nB);
+    int nb = (int)std::min<size_t>(1024, ((a + b) * D + kBlock * 8 - 1) / (kBlock * 8)); if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(kBlock), 0, st, A, nA, lda, B, nB, ldb, D, mpart);
+    hipLaunchKernelGGL(range_final_kernel, dim3(1), dim3(64), 0, st, mpart, nb, range);
+    hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, A, nA, lda, D, D2p, ldqa, range, Aq);
+    hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, B, nB, ldb, D, D2p, ldqb, range, Bq);
+    PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
+    const int n_tiles = (nA + BQ - 1) / BQ;
+    int S = (1024 + n_tiles - 1) / n_tiles;
+    if (S > kMaxSplit) S = kMaxSplit;
+    int maxS = (nB + BM - 1) / BM; if (S > maxS) S = maxS; if (S < 1) S = 1;
+    int chunk = ((nB + S - 1) / S + BM - 1) / BM * BM;
+    S = (nB + chunk - 1) / chunk;
+    hipLaunchKernelGGL(sad16_candidates_kernel, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s);
+    const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
+    hipLaunchKernelGGL(sad16_finalize_kernel, dim3((nA + 3) / 4), dim3(kBlock), 0, st, A, nA, lda, B, nB, ldb, D, range,
+                       part_idx, part_s, S, idx, dist, flag_list, n_flag, force);
+    PCREG_HIP(hipGetLastError());
+    int32_t nf = 0;
+    PCREG_HIP(hipMemcpyAsync(&nf, n_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PCREG_HIP(hipStreamSynchronize(st));
+    if (getenv("PCREG_MATCH_DEBUG")) fprintf(stderr, "[pcreg] sad16: nA=%d nB=%d D=%d S=%d unproven=%d\n", nA, nB, D, S, nf);
+    if (nf > 0) {
+        int slices = std::min(kFbSlices, (nB + kBlock - 1) / kBlock);
+        int slice = (nB + slices - 1) / slices;
+        slices = (nB + slice - 1) / slice;
+        hipLaunchKernelGGL(sad_exact_rows_kernel, dim3(nf, slices), dim3(kBlock), (size_t)D * sizeof(double), st,
+                           A, lda, B, nB, ldb, D, flag_list, nf, slice, fpi, fpd);
+        hipLaunchKernelGGL(merge_top2_kernel_t<double>, dim3((nf + 255) / 256), dim3(256), 0, st, fpi, fpd, slices, nf, fi, fd);
+        hipLaunchKernelGGL(scatter_flagged_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, flag_list, nf, fi, fd, idx, dist);
+        PCREG_HIP(hipGetLastError());
+    }
+    return PCREG_OK;
+}
+
+}  // namespace pcreg

@@ -27,6 +27,14 @@ KERNEL(k_addu,  "v_add_u32 v40, v21, v26")
 KERNEL(k_mov,   "v_mov_b32 v40, v21")
 KERNEL(k_pkmul, "v_pk_mul_f32 v[40:41], v[20:21], v[26:27]")
 KERNEL(k_cmpclass, "v_cmp_class_f32 vcc, v21, v26")
+KERNEL(k_sadu16, "v_sad_u16 v40, v21, v26, v31")
+KERNEL(k_sadu8,  "v_sad_u8 v40, v21, v26, v31")
+KERNEL(k_sadu32, "v_sad_u32 v40, v21, v26, v31")
+KERNEL(k_dot2i,  "v_dot2_i32_i16 v40, v21, v26, v31")
+KERNEL(k_dot4i,  "v_dot4_i32_i8 v40, v21, v26, v31")
+KERNEL(k_dot2f,  "v_dot2_f32_f16 v40, v21, v26, v31")
+KERNEL(k_pkfmah, "v_pk_fma_f16 v40, v21, v26, v31")
+KERNEL(k_madu24, "v_mad_u32_u24 v40, v21, v26, v31")
 typedef void (*kfn)(float*, int);
 int main() {
     float* d; (void)hipMalloc(&d, 8192 * 256 * 4);
@@ -35,7 +43,8 @@ int main() {
     struct { const char* n; kfn f; } ks[] = {{"v_fma_f32", k_fma}, {"v_add_f32", k_add}, {"v_sub_f32", k_sub}, {"v_mul_f32", k_mul}, {"v_min_f32", k_min},
         {"v_max_f32", k_max}, {"v_min3_f32", k_min3}, {"v_med3_f32", k_med3}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cmp_lt_f32 sgpr", k_cmpe64},
         {"v_cndmask_b32", k_cnd}, {"v_and_b32", k_and}, {"v_or3_b32", k_or3}, {"v_min_i32", k_mini}, {"v_add_u32", k_addu}, {"v_mov_b32", k_mov},
-        {"v_pk_mul_f32", k_pkmul}, {"v_cmp_class_f32", k_cmpclass}};
+        {"v_pk_mul_f32", k_pkmul}, {"v_cmp_class_f32", k_cmpclass}, {"v_sad_u16", k_sadu16}, {"v_sad_u8", k_sadu8}, {"v_sad_u32", k_sadu32},
+        {"v_dot2_i32_i16", k_dot2i}, {"v_dot4_i32_i8", k_dot4i}, {"v_dot2_f32_f16", k_dot2f}, {"v_pk_fma_f16", k_pkfmah}, {"v_mad_u32_u24", k_madu24}};
     for (auto& k : ks) {
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {

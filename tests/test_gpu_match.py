@@ -90,3 +90,36 @@ def test_get_matches_empty_and_verbose(capsys):
     out = pc.getMatches(dS[:0], dM, dict(PAR, VERBOSE=1))
     assert out.shape == (0, 2)
     assert "Calculated matches in" in capsys.readouterr().out                 # getMatches.m:58
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact", "fallback"])
+@pytest.mark.parametrize("Q,M,D", [(700, 2500, 981), (257, 130, 33), (3, 2, 5)])
+def test_sad_fast_path_is_the_exact_search(Q, M, D, mode, oracle_c, monkeypatch):
+    """The certified u16 SAD path (match_sad16.hip), the exhaustive fp64 kernel and the
+    all-queries-unproven fallback return the same pairs AND the same fp64 metric values."""
+    import pcreg_amd as pc
+    if mode == "exact":
+        monkeypatch.setenv("PCREG_MATCH_EXACT", "1")
+    if mode == "fallback":
+        monkeypatch.setenv("PCREG_MATCH_FORCE_FALLBACK", "1")
+    dS, dM = _descs(Q, M, D, Q + M + D)
+    dM[M // 2] = dM[0]                                  # duplicate model rows: ties go to the lowest index
+    if M > 100:
+        dM[M - 1] = dM[7]; dS[5] = dM[7]
+    for kw in (dict(Metric="SAD", MatchThreshold=10.0, MaxRatio=0.95, Unique=True),
+               dict(Metric="SAD", MatchThreshold=100.0, MaxRatio=1.0, Unique=False)):
+        pairs, met = pc.matchFeatures(dS, dM, **kw)
+        rp, rm = oracle_c.matchFeatures(dS, dM, kw)
+        np.testing.assert_array_equal(pairs, rp)
+        np.testing.assert_array_equal(met, rm)
+
+
+def test_sad_fast_path_constant_descriptors(oracle_c):
+    """Zero range (all values equal after normalisation): every distance ties at 0."""
+    import pcreg_amd as pc
+    dS = np.full((40, 16), 2.0); dM = np.full((90, 16), 2.0)
+    kw = dict(Metric="SAD", MatchThreshold=100.0, MaxRatio=1.0, Unique=False)
+    pairs, met = pc.matchFeatures(dS, dM, **kw)
+    rp, rm = oracle_c.matchFeatures(dS, dM, kw)
+    np.testing.assert_array_equal(pairs, rp)
+    np.testing.assert_array_equal(met, rm)
