@@ -29,11 +29,23 @@ constexpr int BM = 16 * TM;                 // 64 model rows per tile
 constexpr int DK = 16;                      // feature slab
 
 // ---------------------------------------------------------------- preprocessing
-__global__ void row_l1_kernel(const double* __restrict__ f, int n, int ld, int D, double* __restrict__ out) {
+// One lane per row keeps the oracle's summation order; what a lane CAN do in parallel is fetch:
+// 16 features are loaded back to back (each a coalesced 512-B line per wave) before they are added.
+constexpr int kRowUnroll = 16;
+__global__ __launch_bounds__(64) void row_l1_kernel(const double* __restrict__ f, int n, int ld, int D, double* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const double* p = f + i;
     double s = 0;
-    for (int d = 0; d < D; ++d) s += fabs(f[i + (size_t)d * ld]);            // vecnorm(.,1,2), getMatches.m:24
+    int d = 0;
+    for (; d + kRowUnroll <= D; d += kRowUnroll) {
+        double v[kRowUnroll];
+#pragma unroll
+        for (int u = 0; u < kRowUnroll; ++u) v[u] = p[(size_t)(d + u) * ld];
+#pragma unroll
+        for (int u = 0; u < kRowUnroll; ++u) s += fabs(v[u]);                   // vecnorm(.,1,2), getMatches.m:24
+    }
+    for (; d < D; ++d) s += fabs(p[(size_t)d * ld]);
     out[i] = s;
 }
 // deterministic mean of n values by one workgroup -> *out = factor * mean
@@ -58,14 +70,31 @@ __global__ void preprocess_kernel(const double* __restrict__ in, int n, int ld, 
     }
 }
 // matchFeatures' normalizeX: unit L2 rows, effectively-zero rows -> 0
-__global__ void normalize_rows_kernel(double* __restrict__ f, int n, int ld, int D) {
+__global__ __launch_bounds__(64) void normalize_rows_kernel(double* __restrict__ f, int n, int ld, int D) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    double* p = f + i;
     double s = 0;
-    for (int d = 0; d < D; ++d) { double v = f[i + (size_t)d * ld]; s = fma(v, v, s); }
+    int d = 0;
+    for (; d + kRowUnroll <= D; d += kRowUnroll) {
+        double v[kRowUnroll];
+#pragma unroll
+        for (int u = 0; u < kRowUnroll; ++u) v[u] = p[(size_t)(d + u) * ld];
+#pragma unroll
+        for (int u = 0; u < kRowUnroll; ++u) s = fma(v[u], v[u], s);
+    }
+    for (; d < D; ++d) { double v = p[(size_t)d * ld]; s = fma(v, v, s); }
     double nrm = sqrt(s);
     bool zero = nrm <= (double)FLT_EPSILON;
-    for (int d = 0; d < D; ++d) { double v = f[i + (size_t)d * ld]; f[i + (size_t)d * ld] = zero ? 0.0 : v / nrm; }
+    d = 0;
+    for (; d + kRowUnroll <= D; d += kRowUnroll) {
+        double v[kRowUnroll];
+#pragma unroll
+        for (int u = 0; u < kRowUnroll; ++u) v[u] = p[(size_t)(d + u) * ld];
+#pragma unroll
+        for (int u = 0; u < kRowUnroll; ++u) p[(size_t)(d + u) * ld] = zero ? 0.0 : v[u] / nrm;
+    }
+    for (; d < D; ++d) { double v = p[(size_t)d * ld]; p[(size_t)d * ld] = zero ? 0.0 : v / nrm; }
 }
 
 // ---------------------------------------------------------------- all-pairs + top-2
@@ -291,8 +320,8 @@ int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M,
     double* l1 = (double*)ws; double* col = l1 + (size_t)Q + M;
     int Dp = D + (o.unnormalize ? 1 : 0);
     if (o.unnormalize) {
-        if (Q > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, dS, Q, ldS, D, l1);
-        if (M > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((M + 255) / 256), dim3(256), 0, st, dM, M, ldM, D, l1 + Q);
+        if (Q > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, dS, Q, ldS, D, l1);
+        if (M > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((M + 63) / 64), dim3(64), 0, st, dM, M, ldM, D, l1 + Q);
         hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, l1, Q + M, o.norm_factor, col);
     }
     if (Q > 0) hipLaunchKernelGGL(preprocess_kernel, dim3(1024), dim3(256), 0, st, dS, Q, ldS, D, Dp, col, o.change_metric, o.metric_factor, outS);
@@ -303,7 +332,7 @@ int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M,
 
 int launch_normalize_rows(double* f, int n, int ld, int D, hipStream_t st) {
     if (n <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, f, n, ld, D);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, st, f, n, ld, D);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <algorithm>
+#include <vector>
 
 namespace pcreg {
 
@@ -36,7 +37,7 @@ constexpr int TQ = 8, TM = 4;
 constexpr int BQ = 16 * TQ, BM = 16 * TM;     // 128 x 64 tile
 constexpr int DK2 = 32;                        // feature PAIRS per LDS slab
 constexpr int KC = 4;
-constexpr int kMaxSplit = 16;                  // S * KC <= 64: one candidate per lane in the finalize wave
+constexpr int kMaxSplit = 32;                  // S * KC <= 128: two list entries per lane in the finalize wave
 
 struct Range { double fmin, scale, inv_scale; };
 
@@ -117,12 +118,17 @@ __device__ __forceinline__ void candu_insert_lex(CandU& c, unsigned s, int j) {
 
 // grid = (ceil(nA/BQ), S).  part_* layout [S][nA][KC].  Empty slots: idx -1, score 0xFFFFFFFF.
 // Aq / Bq are the padded layouts of quantize_pack_kernel (lda / ldb multiples of BQ, D2p of DK2).
-__global__ __launch_bounds__(kBlock) void sad16_candidates_kernel(const uint32_t* __restrict__ Aq, int nA, int lda,
+template <bool DRY>
+__global__ __launch_bounds__(kBlock, 3) void sad16_candidates_kernel(const uint32_t* __restrict__ Aq, int nA, int lda,
                                                                   const uint32_t* __restrict__ Bq, int nB, int ldb, int D2p, int chunk,
-                                                                  int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s) {
-    // slabs (24 KiB) and the final merge cells (32 KiB) share one buffer
-    __shared__ __attribute__((aligned(16))) uint32_t smem[64 * 16 * 8];
-    uint32_t* As = smem; uint32_t* Bs = smem + DK2 * BQ; uint32_t* cells = smem;
+                                                                  int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s,
+                                                                  unsigned long long* __restrict__ dbg) {
+    unsigned long long t_start = 0;
+    if (dbg) t_start = __builtin_amdgcn_s_memrealtime();
+    // two slab buffers (2 x 24 KiB, filled by LDS-DMA) and the final merge cells (32 KiB) share one array
+    constexpr int kSlab = DK2 * BQ + DK2 * BM;
+    __shared__ __attribute__((aligned(16))) uint32_t smem[2 * kSlab];
+    uint32_t* cells = smem;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int q0 = blockIdx.x * BQ, sidx = blockIdx.y;
     const int b_begin = sidx * chunk, b_end = min(nB, b_begin + chunk);
@@ -132,58 +138,93 @@ __global__ __launch_bounds__(kBlock) void sad16_candidates_kernel(const uint32_t
 #pragma unroll
         for (int k = 0; k < KC; ++k) { best[r].s[k] = 0xFFFFFFFFu; best[r].i[k] = -1; }
 
-    for (int m0 = b_begin; m0 < b_end; m0 += BM) {
-        unsigned acc[TQ][TM];
-#pragma unroll
-        for (int r = 0; r < TQ; ++r)
-#pragma unroll
-            for (int c = 0; c < TM; ++c) acc[r][c] = 0u;
-        for (int d0 = 0; d0 < D2p; d0 += DK2) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < DK2 * BQ / 4 / kBlock; ++k) {       // 4 x uint4 per thread
-                int e = k * kBlock + tid, r4 = e % (BQ / 4), dd = e / (BQ / 4);
-                *(uint4*)(As + dd * BQ + r4 * 4) = *(const uint4*)(Aq + (size_t)(d0 + dd) * lda + q0 + r4 * 4);
-            }
-#pragma unroll
-            for (int k = 0; k < DK2 * BM / 4 / kBlock; ++k) {       // 2 x uint4 per thread
-                int e = k * kBlock + tid, r4 = e % (BM / 4), dd = e / (BM / 4);
-                *(uint4*)(Bs + dd * BM + r4 * 4) = *(const uint4*)(Bq + (size_t)(d0 + dd) * ldb + m0 + r4 * 4);
-            }
-            __syncthreads();
-#pragma unroll 4
-            for (int dd = 0; dd < DK2; ++dd) {
-                unsigned a[TQ], b[TM];
-#pragma unroll
-                for (int r = 0; r < TQ; ++r) a[r] = As[dd * BQ + tx * TQ + r];
-#pragma unroll
-                for (int c = 0; c < TM; ++c) b[c] = Bs[dd * BM + ty * TM + c];
-#pragma unroll
-                for (int r = 0; r < TQ; ++r)
-#pragma unroll
-                    for (int c = 0; c < TM; ++c) acc[r][c] = __builtin_amdgcn_sad_u16(a[r], b[c], acc[r][c]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < TQ; ++r) {
-            unsigned mn = min(min(acc[r][0], acc[r][1]), min(acc[r][2], acc[r][3]));
-            if (mn < best[r].s[3]) {
-#pragma unroll
-                for (int c = 0; c < TM; ++c) {
-                    int j = m0 + ty * TM + c;
-                    if (j < b_end) candu_insert(best[r], acc[r][c], j);
-                }
-            }
-        }
+    // One flat sequence of slabs over (model tile, feature slab).  Slab it+1 is copied global -> LDS
+    // by `global_load_lds_dwordx4` (no VGPR staging; a wave instruction lands 64 x 16 B contiguously:
+    // two 512-B rows of the A slab or four 256-B rows of the B slab) while slab it is consumed.
+    const int n_slabs = D2p / DK2;
+    const int n_mt = (b_end - b_begin + BM - 1) / BM;
+    const int n_it = n_mt * n_slabs;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // uniform 64-bit base (SGPR pair) + one 32-bit per-lane offset: the saddr form of the DMA load
+    const unsigned a_off = (unsigned)((lane >> 5) * lda + (lane & 31) * 4);
+    const unsigned b_off = (unsigned)((lane >> 4) * ldb + (lane & 15) * 4);
+    const uint32_t* a_base = Aq + q0;
+    const uint32_t* b_base = Bq + b_begin;
+#define PCREG_SAD_DMA(IT, BUF)                                                                                   \
+    {                                                                                                            \
+        const int mt_ = (IT) / n_slabs, d0_ = ((IT) - mt_ * n_slabs) * DK2;                                      \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                          \
+            const int seg = k * 4 + wave;                                                                        \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (size_t)(d0_ + seg * 2) * lda + a_off), \
+                                             (__attribute__((address_space(3))) void*)(smem + (BUF) * kSlab + seg * 256), 16, 0, 0); \
+        }                                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                          \
+            const int seg = k * 4 + wave;                                                                        \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + ((size_t)(d0_ + seg * 4) * ldb + mt_ * BM) + b_off), \
+                                             (__attribute__((address_space(3))) void*)(smem + (BUF) * kSlab + DK2 * BQ + seg * 256), 16, 0, 0); \
+        }                                                                                                        \
     }
+    unsigned acc[TQ][TM];
+#pragma unroll
+    for (int r = 0; r < TQ; ++r)
+#pragma unroll
+        for (int c = 0; c < TM; ++c) acc[r][c] = 0u;
+    if (n_it > 0) PCREG_SAD_DMA(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int slab = 0, m0 = b_begin;
+    for (int it = 0; it < n_it; ++it) {
+        if (it + 1 < n_it) PCREG_SAD_DMA(it + 1, (it + 1) & 1)
+        const uint32_t* As = smem + (it & 1) * kSlab + tx * 4;
+        const uint32_t* Bs = smem + (it & 1) * kSlab + DK2 * BQ + ty * TM;
+        // register double buffering of the LDS reads: feature pair dd+1 is in flight while dd is summed
+        uint4 a0[2], a1[2], b0, b1;
+        a0[0] = *(const uint4*)(As); a0[1] = *(const uint4*)(As + 64); b0 = *(const uint4*)(Bs);
+#define PCREG_SAD_RANK1(A, B)                                                            \
+        {                                                                                \
+            const unsigned av[8] = {A[0].x, A[0].y, A[0].z, A[0].w, A[1].x, A[1].y, A[1].z, A[1].w}; \
+            const unsigned bv[4] = {B.x, B.y, B.z, B.w};                                 \
+            _Pragma("unroll") for (int r = 0; r < TQ; ++r)                               \
+                _Pragma("unroll") for (int c = 0; c < TM; ++c) acc[r][c] = __builtin_amdgcn_sad_u16(av[r], bv[c], acc[r][c]); \
+        }
+#pragma unroll 2
+        for (int dd = 0; dd < DK2; dd += 2) {
+            a1[0] = *(const uint4*)(As + (dd + 1) * BQ); a1[1] = *(const uint4*)(As + (dd + 1) * BQ + 64); b1 = *(const uint4*)(Bs + (dd + 1) * BM);
+            PCREG_SAD_RANK1(a0, b0)
+            if (dd + 2 < DK2) { a0[0] = *(const uint4*)(As + (dd + 2) * BQ); a0[1] = *(const uint4*)(As + (dd + 2) * BQ + 64); b0 = *(const uint4*)(Bs + (dd + 2) * BM); }
+            PCREG_SAD_RANK1(a1, b1)
+        }
+        if (++slab == n_slabs) {                    // a model tile is complete: fold it into the lists
+            slab = 0;
+#pragma unroll
+            for (int r = 0; r < TQ; ++r) {
+                unsigned mn = min(min(acc[r][0], acc[r][1]), min(acc[r][2], acc[r][3]));
+                if (DRY) { asm volatile("" :: "v"(mn)); }
+                else if (mn < best[r].s[3]) {
+#pragma unroll
+                    for (int c = 0; c < TM; ++c) {
+                        int j = m0 + ty * TM + c;
+                        if (j < b_end) candu_insert(best[r], acc[r][c], j);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < TM; ++c) acc[r][c] = 0u;
+            }
+            m0 += BM;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // slab it+1 has landed
+        __syncthreads();                                        // ... and nobody still reads slab it
+    }
+#undef PCREG_SAD_DMA
+#undef PCREG_SAD_RANK1
     // merge the 16 ty-lists of every query (two halves of 64 queries)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < TQ; ++r) {
-            int ql = tx * TQ + r;
-            if ((ql >> 6) == half) {
+            int ql = (r >> 2) * 64 + tx * 4 + (r & 3);      // the register-tile mapping of the main loop
+            if ((r >> 2) == half) {
                 uint32_t* cell = cells + ((ql & 63) * 16 + ty) * 8;
 #pragma unroll
                 for (int k = 0; k < KC; ++k) { cell[k] = best[r].s[k]; cell[4 + k] = (uint32_t)best[r].i[k]; }
@@ -207,26 +248,68 @@ __global__ __launch_bounds__(kBlock) void sad16_candidates_kernel(const uint32_t
             }
         }
     }
+    if (dbg && tid == 0) {          // PCREG_SAD_TIMELINE: residency timeline of the grid (100 MHz clock, HW_ID, XCC_ID)
+        unsigned long long* d = dbg + 4 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+        d[0] = t_start; d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); d[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+}
+
+// ---- row-major copies for the re-rank -----------------------------------------------------------
+// The inputs are MATLAB-shaped (feature-major: a row's D features lie ld*8 bytes apart, one page
+// each), which makes "read row j" 981 translations.  The re-rank reads whole rows, so it gets a
+// row-major copy: 64 x 64 tiles through LDS, coalesced on both sides.
+__global__ __launch_bounds__(kBlock) void transpose_rows_kernel(const double* __restrict__ f, int n, int ld, int D,
+                                                                double* __restrict__ out /* [n][D] */) {
+    __shared__ double tile[64][65];
+    const int i0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int d = d0 + ty + 4 * k, i = i0 + tx;
+        tile[ty + 4 * k][tx] = (d < D && i < n) ? f[i + (size_t)d * ld] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int i = i0 + ty + 4 * k, d = d0 + tx;
+        if (i < n && d < D) out[(size_t)i * D + d] = tile[tx][ty + 4 * k];
+    }
 }
 
 // ---- exact re-rank + certificate: one wave per query, one lane per candidate ----------------------
 __device__ __forceinline__ bool lexd_lt(double da, int ia, double db, int ib) { return da < db || (da == db && (unsigned)ia < (unsigned)ib); }
 
-__global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __restrict__ A, int nA, int lda,
-                                                                const double* __restrict__ B, int nB, int ldb, int D,
+// Entries of a query: S chunks x KC, lane e handles entries e and e + 64 (S <= kMaxSplit = 32).
+// The |a - b| terms of a candidate are order-free, so the whole wave computes them in parallel into
+// LDS (256 features x up to kNC candidates at a time); only the SUM keeps the oracle's order: lane c
+// adds candidate c's terms one by one, s carried from tile to tile.
+constexpr int kNC = 4, kFT = 256, kEPL = 2;
+__global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __restrict__ At, int nA,
+                                                                const double* __restrict__ Bt, int nB, int D,
                                                                 const Range* __restrict__ rp, const int32_t* __restrict__ part_idx,
                                                                 const uint32_t* __restrict__ part_s, int S,
                                                                 int32_t* __restrict__ idx, double* __restrict__ dist,
                                                                 int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven) {
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (qi >= nA) return;
-    const int total = S * KC;                              // <= 64
-    int j = -1; unsigned sq = 0xFFFFFFFFu;
-    if (lane < total) { size_t o = ((size_t)(lane / KC) * nA + qi) * KC + (lane % KC); j = part_idx[o]; sq = part_s[o]; }
-    // the two smallest integer scores of the union, and G = the smallest "4th-best of a chunk"
-    unsigned a1 = sq, a2 = 0xFFFFFFFFu;
-    unsigned g = (lane < total && (lane % KC) == KC - 1 && j >= 0) ? sq : 0xFFFFFFFFu;
+    __shared__ double s_t[kBlock / 64][kNC][kFT];          // 32 KiB
+    __shared__ int s_j[kBlock / 64][64 * kEPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = blockIdx.x * (kBlock / 64) + wave;
+    if (qi >= nA) return;                                  // wave-uniform; no block barrier below
+    const int total = S * KC;                              // <= 64 * kEPL
+    int j[kEPL]; unsigned sq[kEPL];
+    unsigned a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, g = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < kEPL; ++u) {
+        const int e = lane + 64 * u;
+        j[u] = -1; sq[u] = 0xFFFFFFFFu;
+        if (e < total) { size_t o = ((size_t)(e / KC) * nA + qi) * KC + (e % KC); j[u] = part_idx[o]; sq[u] = part_s[o]; }
+        if (j[u] >= 0) {
+            if (sq[u] < a1) { a2 = a1; a1 = sq[u]; } else if (sq[u] < a2) a2 = sq[u];
+            if ((e % KC) == KC - 1) g = min(g, sq[u]);     // a full list: rows outside it score >= its last entry
+        }
+    }
+    // the two smallest integer scores of the union, and G = the smallest "last entry of a full list"
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         unsigned b1 = __shfl_xor(a1, o), b2 = __shfl_xor(a2, o);
@@ -235,16 +318,61 @@ __global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __
         g = min(g, (unsigned)__shfl_xor((int)g, o));
     }
     const unsigned slack = 2u * (unsigned)(D + 1) + 2u;
-    const bool need = j >= 0 && (a2 == 0xFFFFFFFFu || sq <= a2 + slack || a2 > 0xFFFFFFFFu - slack);
-    double d = INFINITY;
-    if (need) {                                            // exact SAD, the oracle's accumulation order
-        const double* a = A + qi; const double* b = B + j;
-        double s = 0.0;
-        for (int k = 0; k < D; ++k) s += fabs(a[(size_t)k * lda] - b[(size_t)k * ldb]);
-        d = s;
+    // compact the candidates that can still be among the two best into s_j
+    int n_need = 0;
+#pragma unroll
+    for (int u = 0; u < kEPL; ++u) {
+        const bool need = j[u] >= 0 && (a2 == 0xFFFFFFFFu || a2 > 0xFFFFFFFFu - slack || sq[u] <= a2 + slack);
+        const unsigned long long m = __ballot(need);
+        if (need) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = j[u];
+        n_need += __popcll(m);
     }
-    int jd = need ? j : -1;
-    double d1 = d, d2 = INFINITY; int i1 = jd, i2 = -1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+
+    double d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;       // lane-private running top-2
+    const double* a = At + (size_t)qi * D;                 // row-major copies: a row is contiguous
+    for (int g0 = 0; g0 < n_need; g0 += kNC) {
+        const int nc = min(kNC, n_need - g0);
+        double sum = 0.0;
+        for (int d0 = 0; d0 < D; d0 += kFT) {
+            // branch-free, clamped addresses: all (1 + kNC) x 4 scattered loads are in flight together
+            double av[kFT / 64], bv[kNC][kFT / 64];
+            size_t dof[kFT / 64];
+#pragma unroll
+            for (int u = 0; u < kFT / 64; ++u) dof[u] = (size_t)min(d0 + lane + 64 * u, D - 1);
+#pragma unroll
+            for (int u = 0; u < kFT / 64; ++u) av[u] = a[dof[u]];
+#pragma unroll
+            for (int c = 0; c < kNC; ++c) {
+                const double* b = Bt + (size_t)s_j[wave][min(g0 + c, n_need - 1)] * D;
+#pragma unroll
+                for (int u = 0; u < kFT / 64; ++u) bv[c][u] = b[dof[u]];
+            }
+#pragma unroll
+            for (int c = 0; c < kNC; ++c)
+#pragma unroll
+                for (int u = 0; u < kFT / 64; ++u)
+                    s_t[wave][c][lane + 64 * u] = (d0 + lane + 64 * u < D) ? fabs(av[u] - bv[c][u]) : 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (lane < nc) {
+                // the oracle's order; terms past D are +0.0, which leaves a non-negative sum unchanged
+                const double* t = s_t[wave][lane];
+                for (int k = 0; k < kFT; k += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = t[k + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum += v[u];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < nc) {
+            const int jc = s_j[wave][g0 + lane];
+            if (lexd_lt(sum, jc, d1, i1)) { d2 = d1; i2 = i1; d1 = sum; i1 = jc; }
+            else if (lexd_lt(sum, jc, d2, i2)) { d2 = sum; i2 = jc; }
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         double e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
@@ -288,8 +416,15 @@ __global__ __launch_bounds__(kBlock) void sad_exact_rows_kernel(const double* __
     for (int j = begin + threadIdx.x; j < end; j += kBlock) {
         const double* b = B + j;
         double s = 0.0;
-#pragma unroll 4
-        for (int d = 0; d < D; ++d) s += fabs(s_a[d] - b[(size_t)d * ldb]);
+        int d = 0;
+        for (; d + 32 <= D; d += 32) {                       // 32 coalesced loads in flight, then the ordered sum
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = b[(size_t)(d + u) * ldb];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += fabs(s_a[d + u] - v[u]);
+        }
+        for (; d < D; ++d) s += fabs(s_a[d] - b[(size_t)d * ldb]);
         if (s < d1) { d2 = d1; i2 = i1; d1 = s; i1 = j; } else if (s < d2) { d2 = s; i2 = j; }   // ascending j: strict
     }
     auto merge = [&](double e1, int k1, double e2, int k2) {
@@ -322,12 +457,13 @@ __global__ void scatter_flagged_kernel(const int32_t* __restrict__ list, int nf,
 
 }  // namespace
 
-// workspace: Range | n_flag | minmax partials | Aq | Bq | part_idx | part_s | flag_list
+// workspace: Range | n_flag | minmax partials | Aq | Bq | At | Bt | part_idx | part_s | flag_list
 //            | fallback: fi | fd | slice partials [kFbSlices][nA][2] (i32, f64)
 size_t sad16_workspace_bytes(int nA, int nB, int D) {
     size_t a = (size_t)(nA > 0 ? nA : 1), b = (size_t)(nB > 0 ? nB : 1);
     size_t D2p = align_up((size_t)(D + 1) / 2, DK2);
     return 256 + 256 + align_up(1024 * 2 * 8, 256) + D2p * align_up(a, BQ) * 4 + D2p * align_up(b, BQ) * 4 +
+           align_up(a * (size_t)D * 8, 256) + align_up(b * (size_t)D * 8, 256) +
            2 * align_up((size_t)kMaxSplit * a * KC * 4, 256) + align_up(a * 4, 256) +
            align_up(a * 2 * 4, 256) + align_up(a * 2 * 8, 256) +
            align_up((size_t)kFbSlices * a * 2 * 4, 256) + align_up((size_t)kFbSlices * a * 2 * 8, 256);
@@ -349,6 +485,8 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     double* mpart = (double*)w;             w += align_up(1024 * 2 * 8, 256);
     uint32_t* Aq = (uint32_t*)w;            w += (size_t)D2p * ldqa * 4;
     uint32_t* Bq = (uint32_t*)w;            w += (size_t)D2p * ldqb * 4;
+    double* At = (double*)w;                w += align_up(a * (size_t)D * 8, 256);
+    double* Bt = (double*)w;                w += align_up(b * (size_t)D * 8, 256);
     int32_t* part_idx = (int32_t*)w;        w += align_up((size_t)kMaxSplit * a * KC * 4, 256);
     uint32_t* part_s = (uint32_t*)w;        w += align_up((size_t)kMaxSplit * a * KC * 4, 256);
     int32_t* flag_list = (int32_t*)w;       w += align_up(a * 4, 256);
@@ -364,21 +502,56 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, A, nA, lda, D, D2p, ldqa, range, Aq);
     hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, B, nB, ldb, D, D2p, ldqb, range, Bq);
     PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
-    const int n_tiles = (nA + BQ - 1) / BQ;
-    int S = (1024 + n_tiles - 1) / n_tiles;
-    if (S > kMaxSplit) S = kMaxSplit;
-    int maxS = (nB + BM - 1) / BM; if (S > maxS) S = maxS; if (S < 1) S = 1;
-    int chunk = ((nB + S - 1) / S + BM - 1) / BM * BM;
-    S = (nB + chunk - 1) / chunk;
-    hipLaunchKernelGGL(sad16_candidates_kernel, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s);
+    // Split B into S chunks so that the grid loads every CU equally: a CU holds 3 workgroups, all
+    // resident at once, so the kernel lasts (workgroups on the fullest CU) x (row tiles per chunk).
+    const int n_tiles = (nA + BQ - 1) / BQ, row_tiles = (nB + BM - 1) / BM;
+    int S = 1, chunk = 0;
+    {
+        // cost ~ (row tiles per chunk) x (workgroups on the fullest CU); one workgroup alone on a CU runs
+        // at about 2/3 of the per-workgroup speed of a full CU (measured sweep: scripts/sad_split_sweep.sh)
+        const char* fs = getenv("PCREG_SAD_SPLITS");            // experiment override
+        const int forced = fs ? atoi(fs) : 0;
+        long best_cost = -1;
+        for (int s_try = 1; s_try <= kMaxSplit && s_try <= row_tiles; ++s_try) {
+            if (forced > 0 && s_try != std::min(forced, std::min(kMaxSplit, row_tiles))) continue;
+            int ct = (row_tiles + s_try - 1) / s_try, s_eff = (row_tiles + ct - 1) / ct;
+            long per_cu = ((long)n_tiles * s_eff + 255) / 256;
+            long cost = std::max(2 * per_cu, 3L) * ct;
+            if (best_cost < 0 || cost <= best_cost) { best_cost = cost; S = s_eff; chunk = ct * BM; }   // ties: more chunks
+        }
+    }
+    unsigned long long* dbg = nullptr;
+    const char* tl = getenv("PCREG_SAD_TIMELINE");      // debug: dump per-block (start, end, HW_ID, XCC_ID) to this file
+    if (tl) PCREG_HIP(hipMalloc(&dbg, (size_t)n_tiles * S * 4 * sizeof(unsigned long long)));
+    if (getenv("PCREG_SAD_DRY"))      // timing experiment only: list maintenance compiled out, results invalid
+        hipLaunchKernelGGL(sad16_candidates_kernel<true>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg);
+    else
+        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg);
     const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
-    hipLaunchKernelGGL(sad16_finalize_kernel, dim3((nA + 3) / 4), dim3(kBlock), 0, st, A, nA, lda, B, nB, ldb, D, range,
+    if (dbg) {
+        std::vector<unsigned long long> h((size_t)n_tiles * S * 4);
+        PCREG_HIP(hipStreamSynchronize(st));
+        PCREG_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(dbg);
+        static int call = 0;
+        char name[512]; snprintf(name, sizeof name, "%s.%d", tl, call++);
+        if (FILE* f = fopen(name, "w")) {
+            for (size_t b = 0; b < h.size() / 4; ++b) fprintf(f, "%zu %llu %llu %llu %llu\n", b, h[4 * b], h[4 * b + 1], h[4 * b + 2], h[4 * b + 3]);
+            fclose(f);
+        }
+    }
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3((nA + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, A, nA, lda, D, At);
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3((nB + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, B, nB, ldb, D, Bt);
+    hipLaunchKernelGGL(sad16_finalize_kernel, dim3((nA + 3) / 4), dim3(kBlock), 0, st, At, nA, Bt, nB, D, range,
                        part_idx, part_s, S, idx, dist, flag_list, n_flag, force);
     PCREG_HIP(hipGetLastError());
     int32_t nf = 0;
     PCREG_HIP(hipMemcpyAsync(&nf, n_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     PCREG_HIP(hipStreamSynchronize(st));
-    if (getenv("PCREG_MATCH_DEBUG")) fprintf(stderr, "[pcreg] sad16: nA=%d nB=%d D=%d S=%d unproven=%d\n", nA, nB, D, S, nf);
+    if (getenv("PCREG_MATCH_DEBUG")) {
+        int occ = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sad16_candidates_kernel<false>, kBlock, 0);
+        fprintf(stderr, "[pcreg] sad16: nA=%d nB=%d D=%d S=%d unproven=%d (candidates kernel: %d blocks/CU)\n", nA, nB, D, S, nf, occ);
+    }
     if (nf > 0) {
         int slices = std::min(kFbSlices, (nB + kBlock - 1) / kBlock);
         int slice = (nB + slices - 1) / slices;

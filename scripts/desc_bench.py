@@ -10,7 +10,7 @@ dM = rng.poisson(3.0, (M, D)).astype(np.float64)
 dS = rng.poisson(3.0, (Q, D)).astype(np.float64)
 k = min(Q, M) // 2
 dS[:k] = dM[rng.choice(M, k, replace=False)] + rng.poisson(0.2, (k, D))
-for metric in ("SAD", "SSD"):
+for metric in (sys.argv[4:] or ("SAD", "SSD")):
     par = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate",
                MatchThreshold=10, MaxRatio=0.99, Metric=metric, Unique=True, VERBOSE=0)
     pc.getMatches(dS[:64], dM[:64], par)
