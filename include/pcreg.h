@@ -226,6 +226,38 @@ int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_de
                      pcreg_dev_ransac_result* out, int32_t* inlier_idx,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- descriptor stage, resident: speedyDescriptors.m:59 -> getMatches.m -> ransac.m --------
+ * (completeExperimentFast.m:131-213 per sphere position) without a host copy in between. */
+
+/* getSpacialHistogramDescriptors.m:25-258 on device buffers.  pts / sample_pts are n x 3
+ * column-major (ld / lds); feat [S][3] and desc [S][980] are ROW-major with capacity S
+ * (row v < V is the v-th surviving keypoint, in sample order); counters[0] = V,
+ * counters[1] = 0 or the size of a support that exceeded the LDS capacity (then the
+ * outputs are invalid: lower max_pts). */
+size_t pcreg_dev_spatial_histogram_descriptors_workspace(int P, int S);
+int pcreg_dev_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                            const pcreg_desc_opts* options, double* feat, double* desc,
+                                            int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
+
+/* getMatches.m:21-59 on device buffers.  layout: PCREG_LAYOUT_FEATURE_MAJOR = MATLAB's
+ * column-major n x D (ld >= n); PCREG_LAYOUT_ROW_MAJOR = dense [n][D] (ld == D), what the
+ * descriptor entry point above emits.  The inputs are not modified.  pairs [Q][2] uint32,
+ * 1-based, ascending surface row; metric [Q] or NULL; *n_pairs device int32.  Q and M are
+ * host integers (grid sizes); the call synchronises the stream once or twice internally
+ * (candidate counts that size the Unique back-search / the fallback). */
+#define PCREG_LAYOUT_FEATURE_MAJOR 0
+#define PCREG_LAYOUT_ROW_MAJOR     1
+size_t pcreg_dev_get_matches_workspace(int Q, int M, int D);
+int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M, int ldM, int D,
+                          int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric,
+                          int32_t* n_pairs, void* workspace, size_t workspace_bytes, void* stream);
+
+/* completeExperimentFast.m:205-206: pts1 = featSurface(matches(:,1),:), pts2 =
+ * featModel(matches(:,2),:) as n x 3 column-major with ld = cap -- the input of
+ * pcreg_dev_ransac (n = *n_pairs stays on the device).  feat* are row-major [.][3]. */
+int pcreg_dev_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featSurface,
+                                  const double* featModel, double* pts1, double* pts2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

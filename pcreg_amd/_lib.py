@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libpcreg_hip.so")
 
 PCREG_OK, PCREG_E_ARG, PCREG_E_HIP, PCREG_E_NODEVICE, PCREG_E_WORKSPACE = 0, 1, 2, 3, 4
 METRIC_SAD, METRIC_SSD = 0, 1
+LAYOUT_FEATURE_MAJOR, LAYOUT_ROW_MAJOR = 0, 1
 
 
 class PcregError(RuntimeError):
@@ -56,6 +57,8 @@ SYMBOLS = [
     "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32",
     "pcreg_dev_filter_top2_f32", "pcreg_dev_unique_points_f32_workspace", "pcreg_dev_unique_points_f32",
     "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
+    "pcreg_dev_spatial_histogram_descriptors_workspace", "pcreg_dev_spatial_histogram_descriptors",
+    "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
 ]
 
 _lib = None
@@ -80,7 +83,8 @@ def lib() -> C.CDLL:
         L.pcreg_last_error.restype = C.c_char_p
         L.pcreg_version.restype = C.c_char_p
         for name in ("pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_unique_points_f32_workspace",
-                     "pcreg_dev_ransac_workspace"):
+                     "pcreg_dev_ransac_workspace", "pcreg_dev_spatial_histogram_descriptors_workspace",
+                     "pcreg_dev_get_matches_workspace"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

@@ -366,6 +366,15 @@ def AlignPoints_KNN_batched(pts_list, C1: bool = False, C2: bool = False):
 
 
 # ------------------------------------------------------- getSpacialHistogramDescriptors
+def _desc_opts(options: dict) -> DescOpts:
+    kk = options["k"]
+    kf = 1.0 if (isinstance(kk, str) and kk == "all") or kk == 1 else float(kk)      # :75
+    mx = options["max_pts"]
+    mx = 2**31 - 1 if (mx == float("inf") or mx > 2**31 - 1) else int(mx)
+    return DescOpts(int(options["min_pts"]), mx, float(options["R"]), (C.c_double * 2)(*[float(v) for v in options["thVar"]]),
+                    kf, int(bool(options["ALIGN_POINTS"])))
+
+
 def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
     """[feat, desc] = getSpacialHistogramDescriptors(pts, sample_pts, options)
     (getSpacialHistogramDescriptors.m:2-183): feat V x 3 keypoint locations, desc V x 980
@@ -377,12 +386,7 @@ def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
     t0 = time.time()
     p, s = _pts3(pts, "pts"), _pts3(sample_pts, "sample_pts")
     P, S = p.shape[0], s.shape[0]
-    kk = options["k"]
-    kf = 1.0 if (isinstance(kk, str) and kk == "all") or kk == 1 else float(kk)      # :75
-    mx = options["max_pts"]
-    mx = 2**31 - 1 if (mx == float("inf") or mx > 2**31 - 1) else int(mx)
-    o = DescOpts(int(options["min_pts"]), mx, float(options["R"]), (C.c_double * 2)(*[float(v) for v in options["thVar"]]),
-                 kf, int(bool(options["ALIGN_POINTS"])))
+    o = _desc_opts(options)
     feat = np.zeros((max(S, 1), 3))
     desc = np.zeros((max(S, 1), 980))
     V = C.c_int(0)

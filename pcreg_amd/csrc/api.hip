@@ -475,4 +475,72 @@ int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_de
                          workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+
+// ---- descriptor stage, resident (speedyDescriptors.m:59 -> getMatches -> ransac without leaving HBM)
+size_t pcreg_dev_spatial_histogram_descriptors_workspace(int P, int S) { return descriptors_workspace_bytes(P, S); }
+
+int pcreg_dev_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                            const pcreg_desc_opts* options, double* feat, double* desc, int32_t* counters,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(pts && sample_pts && options && feat && desc && counters && workspace && P >= 1 && S >= 1 && ld >= P && lds >= S);
+    GUARD();
+    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, feat, desc, counters, counters + 1, workspace,
+                              workspace_bytes, (hipStream_t)stream);
+}
+
+static size_t dev_get_matches_layout(int Q, int M, int D, int Dp, size_t off[6]) {
+    size_t q = (size_t)(Q > 0 ? Q : 1), m = (size_t)(M > 0 ? M : 1), b = 0;
+    off[0] = b; b += align_up(q * D * sizeof(double), 256);            // raw surface, feature-major
+    off[1] = b; b += align_up(m * D * sizeof(double), 256);            // raw model
+    off[2] = b; b += align_up(q * Dp * sizeof(double), 256);           // working copies
+    off[3] = b; b += align_up(m * Dp * sizeof(double), 256);
+    off[4] = b; b += align_up((q + m + 1) * sizeof(double), 256);      // preprocess
+    off[5] = b; b += match_features_workspace_bytes(Q, M, Dp);
+    return b;
+}
+size_t pcreg_dev_get_matches_workspace(int Q, int M, int D) {
+    size_t off[6];
+    return dev_get_matches_layout(Q, M, D, D + 1, off);
+}
+
+int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M, int ldM, int D,
+                          int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(descSurface && descModel && par && pairs && n_pairs && workspace && Q >= 0 && M >= 0 && D >= 1);
+    PCREG_ARG(layout == PCREG_LAYOUT_FEATURE_MAJOR || layout == PCREG_LAYOUT_ROW_MAJOR);
+    PCREG_ARG(layout == PCREG_LAYOUT_ROW_MAJOR ? (ldS >= D && ldM >= D) : (ldS >= Q && ldM >= M));
+    PCREG_ARG(par->metric == PCREG_METRIC_SAD || par->metric == PCREG_METRIC_SSD);
+    GUARD();
+    hipStream_t st = (hipStream_t)stream;
+    if (Q == 0 || M == 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
+    const int Dp = D + (par->unnormalize ? 1 : 0);
+    size_t off[6];
+    size_t need = dev_get_matches_layout(Q, M, D, D + 1, off);
+    if (workspace_bytes < need) { set_error("get_matches workspace too small: %zu < %zu", workspace_bytes, need); return PCREG_E_WORKSPACE; }
+    char* w = (char*)workspace;
+    double *rawS = (double*)(w + off[0]), *rawM = (double*)(w + off[1]), *fS = (double*)(w + off[2]), *fM = (double*)(w + off[3]);
+    const double *inS = descSurface, *inM = descModel;
+    int ls = ldS, lm = ldM;
+    if (layout == PCREG_LAYOUT_ROW_MAJOR) {        // [row][D] (ld = row pitch) -> feature-major
+        if (ldS != D || ldM != D) { set_error("row-major descriptors must be dense (ld == D)"); return PCREG_E_ARG; }
+        TRY(launch_transpose_rows(descSurface, D, D, Q, rawS, st));
+        TRY(launch_transpose_rows(descModel, D, D, M, rawM, st));
+        inS = rawS; inM = rawM; ls = Q; lm = M;
+    }
+    // getMatches.m:24-37 always works on private copies (the caller's descriptors stay untouched)
+    TRY(launch_preprocess(inS, Q, ls, inM, M, lm, D, *par, fS, fM, w + off[4], align_up(((size_t)Q + M + 1) * sizeof(double), 256), st));
+    if (!par->prenormalized) {
+        TRY(launch_normalize_rows(fS, Q, Q, Dp, st));
+        TRY(launch_normalize_rows(fM, M, M, Dp, st));
+    }
+    return launch_match_features(fS, Q, Q, fM, M, M, Dp, *par, pairs, metric, n_pairs, w + off[5], workspace_bytes - off[5], st);
+}
+
+int pcreg_dev_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featSurface,
+                                  const double* featModel, double* pts1, double* pts2, void* stream) {
+    PCREG_ARG(pairs && n_pairs && featSurface && featModel && pts1 && pts2 && cap >= 0);
+    GUARD();
+    return launch_gather_matched_rows(pairs, n_pairs, cap, featSurface, featModel, pts1, pts2, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -87,6 +87,10 @@ int launch_match_features(const double* fS, int Q, int ldS, const double* fM, in
                           const pcreg_match_opts& o, uint32_t* pairs, double* metric, int32_t* P_dev,
                           void* ws, size_t ws_bytes, hipStream_t st);
 
+int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st);
+int launch_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featS, const double* featM,
+                               double* pts1, double* pts2, hipStream_t st);
+
 int launch_align_points_knn(const double* pts, int ld, const int32_t* offsets_dev, int B, int max_n,
                             int C1, int C2, double* aligned, int ld_out, double* coeff, double* c,
                             int32_t* status, hipStream_t st);

@@ -18,6 +18,8 @@
 #include "common.hpp"
 #include "select.hpp"
 #include <cfloat>
+#include <algorithm>
+#include <cstdlib>
 
 namespace pcreg {
 namespace {
@@ -386,6 +388,27 @@ int launch_match_features(const double* fS, int Q, int ldS, const double* fM, in
         keep_ptr = keep;
     }
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(1), dim3(256), 0, st, cand_q, cand_m, keep_ptr, n_cand, dist, pairs, metric, P_dev);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+
+// pts1 = featSurface(matches(:,1),:), pts2 = featModel(matches(:,2),:)   (completeExperimentFast.m:205-206)
+// feat* are row-major [.][3] (what the descriptor kernel emits); pts* are n x 3 column-major, ld = cap.
+__global__ void gather_matched_rows_kernel(const uint32_t* __restrict__ pairs, const int32_t* __restrict__ n_pairs, int cap,
+                                           const double* __restrict__ featS, const double* __restrict__ featM,
+                                           double* __restrict__ pts1, double* __restrict__ pts2) {
+    const int n = min(*n_pairs, cap);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const size_t a = (size_t)(pairs[(size_t)k * 2] - 1u), b = (size_t)(pairs[(size_t)k * 2 + 1] - 1u);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pts1[k + (size_t)c * cap] = featS[a * 3 + c]; pts2[k + (size_t)c * cap] = featM[b * 3 + c]; }
+    }
+}
+int launch_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featS, const double* featM,
+                               double* pts1, double* pts2, hipStream_t st) {
+    if (cap <= 0) return PCREG_OK;
+    hipLaunchKernelGGL(gather_matched_rows_kernel, dim3(std::min(1024, (cap + 255) / 256)), dim3(256), 0, st, pairs, n_pairs, cap, featS, featM, pts1, pts2);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -457,6 +457,15 @@ __global__ void scatter_flagged_kernel(const int32_t* __restrict__ list, int nf,
 
 }  // namespace
 
+// out [n][D] (row-major) = f (n x D, feature-major, leading dimension ld).  The reverse direction is
+// the same call with the roles swapped: launch_transpose_rows(rowmajor, D, D, n, featmajor).
+int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st) {
+    if (n <= 0 || D <= 0) return PCREG_OK;
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3((n + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, f, n, ld, D, out);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
 // workspace: Range | n_flag | minmax partials | Aq | Bq | At | Bt | part_idx | part_s | flag_list
 //            | fallback: fi | fd | slice partials [kFbSlices][nA][2] (i32, f64)
 size_t sad16_workspace_bytes(int nA, int nB, int D) {

@@ -12,6 +12,7 @@ import ctypes as C
 import torch
 
 from ._lib import DevRansacResult, RansacOpts, check, lib
+from . import _lib as _l
 from .sharded import ShardedMatcher
 
 
@@ -148,3 +149,72 @@ class RegistrationPipeline:
         T = np.array(r.T[:]).reshape(4, 4, order="F")
         return dict(T=T, n_inliers=r.n_inliers, numSuccess=r.num_success, maxInliers=r.max_inliers,
                     failed=bool(r.failed), n=r.n, winner=r.winner, inlierIdx=self.inliers[:r.n_inliers].cpu().numpy())
+
+
+class DescriptorPipeline:
+    """One sphere position of completeExperimentFast.m:131-213, resident in HBM:
+    getSpacialHistogramDescriptors (surface + model) -> getMatches -> matched keypoints -> ransac.
+
+    Point sets are [3, N] float64 tensors.  Descriptors stay on the device as row-major [V][980];
+    the only host traffic is the keypoint counts (two int32 reads that size the match grid)."""
+
+    ND = 980
+
+    def __init__(self, device: torch.device | None = None):
+        self.dev = device or torch.device("cuda", torch.cuda.current_device())
+        self._ws = {}
+        self.result = torch.zeros(C.sizeof(DevRansacResult), dtype=torch.uint8, device=self.dev)
+        self.n_pairs = torch.zeros(1, dtype=torch.int32, device=self.dev)
+
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self._ws[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.dev)
+        return t
+
+    def describe(self, pts: torch.Tensor, sample_pts: torch.Tensor, options: dict):
+        """-> (feat [S,3], desc [S,980], V): rows < V are the surviving keypoints in sample order."""
+        from .api import _desc_opts
+        L = lib()
+        o = _desc_opts(options)
+        P, S = pts.shape[1], sample_pts.shape[1]
+        feat = torch.empty((S, 3), dtype=torch.float64, device=self.dev)
+        desc = torch.empty((S, self.ND), dtype=torch.float64, device=self.dev)
+        counters = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        ws = self._workspace("desc", L.pcreg_dev_spatial_histogram_descriptors_workspace(P, S))
+        check(L.pcreg_dev_spatial_histogram_descriptors(_p(pts), P, pts.stride(0), _p(sample_pts), S, sample_pts.stride(0),
+                                                        C.byref(o), _p(feat), _p(desc), _p(counters), _p(ws),
+                                                        C.c_size_t(ws.numel()), _stream()))
+        V, overflow = (int(v) for v in counters.cpu())
+        if overflow:
+            raise ValueError(f"a support holds {overflow} points: more than an LDS-resident support may have (lower max_pts)")
+        return feat, desc, V
+
+    def match(self, descS: torch.Tensor, VS: int, descM: torch.Tensor, VM: int, par: dict):
+        """-> (pairs [VS,2] int32 1-based, n_pairs device int32)."""
+        from .api import _match_opts
+        L = lib()
+        o = _match_opts(par)
+        pairs = torch.empty((max(VS, 1), 2), dtype=torch.int32, device=self.dev)
+        ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(VS, VM, self.ND))
+        check(L.pcreg_dev_get_matches(_p(descS), VS, self.ND, _p(descM), VM, self.ND, self.ND, _l.LAYOUT_ROW_MAJOR,
+                                      C.byref(o), _p(pairs), None, _p(self.n_pairs), _p(ws), C.c_size_t(ws.numel()),
+                                      _stream()))
+        return pairs, self.n_pairs
+
+    def ransac(self, pairs: torch.Tensor, featS: torch.Tensor, featM: torch.Tensor, coef: dict, seed: int = 0):
+        """ransac on featS(pairs(:,1),:) / featM(pairs(:,2),:); result via fetch_result()."""
+        L = lib()
+        cap = pairs.shape[0]
+        self.pts1 = torch.empty((3, cap), dtype=torch.float64, device=self.dev)
+        self.pts2 = torch.empty((3, cap), dtype=torch.float64, device=self.dev)
+        check(L.pcreg_dev_gather_matched_rows(_p(pairs), _p(self.n_pairs), cap, _p(featS), _p(featM), _p(self.pts1),
+                                              _p(self.pts2), _stream()))
+        o = RansacOpts(int(coef["minPtNum"]), int(coef["iterNum"]), float(coef["thDist"]), float(coef["thInlrRatio"]),
+                       int(bool(coef["REFINE"])), 0, int(seed))
+        ws = self._workspace("ransac", L.pcreg_dev_ransac_workspace(cap, o.iterNum))
+        self.inliers = torch.empty(cap, dtype=torch.int32, device=self.dev)
+        check(L.pcreg_dev_ransac(_p(self.pts1), _p(self.pts2), _p(self.n_pairs), cap, cap, C.byref(o), None,
+                                 _p(self.result), _p(self.inliers), _p(ws), C.c_size_t(ws.numel()), _stream()))
+
+    fetch_result = RegistrationPipeline.fetch_result
