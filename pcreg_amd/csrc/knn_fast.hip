@@ -31,6 +31,8 @@
 #include "knn_fast_common.hpp"
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <algorithm>
 
 namespace pcreg {
 namespace {
@@ -63,14 +65,40 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __res
         part[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
-__global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, Prep* __restrict__ prep,
+__global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, int M, Prep* __restrict__ prep,
                                   unsigned* __restrict__ rm2_bits) {
     if (threadIdx.x == 0) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int b = 0; b < nparts; ++b)
             for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
         prep->cx = 0.5f * lo[0] + 0.5f * hi[0]; prep->cy = 0.5f * lo[1] + 0.5f * hi[1]; prep->cz = 0.5f * lo[2] + 0.5f * hi[2];
-        prep->rm2 = 0.0f;
+        {   // an upper bound of max |m~|^2 (and |q~|^2) from the box itself: the seeding margin uses it
+            float ax = 0.5f * (hi[0] - lo[0]), ay = 0.5f * (hi[1] - lo[1]), az = 0.5f * (hi[2] - lo[2]);
+            prep->rm2 = (ax * ax + ay * ay + az * az) * 1.0001f;
+        }
+        float H = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) * 0.5f;
+        float sg = 1.0f;
+        if (H > 0.0f && H < INFINITY) sg = ldexpf(1.0f, 5 - ilogbf(H));        // sigma * H in [32, 64)
+        prep->sigma = sg; prep->inv_sigma2 = 1.0f / (sg * sg);                 // powers of two: exact
+        prep->pad0 = prep->pad1 = 0.0f;
+        // seeding grid: about two model points per cell, at most kSeedMaxCells cells
+        float ext[3], emax = 0.0f;
+        for (int c = 0; c < 3; ++c) { ext[c] = hi[c] - lo[c]; emax = fmaxf(emax, ext[c]); }
+        int n[3] = {1, 1, 1};
+        float h = 1.0f;
+        if (emax > 0.0f && emax < INFINITY) {
+            for (int c = 0; c < 3; ++c) ext[c] = fmaxf(ext[c], emax * 1e-3f);
+            float target = fminf(fmaxf((float)M * 0.5f, 1.0f), (float)kSeedMaxCells * 0.5f);
+            h = cbrtf(ext[0] * ext[1] * ext[2] / target);
+            for (int it = 0; it < 64; ++it) {
+                long tot = 1;
+                for (int c = 0; c < 3; ++c) { n[c] = (int)fminf(ceilf(ext[c] / h), 2048.0f); if (n[c] < 1) n[c] = 1; tot *= n[c]; }
+                if (tot <= kSeedMaxCells) break;
+                h *= 1.2f;
+            }
+        }
+        prep->gx0 = lo[0]; prep->gy0 = lo[1]; prep->gz0 = lo[2]; prep->inv_h = 1.0f / h;
+        prep->nx = n[0]; prep->ny = n[1]; prep->nz = n[2]; prep->ncell = n[0] * n[1] * n[2];
         *rm2_bits = 0u;
     }
 }
@@ -91,6 +119,72 @@ __global__ __launch_bounds__(kBlock) void prep_model_kernel(const float* __restr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) atomicMax(rm2_bits, __float_as_uint(mx));     // max is order-independent
+}
+
+// ---- 1c. seeding: a first threshold per query from a coarse grid of the model ------------------
+// The candidate kernels only touch their sorted lists when a score beats the query's threshold, and a
+// wave pays that slow path whenever ANY of its lanes does.  Starting from +inf every lane does so
+// O(log n) times; starting from "the 4th-nearest of a few model points around the query" almost never.
+// The grid remembers up to kSeedSlots points per cell (whoever arrives first: the threshold is a hint,
+// results never depend on it); a query looks at its 27 cells, takes the 4th-smallest EXACT distance d4
+// and publishes s-space threshold d4 - |q~|^2 plus twice the score error bound, so that its true four
+// nearest are still below it.  Every point that is later skipped was compared with a word >= the final
+// word G, which is all the certificate needs.
+__device__ __forceinline__ int seed_cell(float v, float lo, float inv_h, int n) {
+    int c = (int)floorf((v - lo) * inv_h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+__global__ __launch_bounds__(kBlock) void seed_fill_kernel(const float* __restrict__ m, int M, int ldm, const Prep* __restrict__ prep,
+                                                           int32_t* __restrict__ cnt, int32_t* __restrict__ slots) {
+    const float gx0 = prep->gx0, gy0 = prep->gy0, gz0 = prep->gz0, ih = prep->inv_h;
+    const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
+        int cx = seed_cell(m[i], gx0, ih, nx), cy = seed_cell(m[i + (size_t)ldm], gy0, ih, ny), cz = seed_cell(m[i + 2 * (size_t)ldm], gz0, ih, nz);
+        int cell = (cz * ny + cy) * nx + cx;
+        int k = atomicAdd(&cnt[cell], 1);
+        if (k < kSeedSlots) slots[(size_t)cell * kSeedSlots + k] = i;
+    }
+}
+__global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
+                                                            const Prep* __restrict__ prep,
+                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ slots,
+                                                            int e_mode, unsigned* __restrict__ gthr) {
+    const int qi = blockIdx.x * kBlock + threadIdx.x;
+    if (qi >= Q) return;
+    const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
+    const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
+    const int cx = seed_cell(qx, prep->gx0, prep->inv_h, nx), cy = seed_cell(qy, prep->gy0, prep->inv_h, ny), cz = seed_cell(qz, prep->gz0, prep->inv_h, nz);
+    float d[KC] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    for (int dz = -1; dz <= 1; ++dz) {
+        int z = cz + dz; if (z < 0 || z >= nz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            int y = cy + dy; if (y < 0 || y >= ny) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                int x = cx + dx; if (x < 0 || x >= nx) continue;
+                const int cell = (z * ny + y) * nx + x;
+                const int n = min(cnt[cell], kSeedSlots);
+                for (int k = 0; k < n; ++k) {
+                    const int j = slots[(size_t)cell * kSeedSlots + k];
+                    float ex = qx - m[j], ey = qy - m[j + (size_t)ldm], ez = qz - m[j + 2 * (size_t)ldm];
+                    float dd = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                    if (dd < d[3]) {
+                        if (dd < d[1]) { d[3] = d[2]; d[2] = d[1]; if (dd < d[0]) { d[1] = d[0]; d[0] = dd; } else d[1] = dd; }
+                        else { if (dd < d[2]) { d[3] = d[2]; d[2] = dd; } else d[3] = dd; }
+                    }
+                }
+            }
+        }
+    }
+    unsigned word = 0xFFFFFFFFu;                           // +inf: no hint
+    if (d[3] < INFINITY) {
+        const float tx = qx - prep->cx, ty = qy - prep->cy, tz = qz - prep->cz;
+        const double r2 = (double)tx * tx + (double)ty * ty + (double)tz * tz;
+        const double E = score_error_bound(e_mode, (double)prep->rm2, sqrt(r2));
+        const double u = 5.9604644775390625e-08;
+        const double t = (double)d[3] - r2 + 2.0 * E + 16.0 * u * ((double)d[3] + fabs((double)d[3] - r2));
+        word = f2ord(nextafterf((float)t, INFINITY));
+    }
+    gthr[qi] = word;
 }
 
 template <int QPT_, int UB_, bool DRY = false>
@@ -390,6 +484,12 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_sgpr_kernel(
     }
 }
 
+}  // namespace
+size_t knn_f16_prep_bytes(int M);
+int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
+                              unsigned* rm2, void* mtiles, unsigned* gthr, int32_t* part_idx, float* part_s,
+                              int target_blocks, int max_S, bool dry, int* S_out, hipStream_t st);
+namespace {
 // ---- 3. exact re-rank + certificate: one wave per query ------------------------------------
 __device__ __forceinline__ bool lex_lt_f(float da, int ia, float db, int ib) {
     return da < db || (da == db && (unsigned)ia < (unsigned)ib);
@@ -398,7 +498,7 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
     const Prep* __restrict__ prep, const unsigned* __restrict__ rm2_bits, const unsigned* __restrict__ gthr,
     const int32_t* __restrict__ part_idx, const float* __restrict__ part_s, int S, int kc, int idx_base,
-    int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag) {
+    int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int e_mode) {
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (qi >= Q) return;
@@ -423,8 +523,11 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const float tx = qx - cxf, ty = qy - cyf, tz = qz - czf;       // the same q~ the candidate kernel formed
     const double r2 = (double)tx * tx + (double)ty * ty + (double)tz * tz;
     const double r = sqrt(r2);
-    const double Rm2 = (double)__uint_as_float(*rm2_bits), Rm = sqrt(Rm2);
-    const double Eab = u * (3.0 * Rm2 + 3.03 * (Rm2 + 2.0 * r * Rm) + 4.04 * (r + Rm) * (r + Rm));
+    const double Rm2 = (double)__uint_as_float(*rm2_bits);
+    // e_mode 0: scores from the fp32 fma chain.  e_mode 1: scores from the f16-split matrix-core product
+    // (knn_mfma16.hip): 16 u r R_m for the two-term f16 representations of Q and m (2^-22 relative each) and
+    // 32.1 u (R_m^2 + 2 r R_m) for sixteen fp32 accumulation steps of at most one ulp each.
+    const double Eab = score_error_bound(e_mode, Rm2, r);
     // pass 2: exact distances of every candidate that can still reach the top-2
     const float cut = (float)((double)a2 + 2.0 * Eab + 16.0 * u * fabs((double)a2 + r2));
     const float cut_up = nextafterf(cut, INFINITY);              // float rounding of the cut must not exclude anything
@@ -474,46 +577,60 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     }
 }
 
-// ---- 4a. exact fallback, few queries: one workgroup per flagged query ------------------
-__global__ __launch_bounds__(kBlock) void knn_fallback_block_kernel(
-    const float* __restrict__ q, int ldq, const float* __restrict__ m, int M, int ldm, int idx_base,
-    const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag, int max_active,
-    int32_t* __restrict__ idx, float* __restrict__ dist) {
-    const int nf = *n_flag;
-    if (nf > max_active) return;                                 // the tiled kernel handles big lists
+// ---- 4a. exact fallback, few queries: kFbSlices workgroups per flagged query + a merge ------------
+constexpr int kFew = 1024, kFbSlices = 32;
+__global__ __launch_bounds__(kBlock) void knn_fallback_slice_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ m, int M, int ldm,
+    const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag,
+    int32_t* __restrict__ fb_idx /*[kFew][kFbSlices][2]*/, float* __restrict__ fb_dist) {
+    const int nf = *n_flag, f = blockIdx.x;
+    if (nf > kFew || f >= nf) return;                            // the tiled kernel handles big lists
     __shared__ float sd[kBlock / 64][2];
     __shared__ int si[kBlock / 64][2];
-    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
-        const int qi = flag_list[f];
-        const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
-        float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
-        for (int j = threadIdx.x; j < M; j += kBlock) {           // ascending j per thread: strict '<' keeps ties low
-            float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
-            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            if (d < d2) { if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; } }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
-            int j1 = __shfl_xor(i1, o), j2 = __shfl_xor(i2, o);
-            bool first_mine = lex_lt_f(d1, i1, e1, j1);
-            float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1;
-            float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;
-            float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1 : j2;
-            bool sec_mine = lex_lt_f(x2, y2, x3, y3);
-            d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
-        }
-        const int w = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { sd[w][0] = d1; sd[w][1] = d2; si[w][0] = i1; si[w][1] = i2; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            Top2T<float> t{INFINITY, INFINITY, -1, -1};
-            for (int k = 0; k < kBlock / 64; ++k) { top2_insert_lex_t(t, sd[k][0], si[k][0]); top2_insert_lex_t(t, sd[k][1], si[k][1]); }
-            idx[(size_t)qi * 2] = t.i1 >= 0 ? t.i1 + idx_base : -1; idx[(size_t)qi * 2 + 1] = t.i2 >= 0 ? t.i2 + idx_base : -1;
-            dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
-        }
-        __syncthreads();
+    const int len = (M + kFbSlices - 1) / kFbSlices;
+    const int j0 = blockIdx.y * len, j1 = min(M, j0 + len);
+    const int qi = flag_list[f];
+    const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
+    float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+    for (int j = j0 + threadIdx.x; j < j1; j += kBlock) {         // ascending j per thread: strict '<' keeps ties low
+        float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
+        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        if (d < d2) { if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; } }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+        int j1s = __shfl_xor(i1, o), j2s = __shfl_xor(i2, o);
+        bool first_mine = lex_lt_f(d1, i1, e1, j1s);
+        float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1s;
+        float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;
+        float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1s : j2s;
+        bool sec_mine = lex_lt_f(x2, y2, x3, y3);
+        d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sd[w][0] = d1; sd[w][1] = d2; si[w][0] = i1; si[w][1] = i2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Top2T<float> t{INFINITY, INFINITY, -1, -1};
+        for (int k = 0; k < kBlock / 64; ++k) { top2_insert_lex_t(t, sd[k][0], si[k][0]); top2_insert_lex_t(t, sd[k][1], si[k][1]); }
+        const size_t o = ((size_t)f * kFbSlices + blockIdx.y) * 2;
+        fb_idx[o] = t.i1; fb_idx[o + 1] = t.i2; fb_dist[o] = t.d1; fb_dist[o + 1] = t.d2;
+    }
+}
+__global__ void knn_fallback_merge_kernel(const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag, int idx_base,
+                                          const int32_t* __restrict__ fb_idx, const float* __restrict__ fb_dist,
+                                          int32_t* __restrict__ idx, float* __restrict__ dist) {
+    const int nf = *n_flag, f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nf > kFew || f >= nf) return;
+    Top2T<float> t{INFINITY, INFINITY, -1, -1};
+    for (int sl = 0; sl < kFbSlices; ++sl) {
+        const size_t o = ((size_t)f * kFbSlices + sl) * 2;
+        top2_insert_lex_t(t, fb_dist[o], fb_idx[o]); top2_insert_lex_t(t, fb_dist[o + 1], fb_idx[o + 1]);
+    }
+    const int qi = flag_list[f];
+    idx[(size_t)qi * 2] = t.i1 >= 0 ? t.i1 + idx_base : -1; idx[(size_t)qi * 2 + 1] = t.i2 >= 0 ? t.i2 + idx_base : -1;
+    dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
 }
 
 int pick_splits_fast(int n_tiles, int M, int target) {
@@ -540,17 +657,26 @@ size_t knn2_points_exact_workspace_bytes(int Q, int M);
 //                   | prepared model (16 B/point, padded to whole 16-point tiles)
 //                   | part_idx [S][Q][kc] | part_s | exact-kernel workspace (fallback)
 static constexpr int kPartCap = 40;           // upper bound of S * kc / 16 any variant may use (x16 entries per query)
+static constexpr int kSeedMinM = 64 * 1024;      // below this the lists settle within the first tiles anyway
+static size_t seed_bytes(int M) {
+    if (M < kSeedMinM) return 0;
+    size_t cells = std::min<size_t>((size_t)M / 2 + 4096, (size_t)kSeedMaxCells) + 16;   // bbox_final_kernel's cap
+    cells = (size_t)kSeedMaxCells;                 // (the grid is sized on the device; reserve the cap)
+    return align_up(cells * 4, 256) + align_up(cells * kSeedSlots * 4, 256);
+}
 static size_t fast_fixed_bytes(int Q, int M) {
     size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
     return 256 + 256 + 256 + align_up(512 * 6 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
-           align_up(mm * 16, 256) + 2 * align_up((size_t)kPartCap * 16 * q * 4, 256);
+           align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256) + 2 * align_up((size_t)kPartCap * 16 * q * 4, 256) +
+           seed_bytes(M) + 2 * align_up((size_t)1024 * 32 * 2 * 4, 256);
 }
 
 size_t knn2_points_fast_workspace_bytes(int Q, int M) {
     return fast_fixed_bytes(Q, M) + knn2_points_exact_workspace_bytes(Q, M);
 }
 
-// PCREG_KNN_VARIANT: 0 (default) VALU candidates QPT4/UB8; 11 QPT4/UB4; 12 QPT8/UB8; 13 QPT2/UB8; 19 VALU
+// PCREG_KNN_VARIANT: 40 (default) f16-split matrix-core candidates (knn_mfma16.hip), 41 its timing-only form;
+//                    0 VALU candidates QPT4/UB8 (the previous default); 11 QPT4/UB4; 12 QPT8/UB8; 13 QPT2/UB8; 19 VALU
 //                    timing-only (no insertions); 5 MFMA candidates; 9 MFMA timing-only.
 //                    The fp32 MFMA shares the SIMD's fp32 datapath with the VALU (measured: 32.5 -> 49 cycles per
 //                    MFMA once three VALU ops sit between issues, scripts/ubench/mfma_f32.hip), so the MFMA
@@ -563,7 +689,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     size_t need = knn2_points_fast_workspace_bytes(Q, M);
     if (ws_bytes < need) { set_error("knn (fast) workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
     static const int target_env = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : 0;
-    static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 0;
+    static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 40;
     const bool use_mfma = variant >= 5 && variant < 10;
     size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
     char* w = (char*)ws;
@@ -573,19 +699,37 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     float* bpart = (float*)w;              w += align_up(512 * 6 * sizeof(float), 256);
     unsigned* gthr = (unsigned*)w;         w += align_up(qq * 4, 256);
     int32_t* flag_list = (int32_t*)w;      w += align_up(qq * 4, 256);
-    void* mprep = w;                       w += align_up(mm * 16, 256);
+    void* mprep = w;                       w += align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256);
     int32_t* part_idx = (int32_t*)w;       w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
     float* part_s = (float*)w;             w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
+    int32_t* seed_cnt = (int32_t*)w;       w += M >= kSeedMinM ? align_up((size_t)kSeedMaxCells * 4, 256) : 0;
+    int32_t* seed_slots = (int32_t*)w;     w += M >= kSeedMinM ? align_up((size_t)kSeedMaxCells * kSeedSlots * 4, 256) : 0;
+    int32_t* fb_idx = (int32_t*)w;         w += align_up((size_t)1024 * 32 * 2 * 4, 256);
+    float* fb_dist = (float*)w;            w += align_up((size_t)1024 * 32 * 2 * 4, 256);
     void* ews = w;
     size_t ews_bytes = ws_bytes - (size_t)(w - (char*)ws);
 
     int nb = (M + Q + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, prep, rm2);
-    PCREG_HIP(hipMemsetAsync(gthr, 0xFF, qq * 4, st));            // +inf in the ordered-uint image
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, prep, rm2);
     PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
-    int S = 1, kc = KC;
-    if (use_mfma) {
+    int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0;
+    static const bool no_seed = getenv("PCREG_KNN_NOSEED") && atoi(getenv("PCREG_KNN_NOSEED")) != 0;
+    if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)
+        PCREG_HIP(hipMemsetAsync(seed_cnt, 0, (size_t)kSeedMaxCells * 4, st));
+        int fb = (M + kBlock * 4 - 1) / (kBlock * 4); if (fb > 2048) fb = 2048;
+        hipLaunchKernelGGL(seed_fill_kernel, dim3(fb), dim3(kBlock), 0, st, m, M, ldm, prep, seed_cnt, seed_slots);
+        hipLaunchKernelGGL(seed_query_kernel, dim3((Q + kBlock - 1) / kBlock), dim3(kBlock), 0, st, q, Q, ldq, m, ldm, prep,
+                           seed_cnt, seed_slots, e_mode, gthr);
+    } else {
+        PCREG_HIP(hipMemsetAsync(gthr, 0xFF, qq * 4, st));        // +inf in the ordered-uint image
+    }
+    if (variant == 40 || variant == 41) {        // f16-split matrix-core candidates (41: timing only)
+        kc = 8;
+        int rc = launch_knn_candidates_f16(q, Q, ldq, m, M, ldm, prep, rm2, mprep, gthr, part_idx, part_s,
+                                           target_env > 0 ? target_env : 2048, kPartCap * 2, variant == 41, &S, st);
+        if (rc) return rc;
+    } else if (use_mfma) {
         constexpr int NQ = 8;                    // must match knn_mfma.hip
         const int n_tiles = (M + 15) / 16;
         const int q_blocks = (Q + (kBlock / 64) * NQ * 16 - 1) / ((kBlock / 64) * NQ * 16);
@@ -614,15 +758,6 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
             int pb = (M + kMTile + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
             hipLaunchKernelGGL(prep_model_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, prep, (float4*)mprep, rm2);
         }
-        // seeding pass: 8 slices of 256 points spread over the shard give every query a first
-        // threshold (~0.2 % of the pairs), so the main grid's workgroups do not all start from
-        // +inf and pay the insertion path on their whole first tile.  A skipped point always
-        // has s >= the word it was compared with, so the certificate is unaffected.
-        if (M >= 64 * 1024 && variant != 14 && variant < 20) {
-            const int seeds = 8, slen = 256;
-            hipLaunchKernelGGL((knn_candidates_kernel<4, 8>), dim3((Q + kBlock * 4 - 1) / (kBlock * 4), seeds), dim3(kBlock), 0, st,
-                               q, Q, ldq, (const float4*)mprep, M, slen, M / seeds, prep, gthr, (int32_t*)nullptr, (float*)nullptr);
-        }
         dim3 grid(n_qt, S);
 #define PCREG_CAND_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn_candidates_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s)
         switch (variant) {
@@ -644,12 +779,16 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     }
     PCREG_HIP(hipGetLastError());
     hipLaunchKernelGGL(knn_finalize_kernel, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
-                       part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag);
+                       part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode);
     PCREG_HIP(hipGetLastError());
+    if (getenv("PCREG_KNN_DEBUG")) {
+        int32_t nf = 0;
+        PCREG_HIP(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, st)); PCREG_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[pcreg] knn fast: Q=%d M=%d variant=%d S=%d kc=%d unproven=%d\n", Q, M, variant, S, kc, nf);
+    }
     // fallbacks (both launched; each decides from the device-side count which one works)
-    const int kFew = 1024;
-    hipLaunchKernelGGL(knn_fallback_block_kernel, dim3(kFew), dim3(kBlock), 0, st, q, ldq, m, M, ldm, (int)idx_base,
-                       flag_list, n_flag, kFew, idx, dist);
+    hipLaunchKernelGGL(knn_fallback_slice_kernel, dim3(kFew, kFbSlices), dim3(kBlock), 0, st, q, ldq, m, M, ldm, flag_list, n_flag, fb_idx, fb_dist);
+    hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3(kFew / 256), dim3(256), 0, st, flag_list, n_flag, (int)idx_base, fb_idx, fb_dist, idx, dist);
     PCREG_HIP(hipGetLastError());
     return launch_knn2_points_exact_list(q, Q, ldq, m, M, ldm, idx_base, flag_list, n_flag, kFew, idx, dist, ews, ews_bytes, st);
 }

@@ -10,7 +10,22 @@ constexpr int kBlock = 256;
 constexpr int KC = 4;                        // candidates kept per query and chunk
 constexpr int kMTile = 1024;                 // model points per LDS tile (16 KiB)
 
-struct Prep { float cx, cy, cz, rm2; };      // centre and max |m~|^2, produced on device
+// centre (and, for the f16 matrix-core path, the power-of-two scale that brings the half extent of the
+// joint bounding box into [32, 64) and 1/scale^2), produced on device
+struct Prep {
+    float cx, cy, cz, rm2, sigma, inv_sigma2, pad0, pad1;
+    float gx0, gy0, gz0, inv_h;                  // seeding grid over the joint bounding box (knn_fast.hip, stage 1c)
+    int nx, ny, nz, ncell;
+};
+constexpr int kSeedSlots = 4;                    // model points remembered per grid cell
+constexpr int kSeedMaxCells = 1 << 21;
+
+// rounding bound of the candidate scores, without the d2-dependent part
+__device__ __forceinline__ double score_error_bound(int e_mode, double Rm2, double r) {
+    const double u = 5.9604644775390625e-08, Rm = sqrt(Rm2);
+    return e_mode == 0 ? u * (3.0 * Rm2 + 3.03 * (Rm2 + 2.0 * r * Rm) + 4.04 * (r + Rm) * (r + Rm))
+                       : u * (3.0 * Rm2 + 16.0 * r * Rm + 32.1 * (Rm2 + 2.0 * r * Rm) + 4.04 * (r + Rm) * (r + Rm));
+}
 
 __device__ __forceinline__ unsigned f2ord(float f) {       // order-preserving float -> uint
     unsigned b = __float_as_uint(f);

@@ -1,0 +1,240 @@
+// pcreg_amd/csrc/knn_mfma16.hip -- the candidate stage of knn_fast.hip on the f16 matrix cores.
+//
+// s(q,m) = |m~|^2 - 2 q~.m~ is a dot product; v_mfma_f32_32x32x16_f16 scores 32 model points x 32
+// queries (1024 pairs) per instruction at 16x the fp32 vector rate -- IF the operands are f16.  They
+// are made f16 without giving up fp32-level accuracy by error-free splitting:
+//     x = xh + xl (+ <= 2^-22 |x|),  xh = f16(x), xl = f16(x - xh)
+//     Q.m = Qh mh + Qh ml + Ql mh + Ql ml          (Q = -2 sigma q~, m = sigma m~)
+// i.e. 4 k-slots per coordinate, 12 in all, and |m~|^2 (fp32) as three f16 terms against 1,1,1:
+// 15 of the instruction's 16 k-slots, ONE MFMA per 32 x 32 tile, accumulated in fp32 by the matrix
+// core.  sigma is a power of two that brings the joint bounding box into [-64, 64): every entry
+// stays inside f16's range and scores are exactly sigma^2 times the unscaled ones.
+//     A (model, 32 x 16):   lane l gives point l%32, k-slots 8*(l/32)..+7
+//                           k: [x: mh ml mh ml][y: ...] | [z: mh ml mh ml][w: wh wm wl 0]
+//     B (queries, 16 x 32): lane l gives query l%32, the same k-slots
+//                           k: [x: Qh Qh Ql Ql][y: ...] | [z: Qh Qh Ql Ql][1 1 1 0]
+//     D (32 x 32 fp32):     lane l, register r: model row 8*(r/4) + 4*(l/32) + r%4, query l%32
+// A lane thus sees 16 scores of ONE query per instruction; it folds them with a v_min3 tree and one
+// compare against the query's threshold and only then touches its sorted top-4 -- the VALU work per
+// pair drops from ~4.25 issue slots (3 FMA + selection) to ~1.1, and the FMAs moved to the matrix
+// pipe, which runs concurrently.  The scores are approximations with a larger (but still rigorous)
+// error bound than the fp32 FMA chain (knn_finalize_kernel, e_mode 1):
+// nothing downstream changes -- candidates are re-ranked exactly and certified, failures fall back.
+// Built with -fno-honor-nans and -amdgpu-mfma-vgpr-form (results straight into VGPRs).
+#include "common.hpp"
+#include "knn_fast_common.hpp"
+#include <hip/hip_fp16.h>
+#include <cstdlib>
+
+namespace pcreg {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kT16 = 256;                     // model points per tile: [2 k-halves][256 points][8 f16] = 8 KiB
+constexpr int kRefresh = 16;                  // tiles between two looks at the shared threshold words
+
+__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x; l = (_Float16)(x - (float)h);
+}
+
+// model -> tiles of f16 operands; R_m^2 (unscaled) by atomicMax on the float bits
+__global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __restrict__ m, int M, int ldm,
+                                                                const Prep* __restrict__ prep, uint4* __restrict__ out,
+                                                                int n_tiles, unsigned* __restrict__ rm2_bits) {
+    const float cx = prep->cx, cy = prep->cy, cz = prep->cz, sg = prep->sigma;
+    float mx = 0.0f;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_tiles * kT16; i += gridDim.x * kBlock) {
+        union { f16x8 v; uint4 u; } lo, hi;
+        if (i < M) {
+            float x = m[i] - cx, y = m[i + (size_t)ldm] - cy, z = m[i + 2 * (size_t)ldm] - cz;     // the m~ of the fp32 path
+            mx = fmaxf(mx, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+            x *= sg; y *= sg; z *= sg;                                                         // exact
+            const float w = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));                 // <= 3 * 64^2
+            _Float16 xh, xl, yh, yl, zh, zl;
+            split2(x, xh, xl); split2(y, yh, yl); split2(z, zh, zl);
+            const _Float16 wh = (_Float16)w; const float w1 = w - (float)wh;
+            const _Float16 wm = (_Float16)w1; const _Float16 wl = (_Float16)(w1 - (float)wm);
+            lo.v = f16x8{xh, xl, xh, xl, yh, yl, yh, yl};
+            hi.v = f16x8{zh, zl, zh, zl, wh, wm, wl, (_Float16)0.0f};
+        } else {                                   // padding: score +inf, never a candidate
+            lo.u = make_uint4(0u, 0u, 0u, 0u);
+            hi.u = make_uint4(0u, 0u, 0x00007C00u, 0u);
+        }
+        const size_t t = (size_t)(i / kT16), r = (size_t)(i % kT16);
+        out[t * (2 * kT16) + r] = lo.u;
+        out[t * (2 * kT16) + kT16 + r] = hi.u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(rm2_bits, __float_as_uint(mx));
+}
+
+template <int QG, bool DRY, bool BATCH>
+__global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
+    const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
+    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx /*[S][Q][8]*/,
+    float* __restrict__ part_s) {
+    __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];          // 2 x 8 KiB, filled by LDS-DMA
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int q_base = (blockIdx.x * (kBlock / 64) + wave) * (QG * 32);
+    const float sg = prep->sigma, inv2 = prep->inv_sigma2, sg2 = sg * sg;
+
+    f16x8 bq[QG];
+    float thr[QG];
+    unsigned gseen[QG];
+    Cand cand[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qi = q_base + g * 32 + col;
+        float X = 0.0f, Y = 0.0f, Z = 0.0f, one = 0.0f;
+        if (qi < Q) {
+            X = -2.0f * (sg * (q[qi] - prep->cx)); Y = -2.0f * (sg * (q[qi + (size_t)ldq] - prep->cy));
+            Z = -2.0f * (sg * (q[qi + 2 * (size_t)ldq] - prep->cz)); one = 1.0f;
+        }
+        _Float16 Xh, Xl, Yh, Yl, Zh, Zl;
+        split2(X, Xh, Xl); split2(Y, Yh, Yl); split2(Z, Zh, Zl);
+        const _Float16 o1 = (_Float16)one;
+        bq[g] = half == 0 ? f16x8{Xh, Xh, Xl, Xl, Yh, Yh, Yl, Yl} : f16x8{Zh, Zh, Zl, Zl, o1, o1, o1, (_Float16)0.0f};
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { cand[g].s[k] = INFINITY; cand[g].i[k] = -1; }
+        thr[g] = INFINITY; gseen[g] = 0xFFFFFFFFu;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&tile[0][0];
+    const int t_begin = blockIdx.y * tiles_per_chunk, t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    const int ntile = t_end - t_begin;
+    // wave w copies the 1-KiB segments w and w + 4 of an 8-KiB tile
+#define PCREG_TILE_DMA(T, BUF)                                                                                     \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                                \
+        const int seg = k * 4 + wave;                                                                              \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mt + (size_t)(T) * (2 * kT16) + seg * 64 + lane), \
+                                         (__attribute__((address_space(3))) void*)(&tile[BUF][seg * 64]), 16, 0, 0);   \
+    }
+    if (ntile > 0) { PCREG_TILE_DMA(t_begin, 0) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int t = 0; t < ntile; ++t) {
+        if (t + 1 < ntile) { PCREG_TILE_DMA(t_begin + t + 1, (t + 1) & 1) }
+        if ((t & (kRefresh - 1)) == 0) {          // chunks share one monotone threshold word per query (unscaled units)
+#pragma unroll
+            for (int g = 0; g < QG; ++g) {
+                const int qi = q_base + g * 32 + col;
+                if (qi < Q) {
+                    if (cand[g].s[3] < INFINITY) { unsigned k = f2ord(cand[g].s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
+                    unsigned gv = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gseen[g] = gv;
+                    thr[g] = fminf(fminf(thr[g], ord2f(gv) * sg2), __shfl_xor(thr[g], 32));       // and the sibling half's list
+                }
+            }
+        }
+        // The A operand is read with inline-asm ds_read_b128: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in
+        // front of every compiler-visible LDS read while an LDS-DMA is in flight (it cannot tell the two
+        // buffers apart), which would drain the prefetch of tile t+1 at the top of tile t.
+        const unsigned cur = lds_base + (unsigned)((t & 1) * (2 * kT16) + half * kT16 + col) * 16u;
+        const int jt = (t_begin + t) * kT16 + 4 * half;
+        u32x4 an;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(an) : "v"(cur) : "memory");
+#pragma unroll 2
+        for (int sub = 0; sub < kT16 / 32; ++sub) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an) :: "memory");
+            const f16x8 av = __builtin_bit_cast(f16x8, an);
+            if (sub + 1 < kT16 / 32) asm volatile("ds_read_b128 %0, %1" : "=v"(an) : "v"(cur + (unsigned)(sub + 1) * 512u) : "memory");
+            if (!BATCH) {
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[g], zero, 0, 0, 0);
+                    float m0 = fminf(fminf(d[0], d[1]), d[2]), m1 = fminf(fminf(d[3], d[4]), d[5]);
+                    float m2 = fminf(fminf(d[6], d[7]), d[8]), m3 = fminf(fminf(d[9], d[10]), d[11]);
+                    float m4 = fminf(fminf(d[12], d[13]), d[14]);
+                    float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
+                    if (DRY) { asm volatile("" :: "v"(mn)); }
+                    else if (mn < thr[g]) {
+                        const int jb = jt + sub * 32;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) if (d[r] < thr[g]) cand_insert(cand[g], d[r], jb + 8 * (r / 4) + (r % 4));
+                        thr[g] = fminf(thr[g], cand[g].s[3]);
+                    }
+                }
+            } else {
+                // all QG products first (the matrix pipe works through them back to back), then the QG
+                // reductions, then ONE branch: the slow path is entered if any group of any lane has a hit
+                f32x16 d[QG];
+#pragma unroll
+                for (int g = 0; g < QG; ++g) d[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[g], zero, 0, 0, 0);
+                bool hit = false;
+#pragma unroll
+                for (int g = 0; g < QG; ++g) {
+                    float m0 = fminf(fminf(d[g][0], d[g][1]), d[g][2]), m1 = fminf(fminf(d[g][3], d[g][4]), d[g][5]);
+                    float m2 = fminf(fminf(d[g][6], d[g][7]), d[g][8]), m3 = fminf(fminf(d[g][9], d[g][10]), d[g][11]);
+                    float m4 = fminf(fminf(d[g][12], d[g][13]), d[g][14]);
+                    float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[g][15]));
+                    if (DRY) { asm volatile("" :: "v"(mn)); } else hit |= mn < thr[g];
+                }
+                if (!DRY && hit) {
+                    const int jb = jt + sub * 32;
+#pragma unroll
+                    for (int g = 0; g < QG; ++g) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) if (d[g][r] < thr[g]) cand_insert(cand[g], d[g][r], jb + 8 * (r / 4) + (r % 4));
+                        thr[g] = fminf(thr[g], cand[g].s[3]);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef PCREG_TILE_DMA
+    const int chunk = blockIdx.y;
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+        const int qi = q_base + g * 32 + col;
+        if (qi < Q) {
+            if (cand[g].s[3] < INFINITY) { unsigned k = f2ord(cand[g].s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
+            size_t o = ((size_t)chunk * Q + qi) * 8 + half * 4;
+            *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[g].i[0], cand[g].i[1], cand[g].i[2], cand[g].i[3]);
+            *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[g].s[0] * inv2, cand[g].s[1] * inv2, cand[g].s[2] * inv2, cand[g].s[3] * inv2);
+        }
+    }
+}
+
+}  // namespace
+
+size_t knn_f16_prep_bytes(int M) { return (size_t)((M > 0 ? M : 1) + kT16 - 1) / kT16 * (2 * kT16) * sizeof(uint4); }
+
+// grid: q_blocks x S; kc = 8 list entries per (chunk, query).  Returns S and kc through the pointers.
+int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
+                              unsigned* rm2, void* mtiles, unsigned* gthr, int32_t* part_idx, float* part_s,
+                              int target_blocks, int max_S, bool dry, int* S_out, hipStream_t st) {
+    static const int cfg = getenv("PCREG_KNN_F16_CFG") ? atoi(getenv("PCREG_KNN_F16_CFG")) : 0;   // 0: QG4; 1: QG4 batched; 2: QG2; 3: QG2 batched
+    const int QG = (cfg == 2 || cfg == 3) ? 2 : 4;
+    const int n_tiles = (M + kT16 - 1) / kT16;
+    const int q_blocks = (Q + (kBlock / 64) * QG * 32 - 1) / ((kBlock / 64) * QG * 32);
+    int S = target_blocks / q_blocks; if (S < 1) S = 1;
+    if (S > max_S) S = max_S;
+    if (S > n_tiles) S = n_tiles > 0 ? n_tiles : 1;
+    int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
+    S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
+    *S_out = S;
+    PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * 8 * 4, st));       // -1: empty slots
+    if (M <= 0) return PCREG_OK;
+    int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
+    hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2);
+#define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks, S), dim3(kBlock), 0, st, q, Q, ldq, \
+                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, part_idx, part_s)
+    switch (cfg * 2 + (dry ? 1 : 0)) {
+        case 0: PCREG_F16_LAUNCH(4, false, false); break;  case 1: PCREG_F16_LAUNCH(4, true, false); break;
+        case 2: PCREG_F16_LAUNCH(4, false, true); break;   case 3: PCREG_F16_LAUNCH(4, true, true); break;
+        case 4: PCREG_F16_LAUNCH(2, false, false); break;  case 5: PCREG_F16_LAUNCH(2, true, false); break;
+        case 6: PCREG_F16_LAUNCH(2, false, true); break;   default: PCREG_F16_LAUNCH(2, true, true); break;
+    }
+#undef PCREG_F16_LAUNCH
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+}  // namespace pcreg
