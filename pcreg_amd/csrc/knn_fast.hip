@@ -67,10 +67,15 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __res
 }
 __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, int M, Prep* __restrict__ prep,
                                   unsigned* __restrict__ rm2_bits) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = threadIdx.x; b < nparts; b += 64)              // launched with one wave
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+    }
     if (threadIdx.x == 0) {
-        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int b = 0; b < nparts; ++b)
-            for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
         prep->cx = 0.5f * lo[0] + 0.5f * hi[0]; prep->cy = 0.5f * lo[1] + 0.5f * hi[1]; prep->cz = 0.5f * lo[2] + 0.5f * hi[2];
         {   // an upper bound of max |m~|^2 (and |q~|^2) from the box itself: the seeding margin uses it
             float ax = 0.5f * (hi[0] - lo[0]), ay = 0.5f * (hi[1] - lo[1]), az = 0.5f * (hi[2] - lo[2]);
