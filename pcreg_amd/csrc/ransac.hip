@@ -826,6 +826,272 @@ __global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a)
     }
 }
 
+
+// ================================================================ staged pipeline (large sets)
+// The fused tiled kernel above holds the lane-parallel SVD fits, the scoring sweeps and the
+// moment sweeps in one 219-VGPR body (2 waves per SIMD).  For one large registration
+// (B == 1, n > 1365) the same arithmetic runs as a chain of lean kernels instead:
+//   rs_fit1   one hypothesis per lane: sample + estimateTransform            -> T1, v1
+//   rs_score  TRANSPOSED scoring: a wave keeps 256 correspondences in registers and walks the
+//             hypotheses (their transforms arrive through the scalar cache); no LDS tiles, no
+//             barriers, 17 fp64 ops per pair and nothing else                -> partial counts
+//   rs_moments the refit sweeps of the tiled kernel, two hypotheses per pass -> 27 moments
+//   rs_fit2   one hypothesis per lane: estimateTransform from the moments   -> T2, v2
+//   rs_score  on T2                                                          -> partial counts
+//   rs_finish counts, `has` flags; then the unchanged ransac_select_kernel.
+// Counts are integers (order-free); the moments keep the tiled kernel's summation order
+// (lane-strided partial sums over all points, butterfly over the wave), so every number is
+// the one the fused kernels produce.
+constexpr int kSW = 4, kSS = 4;                 // scoring: waves per workgroup, 64-point slots per wave
+constexpr int kSPts = kSW * kSS * 64;           // 1024 correspondences per workgroup
+constexpr int kSMaxPB = 64;                     // point blocks with a partial-count row each
+constexpr int kSChunk = 160;                    // hypotheses per workgroup
+
+struct StagedArgs {
+    RansacArgs a;
+    double* T1; unsigned char* v1; unsigned char* pass1; unsigned char* v2;
+    double* mom;                 // [iters][27]
+    int32_t* part;               // [kSMaxPB][iters]
+    int pb;                      // point blocks in use
+};
+
+__device__ __forceinline__ int staged_n(const RansacArgs& a) { return min(a.n_dev ? *a.n_dev : a.n_cap, a.n_cap); }
+
+__global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
+    const RansacArgs& a = sa.a;
+    const int n = staged_n(a);
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= a.iters) return;
+    double T1[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T1[k] = 0.0;
+    bool v1 = false;
+    if (n >= a.m && n >= 3) {
+        Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
+        if (a.m == 3) {
+            int s[3]; sample3(a, 0, p, n, s);
+            double A1[3][3], A2[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double q[6]; P.load(s[j], q);
+                A1[j][0] = q[0]; A1[j][1] = q[1]; A1[j][2] = q[2];
+                A2[j][0] = q[3]; A2[j][1] = q[4]; A2[j][2] = q[5];
+            }
+            v1 = fit_3pt(A1, A2, T1);
+        } else {
+            double mom[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+            const int32_t* t = a.sample_idx + (size_t)p * a.m;
+            double os[6];
+            for (int j = 0; j < a.m; ++j) {
+                int idx = min(max(t[j] - 1, 0), n - 1);
+                double q[6]; P.load(idx, q);
+                if (j == 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) os[c] = q[c];
+                }
+                mom_accumulate(mom, q, os);
+            }
+            v1 = fit_moments(a.m, mom, os, T1);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sa.T1[(size_t)p * 12 + k] = T1[k];
+    sa.v1[p] = v1;
+}
+
+// grid (point blocks, hypothesis chunks).  part[pb][h] = inliers of hypothesis h among this block's points.
+__global__ __launch_bounds__(kSW * 64) void rs_score_kernel(StagedArgs sa, const double* __restrict__ TT,
+                                                            const unsigned char* __restrict__ valid) {
+    const RansacArgs& a = sa.a;
+    __shared__ int s_cnt[kSW][kSChunk];
+    const int n = staged_n(a);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h0 = blockIdx.y * kSChunk, h1 = min(a.iters, h0 + kSChunk);
+    const double th = a.thDist;
+    for (int hl = threadIdx.x; hl < kSW * kSChunk; hl += kSW * 64) (&s_cnt[0][0])[hl] = 0;
+    // validity of the chunk's hypotheses as three wave-uniform bit masks (no per-hypothesis load in the loop)
+    unsigned long long vmask[(kSChunk + 63) / 64];
+#pragma unroll
+    for (int k = 0; k < (kSChunk + 63) / 64; ++k) {
+        const int h = h0 + k * 64 + lane;
+        vmask[k] = __ballot(h < h1 && k * 64 + lane < kSChunk && valid[h] != 0);
+    }
+    __syncthreads();
+    for (int pb = blockIdx.x; pb * kSPts < n; pb += gridDim.x) {       // normally one trip
+        double q[kSS][6]; bool act[kSS];
+#pragma unroll
+        for (int s = 0; s < kSS; ++s) {
+            const int i = pb * kSPts + (wave * kSS + s) * 64 + lane;
+            act[s] = i < n;
+            const int ii = act[s] ? i : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { q[s][c] = a.p1[ii + (size_t)c * a.ld]; q[s][3 + c] = a.p2[ii + (size_t)c * a.ld]; }
+        }
+        for (int h = h0; h < h1; ++h) {
+            if (!((vmask[(h - h0) >> 6] >> ((h - h0) & 63)) & 1ull)) continue;   // wave-uniform
+            double T[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T[k] = TT[(size_t)h * 12 + k];   // uniform address: scalar loads
+            pin_translation_vgpr(T);
+            int cnt = 0;
+#pragma unroll
+            for (int s = 0; s < kSS; ++s) cnt += __popcll(__ballot((sqdist(q[s], T) < th) & act[s]));
+            if (lane == 0) s_cnt[wave][h - h0] += cnt;
+        }
+    }
+    __syncthreads();
+    for (int hl = threadIdx.x; hl < h1 - h0; hl += kSW * 64) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < kSW; ++w) c += s_cnt[w][hl];
+        sa.part[(size_t)blockIdx.x * a.iters + h0 + hl] = c;
+    }
+}
+
+// cnt1 / pass1 from the partial counts (one thread per hypothesis)
+__global__ void rs_pass1_kernel(StagedArgs sa) {
+    const RansacArgs& a = sa.a;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= a.iters) return;
+    const int n = staged_n(a);
+    const int thInlr = matlab_round_i(a.ratio * (double)n);
+    int c = 0;
+    for (int pb = 0; pb < sa.pb; ++pb) c += sa.part[(size_t)pb * a.iters + h];
+    const bool v = sa.v1[h] != 0;
+    if (!v) c = 0;
+    const bool pass = v && c >= thInlr;
+    a.cnt1[h] = c; a.cnt2[h] = 0;
+    sa.pass1[h] = pass;
+    if (!a.refine) {
+        a.has[h] = pass;
+        if (pass) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) a.TF[(size_t)h * 12 + k] = sa.T1[(size_t)h * 12 + k];
+        }
+    }
+}
+
+// Refit moments: the tiled kernel's phase 2, two passing hypotheses of every wave per sweep.
+__global__ __launch_bounds__(kTBlock) void rs_moments_kernel(StagedArgs sa) {
+    const RansacArgs& a = sa.a;
+    __shared__ __attribute__((aligned(16))) double sp[2 * 6 * kTile];
+    const int n = staged_n(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wbase = (blockIdx.x * kTW + wave) * a.hpw;
+    const double* g1 = a.p1; const double* g2 = a.p2;
+    const int nh = max(0, min(a.hpw, a.iters - wbase));
+    if (n < a.m || n < 3) return;                                   // block-uniform
+    Pts<false> P{g1, g2, a.ld, nullptr, n};
+    double o[6];
+    P.load(0, o);
+    const double th = a.thDist;
+    // lane l < nh owns hypothesis wbase + l: its transform and inlier count
+    double T1[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T1[k] = 0.0;
+    int c1 = 0; bool pass = false;
+    if (lane < nh) {
+        const int h = wbase + lane;
+        pass = sa.pass1[h] != 0; c1 = a.cnt1[h];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T1[k] = sa.T1[(size_t)h * 12 + k];
+    }
+    unsigned long long todo = __ballot(pass);
+    while (__syncthreads_or(todo != 0)) {                           // every wave of the workgroup sweeps together
+        int hs[2]; bool want[2]; int ch[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            want[k] = todo != 0;
+            hs[k] = want[k] ? __builtin_ctzll(todo) : 0;
+            if (want[k]) todo &= todo - 1;
+            ch[k] = __builtin_amdgcn_readlane(c1, hs[k]);
+        }
+        double T[2][12];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { bcast_T(T1, hs[k], T[k]); pin_translation_vgpr(T[k]); }
+        double acc[2][27];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 27; ++e) acc[k][e] = 0.0;
+        int k3[2] = {0, 0};
+        const bool any3 = (want[0] && ch[0] == 3) || (want[1] && ch[1] == 3);
+        PCREG_TILE_SWEEP_BEGIN
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool in = (sqdist(q, T[k]) < th) & act & want[k];
+                if (in) mom_accumulate(acc[k], q, o);
+                if (any3 && ch[k] == 3 && want[k]) {     // estimateTransform's N == 3 branch needs the points themselves
+                    unsigned long long bal = __ballot(in);
+                    const int r3 = k3[k] + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (in && r3 < 3) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) sa.mom[(size_t)(wbase + hs[k]) * 27 + r3 * 6 + c] = q[c];
+                    }
+                    k3[k] += __popcll(bal);
+                }
+            }
+        PCREG_TILE_SWEEP_END
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (want[k] && ch[k] != 3) {
+#pragma unroll
+                for (int e = 0; e < 27; ++e) {
+                    double tot = wave_sum(acc[k][e]);
+                    if (lane == 0) sa.mom[(size_t)(wbase + hs[k]) * 27 + e] = tot;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
+    const RansacArgs& a = sa.a;
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.iters) return;
+    bool v2 = false;
+    double T2[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T2[k] = 0.0;
+    if (sa.pass1[h]) {
+        const int n = staged_n(a);
+        Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
+        double o[6]; P.load(0, o);
+        double mom[27];
+#pragma unroll
+        for (int e = 0; e < 27; ++e) mom[e] = sa.mom[(size_t)h * 27 + e];
+        const int c1 = a.cnt1[h];
+        if (c1 == 3) {
+            double A1[3][3], A2[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { A1[j][c] = mom[j * 6 + c]; A2[j][c] = mom[j * 6 + 3 + c]; }
+            v2 = fit_3pt(A1, A2, T2);
+        } else {
+            v2 = fit_moments(c1, mom, o, T2);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) a.TF[(size_t)h * 12 + k] = T2[k];
+    sa.v2[h] = v2;
+}
+
+__global__ void rs_finish_kernel(StagedArgs sa) {
+    const RansacArgs& a = sa.a;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= a.iters) return;
+    const int n = staged_n(a);
+    const int thInlr = matlab_round_i(a.ratio * (double)n);
+    int c = 0;
+    for (int pb = 0; pb < sa.pb; ++pb) c += sa.part[(size_t)pb * a.iters + h];
+    const bool v = sa.v2[h] != 0;
+    a.cnt2[h] = v ? c : 0;
+    a.has[h] = v && c >= thInlr;
+}
+
 // ---------------------------------------------------------------- winner + outputs
 // ransac.m:69-98.  One workgroup per registration.
 __global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcreg_dev_ransac_result* out,
@@ -961,9 +1227,14 @@ __global__ void calc_dists_kernel(const double* T16, const double* p1, const dou
 }  // namespace
 
 // ---------------------------------------------------------------- launchers
+static size_t staged_extra_bytes(size_t h) {    // T1 | mom | part | v1 | pass1 | v2
+    return align_up(h * 12 * sizeof(double), 256) + align_up(h * 27 * sizeof(double), 256) +
+           align_up(h * kSMaxPB * sizeof(int32_t), 256) + 3 * align_up(h, 256);
+}
 size_t ransac_workspace_bytes(int iters, int B) {
     size_t h = (size_t)iters * (size_t)B;
-    return align_up(h * 12 * sizeof(double), 256) + 2 * align_up(h * sizeof(int32_t), 256) + align_up(h, 256);
+    return align_up(h * 12 * sizeof(double), 256) + 2 * align_up(h * sizeof(int32_t), 256) + align_up(h, 256) +
+           staged_extra_bytes(h);
 }
 
 int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
@@ -983,7 +1254,7 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
     a.TF = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
     a.cnt1 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.cnt2 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
-    a.has = (unsigned char*)w;
+    a.has = (unsigned char*)w; w += align_up(h, 256);
     long long total = (long long)o.iterNum * B;
     size_t lds = (size_t)n_cap * 6 * sizeof(double);
     if (n_cap > 0 && lds <= 64 * 1024) {
@@ -995,8 +1266,35 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
         int per_block = hpw * kWavesPerBlock;
         dim3 grid((o.iterNum + per_block - 1) / per_block, B);
         hipLaunchKernelGGL(ransac_hyp_kernel<true>, grid, dim3(kBlock), lds, st, a);
+    } else if (B == 1 && !offsets && n_cap >= 4096 && !(getenv("PCREG_RANSAC_FUSED") && atoi(getenv("PCREG_RANSAC_FUSED")))) {
+        // one large registration: the staged chain of lean kernels (see rs_* above)
+        StagedArgs sa{};
+        sa.T1 = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
+        sa.mom = (double*)w; w += align_up(h * 27 * sizeof(double), 256);
+        sa.part = (int32_t*)w; w += align_up(h * kSMaxPB * sizeof(int32_t), 256);
+        sa.v1 = (unsigned char*)w; w += align_up(h, 256);
+        sa.pass1 = (unsigned char*)w; w += align_up(h, 256);
+        sa.v2 = (unsigned char*)w;
+        int pb = (n_cap + kSPts - 1) / kSPts; if (pb > kSMaxPB) pb = kSMaxPB; if (pb < 1) pb = 1;
+        sa.pb = pb;
+        int hpw = (int)((total + 250LL * kTW - 1) / (250LL * kTW));
+        if (hpw < 1) hpw = 1;
+        if (hpw > 16) hpw = 16;
+        a.hpw = hpw;
+        sa.a = a;
+        const int it = o.iterNum;
+        const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
+        hipLaunchKernelGGL(rs_fit1_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
+        hipLaunchKernelGGL(rs_score_kernel, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
+        hipLaunchKernelGGL(rs_pass1_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
+        if (a.refine) {
+            hipLaunchKernelGGL(rs_moments_kernel, dim3((it + hpw * kTW - 1) / (hpw * kTW)), dim3(kTBlock), 0, st, sa);
+            hipLaunchKernelGGL(rs_fit2_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
+            hipLaunchKernelGGL(rs_score_kernel, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const unsigned char*)sa.v2);
+            hipLaunchKernelGGL(rs_finish_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
+        }
     } else {
-        // large sets: 8-wave workgroups share LDS tiles of the correspondences
+        // several large sets: 8-wave workgroups share LDS tiles of the correspondences
         // one workgroup per CU is resident (<= 256 VGPRs x 8 waves); give every wave just enough
         // hypotheses that ~250 workgroups cover the job in a single round (a second, ragged
         // round of workgroups costs a full sweep sequence for a fraction of the CUs)
