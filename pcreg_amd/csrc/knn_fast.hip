@@ -662,7 +662,7 @@ size_t knn2_points_exact_workspace_bytes(int Q, int M);
 //                   | prepared model (16 B/point, padded to whole 16-point tiles)
 //                   | part_idx [S][Q][kc] | part_s | exact-kernel workspace (fallback)
 static constexpr int kPartCap = 40;           // upper bound of S * kc / 16 any variant may use (x16 entries per query)
-static constexpr int kSeedMinM = 64 * 1024;      // below this the lists settle within the first tiles anyway
+static constexpr int kSeedMinM = 16 * 1024;      // below this the lists settle within the first tiles anyway
 static size_t seed_bytes(int M) {
     if (M < kSeedMinM) return 0;
     size_t cells = std::min<size_t>((size_t)M / 2 + 4096, (size_t)kSeedMaxCells) + 16;   // bbox_final_kernel's cap

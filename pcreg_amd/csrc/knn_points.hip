@@ -218,6 +218,27 @@ __global__ void unique_reduce_kernel(const int32_t* __restrict__ part_idx, const
     keep[k] = (bi == cand_q[k]);
 }
 
+// Unique through the certified search (default): the matched model points become the queries of one
+// more top-2 search over the surface; keep[k] = (nearest surface point of model row cand_m[k]) == cand_q[k].
+// d(p, s) uses dx = p - s here and dx = s - p in the forward pass: the same bits (squares of negated values).
+__global__ void unique_gather_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm, int m_lo,
+                                     const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand, float* __restrict__ pts /*[3][Q]*/) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Q) return;
+    const int j = k < *n_cand ? cand_m[k] - m_lo : -1;
+    const bool ok = j >= 0 && j < M;                 // rows of other shards / unused slots: any valid point (ignored later)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pts[k + (size_t)c * Q] = ok ? m[j + (size_t)c * ldm] : q[(size_t)c * ldq];
+}
+__global__ void unique_keep_kernel(const int32_t* __restrict__ idx2, int M, int m_lo, const int32_t* __restrict__ cand_q,
+                                   const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand, int32_t* __restrict__ keep) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= *n_cand) return;
+    const int j = cand_m[k] - m_lo;
+    if (j < 0 || j >= M) return;                     // another shard's row
+    keep[k] = (idx2[(size_t)k * 2] == cand_q[k]);
+}
+
 // Ordered compaction of the kept candidates (three small launches: per-workgroup counts,
 // exclusive scan, scatter) into 1-based pairs and, optionally, the matched coordinates.
 __global__ void gather_count_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
@@ -358,10 +379,17 @@ int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_t
     return run_filter_top2<float>(idx, dist, Q, M_total, thr, ratio, cand_q, cand_m, n_cand, (int32_t*)tmp, st);
 }
 
-size_t unique_points_workspace_bytes(int Q) {
+static size_t unique_direct_bytes(int Q) {
     int n_tiles = (Q + kQTile - 1) / kQTile; if (n_tiles < 1) n_tiles = 1;
     int S = pick_splits(n_tiles, Q > 0 ? Q : 1);
     return 2 * align_up((size_t)S * (size_t)(Q > 0 ? Q : 1) * sizeof(float), 256);
+}
+// gathered points [3][Q] | idx2 [Q][2] | dist2 [Q][2] | search workspace
+size_t unique_points_workspace_bytes(int Q) {
+    size_t q = (size_t)(Q > 0 ? Q : 1);
+    size_t fast = align_up(q * 3 * 4, 256) + 2 * align_up(q * 2 * 4, 256) + knn2_points_workspace_bytes(Q, Q);
+    size_t direct = unique_direct_bytes(Q);
+    return fast > direct ? fast : direct;
 }
 
 int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t m_lo,
@@ -371,6 +399,19 @@ int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int
     if (Q == 0) return PCREG_OK;
     size_t need = unique_points_workspace_bytes(Q);
     if (ws_bytes < need) { set_error("unique workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    if (!use_exact_only() && Q >= 4096) {
+        size_t qq = (size_t)Q;
+        char* w = (char*)ws;
+        float* pts = (float*)w;             w += align_up(qq * 3 * 4, 256);
+        int32_t* idx2 = (int32_t*)w;        w += align_up(qq * 2 * 4, 256);
+        float* dist2 = (float*)w;           w += align_up(qq * 2 * 4, 256);
+        hipLaunchKernelGGL(unique_gather_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo, cand_m, n_cand, pts);
+        int rc = launch_knn2_points_f32(pts, Q, Q, q, Q, ldq, 0, idx2, dist2, w, ws_bytes - (size_t)(w - (char*)ws), st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(unique_keep_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, idx2, M, (int)m_lo, cand_q, cand_m, n_cand, keep);
+        PCREG_HIP(hipGetLastError());
+        return PCREG_OK;
+    }
     int n_tiles = (Q + kQTile - 1) / kQTile;         // capacity: every query matched
     int S = pick_splits(n_tiles, Q);
     int chunk = chunk_of(Q, S);
