@@ -258,6 +258,35 @@ int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const doubl
 int pcreg_dev_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featSurface,
                                   const double* featModel, double* pts1, double* pts2, void* stream);
 
+/* ---- sphere-sweep driver pieces (completeExperimentFast.m:46-225) and its final stage ----
+ * feat is row-major [V][3] (what the descriptor entry point emits). */
+
+/* counts[s] = #{ i : vecnorm(feat(i,:) - centres(s,:)) < R }: the sphere validity test of
+ * completeExperimentFast.m:57-64 (getLocalPoints.m:23-34 reduced to its count). centres [S][3]. */
+int pcreg_dev_sphere_counts(const double* feat, int V, const double* centres, int S, double R,
+                            int32_t* counts, void* stream);
+
+/* getDescriptorMask (completeExperimentFast.m:435-439, margin folded into R) as the ascending
+ * 0-based index list of the rows inside the sphere; *n_out = its length.  `centre` is HOST memory. */
+size_t pcreg_dev_sphere_select_workspace(int V);
+int pcreg_dev_sphere_select(const double* feat, int V, const double centre[3], double R, int32_t* idx,
+                            int32_t* n_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dst(k,:) = src(idx(k),:), k < min(*n, cap): featCur / descCur of completeExperimentFast.m:122-125
+ * (row-major, D doubles per row). */
+int pcreg_dev_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap,
+                              double* dst, void* stream);
+
+/* quickTF.m:5-7: out = [pts, 1] * T (first three columns).  pts/out n x 3 column-major on the
+ * device, T 4x4 column-major in HOST memory (invertTF is a 16-number host operation). */
+int pcreg_dev_quick_tf(const double* pts, int n, int ld, const double T[16], double* out, int ldo, void* stream);
+
+/* completeExperimentFast.m:368-391: inliers = vecnorm(pts1 - pts2) < maxDist, T_refine =
+ * estimateTransform over them.  n = *n_dev <= cap; T16 (device, column-major 4x4, zeros when
+ * empty), info[0] = number of inliers, info[1] = 1 if the transform is empty. */
+int pcreg_dev_refine_by_distance(const double* pts1, const double* pts2, const int32_t* n_dev, int cap, int ld,
+                                 double maxDist, double* T16, int32_t* info, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

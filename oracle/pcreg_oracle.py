@@ -594,3 +594,70 @@ def match_points_f32(q, m, match_threshold_abs, max_ratio, unique=True):
         u = back[:, 0] == qi
         qi, mj = qi[u], mj[u]
     return np.stack([qi + 1, mj + 1], axis=1).astype(np.uint32)
+
+
+# ------------------------------------------------------------------ sphere-sweep driver
+def pcUniformSamples(pts: np.ndarray, d: float) -> np.ndarray:
+    """completeExperimentFast.m:406-414 -- meshgrid over the cloud's X/Y/ZLimits with pitch d;
+    MATLAB's meshgrid + column-major reshape put y fastest, then x, then z."""
+    pts = np.asarray(pts, dtype=np.float64)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    ax = [lo[k] + d * np.arange(int(np.floor((hi[k] - lo[k]) / d + 1e-12)) + 1) for k in range(3)]   # a:d:b
+    X, Y, Z = np.meshgrid(ax[0], ax[1], ax[2])                  # shape (ny, nx, nz), like MATLAB
+    return np.column_stack([X.ravel(order="F"), Y.ravel(order="F"), Z.ravel(order="F")])
+
+
+def getDescriptorMask(featModel: np.ndarray, current_center, R_desc: float, margin: float = 0.0) -> np.ndarray:
+    """completeExperimentFast.m:435-439."""
+    rel = np.asarray(featModel, dtype=np.float64) - np.asarray(current_center, dtype=np.float64)
+    dists = np.sqrt((rel[:, 0] * rel[:, 0] + rel[:, 1] * rel[:, 1]) + rel[:, 2] * rel[:, 2])
+    return dists < (R_desc + margin)
+
+
+def sphere_sweep(featModel, descModel, featSurface, descSurface, par: dict, options: dict, R_desc: float,
+                 d_spheres: float = 5.0, min_pts: int = 1400, putative_thresh: int = 170, seed: int = 0,
+                 get_matches=None, run_ransac=None) -> dict:
+    """completeExperimentFast.m:46-224 on the CPU: sphere centres, validity by descriptor count,
+    getMatches per sphere, putative threshold, ransac per promising sphere, the stats arrays.
+    `seed + trial index` seeds the built-in sampler of each ransac call."""
+    get_matches = get_matches or getMatches
+    run_ransac = run_ransac or ransac
+    featModel = np.asarray(featModel, dtype=np.float64); featSurface = np.asarray(featSurface, dtype=np.float64)
+    centres = pcUniformSamples(featModel, d_spheres)                                     # :49-50
+    num_desc = np.array([int(getDescriptorMask(featModel, c, R_desc).sum()) for c in centres], dtype=np.int64)
+    valid = num_desc >= min_pts                                                          # :57-64 (max_pts = inf)
+    centres = centres[valid]
+    S = len(centres)
+    num_putative = np.zeros(S, dtype=np.int64); num_desc_all = np.zeros(S, dtype=np.int64)
+    matches_cells, idx_cells = [], []
+    for i in range(S):                                                                   # :109-149
+        mask = getDescriptorMask(featModel, centres[i], R_desc, 0.0)
+        idx = np.nonzero(mask)[0]
+        m = get_matches(descSurface, np.asarray(descModel)[idx], dict(par, VERBOSE=0))
+        num_putative[i] = len(m); num_desc_all[i] = len(idx)
+        matches_cells.append(m); idx_cells.append(idx)
+    trial = np.nonzero(num_putative > putative_thresh)[0]                                # :175
+    stats = dict(putative=[], success=[], inliers=[], ratio=[], T=[])
+    for t, i in enumerate(trial):                                                        # :200-224
+        m = matches_cells[i]
+        pts1 = featSurface[m[:, 0].astype(np.int64) - 1]
+        pts2 = featModel[idx_cells[i]][m[:, 1].astype(np.int64) - 1]
+        r = run_ransac(pts1, pts2, dict(options, VERBOSE=0), seed=seed + t)
+        stats["putative"].append(len(m)); stats["success"].append(r["numSuccess"]); stats["inliers"].append(r["maxInliers"])
+        stats["ratio"].append(r["ratio"]); stats["T"].append(r["T"])
+    return dict(centres=centres, num_desc=num_desc_all, num_putative=num_putative, matches=matches_cells,
+                model_rows=idx_cells, trial=trial,
+                statsPutative=np.array(stats["putative"], dtype=np.int64), statsSuccess=np.array(stats["success"], dtype=np.int64),
+                statsInliers=np.array(stats["inliers"], dtype=np.int64), statsRatio=np.array(stats["ratio"], dtype=np.float64),
+                transforms=stats["T"])
+
+
+def refine_by_distance(pts1, pts2, maxDist: float):
+    """completeExperimentFast.m:383-391: inliers by vecnorm(pts1 - pts2) < maxDist, estimateTransform on them.
+    Returns (T or None, inlier_idx 0-based)."""
+    pts1 = np.asarray(pts1, dtype=np.float64); pts2 = np.asarray(pts2, dtype=np.float64)
+    d = pts1 - pts2
+    d1 = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+    inl = np.nonzero(d1 < maxDist)[0]
+    T = estimateTransform(pts1[inl], pts2[inl]) if len(inl) >= 3 else None
+    return T, inl

@@ -59,6 +59,8 @@ SYMBOLS = [
     "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
     "pcreg_dev_spatial_histogram_descriptors_workspace", "pcreg_dev_spatial_histogram_descriptors",
     "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
+    "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select",
+    "pcreg_dev_gather_rows_f64", "pcreg_dev_quick_tf", "pcreg_dev_refine_by_distance",
 ]
 
 _lib = None
@@ -84,7 +86,7 @@ def lib() -> C.CDLL:
         L.pcreg_version.restype = C.c_char_p
         for name in ("pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_unique_points_f32_workspace",
                      "pcreg_dev_ransac_workspace", "pcreg_dev_spatial_histogram_descriptors_workspace",
-                     "pcreg_dev_get_matches_workspace"):
+                     "pcreg_dev_get_matches_workspace", "pcreg_dev_sphere_select_workspace"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

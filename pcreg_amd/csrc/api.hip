@@ -543,4 +543,35 @@ int pcreg_dev_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs,
     return launch_gather_matched_rows(pairs, n_pairs, cap, featSurface, featModel, pts1, pts2, (hipStream_t)stream);
 }
 
+
+// ---- sphere-sweep driver pieces (completeExperimentFast.m:46-225, :291, :356-394), device tier
+int pcreg_dev_sphere_counts(const double* feat, int V, const double* centres, int S, double R, int32_t* counts, void* stream) {
+    PCREG_ARG(feat && centres && counts && V >= 0 && S >= 0);
+    GUARD();
+    return launch_sphere_counts(feat, V, centres, S, R, counts, (hipStream_t)stream);
+}
+size_t pcreg_dev_sphere_select_workspace(int V) { return sphere_select_workspace_bytes(V); }
+int pcreg_dev_sphere_select(const double* feat, int V, const double centre[3], double R, int32_t* idx, int32_t* n_out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(feat && centre && idx && n_out && workspace && V >= 0);
+    GUARD();
+    return launch_sphere_select(feat, V, centre, R, idx, n_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int pcreg_dev_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap, double* dst, void* stream) {
+    PCREG_ARG(src && idx && n && dst && D >= 1 && cap >= 0);
+    GUARD();
+    return launch_gather_rows_f64(src, D, idx, n, cap, dst, (hipStream_t)stream);
+}
+int pcreg_dev_quick_tf(const double* pts, int n, int ld, const double T[16], double* out, int ldo, void* stream) {
+    PCREG_ARG(pts && T && out && n >= 0 && ld >= n && ldo >= n);
+    GUARD();
+    return launch_quick_tf(pts, n, ld, T, out, ldo, (hipStream_t)stream);
+}
+int pcreg_dev_refine_by_distance(const double* pts1, const double* pts2, const int32_t* n_dev, int cap, int ld, double maxDist,
+                                 double* T16, int32_t* info, void* stream) {
+    PCREG_ARG(pts1 && pts2 && n_dev && T16 && info && cap >= 0 && ld >= cap);
+    GUARD();
+    return launch_refine_by_distance(pts1, pts2, n_dev, cap, ld, maxDist, T16, info, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include "../../include/pcreg.h"
 
@@ -86,6 +87,16 @@ int launch_normalize_rows(double* f, int n, int ld, int D, hipStream_t st);
 int launch_match_features(const double* fS, int Q, int ldS, const double* fM, int M, int ldM, int D,
                           const pcreg_match_opts& o, uint32_t* pairs, double* metric, int32_t* P_dev,
                           void* ws, size_t ws_bytes, hipStream_t st);
+
+// sphere-sweep driver pieces (sweep.hip) and the final refine (ransac.hip)
+int launch_sphere_counts(const double* feat, int V, const double* centres, int S, double R, int32_t* counts, hipStream_t st);
+size_t sphere_select_workspace_bytes(int V);
+int launch_sphere_select(const double* feat, int V, const double c[3], double R, int32_t* idx, int32_t* n_out, void* ws, size_t ws_bytes,
+                         hipStream_t st);
+int launch_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap, double* dst, hipStream_t st);
+int launch_quick_tf(const double* pts, int n, int ld, const double T[16], double* out, int ldo, hipStream_t st);
+int launch_refine_by_distance(const double* p1, const double* p2, const int32_t* n_dev, int cap, int ld, double maxDist,
+                              double* T16_dev, int32_t* info_dev, hipStream_t st);
 
 int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st);
 int launch_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featS, const double* featM,

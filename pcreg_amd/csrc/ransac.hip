@@ -1211,6 +1211,69 @@ __global__ __launch_bounds__(64) void estimate_transform_kernel(const double* p1
     if (lane == 0) *empty = ok ? 0 : 1;
 }
 
+// completeExperimentFast.m:368-391: inliers = find(vecnorm(pts1 - pts2, 2, 2) < maxDist), then
+// T_refine = estimateTransform(pts1(inliers,:), pts2(inliers,:)).  One wave; n read from the device.
+__global__ __launch_bounds__(64) void refine_by_distance_kernel(const double* p1, const double* p2, const int32_t* n_dev, int cap,
+                                                                int ld, double maxDist, double* T16, int32_t* info /*[2]: inliers, empty*/) {
+    __shared__ double s3[18];
+    const int lane = threadIdx.x;
+    const int n = min(*n_dev, cap);
+    Pts<false> P{p1, p2, ld, nullptr, n};
+    double T[12]; bool ok = false;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = 0.0;
+    int cnt = 0;
+    if (n > 0) {
+        double o[6]; P.load(0, o);
+        double acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < n;
+            double q[6]; P.load(act ? i : 0, q);
+            const double dx = q[0] - q[3], dy = q[1] - q[4], dz = q[2] - q[5];
+            const bool in = act && sqrt((dx * dx + dy * dy) + dz * dz) < maxDist;
+            const unsigned long long bal = __ballot(in);
+            if (in) mom_accumulate(acc, q, o);
+            if (cnt < 3) {                                   // the N == 3 branch needs the points themselves
+                const int r3 = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+                if (in && r3 < 3) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) s3[r3 * 6 + c] = q[c];
+                }
+            }
+            cnt += __popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (cnt == 3) {
+            double A1[3][3], A2[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { A1[j][c] = s3[j * 6 + c]; A2[j][c] = s3[j * 6 + 3 + c]; }
+            ok = fit_3pt(A1, A2, T);
+        } else if (cnt > 3) {
+            double mom[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) mom[k] = wave_sum(acc[k]);
+            ok = fit_moments(cnt, mom, o, T);
+        }
+    }
+    if (lane < 16) {
+        int k = lane & 3, j = lane >> 2;
+        double v = 0.0;
+        if (ok) {
+            double tv = 0.0;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) if (e == j * 4 + k) tv = T[e];
+            v = (j < 3) ? tv : (k == 3 ? 1.0 : 0.0);
+        }
+        T16[k + 4 * j] = v;
+    }
+    if (lane == 0) { info[0] = cnt; info[1] = ok ? 0 : 1; }
+}
+
 __global__ void calc_dists_kernel(const double* T16, const double* p1, const double* p2, int n, int ld, double* d) {
     double T[12];
 #pragma unroll
@@ -1317,6 +1380,13 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
 int launch_estimate_transform(const double* p1, const double* p2, int n, int ld, double* T16_dev,
                               int32_t* empty_dev, hipStream_t st) {
     hipLaunchKernelGGL(estimate_transform_kernel, dim3(1), dim3(64), 0, st, p1, p2, n, ld, T16_dev, empty_dev);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_refine_by_distance(const double* p1, const double* p2, const int32_t* n_dev, int cap, int ld, double maxDist,
+                              double* T16_dev, int32_t* info_dev, hipStream_t st) {
+    hipLaunchKernelGGL(refine_by_distance_kernel, dim3(1), dim3(64), 0, st, p1, p2, n_dev, cap, ld, maxDist, T16_dev, info_dev);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

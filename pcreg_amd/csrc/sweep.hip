@@ -1,0 +1,124 @@
+// pcreg_amd/csrc/sweep.hip -- the small device pieces of the sphere-sweep driver
+// (completeExperimentFast.m:46-225) and of its final stage (:291, :356-394):
+//   sphere_counts   #{ ||feat - c|| < R } for many centres        getLocalPoints.m:23-34 as used at :57-64
+//   sphere_select   getDescriptorMask (:435-439) as an ordered index list
+//   gather_rows     featCur / descCur = X(mask, :)                 :122-125
+//   quick_tf        quickTF.m:5-7
+// All of it is streaming fp64 work of a few MB: HBM/latency-bound, no tuning beyond coalescing.
+#include "common.hpp"
+#include "select.hpp"
+
+namespace pcreg {
+namespace {
+
+// dists = vecnorm(feat - c, 2, 2): sqrt((dx^2 + dy^2) + dz^2), compared with strict '<'
+__device__ __forceinline__ bool in_sphere(const double* __restrict__ feat, int i, double cx, double cy, double cz, double R) {
+    const double dx = feat[(size_t)i * 3] - cx, dy = feat[(size_t)i * 3 + 1] - cy, dz = feat[(size_t)i * 3 + 2] - cz;
+    return sqrt((dx * dx + dy * dy) + dz * dz) < R;
+}
+
+// one workgroup per centre
+__global__ __launch_bounds__(256) void sphere_counts_kernel(const double* __restrict__ feat, int V, const double* __restrict__ centres,
+                                                            int S, double R, int32_t* __restrict__ counts) {
+    const int s = blockIdx.x;
+    const double cx = centres[(size_t)s * 3], cy = centres[(size_t)s * 3 + 1], cz = centres[(size_t)s * 3 + 2];
+    int c = 0;
+    for (int i = threadIdx.x; i < V; i += 256) c += in_sphere(feat, i, cx, cy, cz, R);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __shared__ int sc[4];
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[s] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+
+__global__ __launch_bounds__(256) void sphere_flag_kernel(const double* __restrict__ feat, int V, double cx, double cy, double cz, double R,
+                                                          int32_t* __restrict__ flag, int32_t* __restrict__ block_cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < V && in_sphere(feat, i, cx, cy, cz, R);
+    if (i < V) flag[i] = in;
+    __shared__ int sc[4];
+    const unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+__global__ __launch_bounds__(256) void sphere_scatter_kernel(const int32_t* __restrict__ flag, int V, const int32_t* __restrict__ block_off,
+                                                             int32_t* __restrict__ idx) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < V && flag[i] != 0;
+    __shared__ int sc[4];
+    const unsigned long long b = __ballot(in);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sc[wave] = __popcll(b);
+    __syncthreads();
+    int base = block_off[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += sc[w];
+    if (in) idx[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
+}
+
+// dst[k][:] = src[idx[k]][:] for k < *n (row-major, D doubles per row); one workgroup per row
+__global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double* __restrict__ src, int D, const int32_t* __restrict__ idx,
+                                                              const int32_t* __restrict__ n, int cap, double* __restrict__ dst) {
+    const int cnt = min(*n, cap);
+    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+        const double* s = src + (size_t)idx[k] * D;
+        double* d = dst + (size_t)k * D;
+        for (int e = threadIdx.x; e < D; e += 256) d[e] = s[e];
+    }
+}
+
+struct TF16 { double t[16]; };
+// pts_tf = [pts, 1] * TF (column-major 4x4), first three columns; pts n x 3 column-major
+__global__ void quick_tf_kernel(const double* __restrict__ pts, int n, int ld, TF16 T, double* __restrict__ out, int ldo) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double x = pts[i], y = pts[i + (size_t)ld], z = pts[i + 2 * (size_t)ld];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)      // the dot product of a row with column j, left to right as MATLAB's mtimes reference loop
+            out[i + (size_t)j * ldo] = ((x * T.t[4 * j] + y * T.t[4 * j + 1]) + z * T.t[4 * j + 2]) + T.t[4 * j + 3];
+    }
+}
+
+}  // namespace
+
+int launch_sphere_counts(const double* feat, int V, const double* centres, int S, double R, int32_t* counts, hipStream_t st) {
+    if (S <= 0) return PCREG_OK;
+    hipLaunchKernelGGL(sphere_counts_kernel, dim3(S), dim3(256), 0, st, feat, V, centres, S, R, counts);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+size_t sphere_select_workspace_bytes(int V) {
+    size_t v = (size_t)(V > 0 ? V : 1);
+    return align_up(v * 4, 256) + align_up((v / 256 + 2) * 4, 256);
+}
+int launch_sphere_select(const double* feat, int V, const double c[3], double R, int32_t* idx, int32_t* n_out, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+    if (V <= 0) { PCREG_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), st)); return PCREG_OK; }
+    if (ws_bytes < sphere_select_workspace_bytes(V)) { set_error("sphere_select workspace too small"); return PCREG_E_WORKSPACE; }
+    int32_t* flag = (int32_t*)ws;
+    int32_t* bc = (int32_t*)((char*)ws + align_up((size_t)V * 4, 256));
+    const int nb = (V + 255) / 256;
+    hipLaunchKernelGGL(sphere_flag_kernel, dim3(nb), dim3(256), 0, st, feat, V, c[0], c[1], c[2], R, flag, bc);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_out);
+    hipLaunchKernelGGL(sphere_scatter_kernel, dim3(nb), dim3(256), 0, st, flag, V, bc, idx);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap, double* dst, hipStream_t st) {
+    if (cap <= 0 || D <= 0) return PCREG_OK;
+    hipLaunchKernelGGL(gather_rows_f64_kernel, dim3(std::min(cap, 8192)), dim3(256), 0, st, src, D, idx, n, cap, dst);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_quick_tf(const double* pts, int n, int ld, const double T[16], double* out, int ldo, hipStream_t st) {
+    if (n <= 0) return PCREG_OK;
+    TF16 t; for (int k = 0; k < 16; ++k) t.t[k] = T[k];
+    hipLaunchKernelGGL(quick_tf_kernel, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, st, pts, n, ld, t, out, ldo);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+}  // namespace pcreg

@@ -196,8 +196,9 @@ class DescriptorPipeline:
         L = lib()
         o = _match_opts(par)
         pairs = torch.empty((max(VS, 1), 2), dtype=torch.int32, device=self.dev)
-        ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(VS, VM, self.ND))
-        check(L.pcreg_dev_get_matches(_p(descS), VS, self.ND, _p(descM), VM, self.ND, self.ND, _l.LAYOUT_ROW_MAJOR,
+        D = descS.shape[1]
+        ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(VS, VM, D))
+        check(L.pcreg_dev_get_matches(_p(descS), VS, D, _p(descM), VM, D, D, _l.LAYOUT_ROW_MAJOR,
                                       C.byref(o), _p(pairs), None, _p(self.n_pairs), _p(ws), C.c_size_t(ws.numel()),
                                       _stream()))
         return pairs, self.n_pairs
