@@ -25,6 +25,7 @@
 #include "select_kth.hpp"
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 namespace pcreg {
 namespace {
@@ -38,7 +39,7 @@ struct Grid {
     double ox, oy, oz, inv;                // origin and 1 / cell edge
     int nx, ny, nz, ncells;
 };
-struct Edges { double r[NR + 1], t[NT + 1], p[NP + 1]; };
+struct Edges { double r[NR + 1], t[NT + 1], p[NP + 1], ct[NT + 1]; };   // ct = cos(t)
 
 __device__ __forceinline__ int cell_coord(double v, double o, double inv, int n) {
     int c = (int)floor((v - o) * inv);
@@ -196,6 +197,20 @@ __device__ __forceinline__ double bsum(double v, double* s_red) {
     __syncthreads();
     return t;
 }
+// N sums at once: the same per-value order as bsum (wave butterfly, then ((w0+w1)+w2)+w3), one barrier pair
+template <int N>
+__device__ __forceinline__ void bsum_n(double (&v)[N], double* s_redn /*[4][N]*/) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wsum(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) s_redn[(threadIdx.x >> 6) * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = ((s_redn[k] + s_redn[N + k]) + s_redn[2 * N + k]) + s_redn[3 * N + k];
+    __syncthreads();
+}
 __device__ __forceinline__ int bsum_i(int v, int* s_red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -238,19 +253,23 @@ __device__ __forceinline__ int hist_loc(double x, const double (&e)[NE]) {
     return k;
 }
 
-__global__ __launch_bounds__(kBlock) void desc_kernel(
+__global__ __launch_bounds__(kBlock, 3) void desc_kernel(
     const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ sz,
     const int32_t* __restrict__ sorted_idx, const int32_t* __restrict__ cell_start, const Grid* __restrict__ gp,
-    const double* __restrict__ kp, int S, int ldk, pcreg_desc_opts o, Edges ed, int cap,
+    const double* __restrict__ kp, int S, int ldk, pcreg_desc_opts o, Edges ed, int cap, int dbg_stop,
     uint32_t* __restrict__ rows /*[S][ND]*/, int32_t* __restrict__ valid, int32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* sd = reinterpret_cast<double*>(smem);                       // [cap] distance to the local centroid, then flags
-    int* lpos = reinterpret_cast<int*>(smem + (size_t)cap * sizeof(double));   // [cap] position in the sorted arrays
-    __shared__ double s_red[4];
+    int* lpos = reinterpret_cast<int*>(smem);                           // [cap] position in the sorted arrays (+ a "kept" flag bit)
+    __shared__ double s_redn[4 * 6];
     __shared__ int s_redi[4];
     __shared__ unsigned s_cnt[ND];
     __shared__ unsigned long long s_u64[8];
-    __shared__ int s_base, s_ok;
+    constexpr int kSmall = 256;
+    __shared__ unsigned long long s_small[kSmall];
+    __shared__ int s_hist[256];
+    __shared__ unsigned long long s_vk;
+    __shared__ int s_nsmall, s_bin, s_below, s_nless, s_neq;
+    __shared__ int s_ok;
     __shared__ double s_m[9];
 
     const Grid g = *gp;
@@ -258,102 +277,245 @@ __global__ __launch_bounds__(kBlock) void desc_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double cx = kp[s], cy = kp[s + (size_t)ldk], cz = kp[s + 2 * (size_t)ldk];
     const double R = o.R;
-    if (tid == 0) { s_base = 0; valid[s] = 0; }
+    if (tid == 0) valid[s] = 0;
     for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
     __syncthreads();
 
     // ---- getLocalPoints: |p - c| < R (strict), from the <= 27 cells around c ----
+    // Nine (dz, dy) rows of three x-adjacent cells each are contiguous runs of the sorted arrays.  Every
+    // row is cut into four wave segments; pass 1 only counts, one barrier turns the 36 counts into list
+    // offsets, pass 2 re-tests and writes -- the list order (row, then ascending position) is the same
+    // as a serial scan's, with two barriers instead of three per 256 candidates.
     const int kx = cell_coord(cx, g.ox, g.inv, g.nx), ky = cell_coord(cy, g.oy, g.inv, g.ny), kz = cell_coord(cz, g.oz, g.inv, g.nz);
     // a keypoint outside the cloud's box by more than one cell has no neighbours: the clamped
     // cell is then farther than R along that axis and the distance test rejects everything
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) {
-        const int zz = kz + dz, yy = ky + dy;
-        if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
-        const int x0 = max(kx - 1, 0), x1 = min(kx + 1, g.nx - 1);
-        const int c0 = (zz * g.ny + yy) * g.nx + x0, c1 = (zz * g.ny + yy) * g.nx + x1;
-        const int b = cell_start[c0], e = cell_start[c1 + 1];         // x-adjacent cells are contiguous
-        for (int j0 = b; j0 < e; j0 += kBlock) {
-            const int j = j0 + tid;
-            bool in = false;
-            if (j < e) {
-                double x = sx[j] - cx, y = sy[j] - cy, z = sz[j] - cz;
-                in = sqrt(x * x + y * y + z * z) < R;                   // getLocalPoints.m:23-25
+    __shared__ int s_seg[9][4];
+    int rb[9], re[9];                               // this wave's segment of every row
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int zz = kz + r / 3 - 1, yy = ky + r % 3 - 1;
+        int b = 0, e = 0;
+        if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
+            const int x0 = max(kx - 1, 0), x1 = min(kx + 1, g.nx - 1);
+            b = cell_start[(zz * g.ny + yy) * g.nx + x0]; e = cell_start[(zz * g.ny + yy) * g.nx + x1 + 1];   // x-adjacent cells are contiguous
+        }
+        const int seg = (((e - b) + 3) / 4 + 63) / 64 * 64;
+        rb[r] = min(e, b + wave * seg); re[r] = min(e, b + (wave + 1) * seg);
+    }
+    // pass 1 streams the candidates ONCE (four 64-point chunks = twelve loads in flight per wave) and keeps
+    // every chunk's ballot; pass 2 replays the ballots, so it touches no global memory
+    constexpr int kMaskCap = 160;                   // chunks per wave whose ballot is kept (beyond: re-tested)
+    __shared__ unsigned long long s_mask[4][kMaskCap];
+    auto in_sphere = [&](int j, int end) -> bool {
+        if (j >= end) return false;
+        const double x = sx[j] - cx, y = sy[j] - cy, z = sz[j] - cz;
+        return sqrt(x * x + y * y + z * z) < R;                             // getLocalPoints.m:23-25
+    };
+    {
+        int ch = 0;                                  // running chunk number of this wave
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            int c = 0;
+            for (int j0 = rb[r]; j0 < re[r]; j0 += 256) {
+                double X[4], Y[4], Z[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u * 64 + lane, re[r] - 1);
+                    X[u] = sx[j]; Y[u] = sy[j]; Z[u] = sz[j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j0 + u * 64 < re[r]) {       // wave-uniform
+                        const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
+                        const bool in = (j0 + u * 64 + lane < re[r]) && sqrt(x * x + y * y + z * z) < R;
+                        const unsigned long long bal = __ballot(in);
+                        if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
+                        ++ch;
+                        c += __popcll(bal);
+                    }
+                }
             }
-            unsigned long long bal = __ballot(in);
-            if (lane == 0) s_redi[wave] = __popcll(bal);
-            __syncthreads();
-            int pos = s_base;
-            for (int w = 0; w < wave; ++w) pos += s_redi[w];
-            pos += __popcll(bal & ((1ull << lane) - 1ull));
-            if (in && pos < cap) lpos[pos] = j;
-            __syncthreads();
-            if (tid == 0) s_base += s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
-            __syncthreads();
+            if (lane == 0) s_seg[r][wave] = c;
         }
     }
-    const int n = s_base;
+    __syncthreads();
+    int n_total = 0, my_base[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w == wave) my_base[r] = n_total; n_total += s_seg[r][w]; }
+    const int n = n_total;
     if (n < 1 || n < o.min_pts || n > o.max_pts) return;                   // getLocalPoints.m:17,31
     if (n > cap) { if (tid == 0) atomicMax(err, n); return; }              // support larger than the LDS list
+    {
+        int ch = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            int pos = my_base[r];
+            for (int j0 = rb[r]; j0 < re[r]; j0 += 64, ++ch) {
+                const unsigned long long bal = ch < kMaskCap ? s_mask[wave][ch] : __ballot(in_sphere(j0 + lane, re[r]));
+                if ((bal >> lane) & 1ull) lpos[pos + __popcll(bal & ((1ull << lane) - 1ull))] = j0 + lane;
+                pos += __popcll(bal);
+            }
+        }
+    }
+    __syncthreads();
+
+    if (dbg_stop == 1) return;            // timing experiments only (PCREG_DESC_STOP)
+    // A pass over the support: thread t visits its entries i = t + 256 r in ascending order; px/py/pz = the
+    // point relative to the keypoint, psel = kept by the K-nearest selection (bit r of selmask).  Four
+    // entries' gathers are issued before the first is used: the sorted cloud sits in the Infinity Cache
+    // (~1-2 us away), so the passes are latency-bound and memory-level parallelism is what they need.
+    unsigned selmask = 0xFFFFFFFFu;                  // cap <= 8191 -> r < 32
+#define PCREG_MY_PTS(...)                                                                            \
+    for (int i0_ = tid, r0_ = 0; i0_ < n; i0_ += 4 * kBlock, r0_ += 4) {                             \
+        double X_[4], Y_[4], Z_[4];                                                                  \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                           \
+            const int j_ = lpos[min(i0_ + u_ * kBlock, n - 1)];                                      \
+            X_[u_] = sx[j_]; Y_[u_] = sy[j_]; Z_[u_] = sz[j_];                                       \
+        }                                                                                            \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                           \
+            const int i = i0_ + u_ * kBlock, pr = r0_ + u_;                                          \
+            if (i < n) {                                                                             \
+                const double px = X_[u_] - cx, py = Y_[u_] - cy, pz = Z_[u_] - cz;                   \
+                const bool psel = (selmask >> pr) & 1u; (void)psel; (void)i;                         \
+                __VA_ARGS__                                                                          \
+            }                                                                                        \
+        }                                                                                            \
+    }
 
     // ---- K nearest to the local centroid (:75-85) ----
     const bool all = o.k >= 1.0;
     const int K = all ? n : (int)floor(n * o.k + 0.5);
     if (K < 2) return;
-    double ax = 0, ay = 0, az = 0;
-    for (int i = tid; i < n; i += kBlock) { int j = lpos[i]; ax += sx[j] - cx; ay += sy[j] - cy; az += sz[j] - cz; }
-    const double gx = bsum(ax, s_red) / n, gy = bsum(ay, s_red) / n, gz = bsum(az, s_red) / n;
+    double a3[3] = {0, 0, 0};
+    PCREG_MY_PTS(a3[0] += px; a3[1] += py; a3[2] += pz;)
+    bsum_n<3>(a3, s_redn);
+    const double gx = a3[0] / n, gy = a3[1] / n, gz = a3[2] / n;
     if (!all) {
-        for (int i = tid; i < n; i += kBlock) {
-            int j = lpos[i];
-            double x = (sx[j] - cx) - gx, y = (sy[j] - cy) - gy, z = (sz[j] - cz) - gz;
-            sd[i] = sqrt(x * x + y * y + z * z);
+#define PCREG_KEY(px, py, pz) kth_key(sqrt(((px) - gx) * ((px) - gx) + ((py) - gy) * ((py) - gy) + ((pz) - gz) * ((pz) - gz)))
+        // every thread keeps the keys of ITS entries in registers (one more gather pass, fully unrolled so
+        // that the register index is a constant); the selection itself then never touches memory
+        unsigned long long kreg[32];
+#pragma unroll
+        for (int t_ = 0; t_ < 8; ++t_) {
+            double X_[4], Y_[4], Z_[4];
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) {
+                const int j_ = lpos[min(tid + (t_ * 4 + u_) * kBlock, n - 1)];
+                X_[u_] = sx[j_]; Y_[u_] = sy[j_]; Z_[u_] = sz[j_];
+            }
+#pragma unroll
+            for (int u_ = 0; u_ < 4; ++u_) kreg[t_ * 4 + u_] = PCREG_KEY(X_[u_] - cx, Y_[u_] - cy, Z_[u_] - cz);
+        }
+#define PCREG_MY_KEYS(...) _Pragma("unroll") for (int pr = 0; pr < 32; ++pr) { const int i = tid + pr * kBlock; if (i < n) { const unsigned long long k = kreg[pr]; (void)i; __VA_ARGS__ } }
+        // K-th smallest by ONE 256-bin histogram over [min, max] (the bin index is monotone in the
+        // distance), then an exact rank inside the bin that holds it; bisection only if that bin is crowded
+        unsigned long long lo = ~0ull, hi = 0ull;
+        PCREG_MY_KEYS(lo = k < lo ? k : lo; hi = k > hi ? k : hi;)
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            const unsigned long long a2 = __shfl_xor(lo, ofs), b2 = __shfl_xor(hi, ofs);
+            lo = a2 < lo ? a2 : lo; hi = b2 > hi ? b2 : hi;
+        }
+        if (lane == 0) { s_u64[wave] = lo; s_u64[4 + wave] = hi; }
+        for (int i = tid; i < 256; i += kBlock) s_hist[i] = 0;
+        if (tid == 0) { s_nsmall = 0; s_vk = 0ull; s_nless = 0; s_neq = 0; }
+        __syncthreads();
+        lo = s_u64[0]; hi = s_u64[4];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { lo = s_u64[w] < lo ? s_u64[w] : lo; hi = s_u64[4 + w] > hi ? s_u64[4 + w] : hi; }
+        const double dlo = __longlong_as_double((long long)lo), dhi = __longlong_as_double((long long)hi);
+        const double scale = dhi > dlo ? 256.0 / (dhi - dlo) : 0.0;
+        auto bin_of = [&](unsigned long long k) -> int {
+            const int bb = (int)((__longlong_as_double((long long)k) - dlo) * scale);
+            return bb > 255 ? 255 : bb;
+        };
+        PCREG_MY_KEYS(atomicAdd(&s_hist[bin_of(k)], 1);)
+        __syncthreads();
+        if (wave == 0) {                             // the bin of the K-th and the number of entries below that bin
+            int c4[4], run = 0;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) { c4[q4] = s_hist[lane * 4 + q4]; run += c4[q4]; }
+            int incl = run;
+#pragma unroll
+            for (int ofs = 1; ofs < 64; ofs <<= 1) { const int t = __shfl_up(incl, ofs); if (lane >= ofs) incl += t; }
+            int before = incl - run;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                if (before < K && K <= before + c4[q4]) { s_bin = lane * 4 + q4; s_below = before; }
+                before += c4[q4];
+            }
         }
         __syncthreads();
-        int n_less = 0;
-        const unsigned long long vK = block_select_kth(sd, n, K, s_u64, s_redi, &n_less);
+        const int bstar = s_bin, below = s_below;
+        PCREG_MY_KEYS(if (bin_of(k) == bstar) { const int q = atomicAdd(&s_nsmall, 1); if (q < kSmall) s_small[q] = k; })
+        __syncthreads();
+        const int m = s_nsmall, Kp = K - below;
+        unsigned long long vK; int n_less, n_eq;
+        if (m <= kSmall) {
+            for (int t = tid; t < m; t += kBlock) {
+                const unsigned long long x = s_small[t];
+                int less = 0, eq = 0;
+                for (int u = 0; u < m; ++u) { const unsigned long long yv = s_small[u]; less += yv < x; eq += yv == x; }
+                if (less < Kp && Kp <= less + eq) { s_vk = x; s_nless = below + less; s_neq = eq; }   // every writer writes the same
+            }
+            __syncthreads();
+            vK = s_vk; n_less = s_nless; n_eq = s_neq;
+        } else {                                     // crowded bin (many equal distances): plain bisection on the keys
+            unsigned long long blo = lo, bhi = hi;
+            while (blo < bhi) {
+                const unsigned long long mid = blo + ((bhi - blo) >> 1);
+                int c = 0;
+                PCREG_MY_KEYS(c += k <= mid;)
+                c = bsum_i(c, s_redi);
+                if (c >= K) bhi = mid; else blo = mid + 1;
+            }
+            vK = blo;
+            int c1 = 0, c2 = 0;
+            PCREG_MY_KEYS(c1 += k < vK; c2 += k == vK;)
+            n_less = bsum_i(c1, s_redi); n_eq = bsum_i(c2, s_redi);
+        }
         const int take_eq = K - n_less;
         // ties at the K-th distance: the stable sort keeps the lowest ORIGINAL indices
-        int n_eq_local = 0;
-        for (int i = tid; i < n; i += kBlock) n_eq_local += ((unsigned long long)__double_as_longlong(sd[i]) == vK);
-        const int n_eq = bsum_i(n_eq_local, s_redi);
-        unsigned selmask = 0u;                       // bit r: element tid + r*256 (cap <= 8191 -> r < 32)
-        for (int i = tid, r = 0; i < n; i += kBlock, ++r) {
-            unsigned long long key = (unsigned long long)__double_as_longlong(sd[i]);
+        unsigned sm = 0u;
+        PCREG_MY_KEYS(
+            const unsigned long long key = k;
             bool sel = key < vK;
             if (key == vK) {
                 if (n_eq == take_eq) sel = true;
                 else {
                     const int me = sorted_idx[lpos[i]];
                     int rank = 0;
-                    for (int t = 0; t < n; ++t)
-                        if ((unsigned long long)__double_as_longlong(sd[t]) == vK && sorted_idx[lpos[t]] < me) ++rank;
+                    for (int t = 0; t < n; ++t) {
+                        const int jt = lpos[t];
+                        const double tx = sx[jt] - cx, ty = sy[jt] - cy, tz = sz[jt] - cz;
+                        if (PCREG_KEY(tx, ty, tz) == vK && sorted_idx[jt] < me) ++rank;
+                    }
                     sel = rank < take_eq;
                 }
             }
-            selmask |= (sel ? 1u : 0u) << r;
-        }
-        __syncthreads();                             // every thread is done reading lpos / sd
-        for (int i = tid, r = 0; i < n; i += kBlock, ++r) if ((selmask >> r) & 1u) lpos[i] |= 0x40000000;
-        __syncthreads();
+            sm |= (sel ? 1u : 0u) << pr;)
+        selmask = sm;
+#undef PCREG_KEY
+#undef PCREG_MY_KEYS
     }
-#define PCREG_SEL(i) (all || (lpos[i] & 0x40000000))
-#define PCREG_POS(i) (lpos[i] & 0x3FFFFFFF)
 
+    if (dbg_stop == 2) return;
     // ---- pca(pts_k, 'eig') (:91) ----
-    double mx = 0, my = 0, mz = 0;
-    {
-        double bx = 0, by = 0, bz = 0;
-        for (int i = tid; i < n; i += kBlock) if (PCREG_SEL(i)) { int j = PCREG_POS(i); bx += sx[j] - cx; by += sy[j] - cy; bz += sz[j] - cz; }
-        mx = bsum(bx, s_red) / K; my = bsum(by, s_red) / K; mz = bsum(bz, s_red) / K;
-    }
+    double b3[3] = {0, 0, 0};
+    PCREG_MY_PTS(if (psel) { b3[0] += px; b3[1] += py; b3[2] += pz; })
+    bsum_n<3>(b3, s_redn);
+    const double mx = b3[0] / K, my = b3[1] / K, mz = b3[2] / K;
     double cv[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < n; i += kBlock) if (PCREG_SEL(i)) {
-        int j = PCREG_POS(i);
-        double x = (sx[j] - cx) - mx, y = (sy[j] - cy) - my, z = (sz[j] - cz) - mz;
-        cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z;
-    }
+    PCREG_MY_PTS(
+        if (psel) {
+            const double x = px - mx, y = py - my, z = pz - mz;
+            cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z;
+        })
+    bsum_n<6>(cv, s_redn);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) cv[k] = bsum(cv[k], s_red) / (double)(K - 1);
+    for (int k = 0; k < 6; ++k) cv[k] = cv[k] / (double)(K - 1);
     if (tid == 0) {
         double A[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
         double V[3][3];
@@ -381,15 +543,15 @@ __global__ __launch_bounds__(kBlock) void desc_kernel(
 #pragma unroll
     for (int k = 0; k < 9; ++k) cu[k] = s_m[k];
     if (o.ALIGN_POINTS) {                                                   // :128-145, vote over the K rows
-        int px = 0, pz = 0;
-        for (int i = tid; i < n; i += kBlock) if (PCREG_SEL(i)) {
-            int j = PCREG_POS(i);
-            double x = (sx[j] - cx) - mx, y = (sy[j] - cy) - my, z = (sz[j] - cz) - mz;
-            px += (x * cu[0] + y * cu[3] + z * cu[6]) > 0;
-            pz += (x * cu[2] + y * cu[5] + z * cu[8]) > 0;
-        }
-        px = bsum_i(px, s_redi); pz = bsum_i(pz, s_redi);
-        double xs = (2.0 * px >= (double)K) ? 1.0 : -1.0, zs = (2.0 * pz >= (double)K) ? 1.0 : -1.0;
+        int vx = 0, vz = 0;
+        PCREG_MY_PTS(
+            if (psel) {
+                const double x = px - mx, y = py - my, z = pz - mz;
+                vx += (x * cu[0] + y * cu[3] + z * cu[6]) > 0;
+                vz += (x * cu[2] + y * cu[5] + z * cu[8]) > 0;
+            })
+        vx = bsum_i(vx, s_redi); vz = bsum_i(vz, s_redi);
+        double xs = (2.0 * vx >= (double)K) ? 1.0 : -1.0, zs = (2.0 * vz >= (double)K) ? 1.0 : -1.0;
         double M[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { M[r * 3] = cu[r * 3] * xs; M[r * 3 + 1] = cu[r * 3 + 1]; M[r * 3 + 2] = cu[r * 3 + 2] * zs; }
@@ -397,21 +559,28 @@ __global__ __launch_bounds__(kBlock) void desc_kernel(
 #pragma unroll
         for (int r = 0; r < 3; ++r) { cu[r * 3] = cu[r * 3] * xs; cu[r * 3 + 1] = cu[r * 3 + 1] * ys; cu[r * 3 + 2] = cu[r * 3 + 2] * zs; }
     }
+    if (dbg_stop == 3) return;
     // ---- spherical histogram over ALL local points (:150-171, histcn.m:108-131) ----
-    for (int i = tid; i < n; i += kBlock) {
-        int j = PCREG_POS(i);
-        double x0 = sx[j] - cx, y0 = sy[j] - cy, z0 = sz[j] - cz, x = x0, y = y0, z = z0;
-        if (o.ALIGN_POINTS) { x = x0 * cu[0] + y0 * cu[3] + z0 * cu[6]; y = x0 * cu[1] + y0 * cu[4] + z0 * cu[7]; z = x0 * cu[2] + y0 * cu[5] + z0 * cu[8]; }
-        double r = sqrt(x * x + y * y + z * z), th = acos(z / r), ph = atan2(y, y);
-        int lr = hist_loc<NR + 1>(r, ed.r), lt = hist_loc<NT + 1>(th, ed.t), lp = hist_loc<NP + 1>(ph, ed.p);
-        if (lr > 0 && lt > 0 && lp > 0) atomicAdd(&s_cnt[(lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1)], 1u);
-    }
+    const double ph_pos = atan2(1.0, 1.0), ph_neg = atan2(-1.0, -1.0);
+    PCREG_MY_PTS(
+        double x = px; double y = py; double z = pz;
+        if (o.ALIGN_POINTS) { x = px * cu[0] + py * cu[3] + pz * cu[6]; y = px * cu[1] + py * cu[4] + pz * cu[7]; z = px * cu[2] + py * cu[5] + pz * cu[8]; }
+        const double r = sqrt(x * x + y * y + z * z); const double u = z / r;
+        // phi = atan2(y, y) (sic, :152) only depends on the sign of y; theta's bin follows from comparing
+        // cos(theta) = z/r with the cosines of the edges unless it is within 1e-13 of one (|acos'| >= 1, so the
+        // computed acos cannot cross that edge); only those points pay for the fp64 acos / atan2
+        const double ph = y > 0.0 ? ph_pos : (y < 0.0 ? ph_neg : atan2(y, y));
+        bool safe = (1.0 - u) > 1e-13 && (u + 1.0) > 1e-13;
+        int lt = 1;
+        _Pragma("unroll") for (int jj = 1; jj < NT; ++jj) { const double dl = u - ed.ct[jj]; safe = safe && fabs(dl) > 1e-13; lt += dl < 0.0; }
+        if (!safe) lt = hist_loc<NT + 1>(acos(u), ed.t);
+        const int lr = hist_loc<NR + 1>(r, ed.r); const int lp = hist_loc<NP + 1>(ph, ed.p);
+        if (lr > 0 && lt > 0 && lp > 0) atomicAdd(&s_cnt[(lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1)], 1u);)
     __syncthreads();
     uint32_t* row = rows + (size_t)s * ND;
     for (int i = tid; i < ND; i += kBlock) row[i] = s_cnt[i];
     if (tid == 0) valid[s] = 1;
-#undef PCREG_SEL
-#undef PCREG_POS
+#undef PCREG_MY_PTS
 }
 
 // ---- compaction of the surviving rows (:177-179) ----------------------------------------------
@@ -502,14 +671,14 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     Edges ed;
     const double r3 = o.R * o.R * o.R, pi = 3.14159265358979323846;
     for (int k = 0; k <= NR; ++k) ed.r[k] = cbrt(k * (r3 / NR));                 // nthroot(0:R^3/10:R^3, 3)
-    for (int k = 0; k <= NT; ++k) ed.t[k] = k * (pi / NT);                       // 0:pi/7:pi
+    for (int k = 0; k <= NT; ++k) { ed.t[k] = k * (pi / NT); ed.ct[k] = cos(ed.t[k]); }   // 0:pi/7:pi
     for (int k = 0; k <= NP; ++k) ed.p[k] = -pi + k * (2 * pi / NP);             // -pi:2*pi/14:pi
     int cap = o.max_pts < 8190 ? o.max_pts + 1 : 8191;
     if (cap < 64) cap = 64;
-    size_t lds = (size_t)cap * (sizeof(double) + sizeof(int));
+    size_t lds = (size_t)cap * sizeof(int);
     PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(desc_kernel, dim3(S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, S, ldk, o,
-                       ed, cap, rows, valid, err_dev);
+                       ed, cap, getenv("PCREG_DESC_STOP") ? atoi(getenv("PCREG_DESC_STOP")) : 0, rows, valid, err_dev);
     PCREG_HIP(hipGetLastError());
     const int nbs = (S + 255) / 256;
     hipLaunchKernelGGL(desc_count_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt);
