@@ -114,25 +114,23 @@ __global__ void grid_cell_prefix_kernel(int32_t* __restrict__ counts, int ntiles
 }
 // exclusive scan of cell totals -> cell_start[0..kMaxCells] (one workgroup)
 __global__ void grid_cell_scan_kernel(const int32_t* __restrict__ cell_total, int32_t* __restrict__ cell_start) {
+    // thread t owns cells [t * 256, (t + 1) * 256): local sums, one 256-wide scan, local replay
     __shared__ int s[256];
-    int carry = 0;
-    for (int b0 = 0; b0 < kMaxCells; b0 += 256) {
-        int i = b0 + threadIdx.x;
-        int v = cell_total[i];
-        s[threadIdx.x] = v;
+    constexpr int kPer = kMaxCells / 256;
+    const int base = threadIdx.x * kPer;
+    int sum = 0;
+    for (int k = 0; k < kPer; ++k) sum += cell_total[base + k];
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {
-            int t = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        cell_start[i] = carry + s[threadIdx.x] - v;
-        int tot = s[255];
+        s[threadIdx.x] += t;
         __syncthreads();
-        carry += tot;
     }
-    if (threadIdx.x == 0) cell_start[kMaxCells] = carry;
+    int run = s[threadIdx.x] - sum;
+    for (int k = 0; k < kPer; ++k) { const int v = cell_total[base + k]; cell_start[base + k] = run; run += v; }
+    if (threadIdx.x == 255) cell_start[kMaxCells] = run;
 }
 // scatter: in-tile rank from a bitonic sort of (cell << 32 | index) keys
 __global__ __launch_bounds__(kBlock) void grid_scatter_kernel(const double* __restrict__ p, int P, int ld,
@@ -181,6 +179,27 @@ __global__ __launch_bounds__(kBlock) void grid_scatter_kernel(const double* __re
         sorted_idx[dst] = idx;
         sx[dst] = p[idx]; sy[dst] = p[idx + (size_t)ld]; sz[dst] = p[idx + 2 * (size_t)ld];
     }
+}
+
+// ---- keypoints in cell order ---------------------------------------------------------------------
+// Workgroup b describes keypoint perm[b]; perm lists the keypoints cell by cell, so that workgroups that
+// run at the same time read the same few cells of the sorted cloud (L2 hits instead of Infinity-Cache
+// round trips).  The order INSIDE a cell is whatever the atomics give: it only schedules work, every
+// result is written to its keypoint's own row.
+__global__ void kp_count_kernel(const double* __restrict__ kp, int S, int ldk, const Grid* __restrict__ gp,
+                                int32_t* __restrict__ kcell, int32_t* __restrict__ kc_total) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int c = cell_of(*gp, kp[s], kp[s + (size_t)ldk], kp[s + 2 * (size_t)ldk]);
+    kcell[s] = c;
+    atomicAdd(&kc_total[c], 1);
+}
+__global__ void kp_scatter_kernel(const int32_t* __restrict__ kcell, int S, const int32_t* __restrict__ kc_start,
+                                  int32_t* __restrict__ kc_fill, int32_t* __restrict__ perm) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int c = kcell[s];
+    perm[kc_start[c] + atomicAdd(&kc_fill[c], 1)] = s;
 }
 
 // ---- per-keypoint descriptor ------------------------------------------------------------------
@@ -256,7 +275,7 @@ __device__ __forceinline__ int hist_loc(double x, const double (&e)[NE]) {
 __global__ __launch_bounds__(kBlock, 3) void desc_kernel(
     const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ sz,
     const int32_t* __restrict__ sorted_idx, const int32_t* __restrict__ cell_start, const Grid* __restrict__ gp,
-    const double* __restrict__ kp, int S, int ldk, pcreg_desc_opts o, Edges ed, int cap, int dbg_stop,
+    const double* __restrict__ kp, const int32_t* __restrict__ perm, int S, int ldk, pcreg_desc_opts o, Edges ed, int cap, int dbg_stop,
     uint32_t* __restrict__ rows /*[S][ND]*/, int32_t* __restrict__ valid, int32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* lpos = reinterpret_cast<int*>(smem);                           // [cap] position in the sorted arrays (+ a "kept" flag bit)
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(kBlock, 3) void desc_kernel(
     __shared__ double s_m[9];
 
     const Grid g = *gp;
-    const int s = blockIdx.x;
+    const int s = perm[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double cx = kp[s], cy = kp[s + (size_t)ldk], cz = kp[s + 2 * (size_t)ldk];
     const double R = o.R;
@@ -622,12 +641,14 @@ __global__ __launch_bounds__(kBlock) void desc_emit_kernel(const uint32_t* __res
 
 // workspace: Grid | bbox partials | cell_total | cell_start | cell_id [P] | counts [tiles][kMaxCells]
 //            | sorted_idx [P] | sx sy sz [P] | rows u32 [S][980] | valid [S] | slot [S] | block counters
+//            | keypoint cell counts / starts / fill | keypoint cell [S] | perm [S]
 size_t descriptors_workspace_bytes(int P, int S) {
     size_t p = (size_t)(P > 0 ? P : 1), s = (size_t)(S > 0 ? S : 1);
     size_t tiles = (p + kSortTile - 1) / kSortTile;
     return 256 + align_up(512 * 6 * 8, 256) + 2 * align_up(((size_t)kMaxCells + 1) * 4, 256) + align_up(p * 4, 256) +
            align_up(tiles * kMaxCells * 4, 256) + align_up(p * 4, 256) + 3 * align_up(p * 8, 256) +
-           align_up(s * ND * 4, 256) + 2 * align_up(s * 4, 256) + align_up((s / 256 + 2) * 4, 256);
+           align_up(s * ND * 4, 256) + 2 * align_up(s * 4, 256) + align_up((s / 256 + 2) * 4, 256) +
+           3 * align_up(((size_t)kMaxCells + 1) * 4, 256) + 2 * align_up(s * 4, 256);
 }
 
 int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o,
@@ -655,7 +676,12 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     uint32_t* rows = (uint32_t*)w;          w += align_up(s * ND * 4, 256);
     int32_t* valid = (int32_t*)w;           w += align_up(s * 4, 256);
     int32_t* slot = (int32_t*)w;            w += align_up(s * 4, 256);
-    int32_t* bcnt = (int32_t*)w;
+    int32_t* bcnt = (int32_t*)w;            w += align_up((s / 256 + 2) * 4, 256);
+    int32_t* kc_total = (int32_t*)w;        w += align_up(((size_t)kMaxCells + 1) * 4, 256);
+    int32_t* kc_start = (int32_t*)w;        w += align_up(((size_t)kMaxCells + 1) * 4, 256);
+    int32_t* kc_fill = (int32_t*)w;         w += align_up(((size_t)kMaxCells + 1) * 4, 256);
+    int32_t* kcell = (int32_t*)w;           w += align_up(s * 4, 256);
+    int32_t* perm = (int32_t*)w;
 
     int nb = (P + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bbox_partial_d_kernel, dim3(nb), dim3(kBlock), 0, st, pts, P, ld, bpart);
@@ -666,6 +692,11 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     hipLaunchKernelGGL(grid_cell_scan_kernel, dim3(1), dim3(256), 0, st, cell_total, cell_start);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(tiles), dim3(kBlock), 0, st, pts, P, ld, cell_id, counts, cell_start,
                        sorted_idx, sx, sy, sz);
+    // keypoints in cell order (kc_total | kc_start | kc_fill are contiguous: one memset)
+    PCREG_HIP(hipMemsetAsync(kc_total, 0, 3 * align_up(((size_t)kMaxCells + 1) * 4, 256), st));
+    hipLaunchKernelGGL(kp_count_kernel, dim3((S + 255) / 256), dim3(256), 0, st, kp, S, ldk, grid, kcell, kc_total);
+    hipLaunchKernelGGL(grid_cell_scan_kernel, dim3(1), dim3(256), 0, st, kc_total, kc_start);
+    hipLaunchKernelGGL(kp_scatter_kernel, dim3((S + 255) / 256), dim3(256), 0, st, kcell, S, kc_start, kc_fill, perm);
     PCREG_HIP(hipGetLastError());
 
     Edges ed;
@@ -677,7 +708,7 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     if (cap < 64) cap = 64;
     size_t lds = (size_t)cap * sizeof(int);
     PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(desc_kernel, dim3(S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, S, ldk, o,
+    hipLaunchKernelGGL(desc_kernel, dim3(S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, perm, S, ldk, o,
                        ed, cap, getenv("PCREG_DESC_STOP") ? atoi(getenv("PCREG_DESC_STOP")) : 0, rows, valid, err_dev);
     PCREG_HIP(hipGetLastError());
     const int nbs = (S + 255) / 256;
