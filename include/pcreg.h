@@ -287,6 +287,21 @@ int pcreg_dev_quick_tf(const double* pts, int n, int ld, const double T[16], dou
 int pcreg_dev_refine_by_distance(const double* pts1, const double* pts2, const int32_t* n_dev, int cap, int ld,
                                  double maxDist, double* T16, int32_t* info, void* stream);
 
+/* ---- on-disk formats of the drivers (host code, no device needed) --------------------------
+ * .pcd clouds (pcread / pcwrite, completeExperimentFast.m:12-13,30,403): ascii, binary and
+ * binary_compressed (LZF) files are read; x/y/z may be float or double, rgb/rgba is returned as
+ * the packed 0x00RRGGBB word.  xyz is n x 3 column-major (ld >= n), like pointCloud.Location. */
+int pcreg_pcd_info(const char* path, int* n_points, int* has_rgb);
+int pcreg_pcd_read(const char* path, float* xyz, int ld, uint32_t* rgb /* n or NULL */, int n);
+int pcreg_pcd_write(const char* path, const float* xyz, int n, int ld, const uint32_t* rgb /* or NULL */,
+                    int binary);
+
+/* .mat descriptor caches (load, completeExperimentFast.m:21-24,312-313): one real numeric
+ * variable of a Level-5 MAT-file (save -v6 / -v7, zlib-compressed elements included; v7.3 = HDF5
+ * is not supported) as column-major doubles.  name NULL or "" = the first numeric array.  Call
+ * with out == NULL for the shape (dimensions beyond the second are folded into cols). */
+int pcreg_mat_read_double(const char* path, const char* name, double* out, int* rows, int* cols);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,7 @@ SYMBOLS = [
     "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
     "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select",
     "pcreg_dev_gather_rows_f64", "pcreg_dev_quick_tf", "pcreg_dev_refine_by_distance",
+    "pcreg_pcd_info", "pcreg_pcd_read", "pcreg_pcd_write", "pcreg_mat_read_double",
 ]
 
 _lib = None

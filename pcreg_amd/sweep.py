@@ -88,7 +88,7 @@ class SphereSweep:
 
     def run(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
             putative_thresh: int = 170, seed: int = 0) -> dict:
-        """completeExperimentFast.m:46-224; same keys as oracle.pcreg_oracle.sphere_sweep."""
+        """completeExperimentFast.m:46-224: centres, num_desc, num_putative, matches, model_rows, trial and the stats arrays."""
         centres = self.sphere_centres(d_spheres)
         valid, _ = self.valid_spheres(centres, R_desc, min_pts)
         centres = centres[valid]
