@@ -732,7 +732,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     if (variant == 40 || variant == 41) {        // f16-split matrix-core candidates (41: timing only)
         kc = 8;
         int rc = launch_knn_candidates_f16(q, Q, ldq, m, M, ldm, prep, rm2, mprep, gthr, part_idx, part_s,
-                                           target_env > 0 ? target_env : 2048, kPartCap * 2, variant == 41, &S, st);
+                                           target_env > 0 ? target_env : 4096, kPartCap * 2, variant == 41, &S, st);
         if (rc) return rc;
     } else if (use_mfma) {
         constexpr int NQ = 8;                    // must match knn_mfma.hip

@@ -33,7 +33,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kT16 = 256;                     // model points per tile: [2 k-halves][256 points][8 f16] = 8 KiB
+constexpr int kT16 = 512;                     // model points per tile: [2 k-halves][512 points][8 f16] = 16 KiB
 constexpr int kRefresh = 16;                  // tiles between two looks at the shared threshold words
 
 __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx /*[S][Q][8]*/,
     float* __restrict__ part_s) {
-    __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];          // 2 x 8 KiB, filled by LDS-DMA
+    __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];          // 2 x 16 KiB, filled by LDS-DMA
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
     const int q_base = (blockIdx.x * (kBlock / 64) + wave) * (QG * 32);
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&tile[0][0];
     const int t_begin = blockIdx.y * tiles_per_chunk, t_end = min(n_tiles, t_begin + tiles_per_chunk);
     const int ntile = t_end - t_begin;
-    // wave w copies the 1-KiB segments w and w + 4 of an 8-KiB tile
+    // wave w copies the 1-KiB segments w, w + 4, ... of a tile
 #define PCREG_TILE_DMA(T, BUF)                                                                                     \
-    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                                \
+    _Pragma("unroll") for (int k = 0; k < kT16 / 128; ++k) {                                                        \
         const int seg = k * 4 + wave;                                                                              \
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mt + (size_t)(T) * (2 * kT16) + seg * 64 + lane), \
                                          (__attribute__((address_space(3))) void*)(&tile[BUF][seg * 64]), 16, 0, 0);   \
