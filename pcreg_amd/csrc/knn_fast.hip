@@ -140,37 +140,49 @@ __device__ __forceinline__ int seed_cell(float v, float lo, float inv_h, int n) 
     return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 __global__ __launch_bounds__(kBlock) void seed_fill_kernel(const float* __restrict__ m, int M, int ldm, const Prep* __restrict__ prep,
-                                                           int32_t* __restrict__ cnt, int32_t* __restrict__ slots) {
+                                                           int32_t* __restrict__ cnt, float4* __restrict__ slots) {
     const float gx0 = prep->gx0, gy0 = prep->gy0, gz0 = prep->gz0, ih = prep->inv_h;
     const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
-        int cx = seed_cell(m[i], gx0, ih, nx), cy = seed_cell(m[i + (size_t)ldm], gy0, ih, ny), cz = seed_cell(m[i + 2 * (size_t)ldm], gz0, ih, nz);
+        const float x = m[i], y = m[i + (size_t)ldm], z = m[i + 2 * (size_t)ldm];
+        int cx = seed_cell(x, gx0, ih, nx), cy = seed_cell(y, gy0, ih, ny), cz = seed_cell(z, gz0, ih, nz);
         int cell = (cz * ny + cy) * nx + cx;
         int k = atomicAdd(&cnt[cell], 1);
-        if (k < kSeedSlots) slots[(size_t)cell * kSeedSlots + k] = i;
+        if (k < kSeedSlots) slots[(size_t)cell * kSeedSlots + k] = make_float4(x, y, z, 0.0f);   // the point itself: one 64-B line per cell
     }
+}
+// eight lanes per query: lane k of the group looks at cells k, k + 8, k + 16, k + 24 of the 27, keeps its
+// own sorted four smallest distances, and three xor-shuffle rounds merge the eight lists
+__device__ __forceinline__ void sort4(float (&d)[4]) {
+#define PCREG_CS(a, b) { const float lo_ = fminf(d[a], d[b]), hi_ = fmaxf(d[a], d[b]); d[a] = lo_; d[b] = hi_; }
+    PCREG_CS(0, 1) PCREG_CS(2, 3) PCREG_CS(0, 2) PCREG_CS(1, 3) PCREG_CS(1, 2)
+#undef PCREG_CS
 }
 __global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
                                                             const Prep* __restrict__ prep,
-                                                            const int32_t* __restrict__ cnt, const int32_t* __restrict__ slots,
+                                                            const int32_t* __restrict__ cnt, const float4* __restrict__ slots,
                                                             int e_mode, unsigned* __restrict__ gthr) {
-    const int qi = blockIdx.x * kBlock + threadIdx.x;
-    if (qi >= Q) return;
-    const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
+    const int qi = (blockIdx.x * kBlock + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const bool live = qi < Q;
+    const int qq = live ? qi : 0;
+    const float qx = q[qq], qy = q[qq + (size_t)ldq], qz = q[qq + 2 * (size_t)ldq];
     const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
     const int cx = seed_cell(qx, prep->gx0, prep->inv_h, nx), cy = seed_cell(qy, prep->gy0, prep->inv_h, ny), cz = seed_cell(qz, prep->gz0, prep->inv_h, nz);
     float d[KC] = {INFINITY, INFINITY, INFINITY, INFINITY};
-    for (int dz = -1; dz <= 1; ++dz) {
-        int z = cz + dz; if (z < 0 || z >= nz) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            int y = cy + dy; if (y < 0 || y >= ny) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                int x = cx + dx; if (x < 0 || x >= nx) continue;
-                const int cell = (z * ny + y) * nx + x;
-                const int n = min(cnt[cell], kSeedSlots);
-                for (int k = 0; k < n; ++k) {
-                    const int j = slots[(size_t)cell * kSeedSlots + k];
-                    float ex = qx - m[j], ey = qy - m[j + (size_t)ldm], ez = qz - m[j + 2 * (size_t)ldm];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c27 = sub + 8 * t;
+        const int x = cx + c27 % 3 - 1, y = cy + (c27 / 3) % 3 - 1, z = cz + c27 / 9 - 1;
+        if (c27 < 27 && x >= 0 && x < nx && y >= 0 && y < ny && z >= 0 && z < nz) {
+            const int cell = (z * ny + y) * nx + x;
+            const int n = min(cnt[cell], kSeedSlots);
+            float4 pp[kSeedSlots];
+#pragma unroll
+            for (int k = 0; k < kSeedSlots; ++k) pp[k] = slots[(size_t)cell * kSeedSlots + k];
+#pragma unroll
+            for (int k = 0; k < kSeedSlots; ++k) {
+                if (k < n) {
+                    float ex = qx - pp[k].x, ey = qy - pp[k].y, ez = qz - pp[k].z;
                     float dd = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
                     if (dd < d[3]) {
                         if (dd < d[1]) { d[3] = d[2]; d[2] = d[1]; if (dd < d[0]) { d[1] = d[0]; d[0] = dd; } else d[1] = dd; }
@@ -180,6 +192,16 @@ __global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restr
             }
         }
     }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {               // the four smallest of two sorted fours: min(a_i, b_{3-i}), then sort
+        float e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = __shfl_xor(d[k], o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = fminf(d[k], e[3 - k]);
+        sort4(d);
+    }
+    if (!live || sub != 0) return;
     unsigned word = 0xFFFFFFFFu;                           // +inf: no hint
     if (d[3] < INFINITY) {
         const float tx = qx - prep->cx, ty = qy - prep->cy, tz = qz - prep->cz;
@@ -667,7 +689,7 @@ static size_t seed_bytes(int M) {
     if (M < kSeedMinM) return 0;
     size_t cells = std::min<size_t>((size_t)M / 2 + 4096, (size_t)kSeedMaxCells) + 16;   // bbox_final_kernel's cap
     cells = (size_t)kSeedMaxCells;                 // (the grid is sized on the device; reserve the cap)
-    return align_up(cells * 4, 256) + align_up(cells * kSeedSlots * 4, 256);
+    return align_up(cells * 4, 256) + align_up(cells * kSeedSlots * 16, 256);
 }
 static size_t fast_fixed_bytes(int Q, int M) {
     size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
@@ -708,7 +730,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     int32_t* part_idx = (int32_t*)w;       w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
     float* part_s = (float*)w;             w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
     int32_t* seed_cnt = (int32_t*)w;       w += M >= kSeedMinM ? align_up((size_t)kSeedMaxCells * 4, 256) : 0;
-    int32_t* seed_slots = (int32_t*)w;     w += M >= kSeedMinM ? align_up((size_t)kSeedMaxCells * kSeedSlots * 4, 256) : 0;
+    float4* seed_slots = (float4*)w;       w += M >= kSeedMinM ? align_up((size_t)kSeedMaxCells * kSeedSlots * 16, 256) : 0;
     int32_t* fb_idx = (int32_t*)w;         w += align_up((size_t)1024 * 32 * 2 * 4, 256);
     float* fb_dist = (float*)w;            w += align_up((size_t)1024 * 32 * 2 * 4, 256);
     void* ews = w;
@@ -724,7 +746,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
         PCREG_HIP(hipMemsetAsync(seed_cnt, 0, (size_t)kSeedMaxCells * 4, st));
         int fb = (M + kBlock * 4 - 1) / (kBlock * 4); if (fb > 2048) fb = 2048;
         hipLaunchKernelGGL(seed_fill_kernel, dim3(fb), dim3(kBlock), 0, st, m, M, ldm, prep, seed_cnt, seed_slots);
-        hipLaunchKernelGGL(seed_query_kernel, dim3((Q + kBlock - 1) / kBlock), dim3(kBlock), 0, st, q, Q, ldq, m, ldm, prep,
+        hipLaunchKernelGGL(seed_query_kernel, dim3((Q * 8 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, q, Q, ldq, m, ldm, prep,
                            seed_cnt, seed_slots, e_mode, gthr);
     } else {
         PCREG_HIP(hipMemsetAsync(gthr, 0xFF, qq * 4, st));        // +inf in the ordered-uint image
