@@ -1094,10 +1094,11 @@ __global__ void rs_finish_kernel(StagedArgs sa) {
 
 // ---------------------------------------------------------------- winner + outputs
 // ransac.m:69-98.  One workgroup per registration.
-__global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcreg_dev_ransac_result* out,
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void ransac_select_kernel(RansacArgs a, pcreg_dev_ransac_result* out,
                                                                int32_t* inlier_idx) {
-    __shared__ unsigned long long s_key[kWavesPerBlock];
-    __shared__ int s_cnt[kWavesPerBlock];
+    __shared__ unsigned long long s_key[(NTHR / 64)];
+    __shared__ int s_cnt[(NTHR / 64)];
     __shared__ double s_T[12];
     __shared__ int s_base;
     const int b = blockIdx.x;
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcr
     const int thInlr = matlab_round_i(a.ratio * (double)n);
     // first index of the maximum: max over (count << 32 | ~index)
     unsigned long long key = 0; int ns = 0;
-    for (int p = threadIdx.x; p < a.iters; p += kBlock) {
+    for (int p = threadIdx.x; p < a.iters; p += NTHR) {
         unsigned long long k = ((unsigned long long)(unsigned)cc[p] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
         key = k > key ? k : key;
         ns += cc[p] >= thInlr;
@@ -1125,7 +1126,7 @@ __global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcr
     __syncthreads();
     key = s_key[0]; ns = s_cnt[0];
 #pragma unroll
-    for (int w = 1; w < kWavesPerBlock; ++w) { key = s_key[w] > key ? s_key[w] : key; ns += s_cnt[w]; }
+    for (int w = 1; w < (NTHR / 64); ++w) { key = s_key[w] > key ? s_key[w] : key; ns += s_cnt[w]; }
     const int winner = a.iters > 0 ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
     const int maxInl = (int)(key >> 32);
     const bool failed = !(a.iters > 0 && a.has[hyp0 + winner]);                 // :75-89
@@ -1149,9 +1150,9 @@ __global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcr
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = s_T[k];
     Pts<false> P{a.p1 + off, a.p2 + off, a.ld, nullptr, n};
-    __shared__ int s_wcnt[kWavesPerBlock];
+    __shared__ int s_wcnt[(NTHR / 64)];
     int32_t* dst = inlier_idx + off;
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
+    for (int i0 = 0; i0 < n; i0 += NTHR) {
         int i = i0 + threadIdx.x;
         bool act = i < n;
         double q[6]; P.load(act ? i : n - 1, q);
@@ -1163,7 +1164,7 @@ __global__ __launch_bounds__(kBlock) void ransac_select_kernel(RansacArgs a, pcr
         for (int w = 0; w < wave; ++w) base += s_wcnt[w];
         if (in) dst[base + __popcll(bal & ((1ull << lane) - 1ull))] = i + 1;
         __syncthreads();
-        if (threadIdx.x == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < NTHR / 64; ++w) tot += s_wcnt[w]; s_base += tot; }
         __syncthreads();
     }
     if (threadIdx.x == 0) r->n_inliers = s_base;
@@ -1370,7 +1371,8 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
         hipLaunchKernelGGL(ransac_hyp_tiled_kernel, grid, dim3(kTBlock), 0, st, a);
     }
     PCREG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ransac_select_kernel, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx);
+    if (n_cap >= 8192) hipLaunchKernelGGL(ransac_select_kernel<1024>, dim3(B), dim3(1024), 0, st, a, out, inlier_idx);   // long inlier lists
+    else hipLaunchKernelGGL(ransac_select_kernel<kBlock>, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx);
     PCREG_HIP(hipGetLastError());
     if (iter_inl) PCREG_HIP(hipMemcpyAsync(iter_inl, a.cnt1, h * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (iter_inl_ref) PCREG_HIP(hipMemcpyAsync(iter_inl_ref, a.cnt2, h * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
