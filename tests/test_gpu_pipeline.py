@@ -78,3 +78,21 @@ def test_fast_path_equals_exact_kernel_on_hard_inputs(oracle_c):
     ridx, rdist = oracle_c.knn2_points_f32(q, m2)
     np.testing.assert_array_equal(idx, ridx)
     np.testing.assert_array_equal(dist, rdist)
+
+
+def test_search_at_full_size_spot_check(oracle_c):
+    """BASELINE's shape and beyond (Q = 100 k, M = 2 M): 1000 random queries against the exhaustive C oracle,
+    indices and fp32 distances bit for bit (the size-independent property: every query is independent)."""
+    import torch
+    from bench import synth
+    from pcreg_amd.device import RegistrationPipeline, soa
+    Q, M = 100_000, 2_000_000
+    model, surf, _ = synth(M, Q)
+    dev = torch.device("cuda", 0)
+    pipe = RegistrationPipeline(Q, M, device=dev)
+    pipe.search_local(soa(torch.from_numpy(surf).to(dev)), soa(torch.from_numpy(model).to(dev)))
+    idx, dist = pipe._local
+    sel = np.random.default_rng(5).choice(Q, 1000, replace=False)
+    ri, rd = oracle_c.knn2_points_f32(surf[sel], model)
+    np.testing.assert_array_equal(idx.cpu().numpy()[sel], ri)
+    np.testing.assert_array_equal(dist.cpu().numpy()[sel], rd)
