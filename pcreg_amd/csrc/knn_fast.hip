@@ -752,7 +752,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
         PCREG_HIP(hipMemsetAsync(gthr, 0xFF, qq * 4, st));        // +inf in the ordered-uint image
     }
     if (variant == 40 || variant == 41) {        // f16-split matrix-core candidates (41: timing only)
-        kc = 8;
+        kc = KC;
         int rc = launch_knn_candidates_f16(q, Q, ldq, m, M, ldm, prep, rm2, mprep, gthr, part_idx, part_s,
                                            target_env > 0 ? target_env : 4096, kPartCap * 2, variant == 41, &S, st);
         if (rc) return rc;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __r
 template <int QG, bool DRY, bool BATCH>
 __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
-    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx /*[S][Q][8]*/,
+    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx /*[S][Q][KC]*/,
     float* __restrict__ part_s) {
     __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];          // 2 x 16 KiB, filled by LDS-DMA
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,15 +189,34 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
         __syncthreads();
     }
 #undef PCREG_TILE_DMA
+    // The two half-waves of a query (lanes l and l ^ 32) merge their sorted fours in registers and lane l < 32
+    // writes ONE list of four per (chunk, query); the merged 4th-best is published too, so every entry dropped
+    // here still has s >= the final threshold word G, which is what the certificate relies on.
     const int chunk = blockIdx.y;
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int qi = q_base + g * 32 + col;
-        if (qi < Q) {
-            if (cand[g].s[3] < INFINITY) { unsigned k = f2ord(cand[g].s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
-            size_t o = ((size_t)chunk * Q + qi) * 8 + half * 4;
-            *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[g].i[0], cand[g].i[1], cand[g].i[2], cand[g].i[3]);
-            *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[g].s[0] * inv2, cand[g].s[1] * inv2, cand[g].s[2] * inv2, cand[g].s[3] * inv2);
+        Cand mine = cand[g];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const float os = __shfl_xor(cand[g].s[k], 32);
+            const int oi = __shfl_xor(cand[g].i[k], 32);
+            // (score, index) order keeps the merge independent of which half holds what
+            if (oi >= 0 && (os < mine.s[3] || (os == mine.s[3] && (unsigned)oi < (unsigned)mine.i[3]))) {
+                int pos = 3;
+#pragma unroll
+                for (int t = 2; t >= 0; --t) if (os < mine.s[t] || (os == mine.s[t] && (unsigned)oi < (unsigned)mine.i[t])) pos = t;
+#pragma unroll
+                for (int t = 3; t > 0; --t) if (t > pos) { mine.s[t] = mine.s[t - 1]; mine.i[t] = mine.i[t - 1]; }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t == pos) { mine.s[t] = os; mine.i[t] = oi; }
+            }
+        }
+        if (qi < Q && half == 0) {
+            if (mine.s[3] < INFINITY) { unsigned k = f2ord(mine.s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
+            size_t o = ((size_t)chunk * Q + qi) * KC;
+            *reinterpret_cast<int4*>(part_idx + o) = make_int4(mine.i[0], mine.i[1], mine.i[2], mine.i[3]);
+            *reinterpret_cast<float4*>(part_s + o) = make_float4(mine.s[0] * inv2, mine.s[1] * inv2, mine.s[2] * inv2, mine.s[3] * inv2);
         }
     }
 }
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
 
 size_t knn_f16_prep_bytes(int M) { return (size_t)((M > 0 ? M : 1) + kT16 - 1) / kT16 * (2 * kT16) * sizeof(uint4); }
 
-// grid: q_blocks x S; kc = 8 list entries per (chunk, query).  Returns S and kc through the pointers.
+// grid: q_blocks x S; KC = 4 list entries per (chunk, query).  Returns S and kc through the pointers.
 int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
                               unsigned* rm2, void* mtiles, unsigned* gthr, int32_t* part_idx, float* part_s,
                               int target_blocks, int max_S, bool dry, int* S_out, hipStream_t st) {
@@ -220,7 +239,7 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
     S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
     *S_out = S;
-    PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * 8 * 4, st));       // -1: empty slots
+    PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * KC * 4, st));      // -1: empty slots
     if (M <= 0) return PCREG_OK;
     int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
     hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2);
