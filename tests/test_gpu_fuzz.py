@@ -1,0 +1,73 @@
+"""Randomised parity sweeps of the certified paths against the exhaustive C oracle: whatever the
+geometry does to the seeding grid, the f16 split or the certificate, the answer must be the oracle's
+bits (unproven queries fall back to the exact kernels)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, n, kind):
+    if kind == "uniform":
+        return rng.uniform([0, 0, 0], [80, 50, 60], (n, 3))
+    if kind == "blobs":
+        c = rng.uniform(-100, 100, (rng.integers(1, 6), 3))
+        return c[rng.integers(0, len(c), n)] + rng.normal(0, rng.uniform(0.01, 3.0), (n, 3))
+    if kind == "plane":                                   # zero extent along z: degenerate grid / scale
+        p = rng.uniform(0, 30, (n, 3)); p[:, 2] = 7.25; return p
+    if kind == "line":
+        t = rng.uniform(0, 1, n); return np.outer(t, [40.0, 0.0, 0.0]) + [1.0, 2.0, 3.0]
+    if kind == "offset":                                  # large coordinates, small spacing: the error bound grows
+        return rng.uniform(0, 5, (n, 3)) + [4000.0, -2500.0, 900.0]
+    if kind == "tiny":
+        return rng.uniform(0, 1e-3, (n, 3))
+    if kind == "dupes":
+        p = rng.uniform(0, 20, (max(n // 3, 1), 3)); return p[rng.integers(0, len(p), n)]
+    raise ValueError(kind)
+
+
+KINDS = ["uniform", "blobs", "plane", "line", "offset", "tiny", "dupes"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_knn2_fuzz(seed, oracle_c):
+    import pcreg_amd as pc
+    rng = np.random.default_rng(1000 + seed)
+    for kind in KINDS:
+        M = int(rng.choice([1, 2, 3, 5, 63, 700, 16383, 16384, 20000, 70000]))
+        Q = int(rng.choice([1, 7, 64, 513, 2500]))
+        m = _cloud(rng, M, kind).astype(np.float32)
+        src = rng.choice(["same", "near", "far"])
+        if src == "same":
+            q = _cloud(rng, Q, kind).astype(np.float32)
+        elif src == "near":                               # noisy copies of model points (ties / tiny distances)
+            q = (m[rng.integers(0, M, Q)] + rng.normal(0, 1e-3, (Q, 3))).astype(np.float32)
+        else:                                             # queries far outside the model's box
+            q = (_cloud(rng, Q, kind) * 3.0 + 500.0).astype(np.float32)
+        idx, dist = pc.knn2_points(q, m)
+        ridx, rdist = oracle_c.knn2_points_f32(q, m)
+        np.testing.assert_array_equal(idx, ridx, err_msg=f"{kind} {src} Q={Q} M={M}")
+        np.testing.assert_array_equal(dist, rdist, err_msg=f"{kind} {src} Q={Q} M={M}")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_match_features_sad_fuzz(seed, oracle_c):
+    """Descriptor matching: counts, constants, duplicates, heavy ties, tiny D, Q > M and Q < M."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(6):
+        Q, M, D = int(rng.choice([1, 3, 130, 700])), int(rng.choice([1, 2, 65, 900, 2600])), int(rng.choice([1, 2, 17, 64, 301]))
+        lam = float(rng.choice([0.05, 1.0, 5.0]))
+        dM = rng.poisson(lam, (M, D)).astype(np.float64)
+        dS = rng.poisson(lam, (Q, D)).astype(np.float64)
+        k = min(Q, M) // 2
+        if k:
+            dS[:k] = dM[rng.choice(M, k, replace=False)] + (rng.poisson(0.2, (k, D)) if rng.random() < 0.7 else 0)
+        if rng.random() < 0.3:
+            dM[rng.integers(0, M)] = dM[0]                 # duplicate model rows
+        for unique in (True, False):
+            kw = dict(Metric="SAD", MatchThreshold=float(rng.choice([5.0, 30.0, 100.0])), MaxRatio=float(rng.choice([0.6, 0.99, 1.0])), Unique=unique)
+            pairs, met = pc.matchFeatures(dS, dM, **kw)
+            rp, rm = oracle_c.matchFeatures(dS, dM, kw)
+            np.testing.assert_array_equal(pairs, rp, err_msg=f"Q={Q} M={M} D={D} {kw}")
+            np.testing.assert_array_equal(met, rm)

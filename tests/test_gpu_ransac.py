@@ -189,3 +189,47 @@ def test_generic_handles_run_on_host():
     coef = dict(minPtNum=2, iterNum=50, thDist=0.05, thInlrRatio=0.5, REFINE=True, VERBOSE=0)
     f, inl, ns, mi, _ = pc.ransac(x, y, coef, fit, dist, seed=1)
     assert abs(f[0, 0] - 2) < 0.01 and abs(f[1, 0] - 1) < 0.05 and mi >= 150
+
+
+@pytest.mark.parametrize("case", ["clean", "outliers", "norefine", "min4", "three_inliers"])
+def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypatch):
+    """n >= 4096 runs the staged chain (rs_fit1 / rs_score / rs_moments / rs_fit2); PCREG_RANSAC_FUSED=1
+    selects the fused tiled kernel.  Both must reproduce the oracle's counts and inlier set."""
+    import pcreg_amd as pc
+    n, iters = 6000, 700
+    p1, p2, _ = rigid_case(n, 4242, noise=0.02, outlier_frac=0.6 if case in ("outliers", "three_inliers") else 0.05)
+    coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=case != "norefine", VERBOSE=0)
+    table = None
+    if case == "min4":
+        rng = np.random.default_rng(8)
+        table = np.stack([rng.permutation(n)[:4] + 1 for _ in range(iters)]).astype(np.int32)
+        coef["minPtNum"] = 4
+    if case == "three_inliers":
+        # every triple (3g, 3g+1, 3g+2) has its OWN rigid motion and the table samples exactly those triples:
+        # each hypothesis has its three sample points as its only inliers, thInlr = round(0.0005 n) = 3, so
+        # the refit is estimateTransform's N == 3 branch (estimateTransform.m:18-37) every time
+        from oracle import pcreg_oracle as o
+        rng = np.random.default_rng(9)
+        p2 = rng.uniform(-50, 50, (n, 3)); p1 = np.empty_like(p2)
+        for g in range(n // 3):
+            R = o.eul2rotm(rng.uniform(-1, 1, 3)); t = rng.uniform(-20, 20, 3)
+            p1[3 * g:3 * g + 3] = p2[3 * g:3 * g + 3] @ R + t
+        table = (np.arange(iters)[:, None] * 3 + np.arange(3)[None, :] + 1).astype(np.int32)
+        coef.update(thDist=1e-6, thInlrRatio=0.0005)
+    ref = oracle_c.ransac(p1, p2, coef, sample_idx=table, seed=21)
+    out = {}
+    for mode in ("staged", "fused"):
+        if mode == "fused":
+            monkeypatch.setenv("PCREG_RANSAC_FUSED", "1")
+        out[mode] = pc.ransac(p1, p2, coef, sample_idx=table, seed=21, return_iter_counts=True)
+    for mode, res in out.items():
+        np.testing.assert_array_equal(res[5], ref["inlrNum"], err_msg=mode)
+        np.testing.assert_array_equal(res[6], ref["inlrNum_refined"], err_msg=mode)
+        assert res[2] == ref["numSuccess"] and res[3] == ref["maxInliers"], mode
+        np.testing.assert_array_equal(np.asarray(res[1]).astype(np.int64), ref["inlierIdx"], err_msg=mode)
+        if not ref["failed"]:
+            assert np.linalg.norm(res[0] - ref["T"]) < T_TOL, mode
+    a, b = out["staged"], out["fused"]
+    np.testing.assert_array_equal(a[0], b[0])            # the two GPU paths agree to the last bit
+    if case == "three_inliers":
+        assert (ref["inlrNum"] == 3).sum() > 100          # the N == 3 refit branch really ran
