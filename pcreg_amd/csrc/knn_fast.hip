@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __res
         part[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
-__global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, int M, Prep* __restrict__ prep,
+__global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, int M, int cell_cap, Prep* __restrict__ prep,
                                   unsigned* __restrict__ rm2_bits) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = threadIdx.x; b < nparts; b += 64)              // launched with one wave
@@ -86,19 +86,19 @@ __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, in
         if (H > 0.0f && H < INFINITY) sg = ldexpf(1.0f, 5 - ilogbf(H));        // sigma * H in [32, 64)
         prep->sigma = sg; prep->inv_sigma2 = 1.0f / (sg * sg);                 // powers of two: exact
         prep->pad0 = prep->pad1 = 0.0f;
-        // seeding grid: about two model points per cell, at most kSeedMaxCells cells
+        // seeding grid: about two model points per cell, at most cell_cap cells (what the workspace holds)
         float ext[3], emax = 0.0f;
         for (int c = 0; c < 3; ++c) { ext[c] = hi[c] - lo[c]; emax = fmaxf(emax, ext[c]); }
         int n[3] = {1, 1, 1};
         float h = 1.0f;
         if (emax > 0.0f && emax < INFINITY) {
             for (int c = 0; c < 3; ++c) ext[c] = fmaxf(ext[c], emax * 1e-3f);
-            float target = fminf(fmaxf((float)M * 0.5f, 1.0f), (float)kSeedMaxCells * 0.5f);
+            float target = fminf(fmaxf((float)M * 0.5f, 1.0f), (float)cell_cap * 0.5f);
             h = cbrtf(ext[0] * ext[1] * ext[2] / target);
             for (int it = 0; it < 64; ++it) {
                 long tot = 1;
                 for (int c = 0; c < 3; ++c) { n[c] = (int)fminf(ceilf(ext[c] / h), 2048.0f); if (n[c] < 1) n[c] = 1; tot *= n[c]; }
-                if (tot <= kSeedMaxCells) break;
+                if (tot <= cell_cap) break;
                 h *= 1.2f;
             }
         }
@@ -685,10 +685,11 @@ size_t knn2_points_exact_workspace_bytes(int Q, int M);
 //                   | part_idx [S][Q][kc] | part_s | exact-kernel workspace (fallback)
 static constexpr int kPartCap = 40;           // upper bound of S * kc / 16 any variant may use (x16 entries per query)
 static constexpr int kSeedMinM = 16 * 1024;      // below this the lists settle within the first tiles anyway
+// the grid is sized on the device (about M/2 cells); this is the capacity it may use
+static size_t seed_cell_cap(int M) { return std::min<size_t>((size_t)kSeedMaxCells, std::max<size_t>(4096, (size_t)M)); }
 static size_t seed_bytes(int M) {
     if (M < kSeedMinM) return 0;
-    size_t cells = std::min<size_t>((size_t)M / 2 + 4096, (size_t)kSeedMaxCells) + 16;   // bbox_final_kernel's cap
-    cells = (size_t)kSeedMaxCells;                 // (the grid is sized on the device; reserve the cap)
+    const size_t cells = seed_cell_cap(M);
     return align_up(cells * 4, 256) + align_up(cells * kSeedSlots * 16, 256);
 }
 static size_t fast_fixed_bytes(int Q, int M) {
@@ -729,8 +730,9 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     void* mprep = w;                       w += align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256);
     int32_t* part_idx = (int32_t*)w;       w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
     float* part_s = (float*)w;             w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
-    int32_t* seed_cnt = (int32_t*)w;       w += M >= kSeedMinM ? align_up((size_t)kSeedMaxCells * 4, 256) : 0;
-    float4* seed_slots = (float4*)w;       w += M >= kSeedMinM ? align_up((size_t)kSeedMaxCells * kSeedSlots * 16, 256) : 0;
+    const size_t seed_cells = seed_cell_cap(M);
+    int32_t* seed_cnt = (int32_t*)w;       w += M >= kSeedMinM ? align_up(seed_cells * 4, 256) : 0;
+    float4* seed_slots = (float4*)w;       w += M >= kSeedMinM ? align_up(seed_cells * kSeedSlots * 16, 256) : 0;
     int32_t* fb_idx = (int32_t*)w;         w += align_up((size_t)1024 * 32 * 2 * 4, 256);
     float* fb_dist = (float*)w;            w += align_up((size_t)1024 * 32 * 2 * 4, 256);
     void* ews = w;
@@ -738,12 +740,12 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
 
     int nb = (M + Q + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, prep, rm2);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2);
     PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
     int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0;
     static const bool no_seed = getenv("PCREG_KNN_NOSEED") && atoi(getenv("PCREG_KNN_NOSEED")) != 0;
     if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)
-        PCREG_HIP(hipMemsetAsync(seed_cnt, 0, (size_t)kSeedMaxCells * 4, st));
+        PCREG_HIP(hipMemsetAsync(seed_cnt, 0, seed_cells * 4, st));
         int fb = (M + kBlock * 4 - 1) / (kBlock * 4); if (fb > 2048) fb = 2048;
         hipLaunchKernelGGL(seed_fill_kernel, dim3(fb), dim3(kBlock), 0, st, m, M, ldm, prep, seed_cnt, seed_slots);
         hipLaunchKernelGGL(seed_query_kernel, dim3((Q * 8 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, q, Q, ldq, m, ldm, prep,
