@@ -746,7 +746,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     static const bool no_seed = getenv("PCREG_KNN_NOSEED") && atoi(getenv("PCREG_KNN_NOSEED")) != 0;
     if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)
         PCREG_HIP(hipMemsetAsync(seed_cnt, 0, seed_cells * 4, st));
-        int fb = (M + kBlock * 4 - 1) / (kBlock * 4); if (fb > 2048) fb = 2048;
+        int fb = (M + kBlock - 1) / kBlock; if (fb > 16384) fb = 16384;     // one point per thread: the atomics want parallelism
         hipLaunchKernelGGL(seed_fill_kernel, dim3(fb), dim3(kBlock), 0, st, m, M, ldm, prep, seed_cnt, seed_slots);
         hipLaunchKernelGGL(seed_query_kernel, dim3((Q * 8 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, q, Q, ldq, m, ldm, prep,
                            seed_cnt, seed_slots, e_mode, gthr);

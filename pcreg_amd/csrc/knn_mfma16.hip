@@ -69,7 +69,10 @@ __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __r
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(rm2_bits, __float_as_uint(mx));
+    __shared__ float s_mx[kBlock / 64];                  // one atomic per workgroup: thousands on one word serialise
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(rm2_bits, __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
 }
 
 template <int QG, bool DRY, bool BATCH>
@@ -241,7 +244,7 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     *S_out = S;
     PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * KC * 4, st));      // -1: empty slots
     if (M <= 0) return PCREG_OK;
-    int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
+    int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 512) pb = 512;
     hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2);
 #define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks, S), dim3(kBlock), 0, st, q, Q, ldq, \
                            (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, part_idx, part_s)
