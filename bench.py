@@ -132,7 +132,7 @@ def main() -> None:
         if k is not None:
             ev[k][1].record()
         pipe.match_after_search(q_soa, model_soa, MATCH_THR_ABS, MATCH_RATIO, unique=True)
-        pipe.ransac(RANSAC_COEF, seed=7)
+        pipe.ransac_sharded(RANSAC_COEF, seed=7)        # one rank: plain ransac(); N ranks: hypotheses split N ways
 
     for _ in range(args.warmup):
         step(None)

@@ -226,6 +226,25 @@ int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_de
                      pcreg_dev_ransac_result* out, int32_t* inlier_idx,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* One registration's hypotheses split over ranks (optional mode): every rank runs the
+ * hypotheses [hyp_begin, hyp_begin + hyp_count) of a job of opts->iterNum -- the built-in sampler and the
+ * first-maximum tie-break (ransac.m:70-72) use the GLOBAL hypothesis index, so the union over ranks is
+ * exactly the single-rank run -- and leaves its share's best in `part` (device).  Combine on the ranks:
+ * key by MAX, num_success by SUM, has / T from the rank whose key equals the maximum; then
+ * pcreg_dev_ransac_finish builds the result and the inlier list from the combined part.  sample_idx,
+ * if given, holds the hyp_count rows of THIS share. */
+typedef struct pcreg_dev_ransac_part {
+    unsigned long long key;          /* (inlier count << 32) | ~global hypothesis index; 0 for an empty share */
+    int32_t num_success, has;        /* hypotheses of the share with count >= thInlr; 1 if the winner holds a transform */
+    double  T[12];                   /* the winner's transform, rows of [R t] (as stored internally) */
+} pcreg_dev_ransac_part;
+int pcreg_dev_ransac_partial(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                             const pcreg_ransac_opts* opts, const int32_t* sample_idx, int hyp_begin, int hyp_count,
+                             pcreg_dev_ransac_part* part, void* workspace, size_t workspace_bytes, void* stream);
+int pcreg_dev_ransac_finish(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                            const pcreg_ransac_opts* opts, const pcreg_dev_ransac_part* combined,
+                            pcreg_dev_ransac_result* out, int32_t* inlier_idx, void* stream);
+
 /* ---- descriptor stage, resident: speedyDescriptors.m:59 -> getMatches.m -> ransac.m --------
  * (completeExperimentFast.m:131-213 per sphere position) without a host copy in between. */
 

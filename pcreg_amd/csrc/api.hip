@@ -476,6 +476,22 @@ int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_de
 }
 
 
+int pcreg_dev_ransac_partial(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                             const pcreg_ransac_opts* opts, const int32_t* sample_idx, int hyp_begin, int hyp_count,
+                             pcreg_dev_ransac_part* part, void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(pts1 && pts2 && opts && part && workspace && n_cap >= 0 && ld >= n_cap);
+    GUARD();
+    return launch_ransac_partial(pts1, pts2, ld, n_dev, n_cap, *opts, sample_idx, hyp_begin, hyp_count, part, workspace,
+                                 workspace_bytes, (hipStream_t)stream);
+}
+int pcreg_dev_ransac_finish(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                            const pcreg_ransac_opts* opts, const pcreg_dev_ransac_part* combined,
+                            pcreg_dev_ransac_result* out, int32_t* inlier_idx, void* stream) {
+    PCREG_ARG(pts1 && pts2 && opts && combined && out && inlier_idx && n_cap >= 0 && ld >= n_cap);
+    GUARD();
+    return launch_ransac_finish(pts1, pts2, ld, n_dev, n_cap, *opts, combined, out, inlier_idx, (hipStream_t)stream);
+}
+
 // ---- descriptor stage, resident (speedyDescriptors.m:59 -> getMatches -> ransac without leaving HBM)
 size_t pcreg_dev_spatial_histogram_descriptors_workspace(int P, int S) { return descriptors_workspace_bytes(P, S); }
 

@@ -54,6 +54,12 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
                   const pcreg_ransac_opts& o, const int32_t* sample_idx_dev,
                   pcreg_dev_ransac_result* out /*B*/, int32_t* inlier_idx, int32_t* iter_inl /*B*iters or null*/,
                   int32_t* iter_inl_ref, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_ransac_partial(const double* p1, const double* p2, int ld, const int32_t* n_dev, int n_cap,
+                          const pcreg_ransac_opts& o, const int32_t* sample_idx_dev, int hyp_begin, int hyp_count,
+                          pcreg_dev_ransac_part* part, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_ransac_finish(const double* p1, const double* p2, int ld, const int32_t* n_dev, int n_cap,
+                         const pcreg_ransac_opts& o, const pcreg_dev_ransac_part* combined,
+                         pcreg_dev_ransac_result* out, int32_t* inlier_idx, hipStream_t st);
 int launch_estimate_transform(const double* p1, const double* p2, int n, int ld, double* T16_dev,
                               int32_t* empty_dev, hipStream_t st);
 int launch_calc_dists(const double* T16_dev, const double* p1, const double* p2, int n, int ld,

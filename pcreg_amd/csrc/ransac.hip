@@ -37,6 +37,7 @@ struct RansacArgs {
     double thDist; double ratio; int refine; unsigned long long seed;
     const int32_t* sample_idx;  // [B*iters][m] 1-based or null
     int hpw;                    // hypotheses per wave (<= 64)
+    int hyp0g;                  // global index of this launch's first hypothesis (hypotheses split over ranks)
     double* TF;                 // [B*iters][12]
     int32_t* cnt1; int32_t* cnt2; unsigned char* has;
 };
@@ -384,7 +385,7 @@ __device__ __forceinline__ void sample3(const RansacArgs& a, int b, int p, int n
         unsigned r[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            unsigned long long h = splitmix64(seed ^ splitmix64((unsigned long long)p * 16ull + j));
+            unsigned long long h = splitmix64(seed ^ splitmix64((unsigned long long)(p + a.hyp0g) * 16ull + j));
             r[j] = (unsigned)(((h >> 32) * (unsigned long long)(unsigned)(n - j)) >> 32);
         }
         unsigned i0 = r[0], i1 = r[1];
@@ -1094,13 +1095,58 @@ __global__ void rs_finish_kernel(StagedArgs sa) {
 
 // ---------------------------------------------------------------- winner + outputs
 // ransac.m:69-98.  One workgroup per registration.
+// result struct + inlierIdx = find(dist < thDist), ascending, 1-based (ransac.m:75-98), by one workgroup
+template <int NTHR>
+__device__ void ransac_emit_result(const RansacArgs& a, int n, int off, pcreg_dev_ransac_result* r, int32_t* inlier_idx,
+                                   bool failed, const double* s_T /*LDS, 12*/, int ns, int maxInl, int winner,
+                                   int* s_base, int* s_wcnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) *s_base = 0;
+    __syncthreads();
+    if (threadIdx.x < 16) {   // column-major 4x4: T(k,j) = R(j,k), T(4,j) = t(j)
+        int k = threadIdx.x & 3, j = threadIdx.x >> 2;
+        double v = 0.0;
+        if (!failed) v = (j < 3) ? s_T[j * 4 + k] : (k == 3 ? 1.0 : 0.0);
+        r->T[k + 4 * j] = v;
+    }
+    if (threadIdx.x == 0) {
+        r->failed = failed; r->num_success = failed ? 0 : ns; r->max_inliers = failed ? 0 : maxInl;
+        r->n = n; r->winner = winner;
+    }
+    if (failed) { if (threadIdx.x == 0) r->n_inliers = 0; return; }
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = s_T[k];
+    Pts<false> P{a.p1 + off, a.p2 + off, a.ld, nullptr, n};
+    int32_t* dst = inlier_idx + off;
+    for (int i0 = 0; i0 < n; i0 += NTHR) {
+        int i = i0 + threadIdx.x;
+        bool act = i < n;
+        double q[6]; P.load(act ? i : n - 1, q);
+        bool in = act && sqdist(q, T) < a.thDist;
+        unsigned long long bal = __ballot(in);
+        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        int base = *s_base;
+        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
+        if (in) dst[base + __popcll(bal & ((1ull << lane) - 1ull))] = i + 1;
+        __syncthreads();
+        if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < NTHR / 64; ++w) tot += s_wcnt[w]; *s_base += tot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) r->n_inliers = *s_base;
+}
+
+// part != nullptr: hypotheses split over ranks -- leave this share's best (global-index key, success
+// count, winner's transform) for the cross-rank combine instead of a result.
 template <int NTHR>
 __global__ __launch_bounds__(NTHR) void ransac_select_kernel(RansacArgs a, pcreg_dev_ransac_result* out,
-                                                               int32_t* inlier_idx) {
+                                                               int32_t* inlier_idx, pcreg_dev_ransac_part* part) {
     __shared__ unsigned long long s_key[(NTHR / 64)];
     __shared__ int s_cnt[(NTHR / 64)];
     __shared__ double s_T[12];
     __shared__ int s_base;
+    __shared__ int s_wcnt[(NTHR / 64)];
     const int b = blockIdx.x;
     const int off = a.offsets ? a.offsets[b] : 0;
     int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
@@ -1109,10 +1155,10 @@ __global__ __launch_bounds__(NTHR) void ransac_select_kernel(RansacArgs a, pcreg
     const size_t hyp0 = (size_t)b * a.iters;
     const int32_t* cc = a.refine ? a.cnt2 + hyp0 : a.cnt1 + hyp0;               // :69-73
     const int thInlr = matlab_round_i(a.ratio * (double)n);
-    // first index of the maximum: max over (count << 32 | ~index)
+    // first index of the maximum: max over (count << 32 | ~index), index = GLOBAL hypothesis number
     unsigned long long key = 0; int ns = 0;
     for (int p = threadIdx.x; p < a.iters; p += NTHR) {
-        unsigned long long k = ((unsigned long long)(unsigned)cc[p] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)p);
+        unsigned long long k = ((unsigned long long)(unsigned)cc[p] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(p + a.hyp0g));
         key = k > key ? k : key;
         ns += cc[p] >= thInlr;
     }
@@ -1127,47 +1173,33 @@ __global__ __launch_bounds__(NTHR) void ransac_select_kernel(RansacArgs a, pcreg
     key = s_key[0]; ns = s_cnt[0];
 #pragma unroll
     for (int w = 1; w < (NTHR / 64); ++w) { key = s_key[w] > key ? s_key[w] : key; ns += s_cnt[w]; }
-    const int winner = a.iters > 0 ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
+    const int winner_g = a.iters > 0 ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
+    const int winner = winner_g - a.hyp0g;
     const int maxInl = (int)(key >> 32);
     const bool failed = !(a.iters > 0 && a.has[hyp0 + winner]);                 // :75-89
-    pcreg_dev_ransac_result* r = out + b;
+    if (part) {
+        if (threadIdx.x < 12) part->T[threadIdx.x] = failed ? 0.0 : a.TF[(hyp0 + winner) * 12 + threadIdx.x];
+        if (threadIdx.x == 0) { part->key = a.iters > 0 ? key : 0ull; part->num_success = ns; part->has = failed ? 0 : 1; }
+        return;
+    }
     if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : a.TF[(hyp0 + winner) * 12 + threadIdx.x];
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    if (threadIdx.x < 16) {   // column-major 4x4: T(k,j) = R(j,k), T(4,j) = t(j)
-        int k = threadIdx.x & 3, j = threadIdx.x >> 2;
-        double v = 0.0;
-        if (!failed) v = (j < 3) ? s_T[j * 4 + k] : (k == 3 ? 1.0 : 0.0);
-        r->T[k + 4 * j] = v;
-    }
-    if (threadIdx.x == 0) {
-        r->failed = failed; r->num_success = failed ? 0 : ns; r->max_inliers = failed ? 0 : maxInl;
-        r->n = n; r->winner = winner;
-    }
-    if (failed) { if (threadIdx.x == 0) r->n_inliers = 0; return; }
-    // inlierIdx = find(dist < thDist), ascending, 1-based (:92)
-    double T[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) T[k] = s_T[k];
-    Pts<false> P{a.p1 + off, a.p2 + off, a.ld, nullptr, n};
+    ransac_emit_result<NTHR>(a, n, off, out + b, inlier_idx, failed, s_T, ns, maxInl, winner_g, &s_base, s_wcnt);
+}
+
+// the combined share (key by MAX, num_success by SUM, has/T from the rank whose key won) -> result + inlier list
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void ransac_finish_kernel(RansacArgs a, const pcreg_dev_ransac_part* part,
+                                                               pcreg_dev_ransac_result* out, int32_t* inlier_idx) {
+    __shared__ double s_T[12];
+    __shared__ int s_base;
     __shared__ int s_wcnt[(NTHR / 64)];
-    int32_t* dst = inlier_idx + off;
-    for (int i0 = 0; i0 < n; i0 += NTHR) {
-        int i = i0 + threadIdx.x;
-        bool act = i < n;
-        double q[6]; P.load(act ? i : n - 1, q);
-        bool in = act && sqdist(q, T) < a.thDist;
-        unsigned long long bal = __ballot(in);
-        if (lane == 0) s_wcnt[wave] = __popcll(bal);
-        __syncthreads();
-        int base = s_base;
-        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
-        if (in) dst[base + __popcll(bal & ((1ull << lane) - 1ull))] = i + 1;
-        __syncthreads();
-        if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < NTHR / 64; ++w) tot += s_wcnt[w]; s_base += tot; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) r->n_inliers = s_base;
+    int n = a.n_dev ? *a.n_dev : a.n_cap;
+    n = min(n, a.n_cap);
+    const unsigned long long key = part->key;
+    const bool failed = part->has == 0;
+    if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : part->T[threadIdx.x];
+    ransac_emit_result<NTHR>(a, n, 0, out, inlier_idx, failed, s_T, part->num_success, (int)(key >> 32),
+                             (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)), &s_base, s_wcnt);
 }
 
 // ---------------------------------------------------------------- single-fit kernels
@@ -1301,10 +1333,10 @@ size_t ransac_workspace_bytes(int iters, int B) {
            staged_extra_bytes(h);
 }
 
-int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
-                  int n_cap, int B, const pcreg_ransac_opts& o, const int32_t* sample_idx_dev,
+static int launch_ransac_impl(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
+                  int n_cap, int B, pcreg_ransac_opts o, const int32_t* sample_idx_dev,
                   pcreg_dev_ransac_result* out, int32_t* inlier_idx, int32_t* iter_inl, int32_t* iter_inl_ref,
-                  void* ws, size_t ws_bytes, hipStream_t st) {
+                  void* ws, size_t ws_bytes, hipStream_t st, int hyp_begin, pcreg_dev_ransac_part* part) {
     PCREG_ARG(o.iterNum >= 1 && o.minPtNum >= 3 && B >= 1 && n_cap >= 0);
     PCREG_ARG(o.minPtNum == 3 || sample_idx_dev != nullptr);   // built-in sampler draws triples
     size_t need = ransac_workspace_bytes(o.iterNum, B);
@@ -1314,7 +1346,7 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
     RansacArgs a{};
     a.p1 = p1; a.p2 = p2; a.ld = ld; a.offsets = offsets; a.n_dev = n_dev; a.n_cap = n_cap;
     a.iters = o.iterNum; a.m = o.minPtNum; a.thDist = o.thDist; a.ratio = o.thInlrRatio;
-    a.refine = o.REFINE != 0; a.seed = o.seed; a.sample_idx = sample_idx_dev;
+    a.refine = o.REFINE != 0; a.seed = o.seed; a.sample_idx = sample_idx_dev; a.hyp0g = hyp_begin;
     a.TF = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
     a.cnt1 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.cnt2 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
@@ -1371,11 +1403,43 @@ int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* off
         hipLaunchKernelGGL(ransac_hyp_tiled_kernel, grid, dim3(kTBlock), 0, st, a);
     }
     PCREG_HIP(hipGetLastError());
-    if (n_cap >= 8192) hipLaunchKernelGGL(ransac_select_kernel<1024>, dim3(B), dim3(1024), 0, st, a, out, inlier_idx);   // long inlier lists
-    else hipLaunchKernelGGL(ransac_select_kernel<kBlock>, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx);
+    if (n_cap >= 8192) hipLaunchKernelGGL(ransac_select_kernel<1024>, dim3(B), dim3(1024), 0, st, a, out, inlier_idx, part);   // long inlier lists
+    else hipLaunchKernelGGL(ransac_select_kernel<kBlock>, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx, part);
     PCREG_HIP(hipGetLastError());
     if (iter_inl) PCREG_HIP(hipMemcpyAsync(iter_inl, a.cnt1, h * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     if (iter_inl_ref) PCREG_HIP(hipMemcpyAsync(iter_inl_ref, a.cnt2, h * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return PCREG_OK;
+}
+
+int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
+                  int n_cap, int B, const pcreg_ransac_opts& o, const int32_t* sample_idx_dev,
+                  pcreg_dev_ransac_result* out, int32_t* inlier_idx, int32_t* iter_inl, int32_t* iter_inl_ref,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+    return launch_ransac_impl(p1, p2, ld, offsets, n_dev, n_cap, B, o, sample_idx_dev, out, inlier_idx, iter_inl, iter_inl_ref,
+                              ws, ws_bytes, st, 0, nullptr);
+}
+
+// hypotheses [hyp_begin, hyp_begin + hyp_count) of one registration of o.iterNum; sample_idx_dev (if any) holds
+// the rows of THIS share
+int launch_ransac_partial(const double* p1, const double* p2, int ld, const int32_t* n_dev, int n_cap,
+                          const pcreg_ransac_opts& o, const int32_t* sample_idx_dev, int hyp_begin, int hyp_count,
+                          pcreg_dev_ransac_part* part, void* ws, size_t ws_bytes, hipStream_t st) {
+    PCREG_ARG(hyp_begin >= 0 && hyp_count >= 0 && hyp_begin + hyp_count <= o.iterNum);
+    if (hyp_count == 0) { PCREG_HIP(hipMemsetAsync(part, 0, sizeof(pcreg_dev_ransac_part), st)); return PCREG_OK; }
+    pcreg_ransac_opts ol = o;
+    ol.iterNum = hyp_count;
+    return launch_ransac_impl(p1, p2, ld, nullptr, n_dev, n_cap, 1, ol, sample_idx_dev, nullptr, nullptr, nullptr, nullptr,
+                              ws, ws_bytes, st, hyp_begin, part);
+}
+
+int launch_ransac_finish(const double* p1, const double* p2, int ld, const int32_t* n_dev, int n_cap,
+                         const pcreg_ransac_opts& o, const pcreg_dev_ransac_part* combined,
+                         pcreg_dev_ransac_result* out, int32_t* inlier_idx, hipStream_t st) {
+    RansacArgs a{};
+    a.p1 = p1; a.p2 = p2; a.ld = ld; a.n_dev = n_dev; a.n_cap = n_cap; a.thDist = o.thDist; a.ratio = o.thInlrRatio;
+    if (n_cap >= 8192) hipLaunchKernelGGL(ransac_finish_kernel<1024>, dim3(1), dim3(1024), 0, st, a, combined, out, inlier_idx);
+    else hipLaunchKernelGGL(ransac_finish_kernel<kBlock>, dim3(1), dim3(kBlock), 0, st, a, combined, out, inlier_idx);
+    PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
 

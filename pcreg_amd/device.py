@@ -13,7 +13,7 @@ import torch
 
 from ._lib import DevRansacResult, RansacOpts, check, lib
 from . import _lib as _l
-from .sharded import ShardedMatcher
+from .sharded import ShardedMatcher, combine_ransac_parts, hypothesis_share
 
 
 def _p(t: torch.Tensor):
@@ -141,6 +141,38 @@ class RegistrationPipeline:
         check(L.pcreg_dev_ransac(_p(pts1), _p(pts2), _p(n_dev), cap, cap, C.byref(o),
                                  _p(sample_idx) if sample_idx is not None else None, _p(self.result), _p(self.inliers),
                                  _p(self.ws_ransac), C.c_size_t(self.ws_ransac.numel()), _stream()))
+
+    def ransac_sharded(self, coef: dict, seed: int = 0):
+        """The same registration with its hypotheses split over the ranks of the group (each rank scores
+        iterNum / world of them, the winner is agreed by three tiny collectives): identical result to
+        ransac(), 1/world of its time.  Falls back to ransac() on one rank."""
+        if self.world == 1:
+            return self.ransac(coef, seed)
+        L = lib()
+        o = RansacOpts(int(coef["minPtNum"]), int(coef["iterNum"]), float(coef["thDist"]), float(coef["thInlrRatio"]),
+                       int(bool(coef["REFINE"])), 0, int(seed))
+        cap = self.pts1.shape[1]
+        begin, count = hypothesis_share(o.iterNum, self.matcher.rank, self.world)
+        need = L.pcreg_dev_ransac_workspace(cap, max(count, 1))
+        if self.ws_ransac is None or self.ws_ransac.numel() < need:
+            self.ws_ransac = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        if self.inliers.numel() < cap:
+            self.inliers = torch.empty(cap, dtype=torch.int32, device=self.dev)
+        part = torch.zeros(14, dtype=torch.int64, device=self.dev)      # pcreg_dev_ransac_part: key | (ns, has) | T[12]
+        check(L.pcreg_dev_ransac_partial(_p(self.pts1), _p(self.pts2), _p(self.n_pairs), cap, cap, C.byref(o), None,
+                                         begin, count, _p(part), _p(self.ws_ransac), C.c_size_t(self.ws_ransac.numel()), _stream()))
+        ns_has = part[1:2].view(torch.int32)                              # [num_success, has]
+        key = part[0:1].clone()
+        ns = ns_has[0:1].to(torch.int64)
+        has_T = torch.cat([ns_has[1:2].to(torch.float64), part[2:14].view(torch.float64)])
+        key, ns, has_T = combine_ransac_parts(key, ns, has_T, self.matcher.group)
+        comb = torch.zeros(14, dtype=torch.int64, device=self.dev)
+        comb[0:1] = key
+        comb[1:2].view(torch.int32)[0:1] = ns.to(torch.int32)
+        comb[1:2].view(torch.int32)[1:2] = (has_T[0:1] > 0.5).to(torch.int32)
+        comb[2:14].view(torch.float64)[:] = has_T[1:13]
+        check(L.pcreg_dev_ransac_finish(_p(self.pts1), _p(self.pts2), _p(self.n_pairs), cap, cap, C.byref(o), _p(comb),
+                                        _p(self.result), _p(self.inliers), _stream()))
 
     def fetch_result(self) -> dict:
         """D2H copy of the last ransac result (synchronises)."""

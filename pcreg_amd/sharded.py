@@ -31,6 +31,28 @@ import torch
 import torch.distributed as dist
 
 
+def hypothesis_share(iter_num: int, rank: int, world: int) -> tuple[int, int]:
+    """[begin, begin + count) of a registration's hypotheses that `rank` evaluates."""
+    share = (iter_num + world - 1) // world
+    begin = min(rank * share, iter_num)
+    return begin, min(share, iter_num - begin)
+
+
+def combine_ransac_parts(key: torch.Tensor, num_success: torch.Tensor, has_T: torch.Tensor, group=None):
+    """Cross-rank winner of one registration whose hypotheses were split over the ranks:
+    key [1] int64 = (inlier count << 32 | ~global hypothesis index) by MAX -- the first maximum of
+    ransac.m:70-72 --, num_success [1] int64 by SUM, has_T [13] float64 = (has, T[12]) taken from the
+    one rank whose key won (every other rank contributes zeros, so the SUM is exact).
+    Three tiny collectives; returns (key, num_success, has_T) identical on every rank."""
+    local_key = key.clone()
+    dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(num_success, op=dist.ReduceOp.SUM, group=group)
+    own = (local_key == key) & (key != 0)
+    has_T = torch.where(own, has_T, torch.zeros_like(has_T))
+    dist.all_reduce(has_T, op=dist.ReduceOp.SUM, group=group)
+    return key, num_success, has_T
+
+
 class ShardedMatcher:
     def __init__(self, ops, Q: int, M_local: int, m_lo: int, M_total: int, group=None):
         self.ops, self.Q, self.M_local, self.m_lo, self.M_total = ops, Q, M_local, m_lo, M_total

@@ -15,14 +15,15 @@ m_lo = rank * M_local
 ms = soa(torch.from_numpy(model[m_lo:m_lo + M_local]).to(dev)); qs = soa(torch.from_numpy(surf).to(dev))
 pipe = RegistrationPipeline(Q, M_local, m_lo=m_lo, M_total=M_local * world, device=dev)
 pairs, p1, p2, n = pipe.match(qs, ms, MATCH_THR_ABS, MATCH_RATIO, True)
-pipe.ransac(dict(RANSAC_COEF, iterNum=1000), seed=7)
+pipe.ransac_sharded(dict(RANSAC_COEF, iterNum=1001), seed=7)      # hypotheses split over the two ranks
 res = pipe.fetch_result(); n = int(n.item())
 from oracle import c_oracle
 ref = c_oracle.match_points_f32(surf, model, MATCH_THR_ABS, MATCH_RATIO, True)
 ok = np.array_equal(pairs[:n].cpu().numpy().astype(np.uint32), ref)
 rp1 = surf[ref[:, 0] - 1].astype(np.float64); rp2 = model[ref[:, 1] - 1].astype(np.float64)
-rr = c_oracle.ransac(rp1, rp2, dict(RANSAC_COEF, iterNum=1000), seed=7)
-ok2 = np.array_equal(res["inlierIdx"].astype(np.int64), rr["inlierIdx"]) and res["numSuccess"] == rr["numSuccess"]
+rr = c_oracle.ransac(rp1, rp2, dict(RANSAC_COEF, iterNum=1001), seed=7)
+ok2 = (np.array_equal(res["inlierIdx"].astype(np.int64), rr["inlierIdx"]) and res["numSuccess"] == rr["numSuccess"]
+       and res["maxInliers"] == rr["maxInliers"] and res["winner"] == int(np.argmax(rr["inlrNum_refined"])) and np.linalg.norm(res["T"] - rr["T"]) < 1e-9)
 print(f"rank {rank}: pairs {n} match_ok={ok} ransac_ok={ok2}", flush=True)
 dist.barrier(); dist.destroy_process_group()
 sys.exit(0 if ok and ok2 else 1)

@@ -233,3 +233,47 @@ def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypa
     np.testing.assert_array_equal(a[0], b[0])            # the two GPU paths agree to the last bit
     if case == "three_inliers":
         assert (ref["inlrNum"] == 3).sum() > 100          # the N == 3 refit branch really ran
+
+
+@pytest.mark.parametrize("n,iters,world", [(900, 1000, 3), (6000, 701, 2), (6000, 64, 8)])
+def test_hypotheses_split_in_shares_equal_the_single_run(n, iters, world):
+    """pcreg_dev_ransac_partial on every share + the MAX/SUM combine + pcreg_dev_ransac_finish
+    == pcreg_dev_ransac, field for field (what the ranks of a multi-GPU job do, in one process)."""
+    import ctypes as C
+    import torch
+    from pcreg_amd import _lib
+    from pcreg_amd._lib import DevRansacResult, RansacOpts
+    from pcreg_amd.device import _p, _stream
+    from pcreg_amd.sharded import hypothesis_share
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    p1, p2, _ = rigid_case(n, 600 + n, noise=0.02, outlier_frac=0.5)
+    t1 = torch.from_numpy(np.ascontiguousarray(p1.T)).to(dev); t2 = torch.from_numpy(np.ascontiguousarray(p2.T)).to(dev)
+    nd = torch.tensor([n], dtype=torch.int32, device=dev)
+    o = RansacOpts(3, iters, 0.05, 0.1, 1, 0, 77)
+    ws = torch.empty(L.pcreg_dev_ransac_workspace(n, iters), dtype=torch.uint8, device=dev)
+    def fetch(res, inl):
+        r = DevRansacResult.from_buffer_copy(res.cpu().numpy().tobytes())
+        return (np.array(r.T[:]), r.n_inliers, r.num_success, r.max_inliers, r.failed, r.n, r.winner, inl[:r.n_inliers].cpu().numpy())
+    res = torch.zeros(C.sizeof(DevRansacResult), dtype=torch.uint8, device=dev); inl = torch.zeros(n, dtype=torch.int32, device=dev)
+    _lib.check(L.pcreg_dev_ransac(_p(t1), _p(t2), _p(nd), n, n, C.byref(o), None, _p(res), _p(inl), _p(ws), C.c_size_t(ws.numel()), _stream()))
+    single = fetch(res, inl)
+    parts = []
+    for r in range(world):
+        begin, count = hypothesis_share(iters, r, world)
+        part = torch.zeros(14, dtype=torch.int64, device=dev)
+        _lib.check(L.pcreg_dev_ransac_partial(_p(t1), _p(t2), _p(nd), n, n, C.byref(o), None, begin, count, _p(part), _p(ws),
+                                              C.c_size_t(ws.numel()), _stream()))
+        parts.append(part.cpu())
+    keys = [int(p[0]) for p in parts]
+    win = int(np.argmax(keys))
+    comb = parts[win].clone()
+    ns_has = comb[1:2].view(torch.int32)
+    ns_has[0] = sum(int(p[1:2].view(torch.int32)[0]) for p in parts)
+    comb = comb.to(dev)
+    res2 = torch.zeros_like(res); inl2 = torch.zeros_like(inl)
+    _lib.check(L.pcreg_dev_ransac_finish(_p(t1), _p(t2), _p(nd), n, n, C.byref(o), _p(comb), _p(res2), _p(inl2), _stream()))
+    split = fetch(res2, inl2)
+    assert not single[4]
+    for a, b in zip(single, split):
+        np.testing.assert_array_equal(a, b)

@@ -129,3 +129,68 @@ def test_world1_is_a_no_op_protocol():
     sm = ShardedMatcher(OracleOps(len(surf)), len(surf), len(model), 0, len(model))
     pairs, p1, p2, n = sm.match(torch.from_numpy(np.ascontiguousarray(surf.T)), torch.from_numpy(np.ascontiguousarray(model.T)), 0.5, 0.8, True)
     np.testing.assert_array_equal(pairs.numpy()[:int(n)].astype(np.uint32), c_oracle.match_points_f32(surf, model, 0.5, 0.8, True))
+
+
+# ---- one registration's hypotheses split over the ranks (pcreg_amd.sharded.combine_ransac_parts) ----
+def _ransac_case():
+    from conftest import rigid_case
+    p1, p2, _ = rigid_case(400, 31, noise=0.02, outlier_frac=0.4)
+    coef = dict(minPtNum=3, iterNum=501, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)     # 501: uneven shares
+    return p1, p2, coef
+
+
+def _ransac_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import c_oracle, pcreg_oracle as o
+    from pcreg_amd.sharded import combine_ransac_parts, hypothesis_share
+    p1, p2, coef = _ransac_case()
+    table = o.sample_table(len(p1), coef["iterNum"], 3, 17)                      # the global sampler stream
+    begin, count = hypothesis_share(coef["iterNum"], rank, world)
+    # this rank's share, by the oracle: counts of its hypotheses, local first maximum, its transform
+    r = c_oracle.ransac(p1, p2, dict(coef, iterNum=count), sample_idx=table[begin:begin + count])
+    counts = r["inlrNum_refined"]
+    thInlr = o.matlab_round(coef["thInlrRatio"] * len(p1))
+    w = int(np.argmax(counts))
+    key = (int(counts[w]) << 32) | (0xFFFFFFFF - (begin + w))
+    has = 0.0 if r["failed"] else 1.0
+    T12 = np.zeros(12) if r["failed"] else np.concatenate([np.append(r["T"][:3, j], r["T"][3, j]) for j in range(3)])
+    k, ns, hT = combine_ransac_parts(torch.tensor([key], dtype=torch.int64), torch.tensor([int((counts >= thInlr).sum())], dtype=torch.int64),
+                                     torch.from_numpy(np.concatenate([[has], T12])))
+    np.savez(os.path.join(out_dir, f"ransac{rank}.npz"), key=k.numpy(), ns=ns.numpy(), hT=hT.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ransac_hypotheses_split_over_two_ranks(tmp_path):
+    from oracle import c_oracle, pcreg_oracle as o
+    c_oracle.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_ransac_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p1, p2, coef = _ransac_case()
+    ref = c_oracle.ransac(p1, p2, coef, sample_idx=o.sample_table(len(p1), coef["iterNum"], 3, 17))
+    assert not ref["failed"]
+    for r in range(2):
+        z = np.load(tmp_path / f"ransac{r}.npz")
+        key = int(z["key"][0])
+        assert key >> 32 == ref["maxInliers"]
+        assert 0xFFFFFFFF - (key & 0xFFFFFFFF) == int(np.argmax(ref["inlrNum_refined"]))     # FIRST maximum, global index
+        assert int(z["ns"][0]) == ref["numSuccess"]
+        assert z["hT"][0] == 1.0
+        T = np.eye(4)
+        for j in range(3):
+            T[:3, j] = z["hT"][1 + 4 * j:4 + 4 * j]; T[3, j] = z["hT"][4 + 4 * j]
+        np.testing.assert_array_equal(T, ref["T"])                                 # the winner's transform, exactly
+
+
+def test_hypothesis_share_covers_everything():
+    from pcreg_amd.sharded import hypothesis_share
+    for iters in (1, 7, 8, 10000, 10001):
+        for world in (1, 2, 3, 8):
+            spans = [hypothesis_share(iters, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == iters
+            pos = 0
+            for b, c in spans:
+                assert b == min(pos, iters) and c >= 0
+                pos += c
