@@ -843,10 +843,10 @@ __global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a)
 // Counts are integers (order-free); the moments keep the tiled kernel's summation order
 // (lane-strided partial sums over all points, butterfly over the wave), so every number is
 // the one the fused kernels produce.
-constexpr int kSW = 4, kSS = 4;                 // scoring: waves per workgroup, 64-point slots per wave
-constexpr int kSPts = kSW * kSS * 64;           // 1024 correspondences per workgroup
+constexpr int kSW = 4, kSS = 8;                 // scoring: waves per workgroup, 64-point slots per wave
+constexpr int kSPts = kSW * kSS * 64;           // 2048 correspondences per workgroup
 constexpr int kSMaxPB = 64;                     // point blocks with a partial-count row each
-constexpr int kSChunk = 160;                    // hypotheses per workgroup
+constexpr int kSChunk = 80;                     // hypotheses per workgroup
 
 struct StagedArgs {
     RansacArgs a;
