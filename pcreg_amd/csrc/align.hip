@@ -3,9 +3,10 @@
 // AlignPoints_KNN.m:17-59, one workgroup per support region:
 //   :17     centroid                                   -> block reduction
 //   :20-26  keep the K = round(0.85 N) points nearest to the centroid.  The reference
-//           does a full stable sort; only the K-th order statistic is needed, so this
-//           kernel runs a bisection SELECT on the distance bit patterns held in LDS (select_kth.hpp)
-//           and resolves ties at the boundary by lowest index (= stable sort order)
+//           does a full stable sort; only the K-th order statistic is needed: one 256-bin
+//           histogram over [min, max] of the distances held in LDS + an exact rank inside the
+//           bin that holds the K-th (bisection, select_kth.hpp, only if that bin is crowded);
+//           ties at the boundary go to the lowest indices (= stable sort order)
 //   :30-34  pca(...,'Algorithm','eig')                 -> 3x3 covariance + Jacobi, then
 //           MathWorks' sign convention (largest-|.| entry of each column positive)
 //   :37-56  majority-sign disambiguation, y from det   -> block reduction of counts
@@ -67,17 +68,36 @@ __device__ void jacobi_eig3(double (&A)[3][3], double (&V)[3][3]) {
     }
 }
 
+// N sums at once: per value the wave butterfly, then ((w0+w1)+w2)+w3 -- block_sum's order, one barrier pair
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double* s_redn /*[4][N]*/) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum_d(v[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) s_redn[(threadIdx.x >> 6) * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = ((s_redn[k] + s_redn[N + k]) + s_redn[2 * N + k]) + s_redn[3 * N + k];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
     const double* __restrict__ pts, int ld, const int32_t* __restrict__ offsets, int C1, int C2,
     double* __restrict__ aligned, int ld_out, double* __restrict__ coeff_out, double* __restrict__ c_out,
     int32_t* __restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) double sd[];    // n distances, later selection flags
-    __shared__ double s_red[4];
+    extern __shared__ __attribute__((aligned(16))) double sd[];    // n distances to the centroid (their bit patterns order them)
+    __shared__ double s_redn[4 * 6];
     __shared__ int s_redi[4];
     __shared__ unsigned long long s_u64[8];
     __shared__ double s_cu[9];       // coeff_unambig, row-major [r][col]
     __shared__ double s_coeff[9];
-    __shared__ int s_base;
+    constexpr int kSmall = 256;
+    __shared__ unsigned long long s_small[kSmall];
+    __shared__ int s_hist[256];
+    __shared__ unsigned long long s_vk;
+    __shared__ int s_nsmall, s_bin, s_below, s_nless, s_neq, s_base;
 
     const int b = blockIdx.x;
     const int off = offsets[b];
@@ -86,57 +106,132 @@ __global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
     const double* px = pts + off; const double* py = px + (size_t)ld; const double* pz = py + (size_t)ld;
     if (n < 2) { if (tid == 0) status[b] = 1; return; }
 
-    // --- 1) centroid (:17)
-    double sx = 0, sy = 0, sz = 0;
-    for (int i = tid; i < n; i += kBlock) { sx += px[i]; sy += py[i]; sz += pz[i]; }
-    const double cx = block_sum(sx, s_red) / n, cy = block_sum(sy, s_red) / n, cz = block_sum(sz, s_red) / n;
+    // A pass over the support: thread t visits i = t, t + 256, ... in order; four points' loads are issued
+    // before the first is used (the support is L2-resident, the passes are latency-bound).
+#define PCREG_AL_PTS(...)                                                                       \
+    for (int i0_ = tid; i0_ < n; i0_ += 4 * kBlock) {                                           \
+        double X_[4], Y_[4], Z_[4];                                                             \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                      \
+            const int ii_ = min(i0_ + u_ * kBlock, n - 1);                                      \
+            X_[u_] = px[ii_]; Y_[u_] = py[ii_]; Z_[u_] = pz[ii_];                               \
+        }                                                                                       \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                      \
+            const int i = i0_ + u_ * kBlock;                                                    \
+            if (i < n) { const double x0 = X_[u_], y0 = Y_[u_], z0 = Z_[u_]; __VA_ARGS__ }      \
+        }                                                                                       \
+    }
 
-    // --- 2) distances to the centroid (:22-23) and radix select of the K-th smallest
+    // --- 1) centroid (:17)
+    double c3[3] = {0, 0, 0};
+    PCREG_AL_PTS(c3[0] += x0; c3[1] += y0; c3[2] += z0;)
+    block_sum_n<3>(c3, s_redn);
+    const double cx = c3[0] / n, cy = c3[1] / n, cz = c3[2] / n;
+
+    // --- 2) distances to the centroid (:22-23); K-th smallest by ONE 256-bin histogram over [min, max]
+    //        (the bin index is monotone in the distance) + an exact rank inside the bin that holds it
     const int K = (int)floor(n * 0.85 + 0.5);                                   // :20-21
-    for (int i = tid; i < n; i += kBlock) {
-        double x = px[i] - cx, y = py[i] - cy, z = pz[i] - cz;
-        sd[i] = sqrt(x * x + y * y + z * z);
+    unsigned long long lo = ~0ull, hi = 0ull;
+    PCREG_AL_PTS(const double x = x0 - cx; const double y = y0 - cy; const double z = z0 - cz;
+                 const double d = sqrt(x * x + y * y + z * z); sd[i] = d;
+                 const unsigned long long k = kth_key(d); lo = k < lo ? k : lo; hi = k > hi ? k : hi;)
+#pragma unroll
+    for (int ofs = 32; ofs > 0; ofs >>= 1) {
+        const unsigned long long a2 = __shfl_xor(lo, ofs), b2 = __shfl_xor(hi, ofs);
+        lo = a2 < lo ? a2 : lo; hi = b2 > hi ? b2 : hi;
+    }
+    if (lane == 0) { s_u64[wave] = lo; s_u64[4 + wave] = hi; }
+    for (int i = tid; i < 256; i += kBlock) s_hist[i] = 0;
+    if (tid == 0) { s_nsmall = 0; s_vk = 0ull; s_nless = 0; s_neq = 0; s_base = 0; }
+    __syncthreads();
+    lo = s_u64[0]; hi = s_u64[4];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { lo = s_u64[w] < lo ? s_u64[w] : lo; hi = s_u64[4 + w] > hi ? s_u64[4 + w] : hi; }
+    const double dlo = __longlong_as_double((long long)lo), dhi = __longlong_as_double((long long)hi);
+    const double scale = dhi > dlo ? 256.0 / (dhi - dlo) : 0.0;
+    auto bin_of = [&](double d) -> int { const int bb = (int)((d - dlo) * scale); return bb > 255 ? 255 : bb; };
+    for (int i = tid; i < n; i += kBlock) atomicAdd(&s_hist[bin_of(sd[i])], 1);
+    __syncthreads();
+    if (wave == 0) {
+        int c4[4], run = 0;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) { c4[q4] = s_hist[lane * 4 + q4]; run += c4[q4]; }
+        int incl = run;
+#pragma unroll
+        for (int ofs = 1; ofs < 64; ofs <<= 1) { const int t = __shfl_up(incl, ofs); if (lane >= ofs) incl += t; }
+        int before = incl - run;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if (before < K && K <= before + c4[q4]) { s_bin = lane * 4 + q4; s_below = before; }
+            before += c4[q4];
+        }
     }
     __syncthreads();
-    int n_less = 0;
-    const unsigned long long vK = block_select_kth(sd, n, K, s_u64, s_redi, &n_less);   // bit pattern of the K-th smallest distance
-    const int take_eq = K - n_less;              // how many of the ties at vK belong to the K nearest
-    // selection flags, ties by ascending index (stable sort order, :24)
-    if (tid == 0) s_base = 0;
+    const int bstar = s_bin, below = s_below;
+    for (int i = tid; i < n; i += kBlock) {
+        const double d = sd[i];
+        if (bin_of(d) == bstar) { const int q = atomicAdd(&s_nsmall, 1); if (q < kSmall) s_small[q] = kth_key(d); }
+    }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += kBlock) {
-        int i = i0 + tid;
-        unsigned long long key = i < n ? (unsigned long long)__double_as_longlong(sd[i]) : ~0ull;
-        bool eq = i < n && key == vK;
-        unsigned long long bal = __ballot(eq);
-        if (lane == 0) s_redi[wave] = __popcll(bal);
+    const int m = s_nsmall, Kp = K - below;
+    unsigned long long vK; int n_less, n_eq;
+    if (m <= kSmall) {
+        for (int t = tid; t < m; t += kBlock) {
+            const unsigned long long x = s_small[t];
+            int less = 0, eq = 0;
+            for (int u = 0; u < m; ++u) { const unsigned long long yv = s_small[u]; less += yv < x; eq += yv == x; }
+            if (less < Kp && Kp <= less + eq) { s_vk = x; s_nless = below + less; s_neq = eq; }     // every writer writes the same
+        }
         __syncthreads();
-        int rank = s_base;
-        for (int w = 0; w < wave; ++w) rank += s_redi[w];
-        rank += __popcll(bal & ((1ull << lane) - 1ull));
-        bool sel = i < n && (key < vK || (eq && rank < take_eq));
+        vK = s_vk; n_less = s_nless; n_eq = s_neq;
+    } else {                                         // crowded bin (many equal distances): bisection on the keys
+        vK = block_select_kth(sd, n, K, s_u64, s_redi, &n_less);
+        int c2 = 0;
+        for (int i = tid; i < n; i += kBlock) c2 += kth_key(sd[i]) == vK;
+        n_eq = block_sum_i(c2, s_redi);
+    }
+    const int take_eq = K - n_less;              // how many of the ties at vK belong to the K nearest
+    // selection flags; ties at the K-th distance by ascending index (stable sort order, :24) -- ranked only
+    // when the boundary really splits a group of equal distances
+    if (n_eq == take_eq) {
         __syncthreads();
-        if (i < n) sd[i] = sel ? 1.0 : 0.0;
-        if (tid == 0) s_base += s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
+        for (int i = tid; i < n; i += kBlock) sd[i] = kth_key(sd[i]) <= vK ? 1.0 : 0.0;
         __syncthreads();
+    } else {
+        for (int i0 = 0; i0 < n; i0 += kBlock) {
+            int i = i0 + tid;
+            unsigned long long key = i < n ? kth_key(sd[i]) : ~0ull;
+            bool eq = i < n && key == vK;
+            unsigned long long bal = __ballot(eq);
+            if (lane == 0) s_redi[wave] = __popcll(bal);
+            __syncthreads();
+            int rank = s_base;
+            for (int w = 0; w < wave; ++w) rank += s_redi[w];
+            rank += __popcll(bal & ((1ull << lane) - 1ull));
+            bool sel = i < n && (key < vK || (eq && rank < take_eq));
+            __syncthreads();
+            if (i < n) sd[i] = sel ? 1.0 : 0.0;
+            if (tid == 0) s_base += s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
+            __syncthreads();
+        }
     }
 
     // --- 3) pca of the K selected, centroid-relative points (:30-34)
     double mx = 0, my = 0, mz = 0;
     if (!C1) {
-        double ax = 0, ay = 0, az = 0;
-        for (int i = tid; i < n; i += kBlock) if (sd[i] != 0.0) { ax += px[i] - cx; ay += py[i] - cy; az += pz[i] - cz; }
-        mx = block_sum(ax, s_red) / K; my = block_sum(ay, s_red) / K; mz = block_sum(az, s_red) / K;
+        double a3[3] = {0, 0, 0};
+        PCREG_AL_PTS(if (sd[i] != 0.0) { a3[0] += x0 - cx; a3[1] += y0 - cy; a3[2] += z0 - cz; })
+        block_sum_n<3>(a3, s_redn);
+        mx = a3[0] / K; my = a3[1] / K; mz = a3[2] / K;
     }
     double cv[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < n; i += kBlock) if (sd[i] != 0.0) {
-        double x = (px[i] - cx) - mx, y = (py[i] - cy) - my, z = (pz[i] - cz) - mz;
-        cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z;
-    }
+    PCREG_AL_PTS(if (sd[i] != 0.0) {
+        const double x = (x0 - cx) - mx; const double y = (y0 - cy) - my; const double z = (z0 - cz) - mz;
+        cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z; })
     double dof = C1 ? (double)K : (double)(K - 1);
     if (dof < 1.0) dof = 1.0;
+    block_sum_n<6>(cv, s_redn);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) cv[k] = block_sum(cv[k], s_red) / dof;
+    for (int k = 0; k < 6; ++k) cv[k] = cv[k] / dof;
     if (tid == 0) {
         double A[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
         double V[3][3];
@@ -163,17 +258,15 @@ __global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
 
     // --- sign disambiguation (:37-56)
     int posx = 0, posz = 0;
-    for (int i = tid; i < n; i += kBlock) {
+    PCREG_AL_PTS(
         if (C2) {
-            double x = px[i], y = py[i], z = pz[i];
-            posx += (x * co[0] + y * co[3] + z * co[6]) > 0;
-            posz += (x * co[2] + y * co[5] + z * co[8]) > 0;
+            posx += (x0 * co[0] + y0 * co[3] + z0 * co[6]) > 0;
+            posz += (x0 * co[2] + y0 * co[5] + z0 * co[8]) > 0;
         } else if (sd[i] != 0.0) {
-            double x = (px[i] - cx) - mx, y = (py[i] - cy) - my, z = (pz[i] - cz) - mz;
+            const double x = (x0 - cx) - mx; const double y = (y0 - cy) - my; const double z = (z0 - cz) - mz;
             posx += (x * co[0] + y * co[3] + z * co[6]) > 0;
             posz += (x * co[2] + y * co[5] + z * co[8]) > 0;
-        }
-    }
+        })
     posx = block_sum_i(posx, s_redi); posz = block_sum_i(posz, s_redi);
     if (tid == 0) {
         double xs = (2.0 * posx >= (double)n) ? 1.0 : -1.0;                    // :45,49 with k = N (:37)
@@ -191,12 +284,11 @@ __global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
 #pragma unroll
     for (int k = 0; k < 9; ++k) cu[k] = s_cu[k];
     double* ox = aligned + off; double* oy = ox + (size_t)ld_out; double* oz = oy + (size_t)ld_out;
-    for (int i = tid; i < n; i += kBlock) {                                    // :59
-        double x = px[i], y = py[i], z = pz[i];
-        ox[i] = x * cu[0] + y * cu[3] + z * cu[6];
-        oy[i] = x * cu[1] + y * cu[4] + z * cu[7];
-        oz[i] = x * cu[2] + y * cu[5] + z * cu[8];
-    }
+    PCREG_AL_PTS(                                                               // :59
+        ox[i] = x0 * cu[0] + y0 * cu[3] + z0 * cu[6];
+        oy[i] = x0 * cu[1] + y0 * cu[4] + z0 * cu[7];
+        oz[i] = x0 * cu[2] + y0 * cu[5] + z0 * cu[8];)
+#undef PCREG_AL_PTS
 }
 
 }  // namespace
