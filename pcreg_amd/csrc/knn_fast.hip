@@ -584,10 +584,12 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
         d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
     }
     // certificate
-    const float G = ord2f(gthr[qi]);
+    const unsigned gword = gthr[qi];
+    const float G = ord2f(gword);
     bool ok;
     if (M <= 2) ok = (i1 >= 0) && (M < 2 || i2 >= 0);          // nothing outside the lists when M <= KC (handled below too)
-    else if (!(G < INFINITY)) ok = true;                         // no chunk ever filled its list: every point is a candidate
+    else if (gword == 0xFFFFFFFFu) ok = true;                    // never published, never seeded: nothing was skipped, every point is a candidate
+    else if (!(G < INFINITY)) ok = false;                        // a published +inf (scores overflowed): no bound, redo exactly
     else {
         double lower = (double)G + r2;
         double E = Eab + 16.0 * u * ((double)d2 + fabs(lower));
