@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __res
     }
 }
 __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, int M, int cell_cap, Prep* __restrict__ prep,
-                                  unsigned* __restrict__ rm2_bits) {
+                                  unsigned* __restrict__ rm2_bits, int32_t* __restrict__ n_flag) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = threadIdx.x; b < nparts; b += 64)              // launched with one wave
         for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
@@ -105,6 +105,7 @@ __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, in
         prep->gx0 = lo[0]; prep->gy0 = lo[1]; prep->gz0 = lo[2]; prep->inv_h = 1.0f / h;
         prep->nx = n[0]; prep->ny = n[1]; prep->nz = n[2]; prep->ncell = n[0] * n[1] * n[2];
         *rm2_bits = 0u;
+        *n_flag = 0;                                   // (saves a memset launch)
     }
 }
 // ---- 1b. model -> {m~, |m~|^2}; R_m^2 by atomicMax on the (non-negative) float bits ----
@@ -742,8 +743,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
 
     int nb = (M + Q + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2);
-    PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2, n_flag);
     int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0;
     static const bool no_seed = getenv("PCREG_KNN_NOSEED") && atoi(getenv("PCREG_KNN_NOSEED")) != 0;
     if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)

@@ -242,8 +242,8 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
     S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
     *S_out = S;
-    PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * KC * 4, st));      // -1: empty slots
-    if (M <= 0) return PCREG_OK;
+    // every (chunk, query) slot is written by the kernel; only an empty model leaves the lists untouched
+    if (M <= 0) { PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * KC * 4, st)); return PCREG_OK; }
     int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 512) pb = 512;
     hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2);
 #define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks, S), dim3(kBlock), 0, st, q, Q, ldq, \

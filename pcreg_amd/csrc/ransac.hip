@@ -959,6 +959,7 @@ __global__ void rs_pass1_kernel(StagedArgs sa) {
     const int n = staged_n(a);
     const int thInlr = matlab_round_i(a.ratio * (double)n);
     int c = 0;
+#pragma unroll 8
     for (int pb = 0; pb < sa.pb; ++pb) c += sa.part[(size_t)pb * a.iters + h];
     const bool v = sa.v1[h] != 0;
     if (!v) c = 0;
@@ -1087,6 +1088,7 @@ __global__ void rs_finish_kernel(StagedArgs sa) {
     const int n = staged_n(a);
     const int thInlr = matlab_round_i(a.ratio * (double)n);
     int c = 0;
+#pragma unroll 8
     for (int pb = 0; pb < sa.pb; ++pb) c += sa.part[(size_t)pb * a.iters + h];
     const bool v = sa.v2[h] != 0;
     a.cnt2[h] = v ? c : 0;
