@@ -290,26 +290,33 @@ __device__ bool fit_3pt(const double (&A1)[3][3], const double (&A2)[3][3], doub
 //   mom[0..2]  = sum(d')      mom[3..5] = sum(m')            (d' = p1-o1, m' = p2-o2)
 //   mom[6..14] = sum(m'_i d'_j), row-major i,j
 //   mom[15..20]= raw Gram of p1 (xx,xy,xz,yy,yz,zz), mom[21..26] = raw Gram of p2.
-__device__ __forceinline__ void mom_accumulate(double (&mom)[27], const double (&p)[6],
-                                               const double (&o)[6]) {
+__device__ __forceinline__ void mom_core(double (&mom)[27], const double (&p)[6], const double (&o)[6]) {
     double d0 = p[0] - o[0], d1 = p[1] - o[1], d2 = p[2] - o[2];
     double m0 = p[3] - o[3], m1 = p[4] - o[4], m2 = p[5] - o[5];
     mom[0] += d0; mom[1] += d1; mom[2] += d2; mom[3] += m0; mom[4] += m1; mom[5] += m2;
     mom[6]  = fma(m0, d0, mom[6]);  mom[7]  = fma(m0, d1, mom[7]);  mom[8]  = fma(m0, d2, mom[8]);
     mom[9]  = fma(m1, d0, mom[9]);  mom[10] = fma(m1, d1, mom[10]); mom[11] = fma(m1, d2, mom[11]);
     mom[12] = fma(m2, d0, mom[12]); mom[13] = fma(m2, d1, mom[13]); mom[14] = fma(m2, d2, mom[14]);
+}
+// the raw Grams only feed the rank test of estimateTransform.m:11-14
+__device__ __forceinline__ void mom_gram(double (&mom)[27], const double (&p)[6]) {
     mom[15] = fma(p[0], p[0], mom[15]); mom[16] = fma(p[0], p[1], mom[16]); mom[17] = fma(p[0], p[2], mom[17]);
     mom[18] = fma(p[1], p[1], mom[18]); mom[19] = fma(p[1], p[2], mom[19]); mom[20] = fma(p[2], p[2], mom[20]);
     mom[21] = fma(p[3], p[3], mom[21]); mom[22] = fma(p[3], p[4], mom[22]); mom[23] = fma(p[3], p[5], mom[23]);
     mom[24] = fma(p[4], p[4], mom[24]); mom[25] = fma(p[4], p[5], mom[25]); mom[26] = fma(p[5], p[5], mom[26]);
 }
+__device__ __forceinline__ void mom_accumulate(double (&mom)[27], const double (&p)[6],
+                                               const double (&o)[6]) {
+    mom_core(mom, p, o);
+    mom_gram(mom, p);
+}
 
 // estimateTransform for N > 3 correspondences given their moments.
-__device__ bool fit_moments(int N, const double (&mom)[27], const double (&o)[6], double (&T)[12]) {
+__device__ bool fit_moments(int N, const double (&mom)[27], const double (&o)[6], double (&T)[12], bool rank_certified = false) {
     if (N < 4) return false;
     double g1[6] = {mom[15], mom[16], mom[17], mom[18], mom[19], mom[20]};
     double g2[6] = {mom[21], mom[22], mom[23], mom[24], mom[25], mom[26]};
-    if (!rank_gram_at_least(g1, N, 3) || !rank_gram_at_least(g2, N, 2)) return false;   // :11-14
+    if (!rank_certified && (!rank_gram_at_least(g1, N, 3) || !rank_gram_at_least(g2, N, 2))) return false;   // :11-14
     double inv = 1.0 / (double)N;
     double cdp[3] = {mom[0] * inv, mom[1] * inv, mom[2] * inv};
     double cmp_[3] = {mom[3] * inv, mom[4] * inv, mom[5] * inv};
@@ -851,12 +858,36 @@ constexpr int kSChunk = 80;                     // hypotheses per workgroup
 struct StagedArgs {
     RansacArgs a;
     double* T1; unsigned char* v1; unsigned char* pass1; unsigned char* v2;
+    unsigned char* cert;         // rank of the inlier set certified from the sample alone (rs_fit1)
+    double* bounds;              // [2]: max |pts1 row|, max |pts2 row|
     double* mom;                 // [iters][27]
     int32_t* part;               // [kSMaxPB][iters]
     int pb;                      // point blocks in use
 };
 
 __device__ __forceinline__ int staged_n(const RansacArgs& a) { return min(a.n_dev ? *a.n_dev : a.n_cap, a.n_cap); }
+
+// max row norms of both point sets: the only global quantity the rank certificate needs
+__global__ __launch_bounds__(1024) void rs_bounds_kernel(StagedArgs sa) {
+    const RansacArgs& a = sa.a;
+    const int n = staged_n(a);
+    __shared__ double s1[16], s2[16];
+    double m1 = 0.0, m2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        double x = a.p1[i], y = a.p1[i + (size_t)a.ld], z = a.p1[i + 2 * (size_t)a.ld];
+        m1 = fmax(m1, x * x + y * y + z * z);
+        x = a.p2[i]; y = a.p2[i + (size_t)a.ld]; z = a.p2[i + 2 * (size_t)a.ld];
+        m2 = fmax(m2, x * x + y * y + z * z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m1 = fmax(m1, __shfl_xor(m1, o)); m2 = fmax(m2, __shfl_xor(m2, o)); }
+    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = m1; s2[threadIdx.x >> 6] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) { m1 = fmax(m1, s1[w]); m2 = fmax(m2, s2[w]); }
+        sa.bounds[0] = sqrt(m1) * (1.0 + 1e-12); sa.bounds[1] = sqrt(m2) * (1.0 + 1e-12);
+    }
+}
 
 __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
     const RansacArgs& a = sa.a;
@@ -866,7 +897,7 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
     double T1[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T1[k] = 0.0;
-    bool v1 = false;
+    bool v1 = false, cert = false;
     if (n >= a.m && n >= 3) {
         Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
         if (a.m == 3) {
@@ -879,6 +910,36 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
                 A2[j][0] = q[3]; A2[j][1] = q[4]; A2[j][2] = q[5];
             }
             v1 = fit_3pt(A1, A2, T1);
+            // Rank certificate for the refit (estimateTransform.m:11-14 on the INLIER rows): the three sample
+            // points are inliers of their own fit, and deleting rows cannot raise a singular value, so
+            // sigma_3(pts1(inliers)) >= sigma_3(sample) >= 2 |det| / |A|_F^2 and sigma_2(pts2(inliers)) >=
+            // (largest 2x2 minor) / |A|_F.  MATLAB's tolerance is N eps(sigma_1) <= N^1.5 2^-52 max|row|.
+            // With a factor 4 to spare the refit may skip the twelve Gram sums and the rank test.
+            if (v1 && a.refine) {
+                bool all_in = true;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double q[6] = {A1[j][0], A1[j][1], A1[j][2], A2[j][0], A2[j][1], A2[j][2]};
+                    all_in = all_in && sqdist(q, T1) < a.thDist;
+                }
+                const double nn = (double)n, tolf = 4.0 * nn * sqrt(nn) * 2.220446049250313e-16;
+                double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { f1 = fma(A1[j][c], A1[j][c], f1); f2 = fma(A2[j][c], A2[j][c], f2); }
+                const double det1 = A1[0][0] * (A1[1][1] * A1[2][2] - A1[1][2] * A1[2][1]) - A1[0][1] * (A1[1][0] * A1[2][2] - A1[1][2] * A1[2][0])
+                                  + A1[0][2] * (A1[1][0] * A1[2][1] - A1[1][1] * A1[2][0]);
+                double mm = 0.0;
+#pragma unroll
+                for (int r0 = 0; r0 < 3; ++r0)
+#pragma unroll
+                    for (int c0 = 0; c0 < 3; ++c0) {
+                        const int r1 = (r0 + 1) % 3, c1 = (c0 + 1) % 3;
+                        mm = fmax(mm, fabs(A2[r0][c0] * A2[r1][c1] - A2[r0][c1] * A2[r1][c0]));
+                    }
+                cert = all_in && f1 > 0.0 && f2 > 0.0 && (2.0 * fabs(det1) / f1 > tolf * sa.bounds[0]) && (mm / sqrt(f2) > tolf * sa.bounds[1]);
+            }
         } else {
             double mom[27];
 #pragma unroll
@@ -900,6 +961,7 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) sa.T1[(size_t)p * 12 + k] = T1[k];
     sa.v1[p] = v1;
+    sa.cert[p] = cert;
 }
 
 // grid (point blocks, hypothesis chunks).  part[pb][h] = inliers of hypothesis h among this block's points.
@@ -993,22 +1055,23 @@ __global__ __launch_bounds__(kTBlock) void rs_moments_kernel(StagedArgs sa) {
     double T1[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T1[k] = 0.0;
-    int c1 = 0; bool pass = false;
+    int c1 = 0; bool pass = false; int certified = 0;
     if (lane < nh) {
         const int h = wbase + lane;
-        pass = sa.pass1[h] != 0; c1 = a.cnt1[h];
+        pass = sa.pass1[h] != 0; c1 = a.cnt1[h]; certified = sa.cert[h];
 #pragma unroll
         for (int k = 0; k < 12; ++k) T1[k] = sa.T1[(size_t)h * 12 + k];
     }
     unsigned long long todo = __ballot(pass);
     while (__syncthreads_or(todo != 0)) {                           // every wave of the workgroup sweeps together
-        int hs[2]; bool want[2]; int ch[2];
+        int hs[2]; bool want[2], gram[2]; int ch[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             want[k] = todo != 0;
             hs[k] = want[k] ? __builtin_ctzll(todo) : 0;
             if (want[k]) todo &= todo - 1;
             ch[k] = __builtin_amdgcn_readlane(c1, hs[k]);
+            gram[k] = __builtin_amdgcn_readlane(certified, hs[k]) == 0;      // wave-uniform: the Gram sums only feed the rank test
         }
         double T[2][12];
 #pragma unroll
@@ -1024,7 +1087,7 @@ __global__ __launch_bounds__(kTBlock) void rs_moments_kernel(StagedArgs sa) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const bool in = (sqdist(q, T[k]) < th) & act & want[k];
-                if (in) mom_accumulate(acc[k], q, o);
+                if (in) { mom_core(acc[k], q, o); if (gram[k]) mom_gram(acc[k], q); }
                 if (any3 && ch[k] == 3 && want[k]) {     // estimateTransform's N == 3 branch needs the points themselves
                     unsigned long long bal = __ballot(in);
                     const int r3 = k3[k] + __popcll(bal & ((1ull << lane) - 1ull));
@@ -1073,7 +1136,7 @@ __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
                 for (int c = 0; c < 3; ++c) { A1[j][c] = mom[j * 6 + c]; A2[j][c] = mom[j * 6 + 3 + c]; }
             v2 = fit_3pt(A1, A2, T2);
         } else {
-            v2 = fit_moments(c1, mom, o, T2);
+            v2 = fit_moments(c1, mom, o, T2, sa.cert[h] != 0);
         }
     }
 #pragma unroll
@@ -1327,7 +1390,7 @@ __global__ void calc_dists_kernel(const double* T16, const double* p1, const dou
 // ---------------------------------------------------------------- launchers
 static size_t staged_extra_bytes(size_t h) {    // T1 | mom | part | v1 | pass1 | v2
     return align_up(h * 12 * sizeof(double), 256) + align_up(h * 27 * sizeof(double), 256) +
-           align_up(h * kSMaxPB * sizeof(int32_t), 256) + 3 * align_up(h, 256);
+           align_up(h * kSMaxPB * sizeof(int32_t), 256) + 4 * align_up(h, 256) + 256;
 }
 size_t ransac_workspace_bytes(int iters, int B) {
     size_t h = (size_t)iters * (size_t)B;
@@ -1372,7 +1435,9 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.part = (int32_t*)w; w += align_up(h * kSMaxPB * sizeof(int32_t), 256);
         sa.v1 = (unsigned char*)w; w += align_up(h, 256);
         sa.pass1 = (unsigned char*)w; w += align_up(h, 256);
-        sa.v2 = (unsigned char*)w;
+        sa.v2 = (unsigned char*)w; w += align_up(h, 256);
+        sa.cert = (unsigned char*)w; w += align_up(h, 256);
+        sa.bounds = (double*)w;
         int pb = (n_cap + kSPts - 1) / kSPts; if (pb > kSMaxPB) pb = kSMaxPB; if (pb < 1) pb = 1;
         sa.pb = pb;
         int hpw = (int)((total + 250LL * kTW - 1) / (250LL * kTW));
@@ -1382,6 +1447,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.a = a;
         const int it = o.iterNum;
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
+        hipLaunchKernelGGL(rs_bounds_kernel, dim3(1), dim3(1024), 0, st, sa);
         hipLaunchKernelGGL(rs_fit1_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
         hipLaunchKernelGGL(rs_score_kernel, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
         hipLaunchKernelGGL(rs_pass1_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);

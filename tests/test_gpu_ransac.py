@@ -191,7 +191,7 @@ def test_generic_handles_run_on_host():
     assert abs(f[0, 0] - 2) < 0.01 and abs(f[1, 0] - 1) < 0.05 and mi >= 150
 
 
-@pytest.mark.parametrize("case", ["clean", "outliers", "norefine", "min4", "three_inliers"])
+@pytest.mark.parametrize("case", ["clean", "outliers", "norefine", "min4", "three_inliers", "planar_pts1", "planar_pts2"])
 def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypatch):
     """n >= 4096 runs the staged chain (rs_fit1 / rs_score / rs_moments / rs_fit2); PCREG_RANSAC_FUSED=1
     selects the fused tiled kernel.  Both must reproduce the oracle's counts and inlier set."""
@@ -216,6 +216,10 @@ def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypa
             p1[3 * g:3 * g + 3] = p2[3 * g:3 * g + 3] @ R + t
         table = (np.arange(iters)[:, None] * 3 + np.arange(3)[None, :] + 1).astype(np.int32)
         coef.update(thDist=1e-6, thInlrRatio=0.0005)
+    if case == "planar_pts1":            # rank(pts1) = 2 for every subset: estimateTransform returns [] (:11-14), nothing is found
+        p1 = p1.copy(); p1[:, 2] = 0.0
+    if case == "planar_pts2":            # rank(pts2) = 2 is still allowed (needs >= 2): fits exist, few inliers
+        p2 = p2.copy(); p2[:, 2] = 0.0
     ref = oracle_c.ransac(p1, p2, coef, sample_idx=table, seed=21)
     out = {}
     for mode in ("staged", "fused"):
@@ -231,6 +235,8 @@ def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypa
             assert np.linalg.norm(res[0] - ref["T"]) < T_TOL, mode
     a, b = out["staged"], out["fused"]
     np.testing.assert_array_equal(a[0], b[0])            # the two GPU paths agree to the last bit
+    if case == "planar_pts1":
+        assert ref["failed"] and a[0].size == 0
     if case == "three_inliers":
         assert (ref["inlrNum"] == 3).sum() > 100          # the N == 3 refit branch really ran
 
