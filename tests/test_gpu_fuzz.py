@@ -71,3 +71,58 @@ def test_match_features_sad_fuzz(seed, oracle_c):
             rp, rm = oracle_c.matchFeatures(dS, dM, kw)
             np.testing.assert_array_equal(pairs, rp, err_msg=f"Q={Q} M={M} D={D} {kw}")
             np.testing.assert_array_equal(met, rm)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_align_points_knn_fuzz(seed, oracle_c):
+    """Supports with heavy ties at the K-th distance (lattices, duplicates, shells), tiny and large sizes:
+    the selection (histogram + exact rank, crowded-bin bisection, tie ranks) must pick the oracle's rows."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(3000 + seed)
+    sups = []
+    for _ in range(40):
+        n = int(rng.choice([2, 3, 5, 64, 257, 1000, 3000, 7000]))
+        kind = rng.choice(["gauss", "lattice", "dupes", "shell", "allsame"])
+        if kind == "gauss":
+            X = rng.normal(size=(n, 3)) * rng.uniform(0.1, 5, 3) + rng.uniform(-100, 100, 3)
+        elif kind == "lattice":
+            X = rng.integers(-2, 3, (n, 3)).astype(float)
+        elif kind == "dupes":
+            base = rng.normal(size=(max(n // 4, 1), 3)); X = base[rng.integers(0, len(base), n)]
+        elif kind == "shell":                     # every point (nearly) equidistant from the centroid: one crowded bin
+            v = rng.normal(size=(n, 3)); X = v / np.linalg.norm(v, axis=1, keepdims=True) * 2.0
+        else:
+            X = np.tile(rng.normal(size=(1, 3)), (n, 1))
+        sups.append(X)
+    al, co, c, status = pc.AlignPoints_KNN_batched(sups)
+    for b, X in enumerate(sups):
+        if status[b]:
+            continue
+        ral, rco, rc = oracle_c.AlignPoints_KNN(X)
+        if not np.isfinite(rco).all():
+            continue
+        assert np.abs(c[b] - rc).max() < 1e-9
+        # degenerate covariances (lattice / identical points) make eigenvectors non-unique: compare what is determined
+        ev = np.linalg.eigvalsh(np.cov((X - X.mean(0)).T)) if len(X) > 1 else np.zeros(3)
+        if ev.min() > 1e-9 and np.min(np.diff(np.sort(ev))) > 1e-6 * ev.max():
+            assert np.abs(co[b] - rco).max() < 1e-7, (b, len(X))
+            assert np.abs(al[b] - ral).max() < 1e-6 * (1 + np.abs(X).max()), (b, len(X))
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_descriptors_fuzz(seed, oracle_c):
+    """Descriptor counts vs the oracle on clouds with duplicated points (ties at the K-th distance) and
+    different densities / option sets."""
+    import pcreg_amd as pc
+    from test_gpu_descriptors import OPT, keypoints, strips
+    rng = np.random.default_rng(4000 + seed)
+    for _ in range(3):
+        base = strips(int(rng.choice([12000, 30000])), int(rng.integers(0, 100)))
+        pts = np.vstack([base, base[::int(rng.choice([2, 3, 5]))]]) if rng.random() < 0.6 else base
+        kp = keypoints(int(rng.choice([40, 150])), int(rng.integers(0, 100)))
+        opt = dict(OPT, min_pts=int(rng.choice([50, 150])), k=float(rng.choice([0.85, 0.6, 0.95])), ALIGN_POINTS=bool(rng.integers(0, 2)),
+                   R=float(rng.choice([2.5, 3.5])))
+        feat, desc = pc.getSpacialHistogramDescriptors(pts, kp, opt)
+        rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(pts, kp, opt)
+        np.testing.assert_array_equal(feat, rfeat)
+        np.testing.assert_array_equal(desc, rdesc)
