@@ -136,6 +136,9 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step(None)
+    import ctypes as C
+    from pcreg_amd._lib import lib as _pclib
+    _pclib().pcreg_dev_search_kernel_timing(1)       # HIP events around the dominant kernel, on its launch stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -150,7 +153,11 @@ def main() -> None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    knn_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))           # the whole search call
+    kms, kn = C.c_float(0.0), C.c_int(0)
+    _pclib().pcreg_dev_search_kernel_ms(C.byref(kms), C.byref(kn))
+    _pclib().pcreg_dev_search_kernel_timing(0)
+    kernel_ms = float(kms.value) if kn.value > 0 else knn_ms                # knn_candidates_f16_kernel alone
     res = pipe.fetch_result()
     n_pairs = int(pipe.n_pairs.item())
 
@@ -158,11 +165,12 @@ def main() -> None:
         pairs_per_step = float(Q) * float(M_total)
         value = pairs_per_step * args.steps / elapsed / 1e9
         # The search runs its dot products on the f16 matrix cores (knn_mfma16.hip): price it against THAT peak,
-        # with the flops of the algorithm it executes (15 k-slots per pair), over the whole search call
-        # (bbox + seeding + prep + candidates + exact re-rank), HIP events on the launch stream.
+        # with the flops of the algorithm it executes (15 k-slots per pair), over the average duration of the
+        # dominant kernel (knn_candidates_f16_kernel), measured live with HIP events on its launch stream
+        # (pcreg_dev_search_kernel_ms; rocprofv3's average for that kernel in profiles/ agrees).
         knn_flops = FLOP_PER_PAIR_MFMA * float(Q) * float(M_local)
-        achieved = knn_flops / (knn_ms * 1e-3) / 1e12
-        fp32_equiv = FLOP_PER_PAIR * float(Q) * float(M_local) / (knn_ms * 1e-3) / 1e12
+        achieved = knn_flops / (kernel_ms * 1e-3) / 1e12
+        fp32_equiv = FLOP_PER_PAIR * float(Q) * float(M_local) / (kernel_ms * 1e-3) / 1e12
         alg_bytes = 4.0 * 3 * (Q + M_local) + 16.0 * Q
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -180,16 +188,17 @@ def main() -> None:
                                    f"top-2 + threshold/ratio/Unique + RANSAC(3,1e4,0.3,0.08,REFINE)",
                        "surface_points": Q, "model_points_total": M_total, "parallelism": f"model-shard x{world}"},
             "registrations_per_s": round(args.steps / elapsed, 2),
-            "knn_kernel": {"ms": round(knn_ms, 4), "gpairs_per_s_per_gpu": round(Q * M_local / (knn_ms * 1e-3) / 1e9, 1)},
+            "knn_kernel": {"ms": round(kernel_ms, 4), "search_call_ms": round(knn_ms, 4), "launches_timed": int(kn.value),
+                           "gpairs_per_s_per_gpu": round(Q * M_local / (knn_ms * 1e-3) / 1e9, 1)},
             "ransac": {"n_pairs": n_pairs, "max_inliers": res["maxInliers"], "num_success": res["numSuccess"],
                        "failed": res["failed"]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "note": "search call (knn_candidates_f16_kernel dominates): one v_mfma_f32_32x32x16_f16 per 32x32 "
+                         "note": "knn_candidates_f16_kernel (HIP events around each launch): one v_mfma_f32_32x32x16_f16 per 32x32 "
                                  "pairs, error-free f16 split, 30 useful flop/pair against the dense f16 matrix peak; the "
                                  "selection VALU (36 of every 66 issue cycles) cannot overlap the MFMA on one SIMD "
                                  "(scripts/ubench/mfma_f16_valu.hip), so this algorithm's ceiling is 0.45; in SURVEY 8d's "
-                                 f"fp32 terms (8 flop/pair) the call runs at {fp32_equiv:.0f} TFLOP/s = "
+                                 f"fp32 terms (8 flop/pair) the kernel runs at {fp32_equiv:.0f} TFLOP/s = "
                                  f"{fp32_equiv / PEAK_FP32_TFLOPS:.2f} x the fp32 vector peak; algorithmic HBM bytes "
                                  f"{alg_bytes / 1e6:.1f} MB -> {alg_bytes / (knn_ms * 1e-3) / 1e9:.1f} GB/s "
                                  f"({alg_bytes / (knn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS:.5f} of HBM peak): not HBM-bound",

@@ -226,6 +226,12 @@ int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_de
                      pcreg_dev_ransac_result* out, int32_t* inlier_idx,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement aid: with timing enabled, the candidates kernel of every (large) point search is
+ * bracketed by two HIP events on its launch stream; pcreg_dev_search_kernel_ms returns the mean
+ * duration over the launches since the previous call (it waits for them) and their number. */
+int pcreg_dev_search_kernel_timing(int enable);
+int pcreg_dev_search_kernel_ms(float* mean_ms, int* launches);
+
 /* One registration's hypotheses split over ranks (optional mode): every rank runs the
  * hypotheses [hyp_begin, hyp_begin + hyp_count) of a job of opts->iterNum -- the built-in sampler and the
  * first-maximum tie-break (ransac.m:70-72) use the GLOBAL hypothesis index, so the union over ranks is

@@ -58,6 +58,7 @@ SYMBOLS = [
     "pcreg_dev_filter_top2_f32", "pcreg_dev_unique_points_f32_workspace", "pcreg_dev_unique_points_f32",
     "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
     "pcreg_dev_ransac_partial", "pcreg_dev_ransac_finish",
+    "pcreg_dev_search_kernel_timing", "pcreg_dev_search_kernel_ms",
     "pcreg_dev_spatial_histogram_descriptors_workspace", "pcreg_dev_spatial_histogram_descriptors",
     "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
     "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select",

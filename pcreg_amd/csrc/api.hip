@@ -492,6 +492,14 @@ int pcreg_dev_ransac_finish(const double* pts1, const double* pts2, const int32_
     return launch_ransac_finish(pts1, pts2, ld, n_dev, n_cap, *opts, combined, out, inlier_idx, (hipStream_t)stream);
 }
 
+// live timing of the search's dominant kernel (HIP events on the launch stream), for bench.py's roofline
+int pcreg_dev_search_kernel_timing(int enable) { GUARD(); knn_f16_timing_enable(enable != 0); return PCREG_OK; }
+int pcreg_dev_search_kernel_ms(float* mean_ms, int* launches) {
+    PCREG_ARG(mean_ms && launches);
+    GUARD();
+    return knn_f16_timing_read(mean_ms, launches);
+}
+
 // ---- descriptor stage, resident (speedyDescriptors.m:59 -> getMatches -> ransac without leaving HBM)
 size_t pcreg_dev_spatial_histogram_descriptors_workspace(int P, int S) { return descriptors_workspace_bytes(P, S); }
 

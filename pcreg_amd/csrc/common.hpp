@@ -104,6 +104,8 @@ int launch_quick_tf(const double* pts, int n, int ld, const double T[16], double
 int launch_refine_by_distance(const double* p1, const double* p2, const int32_t* n_dev, int cap, int ld, double maxDist,
                               double* T16_dev, int32_t* info_dev, hipStream_t st);
 
+void knn_f16_timing_enable(bool on);
+int knn_f16_timing_read(float* mean_ms, int* launches);
 int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st);
 int launch_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featS, const double* featM,
                                double* pts1, double* pts2, hipStream_t st);

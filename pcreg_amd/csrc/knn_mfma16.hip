@@ -25,6 +25,8 @@
 #include "knn_fast_common.hpp"
 #include <hip/hip_fp16.h>
 #include <cstdlib>
+#include <vector>
+#include <utility>
 
 namespace pcreg {
 namespace {
@@ -226,6 +228,25 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
 
 }  // namespace
 
+// ---- live timing of the dominant kernel (bench.py's roofline line) --------------------------------
+// When enabled, the candidates kernel of every search is bracketed by two HIP events on the launch stream;
+// pcreg_dev_search_kernel_ms() returns the mean over the launches since the last call.
+static bool g_time_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_time_ev;
+static size_t g_time_used = 0;
+void knn_f16_timing_enable(bool on) { g_time_on = on; g_time_used = 0; }
+int knn_f16_timing_read(float* mean_ms, int* launches) {
+    double tot = 0.0; int n = 0;
+    for (size_t k = 0; k < g_time_used; ++k) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(g_time_ev[k].second) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, g_time_ev[k].first, g_time_ev[k].second) == hipSuccess) { tot += ms; ++n; }
+    }
+    g_time_used = 0;
+    *mean_ms = n ? (float)(tot / n) : 0.0f; *launches = n;
+    return PCREG_OK;
+}
+
 size_t knn_f16_prep_bytes(int M) { return (size_t)((M > 0 ? M : 1) + kT16 - 1) / kT16 * (2 * kT16) * sizeof(uint4); }
 
 // grid: q_blocks x S; KC = 4 list entries per (chunk, query).  Returns S and kc through the pointers.
@@ -246,6 +267,12 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     if (M <= 0) { PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * KC * 4, st)); return PCREG_OK; }
     int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 512) pb = 512;
     hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (g_time_on && Q * (long long)M >= (1LL << 33)) {          // the main search, not the small Unique back-check
+        if (g_time_used == g_time_ev.size()) { hipEvent_t a, b; PCREG_HIP(hipEventCreate(&a)); PCREG_HIP(hipEventCreate(&b)); g_time_ev.emplace_back(a, b); }
+        ev0 = g_time_ev[g_time_used].first; ev1 = g_time_ev[g_time_used].second; ++g_time_used;
+        PCREG_HIP(hipEventRecord(ev0, st));
+    }
 #define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks, S), dim3(kBlock), 0, st, q, Q, ldq, \
                            (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, part_idx, part_s)
     switch (cfg * 2 + (dry ? 1 : 0)) {
@@ -255,6 +282,7 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
         case 6: PCREG_F16_LAUNCH(2, false, true); break;   default: PCREG_F16_LAUNCH(2, true, true); break;
     }
 #undef PCREG_F16_LAUNCH
+    if (ev1) PCREG_HIP(hipEventRecord(ev1, st));
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
