@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include <cstdarg>
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -63,6 +64,8 @@ void Scratch::release_all() {
     for (int i = 0; i < kSlots; ++i) if (ptr[i]) { (void)hipFree(ptr[i]); ptr[i] = nullptr; size[i] = 0; }
 }
 Scratch& scratch() { static Scratch s; return s; }
+static std::map<hipStream_t, Scratch>& stream_scratches() { static std::map<hipStream_t, Scratch> m; return m; }
+Scratch& stream_scratch(hipStream_t st) { return stream_scratches()[st]; }
 
 // copy an n x cols column-major host matrix (leading dimension ld) to a compact device
 // matrix (leading dimension n)
@@ -101,6 +104,8 @@ int pcreg_set_device(int ordinal) {
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device available"); (void)hipGetLastError(); return PCREG_E_NODEVICE; }
     PCREG_ARG(ordinal >= 0 && ordinal < count);
     scratch().release_all();
+    for (auto& kv : stream_scratches()) kv.second.release_all();
+    stream_scratches().clear();
     if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
     g_device_ok = -1;
     PCREG_HIP(hipSetDevice(ordinal));

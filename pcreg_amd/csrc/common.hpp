@@ -42,6 +42,9 @@ struct Scratch {
     void release_all();
 };
 Scratch& scratch();
+// device-tier temporaries: one Scratch per stream, so that calls on different streams may overlap
+// (a stream runs its own kernels in order, which makes the reuse within it safe)
+Scratch& stream_scratch(hipStream_t st);
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -374,7 +374,7 @@ int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_t
                            int32_t* cand_q, int32_t* cand_m, int32_t* n_cand, hipStream_t st) {
     PCREG_ARG(Q >= 0);
     void* tmp = nullptr;   // flags [Q] + per-workgroup counters
-    int rc = scratch().get(20, ((size_t)Q + (Q + 255) / 256 + 1) * sizeof(int32_t), &tmp);
+    int rc = stream_scratch(st).get(20, ((size_t)Q + (Q + 255) / 256 + 1) * sizeof(int32_t), &tmp);
     if (rc) return rc;
     return run_filter_top2<float>(idx, dist, Q, M_total, thr, ratio, cand_q, cand_m, n_cand, (int32_t*)tmp, st);
 }
@@ -433,7 +433,7 @@ int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int 
     if (Q <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
     const int nb = (Q + 255) / 256;                   // capacity launch: the kernels read the real count
     void* tmp = nullptr;
-    int rc = scratch().get(21, ((size_t)nb + 1) * sizeof(int32_t), &tmp);
+    int rc = stream_scratch(st).get(21, ((size_t)nb + 1) * sizeof(int32_t), &tmp);
     if (rc) return rc;
     int32_t* bc = (int32_t*)tmp;
     hipLaunchKernelGGL(gather_count_kernel, dim3(nb), dim3(256), 0, st, keep, n_cand, bc);

@@ -873,7 +873,21 @@ __global__ __launch_bounds__(1024) void rs_bounds_kernel(StagedArgs sa) {
     const int n = staged_n(a);
     __shared__ double s1[16], s2[16];
     double m1 = 0.0, m2 = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    // one workgroup, latency-bound: keep 4 x 6 loads in flight per thread
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        double v[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { v[u][c] = a.p1[i + u * 1024 + (size_t)c * a.ld]; v[u][3 + c] = a.p2[i + u * 1024 + (size_t)c * a.ld]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            m1 = fmax(m1, v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2]);
+            m2 = fmax(m2, v[u][3] * v[u][3] + v[u][4] * v[u][4] + v[u][5] * v[u][5]);
+        }
+    }
+    for (; i < n; i += 1024) {
         double x = a.p1[i], y = a.p1[i + (size_t)a.ld], z = a.p1[i + 2 * (size_t)a.ld];
         m1 = fmax(m1, x * x + y * y + z * z);
         x = a.p2[i]; y = a.p2[i + (size_t)a.ld]; z = a.p2[i + 2 * (size_t)a.ld];

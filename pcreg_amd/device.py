@@ -97,12 +97,12 @@ class RegistrationPipeline:
     """match (top-2 search -> threshold -> ratio -> Unique) then RANSAC, all resident in HBM."""
 
     def __init__(self, Q: int, M_local: int, m_lo: int = 0, M_total: int | None = None, group=None,
-                 device: torch.device | None = None):
+                 device: torch.device | None = None, replica: bool = False):
         self.dev = device or torch.device("cuda", torch.cuda.current_device())
         self.Q, self.M_local, self.m_lo = Q, M_local, m_lo
         self.M_total = M_total if M_total is not None else M_local
         self.ops = HipOps(Q, M_local, self.dev)
-        self.matcher = ShardedMatcher(self.ops, Q, M_local, m_lo, self.M_total, group)
+        self.matcher = ShardedMatcher(self.ops, Q, M_local, m_lo, self.M_total, group, replica=replica)
         self.world = self.matcher.world
         self.inliers = torch.empty(Q, dtype=torch.int32, device=self.dev)
         self.result = torch.zeros(C.sizeof(DevRansacResult), dtype=torch.uint8, device=self.dev)

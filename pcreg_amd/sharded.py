@@ -54,10 +54,11 @@ def combine_ransac_parts(key: torch.Tensor, num_success: torch.Tensor, has_T: to
 
 
 class ShardedMatcher:
-    def __init__(self, ops, Q: int, M_local: int, m_lo: int, M_total: int, group=None):
+    def __init__(self, ops, Q: int, M_local: int, m_lo: int, M_total: int, group=None, replica: bool = False):
         self.ops, self.Q, self.M_local, self.m_lo, self.M_total = ops, Q, M_local, m_lo, M_total
         self.group = group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # replica: this rank holds the WHOLE model and works alone (crop-parallel batches, pcreg_amd/batch.py)
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized() and not replica) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.idx = self.dist = None
 

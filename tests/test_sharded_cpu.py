@@ -194,3 +194,38 @@ def test_hypothesis_share_covers_everything():
             for b, c in spans:
                 assert b == min(pos, iters) and c >= 0
                 pos += c
+
+
+# ---------------------------------------------------------------- crop-parallel batches (BASELINE cfg 5)
+def _batch_worker(rank, world, port, out_dir, n_crops):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pcreg_amd.batch import ROW, crops_of_rank, gather_rows
+    mine = crops_of_rank(n_crops, rank, world)
+    rows = torch.zeros((len(mine), ROW), dtype=torch.float64)
+    for k, c in enumerate(mine):                      # a recognisable row per crop, stamped with the rank that made it
+        rows[k] = torch.arange(ROW, dtype=torch.float64) * (c + 1)
+        rows[k, 0] = c; rows[k, 1] = rank
+    allr = gather_rows(rows, n_crops)
+    np.save(os.path.join(out_dir, f"batch{rank}.npy"), allr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_crops", [7, 8, 1])
+def test_batch_rows_gather_in_crop_order_world2(tmp_path, n_crops):
+    """Crops are dealt round-robin, every rank ends with every crop's row, in crop order (ragged tail included)."""
+    from pcreg_amd.batch import ROW, crops_of_rank, rows_to_results
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_batch_worker, args=(2, port, str(tmp_path), n_crops), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "batch0.npy"), np.load(tmp_path / "batch1.npy")
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (n_crops, ROW)
+    for c in range(n_crops):
+        assert a[c, 0] == c and a[c, 1] == c % 2 and a[c, 5] == 5 * (c + 1)
+    res = rows_to_results(a)
+    assert [r["crop"] for r in res] == list(range(n_crops)) and res[0]["T"].shape == (4, 4)
+    for world in (1, 2, 3, 8):
+        dealt = sorted(c for r in range(world) for c in crops_of_rank(n_crops, r, world))
+        assert dealt == list(range(n_crops))
