@@ -172,7 +172,7 @@ static int ransac_host(const double* pts1, const double* pts2, int total, int ld
     for (int b = 0; b < B; ++b) { int nb = offsets[b + 1] - offsets[b]; PCREG_ARG(nb >= 0); if (nb > max_n) max_n = nb; }
     PCREG_ARG(offsets[0] == 0 && offsets[B] == total);
     size_t hyps = (size_t)o->iterNum * B;
-    size_t wsb = ransac_workspace_bytes(o->iterNum, B);
+    size_t wsb = ransac_workspace_bytes(o->iterNum, B, max_n);
     void *d1, *d2, *dOff, *dS = nullptr, *dOut, *dInl, *ws, *dI1 = nullptr, *dI2 = nullptr;
     size_t tot = (size_t)(total > 0 ? total : 1);
     TRY(scratch().get(0, sizeof(double) * 3 * tot, &d1));
@@ -469,7 +469,7 @@ int pcreg_dev_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, i
                                    (hipStream_t)stream);
 }
 
-size_t pcreg_dev_ransac_workspace(int n_cap, int iterNum) { (void)n_cap; return ransac_workspace_bytes(iterNum, 1); }
+size_t pcreg_dev_ransac_workspace(int n_cap, int iterNum) { return ransac_workspace_bytes(iterNum, 1, n_cap); }
 
 int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
                      const pcreg_ransac_opts* opts, const int32_t* sample_idx, pcreg_dev_ransac_result* out,

@@ -51,7 +51,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // ---- kernel launchers implemented in the .hip files (device pointers, async) --------
 struct RansacDims { int n_cap; int iters; int B; };
 
-size_t ransac_workspace_bytes(int iters, int B);
+size_t ransac_workspace_bytes(int iters, int B, int n_cap);
 int launch_ransac(const double* p1, const double* p2, int ld, const int32_t* offsets /*B+1 dev or null*/,
                   const int32_t* n_dev /*single registration: device n, or null*/, int n_cap, int B,
                   const pcreg_ransac_opts& o, const int32_t* sample_idx_dev,

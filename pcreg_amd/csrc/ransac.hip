@@ -853,6 +853,12 @@ __global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a)
 constexpr int kSW = 4, kSS = 8;                 // scoring: waves per workgroup, 64-point slots per wave
 constexpr int kSPts = kSW * kSS * 64;           // 2048 correspondences per workgroup
 constexpr int kSMaxPB = 64;                     // point blocks with a partial-count row each
+#ifndef PCREG_MOM_SLOTS
+#define PCREG_MOM_SLOTS 8
+#endif
+constexpr int kStagedMinN = 4096;               // one registration of at least this many correspondences runs staged
+constexpr int kMomSlots = PCREG_MOM_SLOTS;                   // lane-per-hypothesis refit: 64-correspondence slots per chunk
+constexpr int kRec = 16;                        // doubles per correspondence record (15 used)
 constexpr int kSChunk = 80;                     // hypotheses per workgroup
 
 struct StagedArgs {
@@ -863,6 +869,16 @@ struct StagedArgs {
     double* mom;                 // [iters][27]
     int32_t* part;               // [kSMaxPB][iters]
     int pb;                      // point blocks in use
+    // lane-per-hypothesis refit (rs_moments_lane_kernel): the first scoring pass keeps every hypothesis' inlier
+    // mask, the moments are then sums of per-correspondence records under that mask
+    unsigned long long* masks;   // [iters][nslots_cap]: bit (i & 63) of word i / 64 = correspondence i is an inlier
+    int nslots_cap;              // ceil(n_cap / kSPts) * kSPts / 64
+    double* rec;                 // [nslots_cap * 64][kRec]: d(3) m(3) m (x) d (9) relative to correspondence 0
+    double* mpart;               // [chunks][iters][15] partial moments
+    int32_t* pass_list;          // hypotheses on this path, arrival order
+    int32_t* n_pass;
+    unsigned char* dense;        // [iters] refit needs rs_moments_kernel (rank not certified, or the N == 3 branch)
+    int use_lane;
 };
 
 __device__ __forceinline__ int staged_n(const RansacArgs& a) { return min(a.n_dev ? *a.n_dev : a.n_cap, a.n_cap); }
@@ -901,6 +917,24 @@ __global__ __launch_bounds__(1024) void rs_bounds_kernel(StagedArgs sa) {
         for (int w = 1; w < 16; ++w) { m1 = fmax(m1, s1[w]); m2 = fmax(m2, s2[w]); }
         sa.bounds[0] = sqrt(m1) * (1.0 + 1e-12); sa.bounds[1] = sqrt(m2) * (1.0 + 1e-12);
     }
+}
+
+// per-correspondence records of the moment sums (mom_core's fifteen terms), relative to correspondence 0
+__global__ __launch_bounds__(256) void rs_records_kernel(StagedArgs sa) {
+    const RansacArgs& a = sa.a;
+    const int n = staged_n(a);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
+    double o[6], q[6];
+    P.load(0, o); P.load(i, q);
+    const double d0 = q[0] - o[0], d1 = q[1] - o[1], d2 = q[2] - o[2];
+    const double m0 = q[3] - o[3], m1 = q[4] - o[4], m2 = q[5] - o[5];
+    double* r = sa.rec + (size_t)i * kRec;
+    r[0] = d0; r[1] = d1; r[2] = d2; r[3] = m0; r[4] = m1; r[5] = m2;
+    r[6] = m0 * d0; r[7] = m0 * d1; r[8] = m0 * d2;
+    r[9] = m1 * d0; r[10] = m1 * d1; r[11] = m1 * d2;
+    r[12] = m2 * d0; r[13] = m2 * d1; r[14] = m2 * d2; r[15] = 0.0;
 }
 
 __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
@@ -976,9 +1010,12 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
     for (int k = 0; k < 12; ++k) sa.T1[(size_t)p * 12 + k] = T1[k];
     sa.v1[p] = v1;
     sa.cert[p] = cert;
+    if (p == 0) *sa.n_pass = 0;
 }
 
 // grid (point blocks, hypothesis chunks).  part[pb][h] = inliers of hypothesis h among this block's points.
+// EMIT: keep the inlier masks (sa.masks) for the lane-per-hypothesis refit.
+template <bool EMIT>
 __global__ __launch_bounds__(kSW * 64) void rs_score_kernel(StagedArgs sa, const double* __restrict__ TT,
                                                             const unsigned char* __restrict__ valid) {
     const RansacArgs& a = sa.a;
@@ -1013,9 +1050,20 @@ __global__ __launch_bounds__(kSW * 64) void rs_score_kernel(StagedArgs sa, const
             for (int k = 0; k < 12; ++k) T[k] = TT[(size_t)h * 12 + k];   // uniform address: scalar loads
             pin_translation_vgpr(T);
             int cnt = 0;
+            int mine_lo = 0, mine_hi = 0;
 #pragma unroll
-            for (int s = 0; s < kSS; ++s) cnt += __popcll(__ballot((sqdist(q[s], T) < th) & act[s]));
+            for (int s = 0; s < kSS; ++s) {
+                const unsigned long long b = __ballot((sqdist(q[s], T) < th) & act[s]);
+                cnt += __popcll(b);
+                if (EMIT) {                 // ballot s into lane s
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_lo) : "s"((int)(unsigned)b), "n"(s));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_hi) : "s"((int)(unsigned)(b >> 32)), "n"(s));
+                }
+            }
             if (lane == 0) s_cnt[wave][h - h0] += cnt;
+            if (EMIT && lane < kSS)         // one 64-byte row segment per (wave, hypothesis)
+                sa.masks[(size_t)h * sa.nslots_cap + (size_t)pb * (kSPts / 64) + wave * kSS + lane] =
+                    ((unsigned long long)(unsigned)mine_hi << 32) | (unsigned)mine_lo;
         }
     }
     __syncthreads();
@@ -1042,6 +1090,10 @@ __global__ void rs_pass1_kernel(StagedArgs sa) {
     const bool pass = v && c >= thInlr;
     a.cnt1[h] = c; a.cnt2[h] = 0;
     sa.pass1[h] = pass;
+    // refit path: rank certified from the sample and more than three inliers -> masked record sums
+    const bool lane_path = sa.use_lane && a.refine && pass && sa.cert[h] && c >= 4;
+    sa.dense[h] = pass && !lane_path;
+    if (lane_path) sa.pass_list[atomicAdd(sa.n_pass, 1)] = h;
     if (!a.refine) {
         a.has[h] = pass;
         if (pass) {
@@ -1072,7 +1124,7 @@ __global__ __launch_bounds__(kTBlock) void rs_moments_kernel(StagedArgs sa) {
     int c1 = 0; bool pass = false; int certified = 0;
     if (lane < nh) {
         const int h = wbase + lane;
-        pass = sa.pass1[h] != 0; c1 = a.cnt1[h]; certified = sa.cert[h];
+        pass = sa.dense[h] != 0; c1 = a.cnt1[h]; certified = sa.cert[h];
 #pragma unroll
         for (int k = 0; k < 12; ++k) T1[k] = sa.T1[(size_t)h * 12 + k];
     }
@@ -1126,6 +1178,94 @@ __global__ __launch_bounds__(kTBlock) void rs_moments_kernel(StagedArgs sa) {
     }
 }
 
+typedef int rs_i32x16 __attribute__((ext_vector_type(16)));
+typedef int rs_i32x8 __attribute__((ext_vector_type(8)));
+typedef int rs_i32x4 __attribute__((ext_vector_type(4)));
+typedef int rs_i32x2 __attribute__((ext_vector_type(2)));
+struct RecS { rs_i32x16 a; rs_i32x8 b; rs_i32x4 c; rs_i32x2 d; };     // one record in 30 SGPRs
+// hipcc will not select scalar loads here by itself (it sinks the record loads into the divergent branch and
+// turns them into per-lane loads), so the SMEM traffic is written out: issue, then wait for everything.
+#define PCREG_REC_LOAD(R, BASE, OFF)                                                                                   \
+    asm volatile("s_load_dwordx16 %0, %4, %5\n\ts_load_dwordx8 %1, %4, %6\n\ts_load_dwordx4 %2, %4, %7\n\ts_load_dwordx2 %3, %4, %8" \
+                 : "=&s"(R.a), "=&s"(R.b), "=&s"(R.c), "=&s"(R.d)                                                      \
+                 : "s"(BASE), "n"((OFF)), "n"((OFF) + 64), "n"((OFF) + 96), "n"((OFF) + 112))
+#define PCREG_REC_WAIT(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(R.c), "+s"(R.d))
+__device__ __forceinline__ double rs_pair(int lo, int hi) { return __builtin_bit_cast(double, rs_i32x2{lo, hi}); }
+#define PCREG_REC_ADD(ACC, R)                                                                                          \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) ACC[e_] += rs_pair(R.a[2 * e_], R.a[2 * e_ + 1]);             \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) ACC[8 + e_] += rs_pair(R.b[2 * e_], R.b[2 * e_ + 1]);         \
+        ACC[12] += rs_pair(R.c[0], R.c[1]); ACC[13] += rs_pair(R.c[2], R.c[3]); ACC[14] += rs_pair(R.d[0], R.d[1]);    \
+    }
+
+// Refit moments, kLaneHyps hypotheses per LANE: the correspondence records are wave-uniform (scalar loads, SGPR
+// operands), every lane adds them under its own hypotheses' masks.  No LDS, no cross-lane reduction, and each
+// sum runs in index order.  grid (groups of 64 * kLaneHyps listed hypotheses, chunks of kMomSlots * 64
+// correspondences).  Two hypotheses per lane halve the scalar-cache traffic per accumulated pair.
+constexpr int kLaneHyps = 2;
+__global__ __launch_bounds__(64) void rs_moments_lane_kernel(StagedArgs sa, const double* __restrict__ rec,
+                                                            const unsigned long long* __restrict__ masks) {
+    const RansacArgs& a = sa.a;
+    const int n = __builtin_amdgcn_readfirstlane(staged_n(a));
+    const int np = __builtin_amdgcn_readfirstlane(*sa.n_pass);
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x * 64 * kLaneHyps >= np) return;
+    const int nslots = (n + 63) >> 6;
+    const int s0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * kMomSlots);
+    if (s0 >= nslots) return;
+    const int s1 = __builtin_amdgcn_readfirstlane(min(nslots, s0 + kMomSlots));
+    bool live[kLaneHyps]; int h[kLaneHyps]; const unsigned long long* row[kLaneHyps];
+    double acc[kLaneHyps][15];
+    unsigned long long wn[kLaneHyps];
+#pragma unroll
+    for (int j = 0; j < kLaneHyps; ++j) {
+        const int li = (blockIdx.x * kLaneHyps + j) * 64 + lane;
+        live[j] = li < np;
+        h[j] = live[j] ? sa.pass_list[li] : 0;
+        row[j] = masks + (size_t)h[j] * sa.nslots_cap;
+#pragma unroll
+        for (int e = 0; e < 15; ++e) acc[j][e] = 0.0;
+        wn[j] = live[j] ? row[j][s0] : 0ull;
+    }
+    RecS A, B;
+    const double* base = rec + (size_t)s0 * 64 * kRec;
+    PCREG_REC_LOAD(A, base, 0);
+    for (int s = s0; s < s1; ++s) {
+        unsigned lo[kLaneHyps], hi[kLaneHyps];
+#pragma unroll
+        for (int j = 0; j < kLaneHyps; ++j) {
+            lo[j] = (unsigned)wn[j]; hi[j] = (unsigned)(wn[j] >> 32);
+            if (s + 1 < s1) wn[j] = live[j] ? row[j][s + 1] : 0ull;
+        }
+        const double* nbase = base + 64 * kRec;          // the record array is padded past n
+#define PCREG_REC_USE(K, R)                                                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < kLaneHyps; ++j_)                                \
+            if (((K) < 32 ? lo[j_] : hi[j_]) & (1u << ((K) & 31))) PCREG_REC_ADD(acc[j_], R)
+#define PCREG_REC_STEP(K)                                                                       \
+        PCREG_REC_WAIT(A); PCREG_REC_LOAD(B, base, ((K) + 1) * kRec * 8);                       \
+        PCREG_REC_USE(K, A)                                                                     \
+        PCREG_REC_WAIT(B);                                                                      \
+        if ((K) + 2 < 64) { PCREG_REC_LOAD(A, base, ((K) + 2) * kRec * 8); } else { PCREG_REC_LOAD(A, nbase, 0); } \
+        PCREG_REC_USE((K) + 1, B)
+#define PCREG_REC_STEP4(K) PCREG_REC_STEP(K) PCREG_REC_STEP((K) + 2) PCREG_REC_STEP((K) + 4) PCREG_REC_STEP((K) + 6)
+        PCREG_REC_STEP4(0) PCREG_REC_STEP4(8) PCREG_REC_STEP4(16) PCREG_REC_STEP4(24)
+        PCREG_REC_STEP4(32) PCREG_REC_STEP4(40) PCREG_REC_STEP4(48) PCREG_REC_STEP4(56)
+#undef PCREG_REC_STEP4
+#undef PCREG_REC_STEP
+#undef PCREG_REC_USE
+        base = nbase;
+    }
+    PCREG_REC_WAIT(A);                                    // drain the last prefetch before the wave ends
+#pragma unroll
+    for (int j = 0; j < kLaneHyps; ++j) {
+        if (live[j]) {
+            double* out = sa.mpart + ((size_t)blockIdx.y * a.iters + h[j]) * 15;
+#pragma unroll
+            for (int e = 0; e < 15; ++e) out[e] = acc[j][e];
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
     const RansacArgs& a = sa.a;
     const int h = blockIdx.x * 64 + threadIdx.x;
@@ -1139,10 +1279,20 @@ __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
         Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
         double o[6]; P.load(0, o);
         double mom[27];
-#pragma unroll
-        for (int e = 0; e < 27; ++e) mom[e] = sa.mom[(size_t)h * 27 + e];
         const int c1 = a.cnt1[h];
-        if (c1 == 3) {
+        if (!sa.dense[h]) {                         // the chunk partials of rs_moments_lane_kernel, in chunk order
+#pragma unroll
+            for (int e = 0; e < 27; ++e) mom[e] = 0.0;
+            const int nch = (((n + 63) >> 6) + kMomSlots - 1) / kMomSlots;
+            for (int ch = 0; ch < nch; ++ch) {
+                const double* pp = sa.mpart + ((size_t)ch * a.iters + h) * 15;
+#pragma unroll
+                for (int e = 0; e < 15; ++e) mom[e] += pp[e];
+            }
+            v2 = fit_moments(c1, mom, o, T2, true);
+        } else if (c1 == 3) {
+#pragma unroll
+            for (int e = 0; e < 27; ++e) mom[e] = sa.mom[(size_t)h * 27 + e];
             double A1[3][3], A2[3][3];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -1150,6 +1300,8 @@ __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
                 for (int c = 0; c < 3; ++c) { A1[j][c] = mom[j * 6 + c]; A2[j][c] = mom[j * 6 + 3 + c]; }
             v2 = fit_3pt(A1, A2, T2);
         } else {
+#pragma unroll
+            for (int e = 0; e < 27; ++e) mom[e] = sa.mom[(size_t)h * 27 + e];
             v2 = fit_moments(c1, mom, o, T2, sa.cert[h] != 0);
         }
     }
@@ -1402,14 +1554,20 @@ __global__ void calc_dists_kernel(const double* T16, const double* p1, const dou
 }  // namespace
 
 // ---------------------------------------------------------------- launchers
-static size_t staged_extra_bytes(size_t h) {    // T1 | mom | part | v1 | pass1 | v2
-    return align_up(h * 12 * sizeof(double), 256) + align_up(h * 27 * sizeof(double), 256) +
-           align_up(h * kSMaxPB * sizeof(int32_t), 256) + 4 * align_up(h, 256) + 256;
+static size_t staged_slots_cap(int n_cap) { return (size_t)((n_cap + kSPts - 1) / kSPts) * (kSPts / 64); }
+static size_t staged_chunks_cap(int n_cap) { return (staged_slots_cap(n_cap) + kMomSlots - 1) / kMomSlots; }
+static size_t staged_extra_bytes(size_t h, int n_cap) {    // T1 | mom | part | v1 | pass1 | v2 | cert | dense | lane-path buffers
+    size_t b = align_up(h * 12 * sizeof(double), 256) + align_up(h * 27 * sizeof(double), 256) +
+               align_up(h * kSMaxPB * sizeof(int32_t), 256) + 5 * align_up(h, 256) + 256;
+    if (n_cap >= kStagedMinN)
+        b += align_up(h * staged_slots_cap(n_cap) * 8, 256) + align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256) +
+             align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256) + align_up(h * sizeof(int32_t), 256) + 256;
+    return b;
 }
-size_t ransac_workspace_bytes(int iters, int B) {
+size_t ransac_workspace_bytes(int iters, int B, int n_cap) {
     size_t h = (size_t)iters * (size_t)B;
     return align_up(h * 12 * sizeof(double), 256) + 2 * align_up(h * sizeof(int32_t), 256) + align_up(h, 256) +
-           staged_extra_bytes(h);
+           staged_extra_bytes(h, B == 1 ? n_cap : 0);
 }
 
 static int launch_ransac_impl(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
@@ -1418,7 +1576,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
                   void* ws, size_t ws_bytes, hipStream_t st, int hyp_begin, pcreg_dev_ransac_part* part) {
     PCREG_ARG(o.iterNum >= 1 && o.minPtNum >= 3 && B >= 1 && n_cap >= 0);
     PCREG_ARG(o.minPtNum == 3 || sample_idx_dev != nullptr);   // built-in sampler draws triples
-    size_t need = ransac_workspace_bytes(o.iterNum, B);
+    size_t need = ransac_workspace_bytes(o.iterNum, B, n_cap);
     if (ws_bytes < need) { set_error("ransac workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
     size_t h = (size_t)o.iterNum * (size_t)B;
     char* w = (char*)ws;
@@ -1441,7 +1599,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         int per_block = hpw * kWavesPerBlock;
         dim3 grid((o.iterNum + per_block - 1) / per_block, B);
         hipLaunchKernelGGL(ransac_hyp_kernel<true>, grid, dim3(kBlock), lds, st, a);
-    } else if (B == 1 && !offsets && n_cap >= 4096 && !(getenv("PCREG_RANSAC_FUSED") && atoi(getenv("PCREG_RANSAC_FUSED")))) {
+    } else if (B == 1 && !offsets && n_cap >= kStagedMinN && !(getenv("PCREG_RANSAC_FUSED") && atoi(getenv("PCREG_RANSAC_FUSED")))) {
         // one large registration: the staged chain of lean kernels (see rs_* above)
         StagedArgs sa{};
         sa.T1 = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
@@ -1451,7 +1609,15 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.pass1 = (unsigned char*)w; w += align_up(h, 256);
         sa.v2 = (unsigned char*)w; w += align_up(h, 256);
         sa.cert = (unsigned char*)w; w += align_up(h, 256);
-        sa.bounds = (double*)w;
+        sa.dense = (unsigned char*)w; w += align_up(h, 256);
+        sa.bounds = (double*)w; w += 256;
+        sa.nslots_cap = (int)staged_slots_cap(n_cap);
+        sa.masks = (unsigned long long*)w; w += align_up(h * staged_slots_cap(n_cap) * 8, 256);
+        sa.rec = (double*)w; w += align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256);
+        sa.mpart = (double*)w; w += align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256);
+        sa.pass_list = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
+        sa.n_pass = (int32_t*)w; w += 256;
+        sa.use_lane = a.refine && !(getenv("PCREG_RANSAC_NOLANE") && atoi(getenv("PCREG_RANSAC_NOLANE")));
         int pb = (n_cap + kSPts - 1) / kSPts; if (pb > kSMaxPB) pb = kSMaxPB; if (pb < 1) pb = 1;
         sa.pb = pb;
         int hpw = (int)((total + 250LL * kTW - 1) / (250LL * kTW));
@@ -1463,12 +1629,20 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
         hipLaunchKernelGGL(rs_bounds_kernel, dim3(1), dim3(1024), 0, st, sa);
         hipLaunchKernelGGL(rs_fit1_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
-        hipLaunchKernelGGL(rs_score_kernel, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
+        if (sa.use_lane) {
+            hipLaunchKernelGGL(rs_records_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, st, sa);
+            hipLaunchKernelGGL(rs_score_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
+        } else {
+            hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
+        }
         hipLaunchKernelGGL(rs_pass1_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
         if (a.refine) {
+            if (sa.use_lane)
+                hipLaunchKernelGGL(rs_moments_lane_kernel, dim3((it + 64 * kLaneHyps - 1) / (64 * kLaneHyps), (unsigned)staged_chunks_cap(n_cap)), dim3(64), 0, st, sa,
+                                   (const double*)sa.rec, (const unsigned long long*)sa.masks);
             hipLaunchKernelGGL(rs_moments_kernel, dim3((it + hpw * kTW - 1) / (hpw * kTW)), dim3(kTBlock), 0, st, sa);
             hipLaunchKernelGGL(rs_fit2_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
-            hipLaunchKernelGGL(rs_score_kernel, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const unsigned char*)sa.v2);
+            hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const unsigned char*)sa.v2);
             hipLaunchKernelGGL(rs_finish_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
         }
     } else {

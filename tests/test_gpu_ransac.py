@@ -234,11 +234,35 @@ def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypa
         if not ref["failed"]:
             assert np.linalg.norm(res[0] - ref["T"]) < T_TOL, mode
     a, b = out["staged"], out["fused"]
-    np.testing.assert_array_equal(a[0], b[0])            # the two GPU paths agree to the last bit
+    # the staged chain sums the refit moments per lane in index order, the fused kernel per wave in a tree:
+    # same counts and inlier sets (checked above), transforms equal to rounding
+    assert a[0].shape == b[0].shape and (a[0].size == 0 or np.abs(a[0] - b[0]).max() < 1e-11)
     if case == "planar_pts1":
         assert ref["failed"] and a[0].size == 0
     if case == "three_inliers":
         assert (ref["inlrNum"] == 3).sum() > 100          # the N == 3 refit branch really ran
+
+
+@pytest.mark.parametrize("n,iters,frac", [(4097, 300, 0.3), (8191, 257, 0.0), (140001, 130, 0.2)])
+def test_lane_refit_sizes_and_switch(n, iters, frac, oracle_c, monkeypatch):
+    """rs_moments_lane_kernel (masks kept by the first scoring pass, records added per lane) at ragged sizes,
+    past the 64 x 2048 point-block limit of one scoring launch, and against the sweep it replaces
+    (PCREG_RANSAC_NOLANE=1): same counts, same inlier set, transforms equal to rounding."""
+    import pcreg_amd as pc
+    p1, p2, _ = rigid_case(n, 31 + n, noise=0.02, outlier_frac=frac)
+    coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=3)
+    res = pc.ransac(p1, p2, coef, seed=3, return_iter_counts=True)
+    monkeypatch.setenv("PCREG_RANSAC_NOLANE", "1")
+    res_sweep = pc.ransac(p1, p2, coef, seed=3, return_iter_counts=True)
+    assert not ref["failed"] and ref["numSuccess"] > 0
+    for r in (res, res_sweep):
+        np.testing.assert_array_equal(r[5], ref["inlrNum"])
+        np.testing.assert_array_equal(r[6], ref["inlrNum_refined"])
+        assert r[2] == ref["numSuccess"] and r[3] == ref["maxInliers"]
+        np.testing.assert_array_equal(np.asarray(r[1]).astype(np.int64), ref["inlierIdx"])
+        assert np.linalg.norm(r[0] - ref["T"]) < T_TOL
+    assert np.abs(res[0] - res_sweep[0]).max() < 1e-10
 
 
 @pytest.mark.parametrize("n,iters,world", [(900, 1000, 3), (6000, 701, 2), (6000, 64, 8)])
