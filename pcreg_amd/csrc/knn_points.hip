@@ -19,6 +19,7 @@
 // Ties resolve to the lowest model index (MATLAB min / partial-sort behaviour).
 #include "common.hpp"
 #include "select.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -239,6 +240,153 @@ __global__ void unique_keep_kernel(const int32_t* __restrict__ idx2, int M, int 
     keep[k] = (idx2[(size_t)k * 2] == cand_q[k]);
 }
 
+// ---------------------------------------------------------------- Unique back-check on a grid of the queries
+// keep (i, j) iff no other query i' beats i for model point j in the (distance, index) order of the search.
+// That is a range-emptiness question with the candidate's OWN distance as radius (small: j is i's nearest
+// model point), so a uniform grid over the queries answers it exactly with a handful of distance evaluations
+// instead of a second all-pairs search.  Cells hold up to kUgSlots points; a candidate that meets a fuller
+// cell, or whose ball covers too many cells, is re-done by ug_brute_kernel against every query.
+constexpr int kUgSlots = 16;
+constexpr int kUgMaxCells = 4 << 20;
+constexpr int kUgMaxVisit = 343;
+struct UgPrep { float x0, y0, z0, inv_c; int nx, ny, nz, pad; };
+static size_t ug_cells_cap(int Q) { size_t c = 2 * (size_t)Q; if (c < 4096) c = 4096; if (c > (size_t)kUgMaxCells) c = kUgMaxCells; return c; }
+
+__device__ __forceinline__ float ug_d2(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;           // the search's exact formula (sign-symmetric)
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+__device__ __forceinline__ int ug_cell1(float x, float x0, float inv_c, int n) {
+    const int c = (int)floorf((x - x0) * inv_c);                     // monotone in x: the range test relies on it
+    return min(max(c, 0), n - 1);
+}
+
+__global__ __launch_bounds__(1024) void ug_bbox_kernel(const float* __restrict__ q, int Q, int ldq, int cells_cap,
+                                                       UgPrep* __restrict__ prep, int32_t* __restrict__ n_flag) {
+    __shared__ float s_lo[3][16], s_hi[3][16];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i0 = threadIdx.x; i0 < Q; i0 += 4 * 1024) {
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = q[min(i0 + u * 1024, Q - 1) + (size_t)c * ldq];      // clamped repeats are harmless
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[u][c]); hi[c] = fmaxf(hi[c], v[u][c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+        if ((threadIdx.x & 63) == 0) { s_lo[c][threadIdx.x >> 6] = lo[c]; s_hi[c][threadIdx.x >> 6] = hi[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e[3];
+        for (int c = 0; c < 3; ++c) {
+            for (int w = 1; w < 16; ++w) { lo[c] = fminf(lo[c], s_lo[c][w]); hi[c] = fmaxf(hi[c], s_hi[c][w]); }
+            e[c] = fmaxf(hi[c] - lo[c], 0.0f);
+        }
+        // about two cells per query over the occupied extent; flat or degenerate axes get one layer
+        const float emax = fmaxf(e[0], fmaxf(e[1], e[2]));
+        float vol = 1.0f; int dims = 0;
+        for (int c = 0; c < 3; ++c) if (e[c] > 1e-6f * emax) { vol *= e[c]; ++dims; }
+        float cs = dims > 0 ? powf(vol / (2.0f * (float)Q), 1.0f / (float)dims) : 1.0f;
+        if (!(cs > 0.0f) || !isfinite(cs)) cs = 1.0f;
+        int nx, ny, nz;
+        for (;;) {
+            const float inv = 1.0f / cs;
+            const float fx = floorf(e[0] * inv) + 1.0f, fy = floorf(e[1] * inv) + 1.0f, fz = floorf(e[2] * inv) + 1.0f;
+            if (fx * fy * fz <= (float)cells_cap) { nx = (int)fx; ny = (int)fy; nz = (int)fz; break; }
+            cs *= 1.08f;
+        }
+        prep->x0 = lo[0]; prep->y0 = lo[1]; prep->z0 = lo[2]; prep->inv_c = 1.0f / cs;
+        prep->nx = nx; prep->ny = ny; prep->nz = nz; prep->pad = 0;
+        *n_flag = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void ug_fill_kernel(const float* __restrict__ q, int Q, int ldq, const UgPrep* __restrict__ prep,
+                                                      int32_t* __restrict__ cnt, float4* __restrict__ slots) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Q) return;
+    const UgPrep P = *prep;
+    const float x = q[i], y = q[i + (size_t)ldq], z = q[i + 2 * (size_t)ldq];
+    const int cell = (ug_cell1(z, P.z0, P.inv_c, P.nz) * P.ny + ug_cell1(y, P.y0, P.inv_c, P.ny)) * P.nx + ug_cell1(x, P.x0, P.inv_c, P.nx);
+    const int s = atomicAdd(&cnt[cell], 1);
+    if (s < kUgSlots) slots[(size_t)cell * kUgSlots + s] = make_float4(x, y, z, __int_as_float(i));
+}
+
+__global__ __launch_bounds__(64) void ug_check_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
+                                                     int m_lo, const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
+                                                     const int32_t* __restrict__ n_cand, const UgPrep* __restrict__ prep,
+                                                     const int32_t* __restrict__ cnt, const float4* __restrict__ slots,
+                                                     int32_t* __restrict__ keep, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= *n_cand) return;
+    const int j = cand_m[k] - m_lo;
+    if (j < 0 || j >= M) return;                                     // another shard's row
+    const int i = cand_q[k];
+    const UgPrep P = *prep;
+    const float px = m[j], py = m[j + (size_t)ldm], pz = m[j + 2 * (size_t)ldm];
+    const float di = ug_d2(q[i], q[i + (size_t)ldq], q[i + 2 * (size_t)ldq], px, py, pz);
+    const float r = sqrtf(di) * 1.0001f + 1e-30f;                    // covers every point whose rounded distance is <= di
+    const int x0 = ug_cell1(px - r, P.x0, P.inv_c, P.nx), x1 = ug_cell1(px + r, P.x0, P.inv_c, P.nx);
+    const int y0 = ug_cell1(py - r, P.y0, P.inv_c, P.ny), y1 = ug_cell1(py + r, P.y0, P.inv_c, P.ny);
+    const int z0 = ug_cell1(pz - r, P.z0, P.inv_c, P.nz), z1 = ug_cell1(pz + r, P.z0, P.inv_c, P.nz);
+    bool brute = !(di == di) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > kUgMaxVisit;
+    bool kp = true;
+    for (int cz = z0; cz <= z1 && !brute && kp; ++cz)
+        for (int cy = y0; cy <= y1 && !brute && kp; ++cy)
+            for (int cx = x0; cx <= x1 && kp; ++cx) {
+                const int cell = (cz * P.ny + cy) * P.nx + cx;
+                const int c = cnt[cell];
+                if (c > kUgSlots) { brute = true; break; }
+                for (int s = 0; s < c; ++s) {
+                    const float4 t = slots[(size_t)cell * kUgSlots + s];
+                    const int it = __float_as_int(t.w);
+                    const float d = ug_d2(t.x, t.y, t.z, px, py, pz);
+                    if (d < di || (d == di && it < i)) { kp = false; break; }
+                }
+            }
+    if (brute && kp) flag_list[atomicAdd(n_flag, 1)] = k;            // undecided: the exhaustive scan settles it
+    keep[k] = kp && !brute;
+}
+
+// one workgroup per undecided candidate against every query (four loads in flight per thread: the scan is
+// latency-bound)
+__global__ __launch_bounds__(1024) void ug_brute_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm, int m_lo,
+                                                       const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
+                                                       const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag,
+                                                       int32_t* __restrict__ keep) {
+    const int nf = *n_flag;
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
+        const int k = flag_list[f];
+        const int j = cand_m[k] - m_lo, i = cand_q[k];
+        const float px = m[j], py = m[j + (size_t)ldm], pz = m[j + 2 * (size_t)ldm];
+        const float di = ug_d2(q[i], q[i + (size_t)ldq], q[i + 2 * (size_t)ldq], px, py, pz);
+        bool b = false;
+        for (int t0 = threadIdx.x; t0 < Q && !b; t0 += 4 * 1024) {
+            float x[4], y[4], z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = min(t0 + u * 1024, Q - 1);
+                x[u] = q[t]; y[u] = q[t + (size_t)ldq]; z[u] = q[t + 2 * (size_t)ldq];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * 1024;
+                const float d = ug_d2(x[u], y[u], z[u], px, py, pz);
+                b = b || (t < Q && (d < di || (d == di && t < i)));
+            }
+        }
+        const int beaten = __syncthreads_or(b);
+        if (threadIdx.x == 0) keep[k] = !beaten;
+    }
+}
+
 // Ordered compaction of the kept candidates (three small launches: per-workgroup counts,
 // exclusive scan, scatter) into 1-based pairs and, optionally, the matched coordinates.
 __global__ void gather_count_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
@@ -385,11 +533,16 @@ static size_t unique_direct_bytes(int Q) {
     return 2 * align_up((size_t)S * (size_t)(Q > 0 ? Q : 1) * sizeof(float), 256);
 }
 // gathered points [3][Q] | idx2 [Q][2] | dist2 [Q][2] | search workspace
+static size_t unique_grid_bytes(int Q) {   // prep | n_flag | cell counts | cell slots | undecided list
+    return 256 + 256 + align_up(ug_cells_cap(Q) * 4, 256) + align_up(ug_cells_cap(Q) * kUgSlots * 16, 256) +
+           align_up((size_t)(Q > 0 ? Q : 1) * 4, 256);
+}
 size_t unique_points_workspace_bytes(int Q) {
     size_t q = (size_t)(Q > 0 ? Q : 1);
     size_t fast = align_up(q * 3 * 4, 256) + 2 * align_up(q * 2 * 4, 256) + knn2_points_workspace_bytes(Q, Q);
     size_t direct = unique_direct_bytes(Q);
-    return fast > direct ? fast : direct;
+    size_t grid = unique_grid_bytes(Q);
+    return std::max(std::max(fast, direct), grid);
 }
 
 int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t m_lo,
@@ -399,6 +552,25 @@ int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int
     if (Q == 0) return PCREG_OK;
     size_t need = unique_points_workspace_bytes(Q);
     if (ws_bytes < need) { set_error("unique workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    static const int unique_mode = getenv("PCREG_UNIQUE_MODE") ? atoi(getenv("PCREG_UNIQUE_MODE")) : 0;   // 1: second search
+    if (!use_exact_only() && Q >= 4096 && unique_mode == 0) {
+        // grid of the queries + exact range-emptiness test per candidate (see ug_* above)
+        char* w = (char*)ws;
+        UgPrep* prep = (UgPrep*)w;          w += 256;
+        int32_t* n_flag = (int32_t*)w;      w += 256;
+        const size_t cells = ug_cells_cap(Q);
+        int32_t* cnt = (int32_t*)w;         w += align_up(cells * 4, 256);
+        float4* slots = (float4*)w;         w += align_up(cells * kUgSlots * 16, 256);
+        int32_t* flag_list = (int32_t*)w;
+        PCREG_HIP(hipMemsetAsync(cnt, 0, cells * 4, st));
+        hipLaunchKernelGGL(ug_bbox_kernel, dim3(1), dim3(1024), 0, st, q, Q, ldq, (int)cells, prep, n_flag);
+        hipLaunchKernelGGL(ug_fill_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, q, Q, ldq, prep, cnt, slots);
+        hipLaunchKernelGGL(ug_check_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo, cand_q, cand_m, n_cand,
+                           prep, cnt, slots, keep, flag_list, n_flag);
+        hipLaunchKernelGGL(ug_brute_kernel, dim3(512), dim3(1024), 0, st, q, Q, ldq, m, ldm, (int)m_lo, cand_q, cand_m, flag_list, n_flag, keep);
+        PCREG_HIP(hipGetLastError());
+        return PCREG_OK;
+    }
     if (!use_exact_only() && Q >= 4096) {
         size_t qq = (size_t)Q;
         char* w = (char*)ws;

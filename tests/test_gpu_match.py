@@ -123,3 +123,42 @@ def test_sad_fast_path_constant_descriptors(oracle_c):
     rp, rm = oracle_c.matchFeatures(dS, dM, kw)
     np.testing.assert_array_equal(pairs, rp)
     np.testing.assert_array_equal(met, rm)
+
+
+# ---------------------------------------------------------------- Unique back-check on the query grid (Q >= 4096)
+def _unique_case(kind, Q, M, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "volume":
+        model = (rng.random((M, 3)) * [40, 30, 35]).astype(np.float32)
+        surf = (model[rng.choice(M, Q, replace=False)] + rng.normal(0, 0.05, (Q, 3))).astype(np.float32)
+    elif kind == "planar":                       # a flat sheet: one grid layer in z
+        model = (rng.random((M, 3)) * [60, 60, 0]).astype(np.float32)
+        surf = (model[rng.choice(M, Q, replace=False)] + rng.normal(0, 0.04, (Q, 3)) * [1, 1, 0]).astype(np.float32)
+    elif kind == "duplicates":                   # repeated queries: equal distances, the lower index must win
+        model = (rng.random((M, 3)) * [40, 30, 35]).astype(np.float32)
+        base = (model[rng.choice(M, Q // 2, replace=False)] + rng.normal(0, 0.05, (Q // 2, 3))).astype(np.float32)
+        surf = np.concatenate([base, base])[rng.permutation(2 * (Q // 2))]
+    elif kind == "clusters":                     # tight clumps of queries: cells overflow, the exhaustive scan decides
+        model = (rng.random((M, 3)) * [40, 30, 35]).astype(np.float32)
+        ctr = model[rng.choice(M, Q // 32, replace=False)]
+        surf = (np.repeat(ctr, 32, axis=0) + rng.normal(0, 0.01, (Q // 32 * 32, 3))).astype(np.float32)
+    else:                                        # "far": sparse queries far from the model, loose threshold: big balls
+        model = (rng.random((M, 3)) * [40, 30, 35]).astype(np.float32)
+        surf = (rng.random((Q, 3)) * [40, 30, 35] + [0, 0, 3.0]).astype(np.float32)
+    return surf, model
+
+
+@pytest.mark.parametrize("kind,Q,M,thr,ratio", [
+    ("volume", 6000, 30000, 0.25, 0.8), ("volume", 4096, 9000, 1e30, 1.0), ("planar", 5000, 20000, 0.25, 0.9),
+    ("duplicates", 8000, 20000, 0.25, 1.0), ("clusters", 6400, 20000, 1.0, 1.0), ("far", 4500, 5000, 1e30, 1.0)])
+def test_unique_grid_check_equals_oracle(kind, Q, M, thr, ratio, oracle_c):
+    """launch_unique_points_f32's grid path: same pairs as the oracle's column-minimum Unique, ties included."""
+    import pcreg_amd as pc
+    surf, model = _unique_case(kind, Q, M, 5 + Q)
+    ref = oracle_c.match_points_f32(surf, model, thr, ratio, True)
+    loose = oracle_c.match_points_f32(surf, model, thr, ratio, False)
+    got = pc.match_points(surf, model, thr, ratio, True)
+    np.testing.assert_array_equal(got, ref)
+    assert len(ref) > 0
+    if kind in ("duplicates", "clusters"):
+        assert len(ref) < len(loose)             # Unique really removed something
