@@ -40,42 +40,65 @@ namespace {
 // ---- 1a. bounding box of model + queries (two-stage, deterministic) -----------------
 __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __restrict__ m, int M, int ldm,
                                                               const float* __restrict__ q, int Q, int ldq,
-                                                              float* __restrict__ part /*[grid][6]*/) {
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                                                              float* __restrict__ part /*[grid][12]: model lo/hi, query lo/hi*/) {
+    float lo[2][3], hi[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[k][c] = INFINITY; hi[k][c] = -INFINITY; }
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < M + Q; i += gridDim.x * kBlock) {
-        const float* p = i < M ? m + i : q + (i - M);
-        size_t ld = i < M ? (size_t)ldm : (size_t)ldq;
+        const bool is_m = i < M;
+        const float* p = is_m ? m + i : q + (i - M);
+        size_t ld = is_m ? (size_t)ldm : (size_t)ldq;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { float v = p[c * ld]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+        for (int c = 0; c < 3; ++c) {
+            float v = p[c * ld];
+            lo[0][c] = fminf(lo[0][c], is_m ? v : INFINITY); hi[0][c] = fmaxf(hi[0][c], is_m ? v : -INFINITY);
+            lo[1][c] = fminf(lo[1][c], is_m ? INFINITY : v); hi[1][c] = fmaxf(hi[1][c], is_m ? -INFINITY : v);
+        }
     }
-    __shared__ float s[kBlock / 64][6];
+    __shared__ float s[kBlock / 64][12];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
-    }
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo[k][c] = fminf(lo[k][c], __shfl_xor(lo[k][c], o)); hi[k][c] = fmaxf(hi[k][c], __shfl_xor(hi[k][c], o)); }
+        }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { s[threadIdx.x >> 6][c] = lo[c]; s[threadIdx.x >> 6][3 + c] = hi[c]; }
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s[threadIdx.x >> 6][k * 6 + c] = lo[k][c]; s[threadIdx.x >> 6][k * 6 + 3 + c] = hi[k][c]; }
     }
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 12) {
+        const bool is_lo = (threadIdx.x % 6) < 3;
         float v = s[0][threadIdx.x];
-        for (int w = 1; w < kBlock / 64; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-        part[blockIdx.x * 6 + threadIdx.x] = v;
+        for (int w = 1; w < kBlock / 64; ++w) v = is_lo ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+        part[blockIdx.x * 12 + threadIdx.x] = v;
     }
 }
 __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, int M, int cell_cap, Prep* __restrict__ prep,
                                   unsigned* __restrict__ rm2_bits, int32_t* __restrict__ n_flag) {
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float lo2[2][3], hi2[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo2[k][c] = INFINITY; hi2[k][c] = -INFINITY; }
     for (int b = threadIdx.x; b < nparts; b += 64)              // launched with one wave
-        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
+        for (int k = 0; k < 2; ++k)
+            for (int c = 0; c < 3; ++c) { lo2[k][c] = fminf(lo2[k][c], part[b * 12 + k * 6 + c]); hi2[k][c] = fmaxf(hi2[k][c], part[b * 12 + k * 6 + 3 + c]); }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
-    }
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo2[k][c] = fminf(lo2[k][c], __shfl_xor(lo2[k][c], o)); hi2[k][c] = fmaxf(hi2[k][c], __shfl_xor(hi2[k][c], o)); }
+        }
     if (threadIdx.x == 0) {
+        float lo[3], hi[3];                                     // the joint box
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo2[0][c], lo2[1][c]); hi[c] = fmaxf(hi2[0][c], hi2[1][c]); }
         prep->cx = 0.5f * lo[0] + 0.5f * hi[0]; prep->cy = 0.5f * lo[1] + 0.5f * hi[1]; prep->cz = 0.5f * lo[2] + 0.5f * hi[2];
         {   // an upper bound of max |m~|^2 (and |q~|^2) from the box itself: the seeding margin uses it
             float ax = 0.5f * (hi[0] - lo[0]), ay = 0.5f * (hi[1] - lo[1]), az = 0.5f * (hi[2] - lo[2]);
@@ -86,23 +109,29 @@ __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, in
         if (H > 0.0f && H < INFINITY) sg = ldexpf(1.0f, 5 - ilogbf(H));        // sigma * H in [32, 64)
         prep->sigma = sg; prep->inv_sigma2 = 1.0f / (sg * sg);                 // powers of two: exact
         prep->pad0 = prep->pad1 = 0.0f;
-        // seeding grid: about two model points per cell, at most cell_cap cells (what the workspace holds)
-        float ext[3], emax = 0.0f;
-        for (int c = 0; c < 3; ++c) { ext[c] = hi[c] - lo[c]; emax = fmaxf(emax, ext[c]); }
+        // seeding grid: cells of about two model points (density of the MODEL box), laid over the QUERY box
+        // plus one cell of margin -- the only cells a query ever looks at; at most cell_cap cells
+        float mext[3], memax = 0.0f;
+        for (int c = 0; c < 3; ++c) { mext[c] = hi2[0][c] - lo2[0][c]; memax = fmaxf(memax, mext[c]); }
         int n[3] = {1, 1, 1};
-        float h = 1.0f;
-        if (emax > 0.0f && emax < INFINITY) {
-            for (int c = 0; c < 3; ++c) ext[c] = fmaxf(ext[c], emax * 1e-3f);
-            float target = fminf(fmaxf((float)M * 0.5f, 1.0f), (float)cell_cap * 0.5f);
-            h = cbrtf(ext[0] * ext[1] * ext[2] / target);
+        float h = 1.0f, g0[3] = {lo[0], lo[1], lo[2]};
+        const bool have_q = lo2[1][0] <= hi2[1][0];
+        if (memax > 0.0f && memax < INFINITY && have_q) {
+            for (int c = 0; c < 3; ++c) mext[c] = fmaxf(mext[c], memax * 1e-3f);
+            h = cbrtf(mext[0] * mext[1] * mext[2] / fmaxf((float)M * 0.5f, 1.0f));
             for (int it = 0; it < 64; ++it) {
                 long tot = 1;
-                for (int c = 0; c < 3; ++c) { n[c] = (int)fminf(ceilf(ext[c] / h), 2048.0f); if (n[c] < 1) n[c] = 1; tot *= n[c]; }
+                for (int c = 0; c < 3; ++c) {
+                    // clip the query box to the model box grown by one cell: cells farther out hold no model point
+                    const float a = fmaxf(lo2[1][c], lo2[0][c] - h), b = fminf(hi2[1][c], hi2[0][c] + h);
+                    g0[c] = a - h;
+                    n[c] = (int)fminf(ceilf(fmaxf(b - a, 0.0f) / h) + 2.0f, 2048.0f); if (n[c] < 1) n[c] = 1; tot *= n[c];
+                }
                 if (tot <= cell_cap) break;
                 h *= 1.2f;
             }
         }
-        prep->gx0 = lo[0]; prep->gy0 = lo[1]; prep->gz0 = lo[2]; prep->inv_h = 1.0f / h;
+        prep->gx0 = g0[0]; prep->gy0 = g0[1]; prep->gz0 = g0[2]; prep->inv_h = 1.0f / h;
         prep->nx = n[0]; prep->ny = n[1]; prep->nz = n[2]; prep->ncell = n[0] * n[1] * n[2];
         *rm2_bits = 0u;
         *n_flag = 0;                                   // (saves a memset launch)
@@ -146,7 +175,10 @@ __global__ __launch_bounds__(kBlock) void seed_fill_kernel(const float* __restri
     const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
         const float x = m[i], y = m[i + (size_t)ldm], z = m[i + 2 * (size_t)ldm];
-        int cx = seed_cell(x, gx0, ih, nx), cy = seed_cell(y, gy0, ih, ny), cz = seed_cell(z, gz0, ih, nz);
+        // the grid covers the query box plus a margin: model points outside it are never looked at
+        const float fx = floorf((x - gx0) * ih), fy = floorf((y - gy0) * ih), fz = floorf((z - gz0) * ih);
+        if (!(fx >= 0.0f && fx < (float)nx && fy >= 0.0f && fy < (float)ny && fz >= 0.0f && fz < (float)nz)) continue;
+        int cx = (int)fx, cy = (int)fy, cz = (int)fz;
         int cell = (cz * ny + cy) * nx + cx;
         int k = atomicAdd(&cnt[cell], 1);
         if (k < kSeedSlots) slots[(size_t)cell * kSeedSlots + k] = make_float4(x, y, z, 0.0f);   // the point itself: one 64-B line per cell
@@ -697,7 +729,7 @@ static size_t seed_bytes(int M) {
 }
 static size_t fast_fixed_bytes(int Q, int M) {
     size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
-    return 256 + 256 + 256 + align_up(512 * 6 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
+    return 256 + 256 + 256 + align_up(512 * 12 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
            align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256) + 2 * align_up((size_t)kPartCap * 16 * q * 4, 256) +
            seed_bytes(M) + 2 * align_up((size_t)1024 * 32 * 2 * 4, 256);
 }
@@ -727,7 +759,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     Prep* prep = (Prep*)w;                 w += 256;
     unsigned* rm2 = (unsigned*)w;          w += 256;
     int32_t* n_flag = (int32_t*)w;         w += 256;
-    float* bpart = (float*)w;              w += align_up(512 * 6 * sizeof(float), 256);
+    float* bpart = (float*)w;              w += align_up(512 * 12 * sizeof(float), 256);
     unsigned* gthr = (unsigned*)w;         w += align_up(qq * 4, 256);
     int32_t* flag_list = (int32_t*)w;      w += align_up(qq * 4, 256);
     void* mprep = w;                       w += align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256);
