@@ -864,8 +864,9 @@ constexpr int kSChunk = 80;                     // hypotheses per workgroup
 struct StagedArgs {
     RansacArgs a;
     double* T1; unsigned char* v1; unsigned char* pass1; unsigned char* v2;
-    unsigned char* cert;         // rank of the inlier set certified from the sample alone (rs_fit1)
-    double* bounds;              // [2]: max |pts1 row|, max |pts2 row|
+    unsigned char* cert;         // rank of the inlier set certified from the sample alone (rs_fit1 + rs_pass1)
+    double* certq;               // [iters][2]: the sample's singular-value bounds / tolerance factor (0: no certificate)
+    double* bounds;              // [2]: max |pts1 row|^2, max |pts2 row|^2
     double* mom;                 // [iters][27]
     int32_t* part;               // [kSMaxPB][iters]
     int pb;                      // point blocks in use
@@ -883,58 +884,37 @@ struct StagedArgs {
 
 __device__ __forceinline__ int staged_n(const RansacArgs& a) { return min(a.n_dev ? *a.n_dev : a.n_cap, a.n_cap); }
 
-// max row norms of both point sets: the only global quantity the rank certificate needs
-__global__ __launch_bounds__(1024) void rs_bounds_kernel(StagedArgs sa) {
-    const RansacArgs& a = sa.a;
-    const int n = staged_n(a);
-    __shared__ double s1[16], s2[16];
-    double m1 = 0.0, m2 = 0.0;
-    // one workgroup, latency-bound: keep 4 x 6 loads in flight per thread
-    int i = threadIdx.x;
-    for (; i + 3 * 1024 < n; i += 4 * 1024) {
-        double v[4][6];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { v[u][c] = a.p1[i + u * 1024 + (size_t)c * a.ld]; v[u][3 + c] = a.p2[i + u * 1024 + (size_t)c * a.ld]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            m1 = fmax(m1, v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2]);
-            m2 = fmax(m2, v[u][3] * v[u][3] + v[u][4] * v[u][4] + v[u][5] * v[u][5]);
-        }
-    }
-    for (; i < n; i += 1024) {
-        double x = a.p1[i], y = a.p1[i + (size_t)a.ld], z = a.p1[i + 2 * (size_t)a.ld];
-        m1 = fmax(m1, x * x + y * y + z * z);
-        x = a.p2[i]; y = a.p2[i + (size_t)a.ld]; z = a.p2[i + 2 * (size_t)a.ld];
-        m2 = fmax(m2, x * x + y * y + z * z);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { m1 = fmax(m1, __shfl_xor(m1, o)); m2 = fmax(m2, __shfl_xor(m2, o)); }
-    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = m1; s2[threadIdx.x >> 6] = m2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) { m1 = fmax(m1, s1[w]); m2 = fmax(m2, s2[w]); }
-        sa.bounds[0] = sqrt(m1) * (1.0 + 1e-12); sa.bounds[1] = sqrt(m2) * (1.0 + 1e-12);
-    }
-}
-
 // per-correspondence records of the moment sums (mom_core's fifteen terms), relative to correspondence 0
 __global__ __launch_bounds__(256) void rs_records_kernel(StagedArgs sa) {
     const RansacArgs& a = sa.a;
     const int n = staged_n(a);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
-    double o[6], q[6];
-    P.load(0, o); P.load(i, q);
-    const double d0 = q[0] - o[0], d1 = q[1] - o[1], d2 = q[2] - o[2];
-    const double m0 = q[3] - o[3], m1 = q[4] - o[4], m2 = q[5] - o[5];
-    double* r = sa.rec + (size_t)i * kRec;
-    r[0] = d0; r[1] = d1; r[2] = d2; r[3] = m0; r[4] = m1; r[5] = m2;
-    r[6] = m0 * d0; r[7] = m0 * d1; r[8] = m0 * d2;
-    r[9] = m1 * d0; r[10] = m1 * d1; r[11] = m1 * d2;
-    r[12] = m2 * d0; r[13] = m2 * d1; r[14] = m2 * d2; r[15] = 0.0;
+    double m1 = 0.0, m2 = 0.0;
+    if (i < n) {
+        Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
+        double o[6], q[6];
+        P.load(0, o); P.load(i, q);
+        m1 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+        m2 = q[3] * q[3] + q[4] * q[4] + q[5] * q[5];
+        if (sa.use_lane) {
+            const double d0 = q[0] - o[0], d1 = q[1] - o[1], d2 = q[2] - o[2];
+            const double m0 = q[3] - o[3], m1_ = q[4] - o[4], m2_ = q[5] - o[5];
+            double* r = sa.rec + (size_t)i * kRec;
+            r[0] = d0; r[1] = d1; r[2] = d2; r[3] = m0; r[4] = m1_; r[5] = m2_;
+            r[6] = m0 * d0; r[7] = m0 * d1; r[8] = m0 * d2;
+            r[9] = m1_ * d0; r[10] = m1_ * d1; r[11] = m1_ * d2;
+            r[12] = m2_ * d0; r[13] = m2_ * d1; r[14] = m2_ * d2; r[15] = 0.0;
+        }
+    }
+    // max squared row norms of both point sets (the only global quantity the rank certificate needs):
+    // non-negative doubles order like their bit patterns, the maximum is order-free
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) { m1 = fmax(m1, __shfl_xor(m1, o_)); m2 = fmax(m2, __shfl_xor(m2, o_)); }
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (threadIdx.x & ~63) < n) {
+        // a plain read first: most waves find a maximum that already covers theirs and skip the atomic
+        if (m1 > ((volatile double*)sa.bounds)[0]) atomicMax((unsigned long long*)sa.bounds, (unsigned long long)__double_as_longlong(m1));
+        if (m2 > ((volatile double*)sa.bounds)[1]) atomicMax((unsigned long long*)sa.bounds + 1, (unsigned long long)__double_as_longlong(m2));
+    }
 }
 
 __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
@@ -945,7 +925,8 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
     double T1[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T1[k] = 0.0;
-    bool v1 = false, cert = false;
+    bool v1 = false;
+    double cq1 = 0.0, cq2 = 0.0;
     if (n >= a.m && n >= 3) {
         Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
         if (a.m == 3) {
@@ -986,7 +967,8 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
                         const int r1 = (r0 + 1) % 3, c1 = (c0 + 1) % 3;
                         mm = fmax(mm, fabs(A2[r0][c0] * A2[r1][c1] - A2[r0][c1] * A2[r1][c0]));
                     }
-                cert = all_in && f1 > 0.0 && f2 > 0.0 && (2.0 * fabs(det1) / f1 > tolf * sa.bounds[0]) && (mm / sqrt(f2) > tolf * sa.bounds[1]);
+                // compared with tolf * max|row| in rs_pass1_kernel, once rs_records_kernel has the maxima
+                if (all_in && f1 > 0.0 && f2 > 0.0) { cq1 = 2.0 * fabs(det1) / (f1 * tolf); cq2 = mm / (sqrt(f2) * tolf); }
             }
         } else {
             double mom[27];
@@ -1009,8 +991,8 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) sa.T1[(size_t)p * 12 + k] = T1[k];
     sa.v1[p] = v1;
-    sa.cert[p] = cert;
-    if (p == 0) *sa.n_pass = 0;
+    sa.certq[2 * (size_t)p] = cq1; sa.certq[2 * (size_t)p + 1] = cq2;
+    if (p == 0) { *sa.n_pass = 0; sa.bounds[0] = 0.0; sa.bounds[1] = 0.0; }
 }
 
 // grid (point blocks, hypothesis chunks).  part[pb][h] = inliers of hypothesis h among this block's points.
@@ -1091,7 +1073,10 @@ __global__ void rs_pass1_kernel(StagedArgs sa) {
     a.cnt1[h] = c; a.cnt2[h] = 0;
     sa.pass1[h] = pass;
     // refit path: rank certified from the sample and more than three inliers -> masked record sums
-    const bool lane_path = sa.use_lane && a.refine && pass && sa.cert[h] && c >= 4;
+    const bool cert = a.refine && sa.certq[2 * (size_t)h] > sqrt(sa.bounds[0]) * (1.0 + 1e-12) &&
+                      sa.certq[2 * (size_t)h + 1] > sqrt(sa.bounds[1]) * (1.0 + 1e-12);
+    sa.cert[h] = cert;
+    const bool lane_path = sa.use_lane && a.refine && pass && cert && c >= 4;
     sa.dense[h] = pass && !lane_path;
     if (lane_path) sa.pass_list[atomicAdd(sa.n_pass, 1)] = h;
     if (!a.refine) {
@@ -1284,6 +1269,7 @@ __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
 #pragma unroll
             for (int e = 0; e < 27; ++e) mom[e] = 0.0;
             const int nch = (((n + 63) >> 6) + kMomSlots - 1) / kMomSlots;
+#pragma unroll 8
             for (int ch = 0; ch < nch; ++ch) {
                 const double* pp = sa.mpart + ((size_t)ch * a.iters + h) * 15;
 #pragma unroll
@@ -1558,7 +1544,7 @@ static size_t staged_slots_cap(int n_cap) { return (size_t)((n_cap + kSPts - 1) 
 static size_t staged_chunks_cap(int n_cap) { return (staged_slots_cap(n_cap) + kMomSlots - 1) / kMomSlots; }
 static size_t staged_extra_bytes(size_t h, int n_cap) {    // T1 | mom | part | v1 | pass1 | v2 | cert | dense | lane-path buffers
     size_t b = align_up(h * 12 * sizeof(double), 256) + align_up(h * 27 * sizeof(double), 256) +
-               align_up(h * kSMaxPB * sizeof(int32_t), 256) + 5 * align_up(h, 256) + 256;
+               align_up(h * kSMaxPB * sizeof(int32_t), 256) + 5 * align_up(h, 256) + 256 + align_up(h * 2 * sizeof(double), 256);
     if (n_cap >= kStagedMinN)
         b += align_up(h * staged_slots_cap(n_cap) * 8, 256) + align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256) +
              align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256) + align_up(h * sizeof(int32_t), 256) + 256;
@@ -1611,6 +1597,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.cert = (unsigned char*)w; w += align_up(h, 256);
         sa.dense = (unsigned char*)w; w += align_up(h, 256);
         sa.bounds = (double*)w; w += 256;
+        sa.certq = (double*)w; w += align_up(h * 2 * sizeof(double), 256);
         sa.nslots_cap = (int)staged_slots_cap(n_cap);
         sa.masks = (unsigned long long*)w; w += align_up(h * staged_slots_cap(n_cap) * 8, 256);
         sa.rec = (double*)w; w += align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256);
@@ -1627,10 +1614,9 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.a = a;
         const int it = o.iterNum;
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
-        hipLaunchKernelGGL(rs_bounds_kernel, dim3(1), dim3(1024), 0, st, sa);
         hipLaunchKernelGGL(rs_fit1_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
+        if (a.refine) hipLaunchKernelGGL(rs_records_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, st, sa);
         if (sa.use_lane) {
-            hipLaunchKernelGGL(rs_records_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, st, sa);
             hipLaunchKernelGGL(rs_score_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
         } else {
             hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
