@@ -1336,19 +1336,52 @@ __device__ void ransac_emit_result(const RansacArgs& a, int n, int off, pcreg_de
     for (int k = 0; k < 12; ++k) T[k] = s_T[k];
     Pts<false> P{a.p1 + off, a.p2 + off, a.ld, nullptr, n};
     int32_t* dst = inlier_idx + off;
-    for (int i0 = 0; i0 < n; i0 += NTHR) {
-        int i = i0 + threadIdx.x;
-        bool act = i < n;
-        double q[6]; P.load(act ? i : n - 1, q);
-        bool in = act && sqdist(q, T) < a.thDist;
-        unsigned long long bal = __ballot(in);
-        if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    // Ordered compaction in rounds of 32 sweeps: sweep it of the round tests points i0 + it * NTHR + tid (coalesced),
+    // every wave parks its ballot; one scan over the (sweep, wave) counts; then the lanes write.  Two barriers
+    // per round instead of three per sweep.
+    constexpr int NW = NTHR / 64;
+    __shared__ unsigned long long s_bal[32][NW];
+    __shared__ int s_pre[32 * NW];
+    for (int i0 = 0; i0 < n; i0 += 32 * NTHR) {
+        unsigned mine = 0u;
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int i = i0 + it * NTHR + threadIdx.x;
+            const bool act = i < n;
+            double q[6]; P.load(act ? i : n - 1, q);
+            const bool in = act && sqdist(q, T) < a.thDist;
+            const unsigned long long bal = __ballot(in);
+            if (lane == 0) s_bal[it][wave] = bal;
+            mine |= in ? (1u << it) : 0u;
+        }
         __syncthreads();
-        int base = *s_base;
-        for (int w = 0; w < wave; ++w) base += s_wcnt[w];
-        if (in) dst[base + __popcll(bal & ((1ull << lane) - 1ull))] = i + 1;
+        // exclusive scan of the 32 * NW counts in (sweep, wave) order: thread t owns entries [t * E, t * E + E)
+        constexpr int E = (32 * NW + NTHR - 1) / NTHR;           // 1 for NTHR >= 512... entries per thread
+        int cnt[E], tot = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = threadIdx.x * E + e;
+            cnt[e] = k < 32 * NW ? __popcll(s_bal[k / NW][k % NW]) : 0;
+            tot += cnt[e];
+        }
+        int incl = tot;                                          // inclusive scan across the workgroup
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) s_wcnt[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < NTHR / 64; ++w) tot += s_wcnt[w]; *s_base += tot; }
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_wcnt[w];
+        int run = *s_base + wbase + incl - tot;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const int k = threadIdx.x * E + e; if (k < 32 * NW) s_pre[k] = run; run += cnt[e]; }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            if (mine & (1u << it))
+                dst[s_pre[it * NW + wave] + __popcll(s_bal[it][wave] & ((1ull << lane) - 1ull))] = i0 + it * NTHR + threadIdx.x + 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == NTHR - 1) *s_base = run;              // the last thread's running total covers the round
         __syncthreads();
     }
     if (threadIdx.x == 0) r->n_inliers = *s_base;
