@@ -106,7 +106,8 @@ def main() -> None:
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force = os.environ.get("PCREG_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ     # one-rank RCCL rehearsal
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -139,17 +140,17 @@ def main() -> None:
     import ctypes as C
     from pcreg_amd._lib import lib as _pclib
     _pclib().pcreg_dev_search_kernel_timing(1)       # HIP events around the dominant kernel, on its launch stream
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -208,7 +209,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, surf)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -146,7 +146,7 @@ class RegistrationPipeline:
         """The same registration with its hypotheses split over the ranks of the group (each rank scores
         iterNum / world of them, the winner is agreed by three tiny collectives): identical result to
         ransac(), 1/world of its time.  Falls back to ransac() on one rank."""
-        if self.world == 1:
+        if not self.matcher.collective:
             return self.ransac(coef, seed)
         L = lib()
         o = RansacOpts(int(coef["minPtNum"]), int(coef["iterNum"]), float(coef["thDist"]), float(coef["thInlrRatio"]),

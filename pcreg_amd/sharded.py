@@ -27,6 +27,8 @@ tests/test_sharded_cpu.py -- while production passes pcreg_amd.device.HipOps.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -60,6 +62,10 @@ class ShardedMatcher:
         # replica: this rank holds the WHOLE model and works alone (crop-parallel batches, pcreg_amd/batch.py)
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized() and not replica) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # PCREG_FORCE_COLLECTIVES=1: run the collective path even on a one-rank group (rehearses every RCCL call
+        # of the N > 1 protocol -- dtypes, shapes, in-place views -- on a single GPU)
+        self.collective = self.world > 1 or (os.environ.get("PCREG_FORCE_COLLECTIVES") == "1" and not replica
+                                             and dist.is_available() and dist.is_initialized())
         self.idx = self.dist = None
 
     # -- step 1 -----------------------------------------------------------------------
@@ -68,7 +74,7 @@ class ShardedMatcher:
         return self.merge_ranks(idx_l, dist_l)
 
     def merge_ranks(self, idx_l, dist_l):
-        if self.world == 1:
+        if not self.collective:
             self.idx, self.dist = idx_l, dist_l
             return idx_l, dist_l
         idx_all = torch.empty((self.world,) + tuple(idx_l.shape), dtype=idx_l.dtype, device=idx_l.device)
@@ -86,9 +92,9 @@ class ShardedMatcher:
         keep = None
         if unique:
             keep = ops.unique_local(q, model, self.m_lo, cand_q, cand_m, n_cand)
-            if self.world > 1:
+            if self.collective:
                 dist.all_reduce(keep, op=dist.ReduceOp.MAX, group=self.group)
-        if self.world == 1:
+        if not self.collective:
             return ops.gather_pairs(q, model, False, cand_q, cand_m, keep, n_cand)
         # dense [3,Q] table of the candidates' model coordinates: column k is written by
         # the rank owning row cand_m[k], zero elsewhere

@@ -18,3 +18,22 @@ def test_two_ranks_one_gpu():
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("match_ok=True ransac_ok=True") == 2
+
+
+def test_one_rank_rccl_rehearsal_of_every_collective():
+    """PCREG_FORCE_COLLECTIVES=1 sends a one-rank job through the whole N > 1 protocol on RCCL (backend "nccl"):
+    both all_gathers, the MAX / SUM all_reduces of the matcher and the three of the hypothesis-split RANSAC.
+    The registration it finds must be the one the plain single-GPU step finds."""
+    import json
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--model-points", "200000", "--surface-points", "20000"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCREG_FORCE_COLLECTIVES="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py")] + common,
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    forced = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    env2 = {k: v for k, v in os.environ.items() if k != "PCREG_FORCE_COLLECTIVES"}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, env=env2, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    plain = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert forced["ransac"] == plain["ransac"] and not plain["ransac"]["failed"] and plain["ransac"]["n_pairs"] > 1000
