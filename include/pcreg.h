@@ -187,6 +187,10 @@ int pcreg_dev_knn2_points_f32(const float* q, int Q, int ldq, const float* m, in
  * [R][Q][2]) into one top-2 per query, ordering by (dist, idx). */
 int pcreg_dev_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q,
                              int32_t* idx, float* dist, void* stream);
+/* The same with list r starting r * rank_stride ELEMENTS into idx_in / dist_in (>= 2 Q): lets one all_gather
+ * carry a rank's indices and distances in a single buffer. */
+int pcreg_dev_merge_top2_strided_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, size_t rank_stride,
+                                     int32_t* idx, float* dist, void* stream);
 
 /* Threshold + ratio test on a merged top-2: cand_q/cand_m (capacity Q, 0-based,
  * ascending query) and *n_cand (device int32). */
@@ -250,6 +254,11 @@ int pcreg_dev_ransac_partial(const double* pts1, const double* pts2, const int32
 int pcreg_dev_ransac_finish(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
                             const pcreg_ransac_opts* opts, const pcreg_dev_ransac_part* combined,
                             pcreg_dev_ransac_result* out, int32_t* inlier_idx, void* stream);
+/* The same from the n_parts UNCOMBINED parts of all shares (e.g. one all_gather of the 112-byte structs): the
+ * kernel takes the maximum key, sums num_success and uses the winner's transform itself. */
+int pcreg_dev_ransac_finish_parts(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                                  const pcreg_ransac_opts* opts, const pcreg_dev_ransac_part* parts, int n_parts,
+                                  pcreg_dev_ransac_result* out, int32_t* inlier_idx, void* stream);
 
 /* ---- descriptor stage, resident: speedyDescriptors.m:59 -> getMatches.m -> ransac.m --------
  * (completeExperimentFast.m:131-213 per sphere position) without a host copy in between. */

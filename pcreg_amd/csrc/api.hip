@@ -442,6 +442,13 @@ int pcreg_dev_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R,
     return launch_merge_top2_f32(idx_in, dist_in, R, Q, idx, dist, (hipStream_t)stream);
 }
 
+int pcreg_dev_merge_top2_strided_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, size_t rank_stride,
+                                     int32_t* idx, float* dist, void* stream) {
+    PCREG_ARG(idx_in && dist_in && idx && dist);
+    GUARD();
+    return launch_merge_top2_f32(idx_in, dist_in, R, Q, idx, dist, (hipStream_t)stream, rank_stride);
+}
+
 int pcreg_dev_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr_abs, float max_ratio,
                               int32_t* cand_q, int32_t* cand_m, int32_t* n_cand, void* stream) {
     PCREG_ARG(idx && dist && cand_q && cand_m && n_cand);
@@ -495,6 +502,14 @@ int pcreg_dev_ransac_finish(const double* pts1, const double* pts2, const int32_
     PCREG_ARG(pts1 && pts2 && opts && combined && out && inlier_idx && n_cap >= 0 && ld >= n_cap);
     GUARD();
     return launch_ransac_finish(pts1, pts2, ld, n_dev, n_cap, *opts, combined, out, inlier_idx, (hipStream_t)stream);
+}
+
+int pcreg_dev_ransac_finish_parts(const double* pts1, const double* pts2, const int32_t* n_dev, int n_cap, int ld,
+                                  const pcreg_ransac_opts* opts, const pcreg_dev_ransac_part* parts, int n_parts,
+                                  pcreg_dev_ransac_result* out, int32_t* inlier_idx, void* stream) {
+    PCREG_ARG(pts1 && pts2 && opts && parts && n_parts >= 1 && out && inlier_idx && n_cap >= 0 && ld >= n_cap);
+    GUARD();
+    return launch_ransac_finish(pts1, pts2, ld, n_dev, n_cap, *opts, parts, out, inlier_idx, (hipStream_t)stream, n_parts);
 }
 
 // live timing of the search's dominant kernel (HIP events on the launch stream), for bench.py's roofline

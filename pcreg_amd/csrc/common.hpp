@@ -62,7 +62,7 @@ int launch_ransac_partial(const double* p1, const double* p2, int ld, const int3
                           pcreg_dev_ransac_part* part, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_ransac_finish(const double* p1, const double* p2, int ld, const int32_t* n_dev, int n_cap,
                          const pcreg_ransac_opts& o, const pcreg_dev_ransac_part* combined,
-                         pcreg_dev_ransac_result* out, int32_t* inlier_idx, hipStream_t st);
+                         pcreg_dev_ransac_result* out, int32_t* inlier_idx, hipStream_t st, int n_parts = 1);
 int launch_estimate_transform(const double* p1, const double* p2, int n, int ld, double* T16_dev,
                               int32_t* empty_dev, hipStream_t st);
 int launch_calc_dists(const double* T16_dev, const double* p1, const double* p2, int n, int ld,
@@ -73,7 +73,7 @@ int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M
                            int32_t idx_base, int32_t* idx, float* dist, void* ws, size_t ws_bytes,
                            hipStream_t st);
 int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx,
-                          float* dist, hipStream_t st);
+                          float* dist, hipStream_t st, size_t rank_stride = 0);
 int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr,
                            float ratio, int32_t* cand_q, int32_t* cand_m, int32_t* n_cand,
                            hipStream_t st);

@@ -482,7 +482,7 @@ static int knn2_exact_impl(const float* q, int Q, int ldq, const float* m, int M
     if (qlist)
         hipLaunchKernelGGL(merge_top2_list_kernel, dim3(64), dim3(256), 0, st, part_idx, part_dist, S, Q, qlist, n_list, min_active, idx, dist);
     else
-        hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, idx, dist);
+        hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, idx, dist, (size_t)0);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
@@ -510,10 +510,10 @@ int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M
 }
 
 int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx, float* dist,
-                          hipStream_t st) {
-    PCREG_ARG(R >= 1 && Q >= 0);
+                          hipStream_t st, size_t rank_stride) {
+    PCREG_ARG(R >= 1 && Q >= 0 && (rank_stride == 0 || rank_stride >= (size_t)Q * 2));
     if (Q == 0) return PCREG_OK;
-    hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, idx_in, dist_in, R, Q, idx, dist);
+    hipLaunchKernelGGL(merge_top2_kernel_t<float>, dim3((Q + 255) / 256), dim3(256), 0, st, idx_in, dist_in, R, Q, idx, dist, rank_stride);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -271,7 +271,7 @@ int run_score_top2(const double* A, int nA, int lda, const double* B, int nB, in
     else
         hipLaunchKernelGGL(score_top2_kernel<PCREG_METRIC_SSD>, dim3(n_tiles, S), dim3(kBlock), 0, st, A, nA, lda, B, nB, ldb, D, chunk, part_idx, part_dist);
     PCREG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(merge_top2_kernel_t<double>, dim3((nA + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, nA, idx, dist);
+    hipLaunchKernelGGL(merge_top2_kernel_t<double>, dim3((nA + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, nA, idx, dist, (size_t)0);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

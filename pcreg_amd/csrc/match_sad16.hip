@@ -567,7 +567,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
         slices = (nB + slice - 1) / slice;
         hipLaunchKernelGGL(sad_exact_rows_kernel, dim3(nf, slices), dim3(kBlock), (size_t)D * sizeof(double), st,
                            A, lda, B, nB, ldb, D, flag_list, nf, slice, fpi, fpd);
-        hipLaunchKernelGGL(merge_top2_kernel_t<double>, dim3((nf + 255) / 256), dim3(256), 0, st, fpi, fpd, slices, nf, fi, fd);
+        hipLaunchKernelGGL(merge_top2_kernel_t<double>, dim3((nf + 255) / 256), dim3(256), 0, st, fpi, fpd, slices, nf, fi, fd, (size_t)0);
         hipLaunchKernelGGL(scatter_flagged_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, flag_list, nf, fi, fd, idx, dist);
         PCREG_HIP(hipGetLastError());
     }

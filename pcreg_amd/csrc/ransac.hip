@@ -1436,19 +1436,32 @@ __global__ __launch_bounds__(NTHR) void ransac_select_kernel(RansacArgs a, pcreg
     ransac_emit_result<NTHR>(a, n, off, out + b, inlier_idx, failed, s_T, ns, maxInl, winner_g, &s_base, s_wcnt);
 }
 
-// the combined share (key by MAX, num_success by SUM, has/T from the rank whose key won) -> result + inlier list
+// the shares' parts (key by MAX, num_success by SUM, has/T from the share whose key won; n_parts == 1: already
+// combined) -> result + inlier list
 template <int NTHR>
-__global__ __launch_bounds__(NTHR) void ransac_finish_kernel(RansacArgs a, const pcreg_dev_ransac_part* part,
+__global__ __launch_bounds__(NTHR) void ransac_finish_kernel(RansacArgs a, const pcreg_dev_ransac_part* parts, int n_parts,
                                                                pcreg_dev_ransac_result* out, int32_t* inlier_idx) {
     __shared__ double s_T[12];
     __shared__ int s_base;
     __shared__ int s_wcnt[(NTHR / 64)];
+    __shared__ unsigned long long s_key;
+    __shared__ int s_ns, s_win;
     int n = a.n_dev ? *a.n_dev : a.n_cap;
     n = min(n, a.n_cap);
-    const unsigned long long key = part->key;
-    const bool failed = part->has == 0;
+    if (threadIdx.x == 0) {
+        unsigned long long key = 0ull; int ns = 0, win = 0;
+        for (int r = 0; r < n_parts; ++r) {              // keys of different shares differ (global hypothesis index) unless both are 0
+            ns += parts[r].num_success;
+            if (parts[r].key > key) { key = parts[r].key; win = r; }
+        }
+        s_key = key; s_ns = ns; s_win = win;
+    }
+    __syncthreads();
+    const pcreg_dev_ransac_part* part = parts + s_win;
+    const unsigned long long key = s_key;
+    const bool failed = key == 0ull || part->has == 0;
     if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : part->T[threadIdx.x];
-    ransac_emit_result<NTHR>(a, n, 0, out, inlier_idx, failed, s_T, part->num_success, (int)(key >> 32),
+    ransac_emit_result<NTHR>(a, n, 0, out, inlier_idx, failed, s_T, s_ns, (int)(key >> 32),
                              (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)), &s_base, s_wcnt);
 }
 
@@ -1709,11 +1722,12 @@ int launch_ransac_partial(const double* p1, const double* p2, int ld, const int3
 
 int launch_ransac_finish(const double* p1, const double* p2, int ld, const int32_t* n_dev, int n_cap,
                          const pcreg_ransac_opts& o, const pcreg_dev_ransac_part* combined,
-                         pcreg_dev_ransac_result* out, int32_t* inlier_idx, hipStream_t st) {
+                         pcreg_dev_ransac_result* out, int32_t* inlier_idx, hipStream_t st, int n_parts) {
+    PCREG_ARG(n_parts >= 1);
     RansacArgs a{};
     a.p1 = p1; a.p2 = p2; a.ld = ld; a.n_dev = n_dev; a.n_cap = n_cap; a.thDist = o.thDist; a.ratio = o.thInlrRatio;
-    if (n_cap >= 8192) hipLaunchKernelGGL(ransac_finish_kernel<1024>, dim3(1), dim3(1024), 0, st, a, combined, out, inlier_idx);
-    else hipLaunchKernelGGL(ransac_finish_kernel<kBlock>, dim3(1), dim3(kBlock), 0, st, a, combined, out, inlier_idx);
+    if (n_cap >= 8192) hipLaunchKernelGGL(ransac_finish_kernel<1024>, dim3(1), dim3(1024), 0, st, a, combined, n_parts, out, inlier_idx);
+    else hipLaunchKernelGGL(ransac_finish_kernel<kBlock>, dim3(1), dim3(kBlock), 0, st, a, combined, n_parts, out, inlier_idx);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

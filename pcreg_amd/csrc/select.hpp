@@ -25,15 +25,16 @@ __device__ __forceinline__ void top2_insert_lex_t(Top2T<T>& t, T d, int j) {
     }
 }
 
-// Merge R lists [R][Q][2] -> [Q][2].
+// Merge R lists [R][Q][2] -> [Q][2]; list r starts r * rank_stride elements in (0: densely packed, Q * 2).
 template <typename T>
 __global__ void merge_top2_kernel_t(const int32_t* __restrict__ idx_in, const T* __restrict__ dist_in, int R, int Q,
-                                    int32_t* __restrict__ idx, T* __restrict__ dist) {
+                                    int32_t* __restrict__ idx, T* __restrict__ dist, size_t rank_stride = 0) {
     int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= Q) return;
+    if (rank_stride == 0) rank_stride = (size_t)Q * 2;
     Top2T<T> t{(T)INFINITY, (T)INFINITY, -1, -1};
     for (int r = 0; r < R; ++r) {
-        size_t o = ((size_t)r * Q + qi) * 2;
+        size_t o = (size_t)r * rank_stride + (size_t)qi * 2;
         top2_insert_lex_t(t, dist_in[o], idx_in[o]);
         top2_insert_lex_t(t, dist_in[o + 1], idx_in[o + 1]);
     }

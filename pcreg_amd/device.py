@@ -13,7 +13,7 @@ import torch
 
 from ._lib import DevRansacResult, RansacOpts, check, lib
 from . import _lib as _l
-from .sharded import ShardedMatcher, combine_ransac_parts, hypothesis_share
+from .sharded import ShardedMatcher, gather_ransac_parts, hypothesis_share
 
 
 def _p(t: torch.Tensor):
@@ -39,8 +39,9 @@ class HipOps:
         kw = dict(device=device)
         self.ws_knn = torch.empty(max(L.pcreg_dev_knn2_points_f32_workspace(Q, M_local), 256), dtype=torch.uint8, **kw)
         self.ws_unq = torch.empty(max(L.pcreg_dev_unique_points_f32_workspace(Q), 256), dtype=torch.uint8, **kw)
-        self.idx_local = torch.empty((Q, 2), dtype=i32, **kw)
-        self.dist_local = torch.empty((Q, 2), dtype=f32, **kw)
+        self.top2_local = torch.empty((2, Q, 2), dtype=i32, **kw)        # one buffer: a single all_gather carries both
+        self.idx_local = self.top2_local[0]
+        self.dist_local = self.top2_local[1].view(f32)
         self.idx = torch.empty((Q, 2), dtype=i32, **kw)
         self.dist = torch.empty((Q, 2), dtype=f32, **kw)
         self.cand_q = torch.empty(Q, dtype=i32, **kw)
@@ -60,8 +61,8 @@ class HipOps:
         return self.idx_local, self.dist_local
 
     def merge_top2(self, idx_all, dist_all):
-        check(lib().pcreg_dev_merge_top2_f32(_p(idx_all), _p(dist_all), idx_all.shape[0], self.Q, _p(self.idx),
-                                             _p(self.dist), _stream()))
+        check(lib().pcreg_dev_merge_top2_strided_f32(_p(idx_all), _p(dist_all), idx_all.shape[0], self.Q,
+                                                     C.c_size_t(idx_all.stride(0)), _p(self.idx), _p(self.dist), _stream()))
         return self.idx, self.dist
 
     def filter_top2(self, idx, dist, M_total, thr, ratio):
@@ -144,7 +145,7 @@ class RegistrationPipeline:
 
     def ransac_sharded(self, coef: dict, seed: int = 0):
         """The same registration with its hypotheses split over the ranks of the group (each rank scores
-        iterNum / world of them, the winner is agreed by three tiny collectives): identical result to
+        iterNum / world of them, one all_gather of the 112-byte partial results agrees the winner): identical result to
         ransac(), 1/world of its time.  Falls back to ransac() on one rank."""
         if not self.matcher.collective:
             return self.ransac(coef, seed)
@@ -161,18 +162,9 @@ class RegistrationPipeline:
         part = torch.zeros(14, dtype=torch.int64, device=self.dev)      # pcreg_dev_ransac_part: key | (ns, has) | T[12]
         check(L.pcreg_dev_ransac_partial(_p(self.pts1), _p(self.pts2), _p(self.n_pairs), cap, cap, C.byref(o), None,
                                          begin, count, _p(part), _p(self.ws_ransac), C.c_size_t(self.ws_ransac.numel()), _stream()))
-        ns_has = part[1:2].view(torch.int32)                              # [num_success, has]
-        key = part[0:1].clone()
-        ns = ns_has[0:1].to(torch.int64)
-        has_T = torch.cat([ns_has[1:2].to(torch.float64), part[2:14].view(torch.float64)])
-        key, ns, has_T = combine_ransac_parts(key, ns, has_T, self.matcher.group)
-        comb = torch.zeros(14, dtype=torch.int64, device=self.dev)
-        comb[0:1] = key
-        comb[1:2].view(torch.int32)[0:1] = ns.to(torch.int32)
-        comb[1:2].view(torch.int32)[1:2] = (has_T[0:1] > 0.5).to(torch.int32)
-        comb[2:14].view(torch.float64)[:] = has_T[1:13]
-        check(L.pcreg_dev_ransac_finish(_p(self.pts1), _p(self.pts2), _p(self.n_pairs), cap, cap, C.byref(o), _p(comb),
-                                        _p(self.result), _p(self.inliers), _stream()))
+        allp = gather_ransac_parts(part, self.matcher.group)             # the one collective: 112 bytes per rank
+        check(L.pcreg_dev_ransac_finish_parts(_p(self.pts1), _p(self.pts2), _p(self.n_pairs), cap, cap, C.byref(o), _p(allp),
+                                              allp.shape[0], _p(self.result), _p(self.inliers), _stream()))
 
     def fetch_result(self) -> dict:
         """D2H copy of the last ransac result (synchronises)."""

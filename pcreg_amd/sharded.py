@@ -4,14 +4,16 @@ One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  The m
 rows are split in contiguous shards, one per rank; the (small) query set is replicated.
 Exchanges per match:
 
-  1. all_gather of every rank's per-query top-2 (idx i32 + dist f32: Q*16 bytes per rank)
-     followed by a local merge ordered by (dist, idx)  -> identical global top-2 everywhere;
+  1. ONE all_gather of every rank's per-query top-2 (idx i32 and dist f32 in a single [2,Q,2] buffer: Q*16
+     bytes per rank) followed by a local merge ordered by (dist, idx)  -> identical global top-2 everywhere;
   2. threshold / ratio filters run redundantly on every rank (deterministic);
   3. the Unique back-check of a candidate is owned by the rank that holds its model row
-     (the queries are replicated, so the column minimum is shard-local); one
-     all_reduce(MAX) over the keep flags publishes the verdicts;
-  4. the matched model coordinates are assembled with one all_reduce(SUM) of a dense
-     [3, Q] table in which exactly one rank contributes each column (exact: x + 0).
+     (the queries are replicated, so the column minimum is shard-local);
+  4. ONE all_reduce(SUM) of a dense [4, Q] float table publishes the verdicts (row 3: the owner's 0/1
+     flag) and assembles the matched model coordinates (rows 0-2); exactly one rank contributes each
+     column, so the sums are exact (x + 0).
+  RANSAC with its hypotheses split over the ranks adds ONE all_gather of the 112-byte partial results
+  (combine_gathered_parts / pcreg_dev_ransac_finish_parts).  Three collectives per registration in all.
 
 The arithmetic is delegated to an `ops` object so that the protocol itself can be
 exercised on CPU (gloo, world_size 2) with the oracle standing in for the kernels --
@@ -40,19 +42,31 @@ def hypothesis_share(iter_num: int, rank: int, world: int) -> tuple[int, int]:
     return begin, min(share, iter_num - begin)
 
 
-def combine_ransac_parts(key: torch.Tensor, num_success: torch.Tensor, has_T: torch.Tensor, group=None):
-    """Cross-rank winner of one registration whose hypotheses were split over the ranks:
-    key [1] int64 = (inlier count << 32 | ~global hypothesis index) by MAX -- the first maximum of
-    ransac.m:70-72 --, num_success [1] int64 by SUM, has_T [13] float64 = (has, T[12]) taken from the
-    one rank whose key won (every other rank contributes zeros, so the SUM is exact).
-    Three tiny collectives; returns (key, num_success, has_T) identical on every rank."""
-    local_key = key.clone()
-    dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)
-    dist.all_reduce(num_success, op=dist.ReduceOp.SUM, group=group)
-    own = (local_key == key) & (key != 0)
-    has_T = torch.where(own, has_T, torch.zeros_like(has_T))
-    dist.all_reduce(has_T, op=dist.ReduceOp.SUM, group=group)
-    return key, num_success, has_T
+PART_WORDS = 14      # pcreg_dev_ransac_part as int64 words: key | (num_success, has) | T[12]
+
+
+def gather_ransac_parts(part: torch.Tensor, group=None) -> torch.Tensor:
+    """part [PART_WORDS] int64 (this rank's pcreg_dev_ransac_part) -> [world, PART_WORDS], identical on every rank.
+    The one collective of a registration whose hypotheses were split over the ranks."""
+    world = dist.get_world_size(group)
+    allp = torch.empty((world, PART_WORDS), dtype=torch.int64, device=part.device)
+    dist.all_gather_into_tensor(allp.view(-1), part.contiguous().view(-1), group=group)
+    return allp
+
+
+def combine_gathered_parts(allp: torch.Tensor):
+    """What pcreg_dev_ransac_finish_parts does with the gathered parts, on the host (tests, non-HIP callers):
+    key by MAX -- (inlier count << 32 | ~global hypothesis index), the first maximum of ransac.m:70-72 --,
+    num_success by SUM, (has, T[12]) of the share whose key won.  Returns (key, num_success, has, T12)."""
+    import numpy as np
+    a = allp.cpu().numpy()
+    keys = a[:, 0].astype(np.uint64)
+    win = int(np.argmax(keys))
+    ns_has = a[:, 1:2].copy().view(np.int32)                    # [R, 2]: num_success, has
+    T12 = a[win, 2:14].copy().view(np.float64)
+    key = int(keys[win])
+    has = bool(ns_has[win, 1]) and key != 0
+    return key, int(ns_has[:, 0].sum()), has, T12
 
 
 class ShardedMatcher:
@@ -77,12 +91,13 @@ class ShardedMatcher:
         if not self.collective:
             self.idx, self.dist = idx_l, dist_l
             return idx_l, dist_l
-        idx_all = torch.empty((self.world,) + tuple(idx_l.shape), dtype=idx_l.dtype, device=idx_l.device)
-        dist_all = torch.empty((self.world,) + tuple(dist_l.shape), dtype=dist_l.dtype, device=dist_l.device)
-        # flat views: the concatenated 1-D form is what every backend (RCCL, gloo) accepts
-        dist.all_gather_into_tensor(idx_all.view(-1), idx_l.contiguous().view(-1), group=self.group)
-        dist.all_gather_into_tensor(dist_all.view(-1), dist_l.contiguous().view(-1), group=self.group)
-        self.idx, self.dist = self.ops.merge_top2(idx_all, dist_all)
+        # one buffer [2, Q, 2] of 4-byte words per rank: indices, then the distances' bit patterns
+        pack = getattr(self.ops, "top2_local", None)
+        if pack is None:
+            pack = torch.stack([idx_l.contiguous().view(torch.int32), dist_l.contiguous().view(torch.int32)])
+        allp = torch.empty((self.world,) + tuple(pack.shape), dtype=torch.int32, device=pack.device)
+        dist.all_gather_into_tensor(allp.view(-1), pack.view(-1), group=self.group)
+        self.idx, self.dist = self.ops.merge_top2(allp[:, 0], allp[:, 1].view(torch.float32))     # rank stride 4 Q
         return self.idx, self.dist
 
     # -- steps 2-4 ----------------------------------------------------------------------
@@ -92,20 +107,22 @@ class ShardedMatcher:
         keep = None
         if unique:
             keep = ops.unique_local(q, model, self.m_lo, cand_q, cand_m, n_cand)
-            if self.collective:
-                dist.all_reduce(keep, op=dist.ReduceOp.MAX, group=self.group)
         if not self.collective:
             return ops.gather_pairs(q, model, False, cand_q, cand_m, keep, n_cand)
-        # dense [3,Q] table of the candidates' model coordinates: column k is written by
-        # the rank owning row cand_m[k], zero elsewhere
+        # dense [4,Q] table: rows 0-2 = the candidates' model coordinates, row 3 = the Unique verdict; column k
+        # is written by the rank owning row cand_m[k], zero elsewhere, so one SUM both publishes and assembles
         Q = self.Q
         ar = torch.arange(Q, device=cand_m.device, dtype=torch.int32)
         local = (cand_m >= self.m_lo) & (cand_m < self.m_lo + self.M_local) & (ar < n_cand)
         j = torch.where(local, cand_m - self.m_lo, torch.zeros_like(cand_m)).long()
-        table = torch.where(local.unsqueeze(0), model[:, j], torch.zeros((), dtype=model.dtype, device=model.device))
-        table = table.contiguous()
+        table = torch.zeros((4, Q), dtype=model.dtype, device=model.device)
+        table[0:3] = torch.where(local.unsqueeze(0), model[:, j], torch.zeros((), dtype=model.dtype, device=model.device))
+        if unique:
+            table[3] = torch.where(local, keep.to(model.dtype), torch.zeros((), dtype=model.dtype, device=model.device))
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.group)
-        return ops.gather_pairs(q, table, True, cand_q, cand_m, keep, n_cand)
+        if unique:
+            keep = (table[3] > 0.5).to(torch.int32)
+        return ops.gather_pairs(q, table[0:3], True, cand_q, cand_m, keep, n_cand)
 
     def match(self, q, model, thr_abs: float, max_ratio: float, unique: bool = True):
         self.search(q, model)

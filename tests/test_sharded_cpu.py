@@ -131,7 +131,7 @@ def test_world1_is_a_no_op_protocol():
     np.testing.assert_array_equal(pairs.numpy()[:int(n)].astype(np.uint32), c_oracle.match_points_f32(surf, model, 0.5, 0.8, True))
 
 
-# ---- one registration's hypotheses split over the ranks (pcreg_amd.sharded.combine_ransac_parts) ----
+# ---- one registration's hypotheses split over the ranks (pcreg_amd.sharded.gather_ransac_parts / combine_gathered_parts) ----
 def _ransac_case():
     from conftest import rigid_case
     p1, p2, _ = rigid_case(400, 31, noise=0.02, outlier_frac=0.4)
@@ -143,7 +143,7 @@ def _ransac_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import c_oracle, pcreg_oracle as o
-    from pcreg_amd.sharded import combine_ransac_parts, hypothesis_share
+    from pcreg_amd.sharded import PART_WORDS, combine_gathered_parts, gather_ransac_parts, hypothesis_share
     p1, p2, coef = _ransac_case()
     table = o.sample_table(len(p1), coef["iterNum"], 3, 17)                      # the global sampler stream
     begin, count = hypothesis_share(coef["iterNum"], rank, world)
@@ -155,9 +155,14 @@ def _ransac_worker(rank, world, port, out_dir):
     key = (int(counts[w]) << 32) | (0xFFFFFFFF - (begin + w))
     has = 0.0 if r["failed"] else 1.0
     T12 = np.zeros(12) if r["failed"] else np.concatenate([np.append(r["T"][:3, j], r["T"][3, j]) for j in range(3)])
-    k, ns, hT = combine_ransac_parts(torch.tensor([key], dtype=torch.int64), torch.tensor([int((counts >= thInlr).sum())], dtype=torch.int64),
-                                     torch.from_numpy(np.concatenate([[has], T12])))
-    np.savez(os.path.join(out_dir, f"ransac{rank}.npz"), key=k.numpy(), ns=ns.numpy(), hT=hT.numpy())
+    # this rank's pcreg_dev_ransac_part as 14 int64 words: key | (num_success, has) | T[12]
+    part = np.zeros(PART_WORDS, dtype=np.int64)
+    part[0:1].view(np.uint64)[0] = key
+    part[1:2].view(np.int32)[:] = (int((counts >= thInlr).sum()), int(has))
+    part[2:14].view(np.float64)[:] = T12
+    allp = gather_ransac_parts(torch.from_numpy(part))
+    k, ns, h, T = combine_gathered_parts(allp)
+    np.savez(os.path.join(out_dir, f"ransac{rank}.npz"), key=np.array([k], dtype=np.uint64), ns=np.array([ns]), hT=np.concatenate([[float(h)], T]))
     dist.barrier()
     dist.destroy_process_group()
 
