@@ -208,6 +208,13 @@ int pcreg_dev_unique_points_f32(const float* q, int Q, int ldq, const float* m, 
                                 const int32_t* n_cand, int32_t* keep,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* Multi-GPU: this rank's contribution to the [4][Q] candidate table of 4-byte words (rows 0-2: coordinate bits of
+ * the candidates whose model row is in this shard [m_lo, m_lo + M); row 3: their Unique verdict, 1 if keep is NULL;
+ * zero elsewhere).  An integer all_reduce(SUM) over the ranks assembles the table exactly; rows 0-2 then serve as
+ * the `m` of pcreg_dev_gather_pairs_f32 (ldm = Q, identity cand_m) and row 3 as its keep. */
+int pcreg_dev_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
+                             const int32_t* n_cand, int Q, int32_t* table, void* stream);
+
 /* Compact the kept candidates into 1-based pairs (row-major [k][2]) and gather the
  * matched coordinates as double n x 3 (ld = Q): pts1 = surface(query) rows, pts2 =
  * model rows (completeExperimentFast.m:205-206).  m is the FULL model here (or any

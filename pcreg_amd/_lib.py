@@ -54,7 +54,7 @@ SYMBOLS = [
     "pcreg_estimate_transform", "pcreg_calc_dists", "pcreg_ransac", "pcreg_ransac_batched",
     "pcreg_knn2_points_f32", "pcreg_match_points_f32", "pcreg_match_features", "pcreg_get_matches",
     "pcreg_align_points_knn", "pcreg_align_points_knn_batched", "pcreg_spatial_histogram_descriptors",
-    "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32", "pcreg_dev_merge_top2_strided_f32",
+    "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32", "pcreg_dev_merge_top2_strided_f32", "pcreg_dev_cand_table_f32",
     "pcreg_dev_filter_top2_f32", "pcreg_dev_unique_points_f32_workspace", "pcreg_dev_unique_points_f32",
     "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
     "pcreg_dev_ransac_partial", "pcreg_dev_ransac_finish", "pcreg_dev_ransac_finish_parts",

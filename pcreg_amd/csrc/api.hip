@@ -467,6 +467,13 @@ int pcreg_dev_unique_points_f32(const float* q, int Q, int ldq, const float* m, 
                                     (hipStream_t)stream);
 }
 
+int pcreg_dev_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
+                             const int32_t* n_cand, int Q, int32_t* table, void* stream) {
+    PCREG_ARG(m && cand_m && n_cand && table);
+    GUARD();
+    return launch_cand_table_f32(m, M, ldm, m_lo, cand_m, keep, n_cand, Q, table, (hipStream_t)stream);
+}
+
 int pcreg_dev_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm, const int32_t* cand_q,
                                const int32_t* cand_m, const int32_t* keep, const int32_t* n_cand, uint32_t* pairs,
                                double* pts1, double* pts2, int32_t* n_pairs, void* stream) {

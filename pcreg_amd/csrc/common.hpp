@@ -74,6 +74,8 @@ int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M
                            hipStream_t st);
 int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx,
                           float* dist, hipStream_t st, size_t rank_stride = 0);
+int launch_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
+                          const int32_t* n_cand, int Q, int32_t* table, hipStream_t st);
 int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr,
                            float ratio, int32_t* cand_q, int32_t* cand_m, int32_t* n_cand,
                            hipStream_t st);

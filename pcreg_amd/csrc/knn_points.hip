@@ -387,6 +387,27 @@ __global__ __launch_bounds__(1024) void ug_brute_kernel(const float* __restrict_
     }
 }
 
+// Multi-GPU: this rank's contribution to the [4][Q] candidate table (4-byte words): rows 0-2 = coordinate bits of
+// the candidates whose model row lives in this shard, row 3 = their Unique verdict; zero everywhere else, so an
+// integer SUM over the ranks assembles the table exactly.
+__global__ void cand_table_kernel(const float* __restrict__ m, int M, int ldm, int m_lo, const int32_t* __restrict__ cand_m,
+                                  const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand, int Q,
+                                  int32_t* __restrict__ table) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Q) return;
+    int w[4] = {0, 0, 0, 0};
+    if (k < *n_cand) {
+        const int j = cand_m[k] - m_lo;
+        if (j >= 0 && j < M) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) w[c] = __float_as_int(m[j + (size_t)c * ldm]);
+            w[3] = keep ? (keep[k] != 0) : 1;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) table[k + (size_t)c * Q] = w[c];
+}
+
 // Ordered compaction of the kept candidates (three small launches: per-workgroup counts,
 // exclusive scan, scatter) into 1-based pairs and, optionally, the matched coordinates.
 __global__ void gather_count_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
@@ -594,6 +615,15 @@ int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int
                        cand_q, cand_m, n_cand, chunk, part_idx, part_dist);
     hipLaunchKernelGGL(unique_reduce_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, M,
                        (int)m_lo, cand_q, cand_m, n_cand, keep);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
+                          const int32_t* n_cand, int Q, int32_t* table, hipStream_t st) {
+    PCREG_ARG(Q >= 0 && M >= 0);
+    if (Q == 0) return PCREG_OK;
+    hipLaunchKernelGGL(cand_table_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, m, M, ldm, (int)m_lo, cand_m, keep, n_cand, Q, table);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -53,6 +53,7 @@ class HipOps:
         self.pts1 = torch.empty((3, Q), dtype=f64, **kw)
         self.pts2 = torch.empty((3, Q), dtype=f64, **kw)
         self.ident = torch.arange(Q, dtype=i32, **kw)
+        self.table = torch.zeros((4, Q), dtype=i32, **kw)               # multi-GPU candidate table (sharded.py step 4)
 
     def local_top2(self, q, model, m_lo):
         check(lib().pcreg_dev_knn2_points_f32(_p(q), self.Q, q.shape[1], _p(model), model.shape[1], model.shape[1],
@@ -76,6 +77,11 @@ class HipOps:
                                                 C.c_int32(m_lo), _p(cand_q), _p(cand_m), _p(n_cand), _p(self.keep),
                                                 _p(self.ws_unq), C.c_size_t(self.ws_unq.numel()), _stream()))
         return self.keep
+
+    def cand_table(self, model, m_lo, cand_m, keep, n_cand):
+        check(lib().pcreg_dev_cand_table_f32(_p(model), model.shape[1], model.shape[1], C.c_int32(m_lo), _p(cand_m),
+                                             _p(keep) if keep is not None else None, _p(n_cand), self.Q, _p(self.table), _stream()))
+        return self.table
 
     def gather_pairs(self, q, table, table_is_dense, cand_q, cand_m, keep, n_cand):
         L = lib()

@@ -9,9 +9,9 @@ Exchanges per match:
   2. threshold / ratio filters run redundantly on every rank (deterministic);
   3. the Unique back-check of a candidate is owned by the rank that holds its model row
      (the queries are replicated, so the column minimum is shard-local);
-  4. ONE all_reduce(SUM) of a dense [4, Q] float table publishes the verdicts (row 3: the owner's 0/1
-     flag) and assembles the matched model coordinates (rows 0-2); exactly one rank contributes each
-     column, so the sums are exact (x + 0).
+  4. ONE all_reduce(SUM) of a dense [4, Q] table of 4-byte words publishes the verdicts (row 3: the owner's
+     0/1 flag) and assembles the matched model coordinates (rows 0-2: float bit patterns); exactly one rank
+     contributes each column, so the integer sums are exact (x + 0).
   RANSAC with its hypotheses split over the ranks adds ONE all_gather of the 112-byte partial results
   (combine_gathered_parts / pcreg_dev_ransac_finish_parts).  Three collectives per registration in all.
 
@@ -109,20 +109,21 @@ class ShardedMatcher:
             keep = ops.unique_local(q, model, self.m_lo, cand_q, cand_m, n_cand)
         if not self.collective:
             return ops.gather_pairs(q, model, False, cand_q, cand_m, keep, n_cand)
-        # dense [4,Q] table: rows 0-2 = the candidates' model coordinates, row 3 = the Unique verdict; column k
-        # is written by the rank owning row cand_m[k], zero elsewhere, so one SUM both publishes and assembles
-        Q = self.Q
-        ar = torch.arange(Q, device=cand_m.device, dtype=torch.int32)
-        local = (cand_m >= self.m_lo) & (cand_m < self.m_lo + self.M_local) & (ar < n_cand)
-        j = torch.where(local, cand_m - self.m_lo, torch.zeros_like(cand_m)).long()
-        table = torch.zeros((4, Q), dtype=model.dtype, device=model.device)
-        table[0:3] = torch.where(local.unsqueeze(0), model[:, j], torch.zeros((), dtype=model.dtype, device=model.device))
-        if unique:
-            table[3] = torch.where(local, keep.to(model.dtype), torch.zeros((), dtype=model.dtype, device=model.device))
+        # dense [4,Q] table of 4-byte words: rows 0-2 = the candidates' model coordinates (float bits), row 3 = the
+        # Unique verdict; column k is written by the rank owning row cand_m[k], zero elsewhere, so ONE integer SUM
+        # both publishes the verdicts and assembles the coordinates, exactly
+        if hasattr(ops, "cand_table"):
+            table = ops.cand_table(model, self.m_lo, cand_m, keep, n_cand)
+        else:
+            Q = self.Q
+            ar = torch.arange(Q, device=cand_m.device, dtype=torch.int32)
+            local = (cand_m >= self.m_lo) & (cand_m < self.m_lo + self.M_local) & (ar < n_cand)
+            j = torch.where(local, cand_m - self.m_lo, torch.zeros_like(cand_m)).long()
+            table = torch.zeros((4, Q), dtype=torch.int32, device=model.device)
+            table[0:3] = torch.where(local.unsqueeze(0), model[:, j].contiguous().view(torch.int32), torch.zeros((), dtype=torch.int32, device=model.device))
+            table[3] = torch.where(local, (keep != 0).to(torch.int32) if unique else torch.ones_like(cand_m), torch.zeros_like(cand_m))
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.group)
-        if unique:
-            keep = (table[3] > 0.5).to(torch.int32)
-        return ops.gather_pairs(q, table[0:3], True, cand_q, cand_m, keep, n_cand)
+        return ops.gather_pairs(q, table[0:3].view(model.dtype), True, cand_q, cand_m, table[3] if unique else None, n_cand)
 
     def match(self, q, model, thr_abs: float, max_ratio: float, unique: bool = True):
         self.search(q, model)
