@@ -83,7 +83,7 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double* s_redn /*[4]
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void align_points_knn_kernel(
+__global__ __launch_bounds__(kBlock, 3) void align_points_knn_kernel(
     const double* __restrict__ pts, int ld, const int32_t* __restrict__ offsets, int C1, int C2,
     double* __restrict__ aligned, int ld_out, double* __restrict__ coeff_out, double* __restrict__ c_out,
     int32_t* __restrict__ status) {
