@@ -547,31 +547,39 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_sgpr_kernel(
 }  // namespace
 size_t knn_f16_prep_bytes(int M);
 int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
-                              unsigned* rm2, void* mtiles, unsigned* gthr, int32_t* part_idx, float* part_s,
+                              unsigned* rm2, void* mtiles, unsigned* gthr, void* cand_ent, int32_t* cand_cnt,
                               int target_blocks, int max_S, bool dry, int* S_out, hipStream_t st);
 namespace {
 // ---- 3. exact re-rank + certificate: one wave per query ------------------------------------
 __device__ __forceinline__ bool lex_lt_f(float da, int ia, float db, int ib) {
     return da < db || (da == db && (unsigned)ia < (unsigned)ib);
 }
+template <int LPQ>      // lanes per query: 64 for the dense lists (S * kc entries), 8 for the short per-query lists
 __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
     const Prep* __restrict__ prep, const unsigned* __restrict__ rm2_bits, const unsigned* __restrict__ gthr,
     const int32_t* __restrict__ part_idx, const float* __restrict__ part_s, int S, int kc, int idx_base,
-    int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int e_mode) {
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int e_mode,
+    const int32_t* __restrict__ cand_cnt) {
+    const int lane = threadIdx.x & (LPQ - 1);
+    const int qi = blockIdx.x * (kBlock / LPQ) + (threadIdx.x / LPQ);
     if (qi >= Q) return;
     const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
-    const int total = S * kc;      // kc candidates per (chunk, query): 4 (VALU path) or 16 (MFMA path)
+    // cand_cnt == nullptr: dense lists, kc candidates per (chunk, query) at [chunk][query][kc] (VALU / fp32-MFMA paths).
+    // cand_cnt != nullptr: one list per query, cand_cnt[qi] (index, score-bits) pairs at part_idx[(qi * S * kc + e) * 2].
+    const bool sparse = cand_cnt != nullptr;
+    const int total = sparse ? min(cand_cnt[qi], S * kc) : S * kc;
+    const uint2* ent = reinterpret_cast<const uint2*>(part_idx) + (size_t)qi * S * kc;
     // pass 1: the two smallest approximate scores of the union (values only)
     float a1 = INFINITY, a2 = INFINITY;
-    for (int e = lane; e < total; e += 64) {
-        size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc);
-        if (part_idx[o] >= 0) { float s = part_s[o]; if (s < a2) { if (s < a1) { a2 = a1; a1 = s; } else a2 = s; } }
+    for (int e = lane; e < total; e += LPQ) {
+        int j; float s;
+        if (sparse) { const uint2 v = ent[e]; j = (int)v.x; s = __uint_as_float(v.y); }
+        else { size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc); j = part_idx[o]; s = part_s[o]; }
+        if (j >= 0) { if (s < a2) { if (s < a1) { a2 = a1; a1 = s; } else a2 = s; } }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = LPQ / 2; o > 0; o >>= 1) {
         float b1 = __shfl_xor(a1, o), b2 = __shfl_xor(a2, o);
         float n1 = fminf(a1, b1);
         float n2 = fminf(fmaxf(a1, b1), fminf(a2, b2));
@@ -592,10 +600,11 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const float cut = (float)((double)a2 + 2.0 * Eab + 16.0 * u * fabs((double)a2 + r2));
     const float cut_up = nextafterf(cut, INFINITY);              // float rounding of the cut must not exclude anything
     float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
-    for (int e = lane; e < total; e += 64) {
-        size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc);
-        int j = part_idx[o];
-        if (j >= 0 && (part_s[o] <= cut_up || !(a2 < INFINITY))) {
+    for (int e = lane; e < total; e += LPQ) {
+        int j; float sc;
+        if (sparse) { const uint2 v = ent[e]; j = (int)v.x; sc = __uint_as_float(v.y); }
+        else { size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc); j = part_idx[o]; sc = part_s[o]; }
+        if (j >= 0 && (sc <= cut_up || !(a2 < INFINITY))) {
             float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
             float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
             if (lex_lt_f(d, j, d2, i2)) {
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     }
     // wave-shuffle top-2 reduction ordered by (dist, idx); empty slots are (+inf, -1 -> max uint)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = LPQ / 2; o > 0; o >>= 1) {
         float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
         int j1 = __shfl_xor(i1, o), j2 = __shfl_xor(i2, o);
         // merge two sorted pairs
@@ -731,7 +740,7 @@ static size_t fast_fixed_bytes(int Q, int M) {
     size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
     return 256 + 256 + 256 + align_up(512 * 12 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
            align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256) + 2 * align_up((size_t)kPartCap * 16 * q * 4, 256) +
-           seed_bytes(M) + 2 * align_up((size_t)1024 * 32 * 2 * 4, 256);
+           seed_bytes(M) + 2 * align_up((size_t)1024 * 32 * 2 * 4, 256) + align_up(q * 4, 256);
 }
 
 size_t knn2_points_fast_workspace_bytes(int Q, int M) {
@@ -770,6 +779,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     float4* seed_slots = (float4*)w;       w += M >= kSeedMinM ? align_up(seed_cells * kSeedSlots * 16, 256) : 0;
     int32_t* fb_idx = (int32_t*)w;         w += align_up((size_t)1024 * 32 * 2 * 4, 256);
     float* fb_dist = (float*)w;            w += align_up((size_t)1024 * 32 * 2 * 4, 256);
+    int32_t* cand_cnt = (int32_t*)w;       w += align_up(qq * 4, 256);
     void* ews = w;
     size_t ews_bytes = ws_bytes - (size_t)(w - (char*)ws);
 
@@ -777,6 +787,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2, n_flag);
     int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0;
+    bool sparse_lists = false;
     static const bool no_seed = getenv("PCREG_KNN_NOSEED") && atoi(getenv("PCREG_KNN_NOSEED")) != 0;
     if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)
         PCREG_HIP(hipMemsetAsync(seed_cnt, 0, seed_cells * 4, st));
@@ -789,7 +800,8 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     }
     if (variant == 40 || variant == 41) {        // f16-split matrix-core candidates (41: timing only)
         kc = KC;
-        int rc = launch_knn_candidates_f16(q, Q, ldq, m, M, ldm, prep, rm2, mprep, gthr, part_idx, part_s,
+        sparse_lists = true;             // entries of both 4-byte arrays' space: [Q][S * KC] (index, score) pairs
+        int rc = launch_knn_candidates_f16(q, Q, ldq, m, M, ldm, prep, rm2, mprep, gthr, part_idx, cand_cnt,
                                            target_env > 0 ? target_env : 4096, kPartCap * 2, variant == 41, &S, st);
         if (rc) return rc;
     } else if (use_mfma) {
@@ -841,8 +853,12 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
 #undef PCREG_CAND_LAUNCH
     }
     PCREG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(knn_finalize_kernel, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
-                       part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode);
+    if (sparse_lists)
+        hipLaunchKernelGGL(knn_finalize_kernel<8>, dim3((Q + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
+                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)cand_cnt);
+    else
+        hipLaunchKernelGGL(knn_finalize_kernel<64>, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
+                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)nullptr);
     PCREG_HIP(hipGetLastError());
     if (getenv("PCREG_KNN_DEBUG")) {
         int32_t nf = 0;

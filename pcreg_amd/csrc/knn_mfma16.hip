@@ -45,9 +45,11 @@ __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
 // model -> tiles of f16 operands; R_m^2 (unscaled) by atomicMax on the float bits
 __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __restrict__ m, int M, int ldm,
                                                                 const Prep* __restrict__ prep, uint4* __restrict__ out,
-                                                                int n_tiles, unsigned* __restrict__ rm2_bits) {
+                                                                int n_tiles, unsigned* __restrict__ rm2_bits,
+                                                                int32_t* __restrict__ cand_cnt, int Q) {
     const float cx = prep->cx, cy = prep->cy, cz = prep->cz, sg = prep->sigma;
     float mx = 0.0f;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < Q; i += gridDim.x * kBlock) cand_cnt[i] = 0;     // the queries' candidate lists start empty
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_tiles * kT16; i += gridDim.x * kBlock) {
         union { f16x8 v; uint4 u; } lo, hi;
         if (i < M) {
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __r
 template <int QG, bool DRY, bool BATCH>
 __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
-    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx /*[S][Q][KC]*/,
-    float* __restrict__ part_s) {
+    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, uint2* __restrict__ cand_ent /*[Q][cap]: (index, score bits)*/,
+    int32_t* __restrict__ cand_cnt /*[Q]*/, int cap) {
     __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];          // 2 x 16 KiB, filled by LDS-DMA
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
@@ -197,7 +199,6 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
     // The two half-waves of a query (lanes l and l ^ 32) merge their sorted fours in registers and lane l < 32
     // writes ONE list of four per (chunk, query); the merged 4th-best is published too, so every entry dropped
     // here still has s >= the final threshold word G, which is what the certificate relies on.
-    const int chunk = blockIdx.y;
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
         const int qi = q_base + g * 32 + col;
@@ -219,9 +220,18 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
         }
         if (qi < Q && half == 0) {
             if (mine.s[3] < INFINITY) { unsigned k = f2ord(mine.s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
-            size_t o = ((size_t)chunk * Q + qi) * KC;
-            *reinterpret_cast<int4*>(part_idx + o) = make_int4(mine.i[0], mine.i[1], mine.i[2], mine.i[3]);
-            *reinterpret_cast<float4*>(part_s + o) = make_float4(mine.s[0] * inv2, mine.s[1] * inv2, mine.s[2] * inv2, mine.s[3] * inv2);
+            // Only real entries are kept: the list of query qi grows by this (chunk, query)'s valid candidates (most
+            // chunks add none once the thresholds are seeded), in whatever order the chunks finish -- the re-rank
+            // orders by (distance, index), so the order is immaterial.  cap = S * KC: it cannot overflow.
+            int nv = 0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) nv += mine.i[k] >= 0;
+            if (nv > 0) {
+                const int base = atomicAdd(&cand_cnt[qi], nv);
+                uint2* dst = cand_ent + (size_t)qi * cap + base;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) if (k < nv) dst[k] = make_uint2((unsigned)mine.i[k], __float_as_uint(mine.s[k] * inv2));
+            }
         }
     }
 }
@@ -251,7 +261,7 @@ size_t knn_f16_prep_bytes(int M) { return (size_t)((M > 0 ? M : 1) + kT16 - 1) /
 
 // grid: q_blocks x S; KC = 4 list entries per (chunk, query).  Returns S and kc through the pointers.
 int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
-                              unsigned* rm2, void* mtiles, unsigned* gthr, int32_t* part_idx, float* part_s,
+                              unsigned* rm2, void* mtiles, unsigned* gthr, void* cand_ent, int32_t* cand_cnt,
                               int target_blocks, int max_S, bool dry, int* S_out, hipStream_t st) {
     static const int cfg = getenv("PCREG_KNN_F16_CFG") ? atoi(getenv("PCREG_KNN_F16_CFG")) : 0;   // 0: QG4; 1: QG4 batched; 2: QG2; 3: QG2 batched
     const int QG = (cfg == 2 || cfg == 3) ? 2 : 4;
@@ -263,10 +273,10 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
     S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
     *S_out = S;
-    // every (chunk, query) slot is written by the kernel; only an empty model leaves the lists untouched
-    if (M <= 0) { PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * Q * KC * 4, st)); return PCREG_OK; }
+    // the prep kernel empties the per-query lists; an empty model has no prep
+    if (M <= 0) { PCREG_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)Q * 4, st)); return PCREG_OK; }
     int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 512) pb = 512;
-    hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2);
+    hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2, cand_cnt, Q);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (g_time_on && Q * (long long)M >= (1LL << 33)) {          // the main search, not the small Unique back-check
         if (g_time_used == g_time_ev.size()) { hipEvent_t a, b; PCREG_HIP(hipEventCreate(&a)); PCREG_HIP(hipEventCreate(&b)); g_time_ev.emplace_back(a, b); }
@@ -274,7 +284,7 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
         PCREG_HIP(hipEventRecord(ev0, st));
     }
 #define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks, S), dim3(kBlock), 0, st, q, Q, ldq, \
-                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, part_idx, part_s)
+                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC)
     switch (cfg * 2 + (dry ? 1 : 0)) {
         case 0: PCREG_F16_LAUNCH(4, false, false); break;  case 1: PCREG_F16_LAUNCH(4, true, false); break;
         case 2: PCREG_F16_LAUNCH(4, false, true); break;   case 3: PCREG_F16_LAUNCH(4, true, true); break;
