@@ -866,7 +866,7 @@ struct StagedArgs {
     double* T1; unsigned char* v1; unsigned char* pass1; unsigned char* v2;
     unsigned char* cert;         // rank of the inlier set certified from the sample alone (rs_fit1 + rs_pass1)
     double* certq;               // [iters][2]: the sample's singular-value bounds / tolerance factor (0: no certificate)
-    double* bounds;              // [2]: max |pts1 row|^2, max |pts2 row|^2
+    double* bounds;              // [4]: max |pts1 row|^2, max |pts2 row|^2, the same of the rows relative to correspondence 0
     double* mom;                 // [iters][27]
     int32_t* part;               // [kSMaxPB][iters]
     int pb;                      // point blocks in use
@@ -880,6 +880,12 @@ struct StagedArgs {
     int32_t* n_pass;
     unsigned char* dense;        // [iters] refit needs rs_moments_kernel (rank not certified, or the N == 3 branch)
     int use_lane;
+    // fp32-screened scoring (rs_score32_kernel): centred single-precision copies of the correspondences and of
+    // the transforms; a hypothesis with any distance within +-E of thDist is re-scored in fp64 by the same wave
+    float* c32;                  // [6][n32]: p1 - o1 (x,y,z), p2 - o2 (x,y,z) rounded to fp32, o = correspondence 0
+    int n32;                     // row length of c32
+    float* T32a; float* T32b;    // [iters][16]: R (9, rows), t' (3), thlo, thhi, 2 pad -- sample fits / refits
+    int use_f32;
 };
 
 __device__ __forceinline__ int staged_n(const RansacArgs& a) { return min(a.n_dev ? *a.n_dev : a.n_cap, a.n_cap); }
@@ -889,13 +895,20 @@ __global__ __launch_bounds__(256) void rs_records_kernel(StagedArgs sa) {
     const RansacArgs& a = sa.a;
     const int n = staged_n(a);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    double m1 = 0.0, m2 = 0.0;
+    double m1 = 0.0, m2 = 0.0, c1m = 0.0, c2m = 0.0;
     if (i < n) {
         Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
         double o[6], q[6];
         P.load(0, o); P.load(i, q);
         m1 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
         m2 = q[3] * q[3] + q[4] * q[4] + q[5] * q[5];
+        if (sa.use_f32) {
+            double v[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { v[c] = q[c] - o[c]; sa.c32[(size_t)c * sa.n32 + i] = (float)v[c]; }
+            c1m = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+            c2m = v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+        }
         if (sa.use_lane) {
             const double d0 = q[0] - o[0], d1 = q[1] - o[1], d2 = q[2] - o[2];
             const double m0 = q[3] - o[3], m1_ = q[4] - o[4], m2_ = q[5] - o[5];
@@ -909,8 +922,13 @@ __global__ __launch_bounds__(256) void rs_records_kernel(StagedArgs sa) {
     // max squared row norms of both point sets (the only global quantity the rank certificate needs):
     // non-negative doubles order like their bit patterns, the maximum is order-free
 #pragma unroll
-    for (int o_ = 32; o_ > 0; o_ >>= 1) { m1 = fmax(m1, __shfl_xor(m1, o_)); m2 = fmax(m2, __shfl_xor(m2, o_)); }
+    for (int o_ = 32; o_ > 0; o_ >>= 1) {
+        m1 = fmax(m1, __shfl_xor(m1, o_)); m2 = fmax(m2, __shfl_xor(m2, o_));
+        c1m = fmax(c1m, __shfl_xor(c1m, o_)); c2m = fmax(c2m, __shfl_xor(c2m, o_));
+    }
     if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (threadIdx.x & ~63) < n) {
+        if (c1m > ((volatile double*)sa.bounds)[2]) atomicMax((unsigned long long*)sa.bounds + 2, (unsigned long long)__double_as_longlong(c1m));
+        if (c2m > ((volatile double*)sa.bounds)[3]) atomicMax((unsigned long long*)sa.bounds + 3, (unsigned long long)__double_as_longlong(c2m));
         // a plain read first: most waves find a maximum that already covers theirs and skip the atomic
         if (m1 > ((volatile double*)sa.bounds)[0]) atomicMax((unsigned long long*)sa.bounds, (unsigned long long)__double_as_longlong(m1));
         if (m2 > ((volatile double*)sa.bounds)[1]) atomicMax((unsigned long long*)sa.bounds + 1, (unsigned long long)__double_as_longlong(m2));
@@ -992,7 +1010,7 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
     for (int k = 0; k < 12; ++k) sa.T1[(size_t)p * 12 + k] = T1[k];
     sa.v1[p] = v1;
     sa.certq[2 * (size_t)p] = cq1; sa.certq[2 * (size_t)p + 1] = cq2;
-    if (p == 0) { *sa.n_pass = 0; sa.bounds[0] = 0.0; sa.bounds[1] = 0.0; }
+    if (p == 0) { *sa.n_pass = 0; sa.bounds[0] = 0.0; sa.bounds[1] = 0.0; sa.bounds[2] = 0.0; sa.bounds[3] = 0.0; }
 }
 
 // grid (point blocks, hypothesis chunks).  part[pb][h] = inliers of hypothesis h among this block's points.
@@ -1040,6 +1058,150 @@ __global__ __launch_bounds__(kSW * 64) void rs_score_kernel(StagedArgs sa, const
                 if (EMIT) {                 // ballot s into lane s
                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_lo) : "s"((int)(unsigned)b), "n"(s));
                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_hi) : "s"((int)(unsigned)(b >> 32)), "n"(s));
+                }
+            }
+            if (lane == 0) s_cnt[wave][h - h0] += cnt;
+            if (EMIT && lane < kSS)         // one 64-byte row segment per (wave, hypothesis)
+                sa.masks[(size_t)h * sa.nslots_cap + (size_t)pb * (kSPts / 64) + wave * kSS + lane] =
+                    ((unsigned long long)(unsigned)mine_hi << 32) | (unsigned)mine_lo;
+        }
+    }
+    __syncthreads();
+    for (int hl = threadIdx.x; hl < h1 - h0; hl += kSW * 64) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < kSW; ++w) c += s_cnt[w][hl];
+        sa.part[(size_t)blockIdx.x * a.iters + h0 + hl] = c;
+    }
+}
+
+// ---- fp32-screened scoring ---------------------------------------------------------------------------------
+// calcDists in single precision on coordinates relative to correspondence 0: with a = p1 - o1, b = p2 - o2 and
+// t' = t + R o2 - o1 the residual is a - (R b + t').  Rounding analysis (u = 2^-24, A = max|a|, B = max|b|,
+// rho = largest row norm of R, tau = max|t'_c|): every component of R b + t' carries at most 5.1 u (B rho + tau)
+// (two input roundings per product, one for t', three FMA roundings), so each residual component is off by at
+// most e1 + u |r_c| with e1 = u (A + 5.1 (B rho + tau)), and for every true d <= 4 thDist
+//     |d32 - d| <= 2 sqrt(3) sqrt(4 thDist) e1 + 3 e1^2 + 5.2 u 4 thDist  =: E0.
+// E = 1.5 E0 (the slack also covers the ~1e-16-level difference between the centred and the raw fp64 forms).
+// d32 < thDist - E proves an inlier, d32 > thDist + E proves an outlier (for d > 4 thDist the error grows slower
+// than d itself once E <= thDist / 2).  A wave that meets ANY distance in between re-scores that hypothesis with
+// the fp64 sqdist on the raw coordinates -- so every count and every mask is the fp64 one.  E > thDist / 2 or a
+// non-finite E sends everything to fp64.
+__device__ __forceinline__ void make_t32(const double (&T)[12], const double (&o)[6], double A, double B, double th,
+                                         float* __restrict__ out /*16*/) {
+    const double u = 5.9604644775390625e-08;
+    double rho = 0.0, tau = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double tp = T[r * 4 + 3] + (T[r * 4] * o[3] + T[r * 4 + 1] * o[4] + T[r * 4 + 2] * o[5]) - o[r];
+        rho = fmax(rho, sqrt(T[r * 4] * T[r * 4] + T[r * 4 + 1] * T[r * 4 + 1] + T[r * 4 + 2] * T[r * 4 + 2]));
+        tau = fmax(tau, fabs(tp));
+        out[r * 3] = (float)T[r * 4]; out[r * 3 + 1] = (float)T[r * 4 + 1]; out[r * 3 + 2] = (float)T[r * 4 + 2];
+        out[9 + r] = (float)tp;
+    }
+    const double e1 = u * (A + 5.1 * (B * rho + tau));
+    const double E = 1.5 * (2.0 * 1.7320508075688774 * sqrt(4.0 * th) * e1 + 3.0 * e1 * e1 + 5.2 * u * 4.0 * th);
+    float lo = -INFINITY, hi = INFINITY;
+    if (E == E && E <= 0.5 * th && th > 0.0 && tau < 1e30 && A < 1e15 && B < 1e15) {
+        lo = (float)(th - E); if ((double)lo > th - E) lo = nextafterf(lo, -INFINITY);
+        hi = (float)(th + E); if ((double)hi < th + E) hi = nextafterf(hi, INFINITY);
+    }
+    out[12] = lo; out[13] = hi; out[14] = 0.0f; out[15] = 0.0f;
+}
+
+__global__ void rs_t32_kernel(StagedArgs sa, const double* __restrict__ TT, float* __restrict__ out) {
+    const RansacArgs& a = sa.a;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= a.iters) return;
+    const int n = staged_n(a);
+    if (n < 1) return;
+    Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
+    double o[6]; P.load(0, o);
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = TT[(size_t)h * 12 + k];
+    make_t32(T, o, sqrt(sa.bounds[2]) * (1.0 + 1e-12), sqrt(sa.bounds[3]) * (1.0 + 1e-12), a.thDist, out + (size_t)h * 16);
+}
+
+__device__ __forceinline__ float sqdist32(const float (&p)[6], const float (&T)[12]) {      // T: R rows (9), t' (3)
+    const float tx = __builtin_fmaf(p[3], T[0], __builtin_fmaf(p[4], T[1], __builtin_fmaf(p[5], T[2], T[9])));
+    const float ty = __builtin_fmaf(p[3], T[3], __builtin_fmaf(p[4], T[4], __builtin_fmaf(p[5], T[5], T[10])));
+    const float tz = __builtin_fmaf(p[3], T[6], __builtin_fmaf(p[4], T[7], __builtin_fmaf(p[5], T[8], T[11])));
+    const float dx = p[0] - tx, dy = p[1] - ty, dz = p[2] - tz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+// rs_score_kernel with the fp32 screen in front: same grid, same partial counts, same masks.  No branch per slot:
+// the eight slots of a hypothesis are screened straight through, the "somebody is in the band" masks are OR-ed,
+// and only then does the wave decide whether to redo the hypothesis in fp64.
+template <bool EMIT>
+__global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, const double* __restrict__ TT,
+                                                              const float* __restrict__ T32,
+                                                              const unsigned char* __restrict__ valid) {
+    const RansacArgs& a = sa.a;
+    __shared__ int s_cnt[kSW][kSChunk];
+    const int n = staged_n(a);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h0 = blockIdx.y * kSChunk, h1 = min(a.iters, h0 + kSChunk);
+    const double th = a.thDist;
+    for (int hl = threadIdx.x; hl < kSW * kSChunk; hl += kSW * 64) (&s_cnt[0][0])[hl] = 0;
+    unsigned long long vmask[(kSChunk + 63) / 64];
+#pragma unroll
+    for (int k = 0; k < (kSChunk + 63) / 64; ++k) {
+        const int h = h0 + k * 64 + lane;
+        vmask[k] = __ballot(h < h1 && k * 64 + lane < kSChunk && valid[h] != 0);
+    }
+    __syncthreads();
+    for (int pb = blockIdx.x; pb * kSPts < n; pb += gridDim.x) {       // normally one trip
+        float q[kSS][6]; unsigned long long actb[kSS];
+        const int ibase = pb * kSPts + wave * kSS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < kSS; ++s) {
+            const int i = ibase + s * 64;
+            const bool act = i < n;
+            actb[s] = __ballot(act);
+            const int ii = act ? i : 0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) q[s][c] = sa.c32[(size_t)c * sa.n32 + ii];
+        }
+        for (int h = h0; h < h1; ++h) {
+            if (!((vmask[(h - h0) >> 6] >> ((h - h0) & 63)) & 1ull)) continue;   // wave-uniform
+            float T[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T[k] = T32[(size_t)h * 16 + k];         // uniform address: scalar loads
+            const float thlo = T32[(size_t)h * 16 + 12], thhi = T32[(size_t)h * 16 + 13];
+            unsigned long long b[kSS], band = 0ull;
+#pragma unroll
+            for (int s = 0; s < kSS; ++s) {
+                const float d = sqdist32(q[s], T);
+                b[s] = __ballot(d < thlo) & actb[s];
+                band |= __ballot(d <= thhi) & actb[s] & ~b[s];                    // NaN: neither test holds
+            }
+            if (band != 0ull) {                         // rare: the whole hypothesis again, fp64 on the raw coordinates
+                double T64[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) T64[k] = TT[(size_t)h * 12 + k];
+#pragma unroll 1
+                for (int s = 0; s < kSS; ++s) {
+                    const int i = ibase + s * 64;
+                    const bool act = (actb[s] >> lane) & 1ull;
+                    const int ii = act ? i : 0;
+                    double p[6];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { p[c] = a.p1[ii + (size_t)c * a.ld]; p[3 + c] = a.p2[ii + (size_t)c * a.ld]; }
+                    const unsigned long long bb = __ballot((sqdist(p, T64) < th) & act);
+#pragma unroll
+                    for (int s2 = 0; s2 < kSS; ++s2) if (s2 == s) b[s2] = bb;
+                }
+            }
+            int cnt = 0;
+            int mine_lo = 0, mine_hi = 0;
+#pragma unroll
+            for (int s = 0; s < kSS; ++s) {
+                cnt += __popcll(b[s]);
+                if (EMIT) {                 // ballot s into lane s
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_lo) : "s"((int)(unsigned)b[s]), "n"(s));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_hi) : "s"((int)(unsigned)(b[s] >> 32)), "n"(s));
                 }
             }
             if (lane == 0) s_cnt[wave][h - h0] += cnt;
@@ -1294,6 +1456,12 @@ __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) a.TF[(size_t)h * 12 + k] = T2[k];
     sa.v2[h] = v2;
+    if (sa.use_f32 && v2) {
+        const int n32_ = staged_n(a);
+        Pts<false> P32{a.p1, a.p2, a.ld, nullptr, n32_};
+        double o32[6]; P32.load(0, o32);
+        make_t32(T2, o32, sqrt(sa.bounds[2]) * (1.0 + 1e-12), sqrt(sa.bounds[3]) * (1.0 + 1e-12), a.thDist, sa.T32b + (size_t)h * 16);
+    }
 }
 
 __global__ void rs_finish_kernel(StagedArgs sa) {
@@ -1592,7 +1760,8 @@ static size_t staged_extra_bytes(size_t h, int n_cap) {    // T1 | mom | part | 
     size_t b = align_up(h * 12 * sizeof(double), 256) + align_up(h * 27 * sizeof(double), 256) +
                align_up(h * kSMaxPB * sizeof(int32_t), 256) + 5 * align_up(h, 256) + 256 + align_up(h * 2 * sizeof(double), 256);
     if (n_cap >= kStagedMinN)
-        b += align_up(h * staged_slots_cap(n_cap) * 8, 256) + align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256) +
+        b += align_up(staged_slots_cap(n_cap) * 64 * 6 * sizeof(float), 256) + 2 * align_up(h * 16 * sizeof(float), 256) +
+             align_up(h * staged_slots_cap(n_cap) * 8, 256) + align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256) +
              align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256) + align_up(h * sizeof(int32_t), 256) + 256;
     return b;
 }
@@ -1650,7 +1819,12 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.mpart = (double*)w; w += align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256);
         sa.pass_list = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
         sa.n_pass = (int32_t*)w; w += 256;
+        sa.n32 = (int)staged_slots_cap(n_cap) * 64;
+        sa.c32 = (float*)w; w += align_up((size_t)sa.n32 * 6 * sizeof(float), 256);
+        sa.T32a = (float*)w; w += align_up(h * 16 * sizeof(float), 256);
+        sa.T32b = (float*)w; w += align_up(h * 16 * sizeof(float), 256);
         sa.use_lane = a.refine && !(getenv("PCREG_RANSAC_NOLANE") && atoi(getenv("PCREG_RANSAC_NOLANE")));
+        sa.use_f32 = !(getenv("PCREG_RANSAC_F64SCORE") && atoi(getenv("PCREG_RANSAC_F64SCORE")));
         int pb = (n_cap + kSPts - 1) / kSPts; if (pb > kSMaxPB) pb = kSMaxPB; if (pb < 1) pb = 1;
         sa.pb = pb;
         int hpw = (int)((total + 250LL * kTW - 1) / (250LL * kTW));
@@ -1661,8 +1835,14 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         const int it = o.iterNum;
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
         hipLaunchKernelGGL(rs_fit1_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
-        if (a.refine) hipLaunchKernelGGL(rs_records_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, st, sa);
-        if (sa.use_lane) {
+        if (a.refine || sa.use_f32) hipLaunchKernelGGL(rs_records_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, st, sa);
+        if (sa.use_f32) {
+            hipLaunchKernelGGL(rs_t32_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a);
+            if (sa.use_lane)
+                hipLaunchKernelGGL(rs_score32_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1);
+            else
+                hipLaunchKernelGGL(rs_score32_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1);
+        } else if (sa.use_lane) {
             hipLaunchKernelGGL(rs_score_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
         } else {
             hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
@@ -1674,7 +1854,10 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
                                    (const double*)sa.rec, (const unsigned long long*)sa.masks);
             hipLaunchKernelGGL(rs_moments_kernel, dim3((it + hpw * kTW - 1) / (hpw * kTW)), dim3(kTBlock), 0, st, sa);
             hipLaunchKernelGGL(rs_fit2_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
-            hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const unsigned char*)sa.v2);
+            if (sa.use_f32)
+                hipLaunchKernelGGL(rs_score32_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const float*)sa.T32b, (const unsigned char*)sa.v2);
+            else
+                hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const unsigned char*)sa.v2);
             hipLaunchKernelGGL(rs_finish_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
         }
     } else {

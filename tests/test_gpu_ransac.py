@@ -265,6 +265,39 @@ def test_lane_refit_sizes_and_switch(n, iters, frac, oracle_c, monkeypatch):
     assert np.abs(res[0] - res_sweep[0]).max() < 1e-10
 
 
+@pytest.mark.parametrize("big_offset", [False, True])
+def test_fp32_screen_band_is_decided_in_fp64(big_offset, oracle_c, monkeypatch):
+    """rs_score32_kernel screens distances in fp32 and re-scores a hypothesis in fp64 when any distance falls
+    within its certified band around thDist.  Here half of the correspondences sit 1e-7 .. 1e-4 (relative) off the
+    threshold (offset by a vector of squared length thDist (1 +- delta), no noise): deep inside the fp32 band, far
+    outside fp64 rounding, so nearly every hypothesis goes through the band and fp64 must decide it; with
+    big_offset the coordinates are ~4000 and the band is wide.  Counts, inlier sets and the fp64-only run
+    (PCREG_RANSAC_F64SCORE=1) must agree with the oracle exactly."""
+    import pcreg_amd as pc
+    n, iters, th = 6000, 400, 0.05
+    p1, p2, _ = rigid_case(n, 1234, noise=0.0, outlier_frac=0.0)
+    rng = np.random.default_rng(99)
+    delta = rng.choice([-1.0, 1.0], n // 2) * 10.0 ** rng.uniform(-7, -4, n // 2)
+    v = rng.normal(size=(n // 2, 3)); v *= (np.sqrt(th * (1.0 + delta)) / np.linalg.norm(v, axis=1))[:, None]
+    p1 = p1.copy(); p1[::2] += v
+    if big_offset:
+        p1 = p1 + 4000.0; p2 = p2 + np.array([3900.0, -4100.0, 4050.0])
+    coef = dict(minPtNum=3, iterNum=iters, thDist=th, thInlrRatio=0.2, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=11)
+    res = pc.ransac(p1, p2, coef, seed=11, return_iter_counts=True)
+    monkeypatch.setenv("PCREG_RANSAC_F64SCORE", "1")
+    res64 = pc.ransac(p1, p2, coef, seed=11, return_iter_counts=True)
+    assert not ref["failed"]
+    near = np.abs(np.asarray(ref["inlrNum"]) - n // 2) < n // 4          # hypotheses that split the cloud at the boundary
+    assert near.sum() > 10
+    for r in (res, res64):
+        np.testing.assert_array_equal(r[5], ref["inlrNum"])
+        np.testing.assert_array_equal(r[6], ref["inlrNum_refined"])
+        assert r[2] == ref["numSuccess"] and r[3] == ref["maxInliers"]
+        np.testing.assert_array_equal(np.asarray(r[1]).astype(np.int64), ref["inlierIdx"])
+        assert np.linalg.norm(r[0] - ref["T"]) < T_TOL
+
+
 @pytest.mark.parametrize("n,iters,world", [(900, 1000, 3), (6000, 701, 2), (6000, 64, 8)])
 def test_hypotheses_split_in_shares_equal_the_single_run(n, iters, world):
     """pcreg_dev_ransac_partial on every share + the MAX/SUM combine + pcreg_dev_ransac_finish
