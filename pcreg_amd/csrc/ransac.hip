@@ -859,7 +859,10 @@ constexpr int kSMaxPB = 64;                     // point blocks with a partial-c
 constexpr int kStagedMinN = 4096;               // one registration of at least this many correspondences runs staged
 constexpr int kMomSlots = PCREG_MOM_SLOTS;                   // lane-per-hypothesis refit: 64-correspondence slots per chunk
 constexpr int kRec = 16;                        // doubles per correspondence record (15 used)
-constexpr int kSChunk = 80;                     // hypotheses per workgroup
+#ifndef PCREG_SCHUNK
+#define PCREG_SCHUNK 32
+#endif
+constexpr int kSChunk = PCREG_SCHUNK;                     // hypotheses per workgroup
 
 struct StagedArgs {
     RansacArgs a;
