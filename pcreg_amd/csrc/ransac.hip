@@ -899,6 +899,11 @@ __global__ __launch_bounds__(256) void rs_records_kernel(StagedArgs sa) {
     const int n = staged_n(a);
     const int i = blockIdx.x * 256 + threadIdx.x;
     double m1 = 0.0, m2 = 0.0, c1m = 0.0, c2m = 0.0;
+    if (i >= n && sa.use_lane && i < sa.nslots_cap * 64) {      // padding records must be finite: the sums multiply them by 0
+        double* r = sa.rec + (size_t)i * kRec;
+#pragma unroll
+        for (int e = 0; e < kRec; ++e) r[e] = 0.0;
+    }
     if (i < n) {
         Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
         double o[6], q[6];
@@ -1348,6 +1353,14 @@ __device__ __forceinline__ double rs_pair(int lo, int hi) { return __builtin_bit
         ACC[12] += rs_pair(R.c[0], R.c[1]); ACC[13] += rs_pair(R.c[2], R.c[3]); ACC[14] += rs_pair(R.d[0], R.d[1]);    \
     }
 
+#define PCREG_REC_FMA(ACC, R, F)                                                                                       \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) ACC[e_] = __builtin_fma(rs_pair(R.a[2 * e_], R.a[2 * e_ + 1]), F, ACC[e_]);         \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) ACC[8 + e_] = __builtin_fma(rs_pair(R.b[2 * e_], R.b[2 * e_ + 1]), F, ACC[8 + e_]); \
+        ACC[12] = __builtin_fma(rs_pair(R.c[0], R.c[1]), F, ACC[12]); ACC[13] = __builtin_fma(rs_pair(R.c[2], R.c[3]), F, ACC[13]);          \
+        ACC[14] = __builtin_fma(rs_pair(R.d[0], R.d[1]), F, ACC[14]);                                                  \
+    }
+
 // Refit moments, kLaneHyps hypotheses per LANE: the correspondence records are wave-uniform (scalar loads, SGPR
 // operands), every lane adds them under its own hypotheses' masks.  No LDS, no cross-lane reduction, and each
 // sum runs in index order.  grid (groups of 64 * kLaneHyps listed hypotheses, chunks of kMomSlots * 64
@@ -1389,8 +1402,12 @@ __global__ __launch_bounds__(64) void rs_moments_lane_kernel(StagedArgs sa, cons
         }
         const double* nbase = base + 64 * kRec;          // the record array is padded past n
 #define PCREG_REC_USE(K, R)                                                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < kLaneHyps; ++j_)                                \
-            if (((K) < 32 ? lo[j_] : hi[j_]) & (1u << ((K) & 31))) PCREG_REC_ADD(acc[j_], R)
+        _Pragma("unroll") for (int j_ = 0; j_ < kLaneHyps; ++j_) {                              \
+            /* no branch: acc = fma(record, bit ? 1.0 : 0.0, acc) -- the same bits as a masked add (records are finite) */ \
+            const unsigned bit_ = (((K) < 32 ? lo[j_] : hi[j_]) >> ((K) & 31)) & 1u;            \
+            const double f_ = rs_pair(0, (int)((0u - bit_) & 0x3FF00000u));                     \
+            PCREG_REC_FMA(acc[j_], R, f_)                                                       \
+        }
 #define PCREG_REC_STEP(K)                                                                       \
         PCREG_REC_WAIT(A); PCREG_REC_LOAD(B, base, ((K) + 1) * kRec * 8);                       \
         PCREG_REC_USE(K, A)                                                                     \
@@ -1838,7 +1855,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         const int it = o.iterNum;
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
         hipLaunchKernelGGL(rs_fit1_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
-        if (a.refine || sa.use_f32) hipLaunchKernelGGL(rs_records_kernel, dim3((n_cap + 255) / 256), dim3(256), 0, st, sa);
+        if (a.refine || sa.use_f32) hipLaunchKernelGGL(rs_records_kernel, dim3((unsigned)((staged_slots_cap(n_cap) * 64 + 255) / 256)), dim3(256), 0, st, sa);
         if (sa.use_f32) {
             hipLaunchKernelGGL(rs_t32_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a);
             if (sa.use_lane)
