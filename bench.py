@@ -4,11 +4,13 @@
 
 One "step" = one pass of the hot path over one synthetic registration problem, all
 inputs already resident in HBM:
-    top-2 search of every surface point over the model shard   (knn2_points_kernel)
-    [N > 1: all_gather of the per-rank top-2 lists + merge]     (RCCL over xGMI)
-    threshold + ratio test + Unique back-check + pair gather
+    top-2 search of every surface point over the model shard   (knn_candidates_f16_kernel + exact re-rank)
+    [N > 1: one all_gather of the per-rank top-2 lists + merge] (RCCL over xGMI)
+    threshold + ratio test + Unique back-check (query grid) + pair gather
+    [N > 1: one integer all_reduce of the candidate table]
     RANSAC (minPtNum 3, iterNum 1e4, thDist 0.3, thInlrRatio 0.08, REFINE;
             completeExperimentFast.m:169-173) on the surviving pairs
+    [N > 1: hypotheses split over the ranks, one all_gather of the partial results]
 `value` = surface points x model points (all ranks) x steps / wall time: end-to-end
 Gpairs/s including the filters and RANSAC; 1 / ms_per_step is registrations/s.
 
