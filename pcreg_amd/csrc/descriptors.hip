@@ -272,7 +272,7 @@ __device__ __forceinline__ int hist_loc(double x, const double (&e)[NE]) {
     return k;
 }
 
-__global__ __launch_bounds__(kBlock, 3) void desc_kernel(
+__global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ sz,
     const int32_t* __restrict__ sorted_idx, const int32_t* __restrict__ cell_start, const Grid* __restrict__ gp,
     const double* __restrict__ kp, const int32_t* __restrict__ perm, int S, int ldk, pcreg_desc_opts o, Edges ed, int cap, int dbg_stop,
