@@ -83,11 +83,18 @@ template <int QG, bool DRY, bool BATCH>
 __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr, uint2* __restrict__ cand_ent /*[Q][cap]: (index, score bits)*/,
-    int32_t* __restrict__ cand_cnt /*[Q]*/, int cap) {
+    int32_t* __restrict__ cand_cnt /*[Q]*/, int cap, int q_blocks, int xcd_map) {
     __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];          // 2 x 16 KiB, filled by LDS-DMA
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
-    const int q_base = (blockIdx.x * (kBlock / 64) + wave) * (QG * 32);
+    // workgroup -> (query block, model chunk).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share
+    // one), so with xcd_map (chunk count a multiple of 8) the XCD that runs workgroup b owns the chunks c with
+    // c % 8 == b % 8 and walks them one after the other, all query blocks of a chunk back to back: every XCD's L2
+    // then fetches an eighth of the prepared model once, instead of all of it.  Placement is speed only.
+    int qb, chunk;
+    if (xcd_map) { const int j = (int)blockIdx.x >> 3; chunk = (j / q_blocks) * 8 + ((int)blockIdx.x & 7); qb = j % q_blocks; }
+    else { qb = (int)blockIdx.x % q_blocks; chunk = (int)blockIdx.x / q_blocks; }
+    const int q_base = (qb * (kBlock / 64) + wave) * (QG * 32);
     const float sg = prep->sigma, inv2 = prep->inv_sigma2, sg2 = sg * sg;
 
     f16x8 bq[QG];
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
         thr[g] = INFINITY; gseen[g] = 0xFFFFFFFFu;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&tile[0][0];
-    const int t_begin = blockIdx.y * tiles_per_chunk, t_end = min(n_tiles, t_begin + tiles_per_chunk);
+    const int t_begin = chunk * tiles_per_chunk, t_end = min(n_tiles, t_begin + tiles_per_chunk);
     const int ntile = t_end - t_begin;
     // wave w copies the 1-KiB segments w, w + 4, ... of a tile
 #define PCREG_TILE_DMA(T, BUF)                                                                                     \
@@ -272,6 +279,13 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     if (S > n_tiles) S = n_tiles > 0 ? n_tiles : 1;
     int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
     S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
+    // XCD-aware placement wants the chunk count to be a multiple of 8 (trailing chunks may be empty)
+    static const bool no_xcd = getenv("PCREG_KNN_NOXCD") && atoi(getenv("PCREG_KNN_NOXCD")) != 0;
+    const int xcd_map = (!no_xcd && S >= 8) ? 1 : 0;
+    if (xcd_map) {
+        S = S / 8 * 8;
+        tiles_per_chunk = (n_tiles + S - 1) / S;
+    }
     *S_out = S;
     // the prep kernel empties the per-query lists; an empty model has no prep
     if (M <= 0) { PCREG_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)Q * 4, st)); return PCREG_OK; }
@@ -283,8 +297,8 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
         ev0 = g_time_ev[g_time_used].first; ev1 = g_time_ev[g_time_used].second; ++g_time_used;
         PCREG_HIP(hipEventRecord(ev0, st));
     }
-#define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks, S), dim3(kBlock), 0, st, q, Q, ldq, \
-                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC)
+#define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks * S), dim3(kBlock), 0, st, q, Q, ldq, \
+                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map)
     switch (cfg * 2 + (dry ? 1 : 0)) {
         case 0: PCREG_F16_LAUNCH(4, false, false); break;  case 1: PCREG_F16_LAUNCH(4, true, false); break;
         case 2: PCREG_F16_LAUNCH(4, false, true); break;   case 3: PCREG_F16_LAUNCH(4, true, true); break;
