@@ -654,39 +654,42 @@ __global__ __launch_bounds__(kBlock) void knn_fallback_slice_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ m, int M, int ldm,
     const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag,
     int32_t* __restrict__ fb_idx /*[kFew][kFbSlices][2]*/, float* __restrict__ fb_dist) {
-    const int nf = *n_flag, f = blockIdx.x;
-    if (nf > kFew || f >= nf) return;                            // the tiled kernel handles big lists
+    const int nf = *n_flag;
+    if (nf > kFew) return;                                       // the tiled kernel handles big lists
     __shared__ float sd[kBlock / 64][2];
     __shared__ int si[kBlock / 64][2];
     const int len = (M + kFbSlices - 1) / kFbSlices;
     const int j0 = blockIdx.y * len, j1 = min(M, j0 + len);
-    const int qi = flag_list[f];
-    const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
-    float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
-    for (int j = j0 + threadIdx.x; j < j1; j += kBlock) {         // ascending j per thread: strict '<' keeps ties low
-        float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
-        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        if (d < d2) { if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; } }
-    }
+    for (int f = blockIdx.x; f < nf; f += gridDim.x) {           // a small grid: usually there is nothing to do
+        const int qi = flag_list[f];
+        const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
+        float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+        for (int j = j0 + threadIdx.x; j < j1; j += kBlock) {     // ascending j per thread: strict '<' keeps ties low
+            float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (d < d2) { if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; } }
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
-        int j1s = __shfl_xor(i1, o), j2s = __shfl_xor(i2, o);
-        bool first_mine = lex_lt_f(d1, i1, e1, j1s);
-        float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1s;
-        float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;
-        float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1s : j2s;
-        bool sec_mine = lex_lt_f(x2, y2, x3, y3);
-        d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sd[w][0] = d1; sd[w][1] = d2; si[w][0] = i1; si[w][1] = i2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Top2T<float> t{INFINITY, INFINITY, -1, -1};
-        for (int k = 0; k < kBlock / 64; ++k) { top2_insert_lex_t(t, sd[k][0], si[k][0]); top2_insert_lex_t(t, sd[k][1], si[k][1]); }
-        const size_t o = ((size_t)f * kFbSlices + blockIdx.y) * 2;
-        fb_idx[o] = t.i1; fb_idx[o + 1] = t.i2; fb_dist[o] = t.d1; fb_dist[o + 1] = t.d2;
+        for (int o = 32; o > 0; o >>= 1) {
+            float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+            int j1s = __shfl_xor(i1, o), j2s = __shfl_xor(i2, o);
+            bool first_mine = lex_lt_f(d1, i1, e1, j1s);
+            float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1s;
+            float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;
+            float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1s : j2s;
+            bool sec_mine = lex_lt_f(x2, y2, x3, y3);
+            d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
+        }
+        const int w = threadIdx.x >> 6;
+        __syncthreads();                                          // the previous trip's readers are done with sd / si
+        if ((threadIdx.x & 63) == 0) { sd[w][0] = d1; sd[w][1] = d2; si[w][0] = i1; si[w][1] = i2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Top2T<float> t{INFINITY, INFINITY, -1, -1};
+            for (int k = 0; k < kBlock / 64; ++k) { top2_insert_lex_t(t, sd[k][0], si[k][0]); top2_insert_lex_t(t, sd[k][1], si[k][1]); }
+            const size_t o = ((size_t)f * kFbSlices + blockIdx.y) * 2;
+            fb_idx[o] = t.i1; fb_idx[o + 1] = t.i2; fb_dist[o] = t.d1; fb_dist[o + 1] = t.d2;
+        }
     }
 }
 __global__ void knn_fallback_merge_kernel(const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag, int idx_base,
@@ -866,7 +869,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
         fprintf(stderr, "[pcreg] knn fast: Q=%d M=%d variant=%d S=%d kc=%d unproven=%d\n", Q, M, variant, S, kc, nf);
     }
     // fallbacks (both launched; each decides from the device-side count which one works)
-    hipLaunchKernelGGL(knn_fallback_slice_kernel, dim3(kFew, kFbSlices), dim3(kBlock), 0, st, q, ldq, m, M, ldm, flag_list, n_flag, fb_idx, fb_dist);
+    hipLaunchKernelGGL(knn_fallback_slice_kernel, dim3(64, kFbSlices), dim3(kBlock), 0, st, q, ldq, m, M, ldm, flag_list, n_flag, fb_idx, fb_dist);
     hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3(kFew / 256), dim3(256), 0, st, flag_list, n_flag, (int)idx_base, fb_idx, fb_dist, idx, dist);
     PCREG_HIP(hipGetLastError());
     return launch_knn2_points_exact_list(q, Q, ldq, m, M, ldm, idx_base, flag_list, n_flag, kFew, idx, dist, ews, ews_bytes, st);

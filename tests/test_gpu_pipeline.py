@@ -96,3 +96,17 @@ def test_search_at_full_size_spot_check(oracle_c):
     ri, rd = oracle_c.knn2_points_f32(surf[sel], model)
     np.testing.assert_array_equal(idx.cpu().numpy()[sel], ri)
     np.testing.assert_array_equal(dist.cpu().numpy()[sel], rd)
+
+
+def test_few_hundred_unproven_queries_take_the_sliced_fallback(oracle_c):
+    """700 queries that all fail the certificate (a model point 1e6 away inflates the rounding bound): fewer than
+    1024, so the sliced exact fallback runs, every workgroup looping over several flagged queries."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(19)
+    m = (rng.random((40000, 3)) * 5 + 4000.0).astype(np.float32)
+    q = (m[rng.choice(40000, 700)] + rng.normal(0, 0.05, (700, 3))).astype(np.float32)
+    m = np.vstack([m, np.array([[9e5, -9e5, 9e5]], np.float32)])
+    idx, dist = pc.knn2_points(q, m)
+    ridx, rdist = oracle_c.knn2_points_f32(q, m)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)
