@@ -11,7 +11,11 @@ def case(n, frac_out, seed=0):
     p1 = p2 @ R + t + rng.normal(0, 0.05, p2.shape)
     k = int(frac_out * n); p1[:k] = rng.uniform(0, 40, (k, 3))
     return p1, p2
-for n, iters, refine, fo in [(32558, 10000, True, 0.0), (32558, 10000, False, 0.0), (32558, 10000, True, 0.97), (8000, 10000, True, 0.0), (2000, 10000, True, 0.0), (1000, 20000, True, 0.0), (1000, 20000, True, 0.95)]:
+CASES = [(32558, 10000, True, 0.0), (32558, 10000, False, 0.0), (32558, 10000, True, 0.97), (8000, 10000, True, 0.0), (2000, 10000, True, 0.0), (1000, 20000, True, 0.0), (1000, 20000, True, 0.95)]
+if len(sys.argv) > 1:
+    CASES = [tuple(float(x) if '.' in x else int(x) for x in a.split(',')) for a in sys.argv[1:]]
+    CASES = [(int(n), int(it), bool(int(r)), float(fo)) for n, it, r, fo in CASES]
+for n, iters, refine, fo in CASES:
     p1, p2 = case(n, fo)
     pipe = RegistrationPipeline(n, 16, device=dev)
     t1 = torch.from_numpy(np.ascontiguousarray(p1.T)).to(dev); t2 = torch.from_numpy(np.ascontiguousarray(p2.T)).to(dev)
