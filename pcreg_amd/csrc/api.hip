@@ -315,8 +315,7 @@ static int match_host(const double* f1, int Q, int ld1, const double* f2, int M,
         TRY(upload_cols(f2, M, ld2, D, (double*)dM, g_stream));
     }
     if (!o->prenormalized) {
-        TRY(launch_normalize_rows((double*)dS, Q, Q, Dp, g_stream));
-        TRY(launch_normalize_rows((double*)dM, M, M, Dp, g_stream));
+        TRY(launch_normalize_rows2((double*)dS, Q, Q, (double*)dM, M, M, Dp, g_stream));
     }
     TRY(launch_match_features((double*)dS, Q, Q, (double*)dM, M, M, Dp, *o, (uint32_t*)dpairs,
                               metric ? (double*)dmet : nullptr, (int32_t*)dcnt, ws, wsb, g_stream));
@@ -581,8 +580,7 @@ int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const doubl
     // getMatches.m:24-37 always works on private copies (the caller's descriptors stay untouched)
     TRY(launch_preprocess(inS, Q, ls, inM, M, lm, D, *par, fS, fM, w + off[4], align_up(((size_t)Q + M + 1) * sizeof(double), 256), st));
     if (!par->prenormalized) {
-        TRY(launch_normalize_rows(fS, Q, Q, Dp, st));
-        TRY(launch_normalize_rows(fM, M, M, Dp, st));
+        TRY(launch_normalize_rows2(fS, Q, Q, fM, M, M, Dp, st));
     }
     return launch_match_features(fS, Q, Q, fM, M, M, Dp, *par, pairs, metric, n_pairs, w + off[5], workspace_bytes - off[5], st);
 }

@@ -95,6 +95,7 @@ int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M,
                       const pcreg_match_opts& o, double* outS, double* outM, void* ws, size_t ws_bytes,
                       hipStream_t st);
 int launch_normalize_rows(double* f, int n, int ld, int D, hipStream_t st);
+int launch_normalize_rows2(double* f, int n, int ld, double* f2, int n2, int ld2, int D, hipStream_t st);
 int launch_match_features(const double* fS, int Q, int ldS, const double* fM, int M, int ldM, int D,
                           const pcreg_match_opts& o, uint32_t* pairs, double* metric, int32_t* P_dev,
                           void* ws, size_t ws_bytes, hipStream_t st);

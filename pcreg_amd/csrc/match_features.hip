@@ -34,10 +34,14 @@ constexpr int DK = 16;                      // feature slab
 // One lane per row keeps the oracle's summation order; what a lane CAN do in parallel is fetch:
 // 16 features are loaded back to back (each a coalesced 512-B line per wave) before they are added.
 constexpr int kRowUnroll = 16;
-__global__ __launch_bounds__(64) void row_l1_kernel(const double* __restrict__ f, int n, int ld, int D, double* __restrict__ out) {
+// rows of f (n) and of f2 (n2) in ONE launch: the kernel is latency-bound (one lane per row), so the second matrix
+// rides along for free; out[0..n) and out[n..n+n2)
+__global__ __launch_bounds__(64) void row_l1_kernel(const double* __restrict__ f, int n, int ld,
+                                                    const double* __restrict__ f2, int n2, int ld2, int D, double* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double* p = f + i;
+    if (i >= n + n2) return;
+    const double* p = i < n ? f + i : f2 + (i - n);
+    if (i >= n) ld = ld2;
     double s = 0;
     int d = 0;
     for (; d + kRowUnroll <= D; d += kRowUnroll) {
@@ -72,10 +76,12 @@ __global__ void preprocess_kernel(const double* __restrict__ in, int n, int ld, 
     }
 }
 // matchFeatures' normalizeX: unit L2 rows, effectively-zero rows -> 0
-__global__ __launch_bounds__(64) void normalize_rows_kernel(double* __restrict__ f, int n, int ld, int D) {
+__global__ __launch_bounds__(64) void normalize_rows_kernel(double* __restrict__ f, int n, int ld,
+                                                            double* __restrict__ f2, int n2, int ld2, int D) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double* p = f + i;
+    if (i >= n + n2) return;
+    double* p = i < n ? f + i : f2 + (i - n);
+    if (i >= n) ld = ld2;
     double s = 0;
     int d = 0;
     for (; d + kRowUnroll <= D; d += kRowUnroll) {
@@ -322,8 +328,7 @@ int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M,
     double* l1 = (double*)ws; double* col = l1 + (size_t)Q + M;
     int Dp = D + (o.unnormalize ? 1 : 0);
     if (o.unnormalize) {
-        if (Q > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, dS, Q, ldS, D, l1);
-        if (M > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((M + 63) / 64), dim3(64), 0, st, dM, M, ldM, D, l1 + Q);
+        if (Q + M > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((Q + M + 63) / 64), dim3(64), 0, st, dS, Q, ldS, dM, M, ldM, D, l1);
         hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, l1, Q + M, o.norm_factor, col);
     }
     if (Q > 0) hipLaunchKernelGGL(preprocess_kernel, dim3(1024), dim3(256), 0, st, dS, Q, ldS, D, Dp, col, o.change_metric, o.metric_factor, outS);
@@ -334,7 +339,14 @@ int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M,
 
 int launch_normalize_rows(double* f, int n, int ld, int D, hipStream_t st) {
     if (n <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, st, f, n, ld, D);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, st, f, n, ld, (double*)nullptr, 0, 0, D);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+// both descriptor sets in one launch
+int launch_normalize_rows2(double* f, int n, int ld, double* f2, int n2, int ld2, int D, hipStream_t st) {
+    if (n + n2 <= 0) return PCREG_OK;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + n2 + 63) / 64), dim3(64), 0, st, f, n, ld, f2, n2, ld2, D);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

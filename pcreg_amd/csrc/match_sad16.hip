@@ -64,9 +64,11 @@ __global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const double* __
     }
 }
 __global__ void range_final_kernel(const double* __restrict__ part, int nparts, Range* __restrict__ r) {
+    double lo = INFINITY, hi = -INFINITY;                        // launched with one wave; min / max are order-free
+    for (int b = threadIdx.x; b < nparts; b += 64) { lo = fmin(lo, part[2 * b]); hi = fmax(hi, part[2 * b + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
     if (threadIdx.x != 0) return;
-    double lo = INFINITY, hi = -INFINITY;
-    for (int b = 0; b < nparts; ++b) { lo = fmin(lo, part[2 * b]); hi = fmax(hi, part[2 * b + 1]); }
     if (!(hi > lo)) hi = lo + 1.0;                 // constant (or empty) input: any scale works
     r->fmin = lo; r->scale = 65535.0 / (hi - lo); r->inv_scale = (hi - lo) / 65535.0;
 }
