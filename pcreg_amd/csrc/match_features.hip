@@ -31,28 +31,55 @@ constexpr int BM = 16 * TM;                 // 64 model rows per tile
 constexpr int DK = 16;                      // feature slab
 
 // ---------------------------------------------------------------- preprocessing
-// One lane per row keeps the oracle's summation order; what a lane CAN do in parallel is fetch:
-// 16 features are loaded back to back (each a coalesced 512-B line per wave) before they are added.
-constexpr int kRowUnroll = 16;
-// rows of f (n) and of f2 (n2) in ONE launch: the kernel is latency-bound (one lane per row), so the second matrix
-// rides along for free; out[0..n) and out[n..n+n2)
-__global__ __launch_bounds__(64) void row_l1_kernel(const double* __restrict__ f, int n, int ld,
-                                                    const double* __restrict__ f2, int n2, int ld2, int D, double* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n + n2) return;
-    const double* p = i < n ? f + i : f2 + (i - n);
-    if (i >= n) ld = ld2;
-    double s = 0;
-    int d = 0;
-    for (; d + kRowUnroll <= D; d += kRowUnroll) {
-        double v[kRowUnroll];
-#pragma unroll
-        for (int u = 0; u < kRowUnroll; ++u) v[u] = p[(size_t)(d + u) * ld];
-#pragma unroll
-        for (int u = 0; u < kRowUnroll; ++u) s += fabs(v[u]);                   // vecnorm(.,1,2), getMatches.m:24
+// One lane per row keeps the oracle's summation order (features in ascending order); what the other lanes CAN do
+// is fetch.  A workgroup owns 64 rows: all 256 threads stage a 64-row x 48-feature tile in LDS (coalesced along the
+// rows, 12 loads per thread in flight, the next tile's loads issued before the current tile is consumed), and wave 0
+// -- lane r = row r -- adds the tile's features in order.  The two descriptor sets share one launch.
+constexpr int kRT = 64, kFT = 48;
+struct RowSrc { const double* p; int ld; int rows; };           // first row of this workgroup, leading dimension, rows here
+__device__ __forceinline__ RowSrc row_src(const double* f, int n, int ld, const double* f2, int n2, int ld2) {
+    const int nb1 = (n + kRT - 1) / kRT;
+    const int b = blockIdx.x;
+    if (b < nb1) return RowSrc{f + (size_t)b * kRT, ld, min(kRT, n - b * kRT)};
+    return RowSrc{f2 + (size_t)(b - nb1) * kRT, ld2, min(kRT, n2 - (b - nb1) * kRT)};
+}
+// MODE 0: sum |v| (vecnorm(.,1,2), getMatches.m:24); MODE 1: sum v^2 with fma (matchFeatures' normalizeX)
+template <int MODE>
+__device__ __forceinline__ double row_reduce(const RowSrc& src, int D, double (*tile)[kFT][kRT]) {
+    const int tid = threadIdx.x, r = tid & (kRT - 1), fq = tid >> 6;          // thread loads features fq, fq + 4, ...
+    const int ntiles = (D + kFT - 1) / kFT;
+    double v[kFT / 4];
+#define PCREG_ROW_FETCH(T)                                                                          \
+    _Pragma("unroll") for (int k = 0; k < kFT / 4; ++k) {                                            \
+        const int d = (T) * kFT + fq + 4 * k;                                                        \
+        v[k] = (d < D && r < src.rows) ? src.p[(size_t)d * src.ld + r] : 0.0;                        \
     }
-    for (; d < D; ++d) s += fabs(p[(size_t)d * ld]);
-    out[i] = s;
+#define PCREG_ROW_STASH(BUF)                                                                        \
+    _Pragma("unroll") for (int k = 0; k < kFT / 4; ++k) tile[BUF][fq + 4 * k][r] = v[k];
+    double s = 0.0;
+    PCREG_ROW_FETCH(0) PCREG_ROW_STASH(0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) { PCREG_ROW_FETCH(t + 1) }
+        if (tid < kRT) {
+            const int dn = min(kFT, D - t * kFT);
+            for (int d = 0; d < dn; ++d) { const double x = tile[t & 1][d][r]; if (MODE == 0) s += fabs(x); else s = fma(x, x, s); }
+        }
+        if (t + 1 < ntiles) { PCREG_ROW_STASH((t + 1) & 1) }
+        __syncthreads();
+    }
+#undef PCREG_ROW_FETCH
+#undef PCREG_ROW_STASH
+    return s;                                                                  // valid in threads 0..63 (row r)
+}
+__global__ __launch_bounds__(256) void row_l1_kernel(const double* __restrict__ f, int n, int ld,
+                                                     const double* __restrict__ f2, int n2, int ld2, int D, double* __restrict__ out) {
+    __shared__ double tile[2][kFT][kRT];
+    const RowSrc src = row_src(f, n, ld, f2, n2, ld2);
+    const double s = row_reduce<0>(src, D, tile);
+    const int nb1 = (n + kRT - 1) / kRT;
+    const int row0 = (int)blockIdx.x < nb1 ? (int)blockIdx.x * kRT : n + ((int)blockIdx.x - nb1) * kRT;
+    if ((int)threadIdx.x < src.rows) out[row0 + threadIdx.x] = s;
 }
 // deterministic mean of n values by one workgroup -> *out = factor * mean
 __global__ void mean_kernel(const double* __restrict__ v, int n, double factor, double* __restrict__ out) {
@@ -76,33 +103,26 @@ __global__ void preprocess_kernel(const double* __restrict__ in, int n, int ld, 
     }
 }
 // matchFeatures' normalizeX: unit L2 rows, effectively-zero rows -> 0
-__global__ __launch_bounds__(64) void normalize_rows_kernel(double* __restrict__ f, int n, int ld,
-                                                            double* __restrict__ f2, int n2, int ld2, int D) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n + n2) return;
-    double* p = i < n ? f + i : f2 + (i - n);
-    if (i >= n) ld = ld2;
-    double s = 0;
-    int d = 0;
-    for (; d + kRowUnroll <= D; d += kRowUnroll) {
-        double v[kRowUnroll];
+__global__ __launch_bounds__(256) void normalize_rows_kernel(double* __restrict__ f, int n, int ld,
+                                                             double* __restrict__ f2, int n2, int ld2, int D) {
+    __shared__ double tile[2][kFT][kRT];
+    __shared__ double s_nrm[kRT];
+    const RowSrc src = row_src(f, n, ld, f2, n2, ld2);
+    const double s = row_reduce<1>(src, D, tile);
+    if (threadIdx.x < kRT) s_nrm[threadIdx.x] = sqrt(s);
+    __syncthreads();
+    double* p = const_cast<double*>(src.p);
+    const int r = threadIdx.x & (kRT - 1);
+    if (r >= src.rows) return;
+    const double nrm = s_nrm[r];
+    const bool zero = nrm <= (double)FLT_EPSILON;
+    for (int d0 = threadIdx.x >> 6; d0 < D; d0 += 4 * 8) {                     // 8 loads in flight per thread
+        double v[8];
 #pragma unroll
-        for (int u = 0; u < kRowUnroll; ++u) v[u] = p[(size_t)(d + u) * ld];
+        for (int k = 0; k < 8; ++k) { const int d = d0 + 4 * k; v[k] = d < D ? p[(size_t)d * src.ld + r] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < kRowUnroll; ++u) s = fma(v[u], v[u], s);
+        for (int k = 0; k < 8; ++k) { const int d = d0 + 4 * k; if (d < D) p[(size_t)d * src.ld + r] = zero ? 0.0 : v[k] / nrm; }
     }
-    for (; d < D; ++d) { double v = p[(size_t)d * ld]; s = fma(v, v, s); }
-    double nrm = sqrt(s);
-    bool zero = nrm <= (double)FLT_EPSILON;
-    d = 0;
-    for (; d + kRowUnroll <= D; d += kRowUnroll) {
-        double v[kRowUnroll];
-#pragma unroll
-        for (int u = 0; u < kRowUnroll; ++u) v[u] = p[(size_t)(d + u) * ld];
-#pragma unroll
-        for (int u = 0; u < kRowUnroll; ++u) p[(size_t)(d + u) * ld] = zero ? 0.0 : v[u] / nrm;
-    }
-    for (; d < D; ++d) { double v = p[(size_t)d * ld]; p[(size_t)d * ld] = zero ? 0.0 : v / nrm; }
 }
 
 // ---------------------------------------------------------------- all-pairs + top-2
@@ -328,7 +348,7 @@ int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M,
     double* l1 = (double*)ws; double* col = l1 + (size_t)Q + M;
     int Dp = D + (o.unnormalize ? 1 : 0);
     if (o.unnormalize) {
-        if (Q + M > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((Q + M + 63) / 64), dim3(64), 0, st, dS, Q, ldS, dM, M, ldM, D, l1);
+        if (Q + M > 0) hipLaunchKernelGGL(row_l1_kernel, dim3((Q + kRT - 1) / kRT + (M + kRT - 1) / kRT), dim3(256), 0, st, dS, Q, ldS, dM, M, ldM, D, l1);
         hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, l1, Q + M, o.norm_factor, col);
     }
     if (Q > 0) hipLaunchKernelGGL(preprocess_kernel, dim3(1024), dim3(256), 0, st, dS, Q, ldS, D, Dp, col, o.change_metric, o.metric_factor, outS);
@@ -339,14 +359,14 @@ int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M,
 
 int launch_normalize_rows(double* f, int n, int ld, int D, hipStream_t st) {
     if (n <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, st, f, n, ld, (double*)nullptr, 0, 0, D);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + kRT - 1) / kRT), dim3(256), 0, st, f, n, ld, (double*)nullptr, 0, 0, D);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
 // both descriptor sets in one launch
 int launch_normalize_rows2(double* f, int n, int ld, double* f2, int n2, int ld2, int D, hipStream_t st) {
     if (n + n2 <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + n2 + 63) / 64), dim3(64), 0, st, f, n, ld, f2, n2, ld2, D);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((n + kRT - 1) / kRT + (n2 + kRT - 1) / kRT), dim3(256), 0, st, f, n, ld, f2, n2, ld2, D);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
