@@ -406,11 +406,15 @@ __global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __
 constexpr int kFbSlices = 64;
 __global__ __launch_bounds__(kBlock) void sad_exact_rows_kernel(const double* __restrict__ A, int lda,
                                                                 const double* __restrict__ B, int nB, int ldb, int D,
-                                                                const int32_t* __restrict__ list, int nf, int slice,
+                                                                const int32_t* __restrict__ list, const int32_t* __restrict__ n_flag,
+                                                                int cap, int slice,
                                                                 int32_t* __restrict__ part_idx, double* __restrict__ part_dist) {
     extern __shared__ double s_a[];                           // D doubles
     __shared__ double s_d[4][2]; __shared__ int s_i[4][2];
-    const int k = blockIdx.x, qi = list[k];
+    const int nf = min(*n_flag, cap);                         // device-side count: no host round trip (usually 0 .. 9)
+    for (int k = blockIdx.x; k < nf; k += gridDim.x) {
+    const int qi = list[k];
+    __syncthreads();                                          // the previous trip's readers are done with s_a / s_d
     for (int d = threadIdx.x; d < D; d += kBlock) s_a[d] = A[qi + (size_t)d * lda];
     __syncthreads();
     const int begin = blockIdx.y * slice, end = min(nB, begin + slice);
@@ -444,17 +448,27 @@ __global__ __launch_bounds__(kBlock) void sad_exact_rows_kernel(const double* __
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) merge(s_d[w][0], s_i[w][0], s_d[w][1], s_i[w][1]);
-        size_t o = ((size_t)blockIdx.y * nf + k) * 2;        // [slice][nf][2]: merge_top2_kernel_t layout
+        size_t o = ((size_t)blockIdx.y * cap + k) * 2;       // [slice][cap][2]
         part_idx[o] = i1; part_idx[o + 1] = i2; part_dist[o] = d1; part_dist[o + 1] = d2;
     }
+    }
 }
-__global__ void scatter_flagged_kernel(const int32_t* __restrict__ list, int nf, const int32_t* __restrict__ fi,
-                                       const double* __restrict__ fd, int32_t* __restrict__ idx, double* __restrict__ dist) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nf) return;
-    int qi = list[k];
-    idx[(size_t)qi * 2] = fi[(size_t)k * 2]; idx[(size_t)qi * 2 + 1] = fi[(size_t)k * 2 + 1];
-    dist[(size_t)qi * 2] = fd[(size_t)k * 2]; dist[(size_t)qi * 2 + 1] = fd[(size_t)k * 2 + 1];
+// merge the slices' top-2 of every flagged row by (distance, index) and put the result in its place
+__global__ void sad_fallback_finish_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ n_flag, int cap, int slices,
+                                           const int32_t* __restrict__ part_idx, const double* __restrict__ part_dist,
+                                           int32_t* __restrict__ idx, double* __restrict__ dist) {
+    const int nf = min(*n_flag, cap);
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nf; k += gridDim.x * blockDim.x) {
+        Top2T<double> t{INFINITY, INFINITY, -1, -1};
+        for (int sl = 0; sl < slices; ++sl) {
+            const size_t o = ((size_t)sl * cap + k) * 2;
+            top2_insert_lex_t(t, part_dist[o], part_idx[o]);
+            top2_insert_lex_t(t, part_dist[o + 1], part_idx[o + 1]);
+        }
+        const int qi = list[k];
+        idx[(size_t)qi * 2] = t.i1; idx[(size_t)qi * 2 + 1] = t.i2;
+        dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
+    }
 }
 
 }  // namespace
@@ -481,7 +495,7 @@ size_t sad16_workspace_bytes(int nA, int nB, int D) {
 }
 
 // Top-2 of every row of A against all rows of B under SAD: indices and fp64 distances identical to
-// the exhaustive fp64 search (launch_score_top2_exact).  One host sync (the unproven-query count).
+// the exhaustive fp64 search (launch_score_top2_exact).  No host round trip.
 int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, int ldb, int D,
                    int32_t* idx, double* dist, void* ws, size_t ws_bytes, hipStream_t st) {
     PCREG_ARG(nA >= 1 && nB >= 1 && D >= 1);
@@ -501,8 +515,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     int32_t* part_idx = (int32_t*)w;        w += align_up((size_t)kMaxSplit * a * KC * 4, 256);
     uint32_t* part_s = (uint32_t*)w;        w += align_up((size_t)kMaxSplit * a * KC * 4, 256);
     int32_t* flag_list = (int32_t*)w;       w += align_up(a * 4, 256);
-    int32_t* fi = (int32_t*)w;              w += align_up(a * 2 * 4, 256);
-    double* fd = (double*)w;                w += align_up(a * 2 * 8, 256);
+    w += align_up(a * 2 * 4, 256) + align_up(a * 2 * 8, 256);      // (formerly the merged fallback rows)
     int32_t* fpi = (int32_t*)w;             w += align_up((size_t)kFbSlices * a * 2 * 4, 256);
     double* fpd = (double*)w;
 
@@ -556,21 +569,21 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     hipLaunchKernelGGL(sad16_finalize_kernel, dim3((nA + 3) / 4), dim3(kBlock), 0, st, At, nA, Bt, nB, D, range,
                        part_idx, part_s, S, idx, dist, flag_list, n_flag, force);
     PCREG_HIP(hipGetLastError());
-    int32_t nf = 0;
-    PCREG_HIP(hipMemcpyAsync(&nf, n_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PCREG_HIP(hipStreamSynchronize(st));
-    if (getenv("PCREG_MATCH_DEBUG")) {
+    if (getenv("PCREG_MATCH_DEBUG")) {                       // the only host round trip of the call, debugging only
+        int32_t nf = 0;
+        PCREG_HIP(hipMemcpyAsync(&nf, n_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PCREG_HIP(hipStreamSynchronize(st));
         int occ = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sad16_candidates_kernel<false>, kBlock, 0);
         fprintf(stderr, "[pcreg] sad16: nA=%d nB=%d D=%d S=%d unproven=%d (candidates kernel: %d blocks/CU)\n", nA, nB, D, S, nf, occ);
     }
-    if (nf > 0) {
+    {   // unproven rows: exact fp64 rows, sliced over B; both kernels read the count on the device
         int slices = std::min(kFbSlices, (nB + kBlock - 1) / kBlock);
         int slice = (nB + slices - 1) / slices;
         slices = (nB + slice - 1) / slice;
-        hipLaunchKernelGGL(sad_exact_rows_kernel, dim3(nf, slices), dim3(kBlock), (size_t)D * sizeof(double), st,
-                           A, lda, B, nB, ldb, D, flag_list, nf, slice, fpi, fpd);
-        hipLaunchKernelGGL(merge_top2_kernel_t<double>, dim3((nf + 255) / 256), dim3(256), 0, st, fpi, fpd, slices, nf, fi, fd, (size_t)0);
-        hipLaunchKernelGGL(scatter_flagged_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, flag_list, nf, fi, fd, idx, dist);
+        hipLaunchKernelGGL(sad_exact_rows_kernel, dim3(std::min(nA, 64), slices), dim3(kBlock), (size_t)D * sizeof(double), st,
+                           A, lda, B, nB, ldb, D, flag_list, n_flag, nA, slice, fpi, fpd);
+        hipLaunchKernelGGL(sad_fallback_finish_kernel, dim3(std::min((nA + 255) / 256, 64)), dim3(256), 0, st, flag_list, n_flag, nA, slices,
+                           fpi, fpd, idx, dist);
         PCREG_HIP(hipGetLastError());
     }
     return PCREG_OK;
