@@ -284,8 +284,8 @@ int pcreg_dev_spatial_histogram_descriptors(const double* pts, int P, int ld, co
  * column-major n x D (ld >= n); PCREG_LAYOUT_ROW_MAJOR = dense [n][D] (ld == D), what the
  * descriptor entry point above emits.  The inputs are not modified.  pairs [Q][2] uint32,
  * 1-based, ascending surface row; metric [Q] or NULL; *n_pairs device int32.  Q and M are
- * host integers (grid sizes); with Unique the call synchronises the stream ONCE (the candidate
- * count that sizes the back-search); without Unique it does not synchronise. */
+ * host integers (grid sizes); with Unique and Q*Q*D > 2e10 the call synchronises the stream ONCE (the
+ * candidate count that sizes the back-search); otherwise it does not synchronise. */
 #define PCREG_LAYOUT_FEATURE_MAJOR 0
 #define PCREG_LAYOUT_ROW_MAJOR     1
 size_t pcreg_dev_get_matches_workspace(int Q, int M, int D);

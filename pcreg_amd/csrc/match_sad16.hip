@@ -44,12 +44,14 @@ struct Range { double fmin, scale, inv_scale; };
 // ---- range (two-stage, deterministic) --------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const double* __restrict__ A, int nA, int lda,
                                                                 const double* __restrict__ B, int nB, int ldb, int D,
-                                                                double* __restrict__ part) {
+                                                                double* __restrict__ part, const int32_t* __restrict__ nA_live) {
+    // nA_live (device, may be null): only the first *nA_live rows of A hold data (the rest of the capacity is skipped)
+    const int live = nA_live ? min(nA, *nA_live) : nA;
     double lo = INFINITY, hi = -INFINITY;
     const size_t eA = (size_t)nA * D, eB = (size_t)nB * D;
     for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < eA + eB; e += (size_t)gridDim.x * kBlock) {
         double v;
-        if (e < eA) v = A[e % nA + (e / nA) * (size_t)lda];
+        if (e < eA) { if ((int)(e % nA) >= live) continue; v = A[e % nA + (e / nA) * (size_t)lda]; }
         else { size_t f = e - eA; v = B[f % nB + (f / nB) * (size_t)ldb]; }
         lo = fmin(lo, v); hi = fmax(hi, v);
     }
@@ -75,7 +77,9 @@ __global__ void range_final_kernel(const double* __restrict__ part, int nparts, 
 // f (n x D, ld) -> packed u16 pairs [D2p][ldq]; D2p = D2 rounded up to DK2, ldq = n rounded up to BQ;
 // padding is zero, so the tile loads of the candidates kernel need no bounds checks.
 __global__ __launch_bounds__(kBlock) void quantize_pack_kernel(const double* __restrict__ f, int n, int ld, int D, int D2p, int ldq,
-                                                               const Range* __restrict__ rp, uint32_t* __restrict__ out) {
+                                                               const Range* __restrict__ rp, uint32_t* __restrict__ out,
+                                                               const int32_t* __restrict__ n_live) {
+    if (n_live) n = min(n, *n_live);                      // rows past the live count quantise to zero like the padding
     const double f0 = rp->fmin, scale = rp->scale;
     size_t total = (size_t)ldq * D2p;
     for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlock) {
@@ -124,7 +128,8 @@ template <bool DRY>
 __global__ __launch_bounds__(kBlock, 3) void sad16_candidates_kernel(const uint32_t* __restrict__ Aq, int nA, int lda,
                                                                   const uint32_t* __restrict__ Bq, int nB, int ldb, int D2p, int chunk,
                                                                   int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s,
-                                                                  unsigned long long* __restrict__ dbg) {
+                                                                  unsigned long long* __restrict__ dbg, const int32_t* __restrict__ nA_live) {
+    if (nA_live && (int)blockIdx.x * BQ >= *nA_live) return;          // a query tile beyond the live rows: nothing to do
     unsigned long long t_start = 0;
     if (dbg) t_start = __builtin_amdgcn_s_memrealtime();
     // two slab buffers (2 x 24 KiB, filled by LDS-DMA) and the final merge cells (32 KiB) share one array
@@ -262,9 +267,10 @@ __global__ __launch_bounds__(kBlock, 3) void sad16_candidates_kernel(const uint3
 // each), which makes "read row j" 981 translations.  The re-rank reads whole rows, so it gets a
 // row-major copy: 64 x 64 tiles through LDS, coalesced on both sides.
 __global__ __launch_bounds__(kBlock) void transpose_rows_kernel(const double* __restrict__ f, int n, int ld, int D,
-                                                                double* __restrict__ out /* [n][D] */) {
+                                                                double* __restrict__ out /* [n][D] */, const int32_t* __restrict__ n_live) {
     __shared__ double tile[64][65];
     const int i0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    if (n_live) { n = min(n, *n_live); if (i0 >= n) return; }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -292,12 +298,13 @@ __global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __
                                                                 const Range* __restrict__ rp, const int32_t* __restrict__ part_idx,
                                                                 const uint32_t* __restrict__ part_s, int S,
                                                                 int32_t* __restrict__ idx, double* __restrict__ dist,
-                                                                int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven) {
+                                                                int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven,
+                                                                const int32_t* __restrict__ nA_live) {
     __shared__ double s_t[kBlock / 64][kNC][kFT];          // 32 KiB
     __shared__ int s_j[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qi = blockIdx.x * (kBlock / 64) + wave;
-    if (qi >= nA) return;                                  // wave-uniform; no block barrier below
+    if (qi >= nA || (nA_live && qi >= *nA_live)) return;   // wave-uniform; no block barrier below
     const int total = S * KC;                              // <= 64 * kEPL
     int j[kEPL]; unsigned sq[kEPL];
     unsigned a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, g = 0xFFFFFFFFu;
@@ -477,7 +484,7 @@ __global__ void sad_fallback_finish_kernel(const int32_t* __restrict__ list, con
 // the same call with the roles swapped: launch_transpose_rows(rowmajor, D, D, n, featmajor).
 int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st) {
     if (n <= 0 || D <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(transpose_rows_kernel, dim3((n + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, f, n, ld, D, out);
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3((n + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, f, n, ld, D, out, (const int32_t*)nullptr);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
@@ -496,8 +503,10 @@ size_t sad16_workspace_bytes(int nA, int nB, int D) {
 
 // Top-2 of every row of A against all rows of B under SAD: indices and fp64 distances identical to
 // the exhaustive fp64 search (launch_score_top2_exact).  No host round trip.
+// nA_live (device int32, may be null): only the first *nA_live of the nA rows of A are real; everything is sized and
+// strided by nA, the kernels skip the rest -- lets a caller run on a capacity without reading the count back.
 int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, int ldb, int D,
-                   int32_t* idx, double* dist, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int32_t* idx, double* dist, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* nA_live) {
     PCREG_ARG(nA >= 1 && nB >= 1 && D >= 1);
     size_t need = sad16_workspace_bytes(nA, nB, D);
     if (ws_bytes < need) { set_error("sad16 workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
@@ -521,10 +530,10 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
 
     PCREG_ARG(lda >= nA && ldb >= nB);
     int nb = (int)std::min<size_t>(1024, ((a + b) * D + kBlock * 8 - 1) / (kBlock * 8)); if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(kBlock), 0, st, A, nA, lda, B, nB, ldb, D, mpart);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(nb), dim3(kBlock), 0, st, A, nA, lda, B, nB, ldb, D, mpart, nA_live);
     hipLaunchKernelGGL(range_final_kernel, dim3(1), dim3(64), 0, st, mpart, nb, range);
-    hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, A, nA, lda, D, D2p, ldqa, range, Aq);
-    hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, B, nB, ldb, D, D2p, ldqb, range, Bq);
+    hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, A, nA, lda, D, D2p, ldqa, range, Aq, nA_live);
+    hipLaunchKernelGGL(quantize_pack_kernel, dim3(2048), dim3(kBlock), 0, st, B, nB, ldb, D, D2p, ldqb, range, Bq, (const int32_t*)nullptr);
     PCREG_HIP(hipMemsetAsync(n_flag, 0, sizeof(int32_t), st));
     // Split B into S chunks so that the grid loads every CU equally: a CU holds 3 workgroups, all
     // resident at once, so the kernel lasts (workgroups on the fullest CU) x (row tiles per chunk).
@@ -548,9 +557,9 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     const char* tl = getenv("PCREG_SAD_TIMELINE");      // debug: dump per-block (start, end, HW_ID, XCC_ID) to this file
     if (tl) PCREG_HIP(hipMalloc(&dbg, (size_t)n_tiles * S * 4 * sizeof(unsigned long long)));
     if (getenv("PCREG_SAD_DRY"))      // timing experiment only: list maintenance compiled out, results invalid
-        hipLaunchKernelGGL(sad16_candidates_kernel<true>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg);
+        hipLaunchKernelGGL(sad16_candidates_kernel<true>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live);
     else
-        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg);
+        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live);
     const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
     if (dbg) {
         std::vector<unsigned long long> h((size_t)n_tiles * S * 4);
@@ -564,10 +573,10 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
             fclose(f);
         }
     }
-    hipLaunchKernelGGL(transpose_rows_kernel, dim3((nA + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, A, nA, lda, D, At);
-    hipLaunchKernelGGL(transpose_rows_kernel, dim3((nB + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, B, nB, ldb, D, Bt);
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3((nA + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, A, nA, lda, D, At, nA_live);
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3((nB + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, B, nB, ldb, D, Bt, (const int32_t*)nullptr);
     hipLaunchKernelGGL(sad16_finalize_kernel, dim3((nA + 3) / 4), dim3(kBlock), 0, st, At, nA, Bt, nB, D, range,
-                       part_idx, part_s, S, idx, dist, flag_list, n_flag, force);
+                       part_idx, part_s, S, idx, dist, flag_list, n_flag, force, nA_live);
     PCREG_HIP(hipGetLastError());
     if (getenv("PCREG_MATCH_DEBUG")) {                       // the only host round trip of the call, debugging only
         int32_t nf = 0;
