@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_sgpr_kernel(
 size_t knn_f16_prep_bytes(int M);
 int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
                               unsigned* rm2, void* mtiles, unsigned* gthr, void* cand_ent, int32_t* cand_cnt,
-                              int target_blocks, int max_S, bool dry, int* S_out, hipStream_t st);
+                              int target_blocks, int max_S, bool dry, int* S_out, int* group16_out, hipStream_t st);
 namespace {
 // ---- 3. exact re-rank + certificate: one wave per query ------------------------------------
 __device__ __forceinline__ bool lex_lt_f(float da, int ia, float db, int ib) {
@@ -560,7 +560,10 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const Prep* __restrict__ prep, const unsigned* __restrict__ rm2_bits, const unsigned* __restrict__ gthr,
     const int32_t* __restrict__ part_idx, const float* __restrict__ part_s, int S, int kc, int idx_base,
     int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int e_mode,
-    const int32_t* __restrict__ cand_cnt) {
+    const int32_t* __restrict__ cand_cnt, int group16) {
+    // group16 (sparse lists of the pipelined f16 kernel): an entry is (first row jb, minimum score) of the 16 model
+    // points jb + 8 (r / 4) + r % 4, r = 0..15, that one lane of knn_candidates_f16_pipe_kernel scored together;
+    // pass 2 expands every entry that can still matter.  Points past M (tile padding) are skipped.
     const int lane = threadIdx.x & (LPQ - 1);
     const int qi = blockIdx.x * (kBlock / LPQ) + (threadIdx.x / LPQ);
     if (qi >= Q) return;
@@ -605,10 +608,15 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
         if (sparse) { const uint2 v = ent[e]; j = (int)v.x; sc = __uint_as_float(v.y); }
         else { size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc); j = part_idx[o]; sc = part_s[o]; }
         if (j >= 0 && (sc <= cut_up || !(a2 < INFINITY))) {
-            float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
-            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            if (lex_lt_f(d, j, d2, i2)) {
-                if (lex_lt_f(d, j, d1, i1)) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; }
+            const int nr = group16 ? 16 : 1;
+            for (int r = 0; r < nr; ++r) {
+                const int jj = group16 ? j + 8 * (r >> 2) + (r & 3) : j;
+                if (jj >= M) continue;
+                float dx = qx - m[jj], dy = qy - m[jj + (size_t)ldm], dz = qz - m[jj + 2 * (size_t)ldm];
+                float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                if (lex_lt_f(d, jj, d2, i2)) {
+                    if (lex_lt_f(d, jj, d1, i1)) { d2 = d1; i2 = i1; d1 = d; i1 = jj; } else { d2 = d; i2 = jj; }
+                }
             }
         }
     }
@@ -789,7 +797,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     int nb = (M + Q + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2, n_flag);
-    int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0;
+    int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0, group16 = 0;
     bool sparse_lists = false;
     static const bool no_seed = getenv("PCREG_KNN_NOSEED") && atoi(getenv("PCREG_KNN_NOSEED")) != 0;
     if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)
@@ -805,7 +813,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
         kc = KC;
         sparse_lists = true;             // entries of both 4-byte arrays' space: [Q][S * KC] (index, score) pairs
         int rc = launch_knn_candidates_f16(q, Q, ldq, m, M, ldm, prep, rm2, mprep, gthr, part_idx, cand_cnt,
-                                           target_env > 0 ? target_env : 4096, kPartCap * 2, variant == 41, &S, st);
+                                           target_env > 0 ? target_env : 4096, kPartCap * 2, variant == 41, &S, &group16, st);
         if (rc) return rc;
     } else if (use_mfma) {
         constexpr int NQ = 8;                    // must match knn_mfma.hip
@@ -858,10 +866,10 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     PCREG_HIP(hipGetLastError());
     if (sparse_lists)
         hipLaunchKernelGGL(knn_finalize_kernel<8>, dim3((Q + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
-                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)cand_cnt);
+                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)cand_cnt, group16);
     else
         hipLaunchKernelGGL(knn_finalize_kernel<64>, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
-                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)nullptr);
+                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)nullptr, 0);
     PCREG_HIP(hipGetLastError());
     if (getenv("PCREG_KNN_DEBUG")) {
         int32_t nf = 0;
