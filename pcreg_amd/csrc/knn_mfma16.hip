@@ -25,8 +25,6 @@
 #include "knn_fast_common.hpp"
 #include <hip/hip_fp16.h>
 #include <cstdlib>
-#include <algorithm>
-#include <cmath>
 #include <vector>
 #include <utility>
 
@@ -81,175 +79,10 @@ __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __r
     if (threadIdx.x == 0) atomicMax(rm2_bits, __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
 }
 
-template <int QG, bool DRY, bool BATCH>
-__global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
-    const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
-    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, uint2* __restrict__ cand_ent /*[Q][cap]: (index, score bits)*/,
-    int32_t* __restrict__ cand_cnt /*[Q]*/, int cap, int q_blocks, int xcd_map) {
-    __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];          // 2 x 16 KiB, filled by LDS-DMA
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = lane & 31, half = lane >> 5;
-    // workgroup -> (query block, model chunk).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share
-    // one), so with xcd_map (chunk count a multiple of 8) the XCD that runs workgroup b owns the chunks c with
-    // c % 8 == b % 8 and walks them one after the other, all query blocks of a chunk back to back: every XCD's L2
-    // then fetches an eighth of the prepared model once, instead of all of it.  Placement is speed only.
-    int qb, chunk;
-    if (xcd_map) { const int j = (int)blockIdx.x >> 3; chunk = (j / q_blocks) * 8 + ((int)blockIdx.x & 7); qb = j % q_blocks; }
-    else { qb = (int)blockIdx.x % q_blocks; chunk = (int)blockIdx.x / q_blocks; }
-    const int q_base = (qb * (kBlock / 64) + wave) * (QG * 32);
-    const float sg = prep->sigma, inv2 = prep->inv_sigma2, sg2 = sg * sg;
-
-    f16x8 bq[QG];
-    float thr[QG];
-    unsigned gseen[QG];
-    Cand cand[QG];
-#pragma unroll
-    for (int g = 0; g < QG; ++g) {
-        const int qi = q_base + g * 32 + col;
-        float X = 0.0f, Y = 0.0f, Z = 0.0f, one = 0.0f;
-        if (qi < Q) {
-            X = -2.0f * (sg * (q[qi] - prep->cx)); Y = -2.0f * (sg * (q[qi + (size_t)ldq] - prep->cy));
-            Z = -2.0f * (sg * (q[qi + 2 * (size_t)ldq] - prep->cz)); one = 1.0f;
-        }
-        _Float16 Xh, Xl, Yh, Yl, Zh, Zl;
-        split2(X, Xh, Xl); split2(Y, Yh, Yl); split2(Z, Zh, Zl);
-        const _Float16 o1 = (_Float16)one;
-        bq[g] = half == 0 ? f16x8{Xh, Xh, Xl, Xl, Yh, Yh, Yl, Yl} : f16x8{Zh, Zh, Zl, Zl, o1, o1, o1, (_Float16)0.0f};
-#pragma unroll
-        for (int k = 0; k < KC; ++k) { cand[g].s[k] = INFINITY; cand[g].i[k] = -1; }
-        thr[g] = INFINITY; gseen[g] = 0xFFFFFFFFu;
-    }
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)&tile[0][0];
-    const int t_begin = chunk * tiles_per_chunk, t_end = min(n_tiles, t_begin + tiles_per_chunk);
-    const int ntile = t_end - t_begin;
-    // wave w copies the 1-KiB segments w, w + 4, ... of a tile
-#define PCREG_TILE_DMA(T, BUF)                                                                                     \
-    _Pragma("unroll") for (int k = 0; k < kT16 / 128; ++k) {                                                        \
-        const int seg = k * 4 + wave;                                                                              \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mt + (size_t)(T) * (2 * kT16) + seg * 64 + lane), \
-                                         (__attribute__((address_space(3))) void*)(&tile[BUF][seg * 64]), 16, 0, 0);   \
-    }
-    if (ntile > 0) { PCREG_TILE_DMA(t_begin, 0) }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int t = 0; t < ntile; ++t) {
-        if (t + 1 < ntile) { PCREG_TILE_DMA(t_begin + t + 1, (t + 1) & 1) }
-        if ((t & (kRefresh - 1)) == 0) {          // chunks share one monotone threshold word per query (unscaled units)
-#pragma unroll
-            for (int g = 0; g < QG; ++g) {
-                const int qi = q_base + g * 32 + col;
-                if (qi < Q) {
-                    if (cand[g].s[3] < INFINITY) { unsigned k = f2ord(cand[g].s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
-                    unsigned gv = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    gseen[g] = gv;
-                    thr[g] = fminf(fminf(thr[g], ord2f(gv) * sg2), __shfl_xor(thr[g], 32));       // and the sibling half's list
-                }
-            }
-        }
-        // The A operand is read with inline-asm ds_read_b128: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in
-        // front of every compiler-visible LDS read while an LDS-DMA is in flight (it cannot tell the two
-        // buffers apart), which would drain the prefetch of tile t+1 at the top of tile t.
-        const unsigned cur = lds_base + (unsigned)((t & 1) * (2 * kT16) + half * kT16 + col) * 16u;
-        const int jt = (t_begin + t) * kT16 + 4 * half;
-        u32x4 an;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(an) : "v"(cur) : "memory");
-#pragma unroll 2
-        for (int sub = 0; sub < kT16 / 32; ++sub) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(an) :: "memory");
-            const f16x8 av = __builtin_bit_cast(f16x8, an);
-            if (sub + 1 < kT16 / 32) asm volatile("ds_read_b128 %0, %1" : "=v"(an) : "v"(cur + (unsigned)(sub + 1) * 512u) : "memory");
-            if (!BATCH) {
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[g], zero, 0, 0, 0);
-                    float m0 = fminf(fminf(d[0], d[1]), d[2]), m1 = fminf(fminf(d[3], d[4]), d[5]);
-                    float m2 = fminf(fminf(d[6], d[7]), d[8]), m3 = fminf(fminf(d[9], d[10]), d[11]);
-                    float m4 = fminf(fminf(d[12], d[13]), d[14]);
-                    float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
-                    if (DRY) { asm volatile("" :: "v"(mn)); }
-                    else if (mn < thr[g]) {
-                        const int jb = jt + sub * 32;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) if (d[r] < thr[g]) cand_insert(cand[g], d[r], jb + 8 * (r / 4) + (r % 4));
-                        thr[g] = fminf(thr[g], cand[g].s[3]);
-                    }
-                }
-            } else {
-                // all QG products first (the matrix pipe works through them back to back), then the QG
-                // reductions, then ONE branch: the slow path is entered if any group of any lane has a hit
-                f32x16 d[QG];
-#pragma unroll
-                for (int g = 0; g < QG; ++g) d[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[g], zero, 0, 0, 0);
-                bool hit = false;
-#pragma unroll
-                for (int g = 0; g < QG; ++g) {
-                    float m0 = fminf(fminf(d[g][0], d[g][1]), d[g][2]), m1 = fminf(fminf(d[g][3], d[g][4]), d[g][5]);
-                    float m2 = fminf(fminf(d[g][6], d[g][7]), d[g][8]), m3 = fminf(fminf(d[g][9], d[g][10]), d[g][11]);
-                    float m4 = fminf(fminf(d[g][12], d[g][13]), d[g][14]);
-                    float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[g][15]));
-                    if (DRY) { asm volatile("" :: "v"(mn)); } else hit |= mn < thr[g];
-                }
-                if (!DRY && hit) {
-                    const int jb = jt + sub * 32;
-#pragma unroll
-                    for (int g = 0; g < QG; ++g) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) if (d[g][r] < thr[g]) cand_insert(cand[g], d[g][r], jb + 8 * (r / 4) + (r % 4));
-                        thr[g] = fminf(thr[g], cand[g].s[3]);
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#undef PCREG_TILE_DMA
-    // The two half-waves of a query (lanes l and l ^ 32) merge their sorted fours in registers and lane l < 32
-    // writes ONE list of four per (chunk, query); the merged 4th-best is published too, so every entry dropped
-    // here still has s >= the final threshold word G, which is what the certificate relies on.
-#pragma unroll
-    for (int g = 0; g < QG; ++g) {
-        const int qi = q_base + g * 32 + col;
-        Cand mine = cand[g];
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const float os = __shfl_xor(cand[g].s[k], 32);
-            const int oi = __shfl_xor(cand[g].i[k], 32);
-            // (score, index) order keeps the merge independent of which half holds what
-            if (oi >= 0 && (os < mine.s[3] || (os == mine.s[3] && (unsigned)oi < (unsigned)mine.i[3]))) {
-                int pos = 3;
-#pragma unroll
-                for (int t = 2; t >= 0; --t) if (os < mine.s[t] || (os == mine.s[t] && (unsigned)oi < (unsigned)mine.i[t])) pos = t;
-#pragma unroll
-                for (int t = 3; t > 0; --t) if (t > pos) { mine.s[t] = mine.s[t - 1]; mine.i[t] = mine.i[t - 1]; }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) if (t == pos) { mine.s[t] = os; mine.i[t] = oi; }
-            }
-        }
-        if (qi < Q && half == 0) {
-            if (mine.s[3] < INFINITY) { unsigned k = f2ord(mine.s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
-            // Only real entries are kept: the list of query qi grows by this (chunk, query)'s valid candidates (most
-            // chunks add none once the thresholds are seeded), in whatever order the chunks finish -- the re-rank
-            // orders by (distance, index), so the order is immaterial.  cap = S * KC: it cannot overflow.
-            int nv = 0;
-#pragma unroll
-            for (int k = 0; k < KC; ++k) nv += mine.i[k] >= 0;
-            if (nv > 0) {
-                const int base = atomicAdd(&cand_cnt[qi], nv);
-                uint2* dst = cand_ent + (size_t)qi * cap + base;
-#pragma unroll
-                for (int k = 0; k < KC; ++k) if (k < nv) dst[k] = make_uint2((unsigned)mine.i[k], __float_as_uint(mine.s[k] * inv2));
-            }
-        }
-    }
-}
-
-
-// ---- software-pipelined form (default) ------------------------------------------------------------
-// The loop above issues MFMA -> (wait for it) -> min tree -> compare -> branch, so inside one wave the matrix
+// ---- the candidate kernel: software-pipelined ------------------------------------------------------
+// Round 1's loop (git history: knn_candidates_f16_kernel) issued MFMA -> (wait for it) -> min tree -> compare -> branch, so inside one wave the matrix
 // pipe and the VALU strictly alternate (the ISA shows `v_mfma ... s_nop 9 ... v_min3 x8 ... v_cmp ... s_cbranch`)
-// and all overlap is left to the co-resident waves; and its list update walks the 16 scores of a hit with one
+// and all overlap was left to the co-resident waves; and its list update walked the 16 scores of a hit with one
 // compare + branch each, ~1000 cycles during which the wave's three siblings end up waiting at the tile barrier
 // (rocprofv3: 0.19 of 1.67 ms; without the barrier 1.48).  This form changes both:
 //  * two accumulator tiles: the product of step j + 1 is issued first and the selection of step j (min tree +
@@ -266,13 +99,12 @@ __global__ __launch_bounds__(kBlock) void knn_candidates_f16_kernel(
 // Rule for the inline-asm A reads (the compiler believes an asm output is ready at once): a ds_read's destination
 // is never loop-carried in flight; it is waited for inside the iteration that issued it and only waited values
 // cross the back edge (tests/test_isa_lint.py checks the emitted ISA for a VGPR read between load and wait).
-template <int QG, int EXP>   // EXP (timing experiments, results invalid unless 0): 1 no compare, 2 compare but no list update, 3 = 1 without the tile barrier, 4 = 0 without the tile barrier, 5 = 2 without the tile copies, 6 = 1 without the tile copies
+template <int QG, bool DRY>   // DRY: timing only (no compare, no lists; PCREG_KNN_VARIANT=41)
 __global__ __launch_bounds__(kBlock, 4) void knn_candidates_f16_pipe_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr, uint2* __restrict__ cand_ent, int32_t* __restrict__ cand_cnt,
     int cap, int q_blocks, int xcd_map, int n_chunks) {
     static_assert(QG % 2 == 0, "two accumulator tiles alternate: an even number of steps per sub-tile");
-    constexpr bool DRY = EXP == 1 || EXP == 3 || EXP == 6;
     __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
@@ -318,7 +150,7 @@ __global__ __launch_bounds__(kBlock, 4) void knn_candidates_f16_pipe_kernel(
     const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int kSubs = kT16 / 32;
     for (int t = 0; t < ntile; ++t) {
-        if (EXP < 5 && t + 1 < ntile) { PCREG_TILE_DMA(t_begin + t + 1, (t + 1) & 1) }
+        if (t + 1 < ntile) { PCREG_TILE_DMA(t_begin + t + 1, (t + 1) & 1) }
         if ((t & (kRefresh - 1)) == 0) {          // chunks share one monotone threshold word per query (unscaled units)
 #pragma unroll
             for (int g = 0; g < QG; ++g) {
@@ -362,13 +194,6 @@ __global__ __launch_bounds__(kBlock, 4) void knn_candidates_f16_pipe_kernel(
 #pragma unroll
                 for (int g = 0; g < QG; ++g) {
                     f32x16 dnext;
-                    if (EXP == 7 || EXP == 9) __builtin_amdgcn_s_setprio(EXP == 9 ? 3 : 1);
-                    if (EXP == 8 || EXP == 10) __builtin_amdgcn_s_setprio(0);
-                    if (EXP == 11) asm volatile("s_nop 0");
-                    if (EXP == 13) asm volatile("s_nop 1");
-                    if (EXP == 14) asm volatile("s_nop 3");
-                    if (EXP == 15) asm volatile("s_nop 7");
-                    if (EXP == 12) __builtin_amdgcn_s_setprio(1);
                     if (g + 1 < QG) {
                         dnext = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bq[g + 1], zero, 0, 0, 0);
                     } else {
@@ -376,17 +201,14 @@ __global__ __launch_bounds__(kBlock, 4) void knn_candidates_f16_pipe_kernel(
                         avn = __builtin_bit_cast(f16x8, an);
                         dnext = __builtin_amdgcn_mfma_f32_32x32x16_f16(avn, bq[0], zero, 0, 0, 0);    // after sub 15: a product nobody reads
                     }
-                    if (EXP == 7 || EXP == 9) __builtin_amdgcn_s_setprio(0);
-                    if (EXP == 8) __builtin_amdgcn_s_setprio(1);
-                    if (EXP == 12 && g == QG - 1) __builtin_amdgcn_s_setprio(0);
                     const f32x16 d = dprev;
-                    float m0 = fminf(fminf(d[0], d[1]), d[2]), m1 = fminf(fminf(d[3], d[4]), d[5]);
-                    float m2 = fminf(fminf(d[6], d[7]), d[8]), m3 = fminf(fminf(d[9], d[10]), d[11]);
-                    float m4 = fminf(fminf(d[12], d[13]), d[14]);
+                    const float m0 = fminf(fminf(d[0], d[1]), d[2]), m1 = fminf(fminf(d[3], d[4]), d[5]);
+                    const float m2 = fminf(fminf(d[6], d[7]), d[8]), m3 = fminf(fminf(d[9], d[10]), d[11]);
+                    const float m4 = fminf(fminf(d[12], d[13]), d[14]);
                     const float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
-                    mnk[ss][g] = mn;
                     if (DRY) { asm volatile("" :: "v"(mn)); hit[ss][g] = 0; }
                     else hit[ss][g] = __builtin_amdgcn_ballot_w64(mn < thr[g]);
+                    mnk[ss][g] = mn;
                     dprev = dnext;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // the MFMA first, the selection under it
                     __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
@@ -397,8 +219,7 @@ __global__ __launch_bounds__(kBlock, 4) void knn_candidates_f16_pipe_kernel(
             unsigned long long any = 0;
 #pragma unroll
             for (int g = 0; g < QG; ++g) any |= hit[0][g] | hit[1][g];
-            if (EXP == 2 || EXP == 5) asm volatile("" :: "s"(any));
-            if (!DRY && EXP != 2 && EXP != 5 && any != 0) {        // wave-uniform, rare
+            if (!DRY && any != 0) {        // wave-uniform, rare
 #pragma unroll
                 for (int g = 0; g < QG; ++g) {
 #pragma unroll
@@ -411,7 +232,7 @@ __global__ __launch_bounds__(kBlock, 4) void knn_candidates_f16_pipe_kernel(
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (EXP != 3 && EXP != 4) __syncthreads();
+        __syncthreads();
     }
 #undef PCREG_TILE_DMA
     // The two half-waves of a query (lanes l and l ^ 32) merge their sorted fours in registers and lane l < 32
@@ -477,11 +298,8 @@ size_t knn_f16_prep_bytes(int M) { return (size_t)((M > 0 ? M : 1) + kT16 - 1) /
 int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
                               unsigned* rm2, void* mtiles, unsigned* gthr, void* cand_ent, int32_t* cand_cnt,
                               int target_blocks, int max_S, bool dry, int* S_out, int* group16_out, hipStream_t st) {
-    // 4 (default): pipelined, group entries; 5: the same with two query groups per wave; 0..3: the serial round-1 forms
-    // (QG4, QG4 batched, QG2, QG2 batched), point entries
-    static const int cfg = getenv("PCREG_KNN_F16_CFG") ? atoi(getenv("PCREG_KNN_F16_CFG")) : 4;
-    *group16_out = (cfg == 4 || cfg == 5) ? 1 : 0;
-    const int QG = (cfg == 2 || cfg == 3 || cfg == 5) ? 2 : 4;
+    constexpr int QG = 4;
+    *group16_out = 1;                       // list entries are groups of 16 model points (knn_finalize_kernel expands them)
     const int n_tiles = (M + kT16 - 1) / kT16;
     const int q_blocks = (Q + (kBlock / 64) * QG * 32 - 1) / ((kBlock / 64) * QG * 32);
     int S = target_blocks / q_blocks; if (S < 1) S = 1;
@@ -489,27 +307,10 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     if (S > n_tiles) S = n_tiles > 0 ? n_tiles : 1;
     int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
     S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
-    // XCD-aware placement wants the chunk count to be a multiple of 8 (trailing chunks may be empty)
-    static const bool no_xcd = getenv("PCREG_KNN_NOXCD") && atoi(getenv("PCREG_KNN_NOXCD")) != 0;
-    const int xcd_map = (!no_xcd && S >= 8) ? 1 : 0;
-    if (xcd_map) {
-        S = S / 8 * 8;
-        tiles_per_chunk = (n_tiles + S - 1) / S;
-    }
-    int grid_chunks = S;
-    if ((cfg == 4 || cfg == 5) && n_tiles > 0 && !no_xcd) {
-        // pipelined form: any chunk count works (the grid rounds it up to a multiple of 8, surplus workgroups leave at
-        // once).  PCREG_KNN_F16_S overrides the default (sweeps: 40 and 72 are equally good at 50 k x 1 M, a
-        // "fill the last round" rule was not better -- workgroups are not dispatched in rounds).
-        static const int s_env = getenv("PCREG_KNN_F16_S") ? atoi(getenv("PCREG_KNN_F16_S")) : 0;
-        if (s_env > 0) {
-            S = std::min(s_env, std::min(max_S, n_tiles));
-            tiles_per_chunk = (n_tiles + S - 1) / S;
-            S = (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
-        }
-        grid_chunks = S >= 8 ? (S + 7) / 8 * 8 : S;
-    }
-    const int xcd_on = (cfg == 4 || cfg == 5) ? ((!no_xcd && S >= 8) ? 1 : 0) : xcd_map;
+    // XCD-aware placement deals chunk c to the XCD that runs workgroups b = c (mod 8): the grid rounds the chunk count
+    // up to a multiple of 8 and the surplus workgroups leave at once
+    const int xcd_map = S >= 8 ? 1 : 0;
+    const int grid_chunks = xcd_map ? (S + 7) / 8 * 8 : S;
     *S_out = S;
     // the prep kernel empties the per-query lists; an empty model has no prep
     if (M <= 0) { PCREG_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)Q * 4, st)); return PCREG_OK; }
@@ -521,21 +322,10 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
         ev0 = g_time_ev[g_time_used].first; ev1 = g_time_ev[g_time_used].second; ++g_time_used;
         PCREG_HIP(hipEventRecord(ev0, st));
     }
-#define PCREG_F16_LAUNCH(QGV, DRYV, BV) hipLaunchKernelGGL((knn_candidates_f16_kernel<QGV, DRYV, BV>), dim3(q_blocks * S), dim3(kBlock), 0, st, q, Q, ldq, \
-                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map)
-#define PCREG_F16_PIPE(QGV, DRYV) hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<QGV, DRYV>), dim3(q_blocks * grid_chunks), dim3(kBlock), 0, st, q, Q, ldq, \
-                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_on, S)
-    static const int exp_mode = getenv("PCREG_KNN_F16_EXP") ? atoi(getenv("PCREG_KNN_F16_EXP")) : 0;
-    if (cfg == 4) { switch (dry ? 1 : exp_mode) { case 1: PCREG_F16_PIPE(4, 1); break; case 2: PCREG_F16_PIPE(4, 2); break; case 3: PCREG_F16_PIPE(4, 3); break; case 4: PCREG_F16_PIPE(4, 4); break; case 5: PCREG_F16_PIPE(4, 5); break; case 6: PCREG_F16_PIPE(4, 6); break; case 7: PCREG_F16_PIPE(4, 7); break; case 8: PCREG_F16_PIPE(4, 8); break; case 9: PCREG_F16_PIPE(4, 9); break; case 10: PCREG_F16_PIPE(4, 10); break; case 11: PCREG_F16_PIPE(4, 11); break; case 12: PCREG_F16_PIPE(4, 12); break; case 13: PCREG_F16_PIPE(4, 13); break; case 14: PCREG_F16_PIPE(4, 14); break; case 15: PCREG_F16_PIPE(4, 15); break; default: PCREG_F16_PIPE(4, 0); } }
-    else if (cfg == 5) { if (dry) PCREG_F16_PIPE(2, 1); else PCREG_F16_PIPE(2, 0); }
-    else
-    switch (cfg * 2 + (dry ? 1 : 0)) {
-        case 0: PCREG_F16_LAUNCH(4, false, false); break;  case 1: PCREG_F16_LAUNCH(4, true, false); break;
-        case 2: PCREG_F16_LAUNCH(4, false, true); break;   case 3: PCREG_F16_LAUNCH(4, true, true); break;
-        case 4: PCREG_F16_LAUNCH(2, false, false); break;  case 5: PCREG_F16_LAUNCH(2, true, false); break;
-        case 6: PCREG_F16_LAUNCH(2, false, true); break;   default: PCREG_F16_LAUNCH(2, true, true); break;
-    }
-#undef PCREG_F16_LAUNCH
+#define PCREG_F16_PIPE(DRYV) hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<QG, DRYV>), dim3(q_blocks * grid_chunks), dim3(kBlock), 0, st, q, Q, ldq, \
+                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map, S)
+    if (dry) PCREG_F16_PIPE(true); else PCREG_F16_PIPE(false);
+#undef PCREG_F16_PIPE
     if (ev1) PCREG_HIP(hipEventRecord(ev1, st));
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;

@@ -1,0 +1,114 @@
+// tests/mexstub/mex_driver.cpp -- TEST INFRASTRUCTURE.  Plays MATLAB for mex/pcreg_mex.cpp: builds the
+// mxArrays the matlab/*.m wrappers would pass (column-major doubles, the coef / par / options structs,
+// the int32 sample table), calls mexFunction, and hands the outputs back through a plain C interface
+// that tests/test_mex_shim.py drives with ctypes.  Returns 0, or 1 with the raised id:message in err.
+#include "mex.h"
+#include <algorithm>
+
+int g_mex_live_arrays = 0;
+
+static mxArray* dmat(const double* p, size_t m, size_t n) { mxArray* a = mxCreateDoubleMatrix(m, n, mxREAL); if (m * n > 0) memcpy(mxGetPr(a), p, m * n * 8); return a; }
+static void put(mxArray* s, const char* k, double v) { mxSetField(s, 0, k, mxCreateDoubleScalar(v)); }
+
+static int call(int nlhs, mxArray** plhs, std::vector<mxArray*>& rhs, char* err, int errlen) {
+    int rc = 0;
+    try { mexFunction(nlhs, plhs, (int)rhs.size(), const_cast<const mxArray**>(rhs.data())); }
+    catch (const MexError& e) { snprintf(err, errlen, "%s: %s", e.id.c_str(), e.msg.c_str()); rc = 1; }
+    for (mxArray* a : rhs) mxDestroyArray(a);
+    return rc;
+}
+
+extern "C" {
+
+int drv_live_arrays() { return g_mex_live_arrays; }
+
+int drv_estimate_transform(const double* p1, const double* p2, int n, double* T16, int* empty, char* err, int errlen) {
+    std::vector<mxArray*> rhs{mxCreateString("estimateTransform"), dmat(p1, n, 3), dmat(p2, n, 3)};
+    mxArray* lhs[1] = {nullptr};
+    if (call(1, lhs, rhs, err, errlen)) return 1;
+    *empty = mxIsEmpty(lhs[0]);
+    if (!*empty) memcpy(T16, mxGetPr(lhs[0]), 128);
+    mxDestroyArray(lhs[0]);
+    return 0;
+}
+
+int drv_calc_dists(const double* T16, const double* p1, const double* p2, int n, double* d, char* err, int errlen) {
+    std::vector<mxArray*> rhs{mxCreateString("calcDists"), dmat(T16, 4, 4), dmat(p1, n, 3), dmat(p2, n, 3)};
+    mxArray* lhs[1] = {nullptr};
+    if (call(1, lhs, rhs, err, errlen)) return 1;
+    memcpy(d, mxGetPr(lhs[0]), (size_t)n * 8);
+    mxDestroyArray(lhs[0]);
+    return 0;
+}
+
+// coef = {minPtNum, iterNum, thDist, thInlrRatio, REFINE}; sample: minPtNum x iterNum int32 (column per hypothesis) or NULL
+int drv_ransac(const double* p1, const double* p2, int n, const double* coef5, const int32_t* sample, double seed,
+               double* T16, double* inlier_idx, int* n_inl, int* num_success, int* max_inl, int* failed, char* err, int errlen) {
+    mxArray* c = mxCreateStructMatrix(1, 1, 0, nullptr);
+    put(c, "minPtNum", coef5[0]); put(c, "iterNum", coef5[1]); put(c, "thDist", coef5[2]); put(c, "thInlrRatio", coef5[3]);
+    put(c, "REFINE", coef5[4]); put(c, "VERBOSE", 0);
+    mxArray* si;
+    if (sample) { si = mxCreateNumericMatrix((size_t)coef5[0], (size_t)coef5[1], mxINT32_CLASS, mxREAL); memcpy(mxGetData(si), sample, (size_t)coef5[0] * (size_t)coef5[1] * 4); }
+    else si = mxCreateDoubleMatrix(0, 0, mxREAL);
+    std::vector<mxArray*> rhs{mxCreateString("ransac"), dmat(p1, n, 3), dmat(p2, n, 3), c, si, mxCreateDoubleScalar(seed)};
+    mxArray* lhs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (call(5, lhs, rhs, err, errlen)) return 1;
+    *failed = (int)mxGetScalar(lhs[4]);
+    if (!*failed) memcpy(T16, mxGetPr(lhs[0]), 128);
+    *n_inl = (int)(mxGetM(lhs[1]) * mxGetN(lhs[1]));
+    if (*n_inl) memcpy(inlier_idx, mxGetPr(lhs[1]), (size_t)*n_inl * 8);
+    *num_success = (int)mxGetScalar(lhs[2]); *max_inl = (int)mxGetScalar(lhs[3]);
+    for (mxArray* a : lhs) mxDestroyArray(a);
+    return 0;
+}
+
+// par = {MatchThreshold, MaxRatio, Unique, UNNORMALIZE, norm_factor, CHANGE_METRIC, metric_factor}; metric "SAD" | "SSD"
+int drv_get_matches(const double* dS, int Q, const double* dM, int M, int D, const char* metric, const double* par7,
+                    uint32_t* pairs_colmajor /* cap Q x 2 */, int* P, char* err, int errlen) {
+    mxArray* p = mxCreateStructMatrix(1, 1, 0, nullptr);
+    mxSetField(p, 0, "Metric", mxCreateString(metric)); mxSetField(p, 0, "Method", mxCreateString("Approximate"));
+    put(p, "MatchThreshold", par7[0]); put(p, "MaxRatio", par7[1]); put(p, "Unique", par7[2]); put(p, "UNNORMALIZE", par7[3]);
+    put(p, "norm_factor", par7[4]); put(p, "CHANGE_METRIC", par7[5]); put(p, "metric_factor", par7[6]); put(p, "VERBOSE", 0);
+    std::vector<mxArray*> rhs{mxCreateString("getMatches"), dmat(dS, Q, D), dmat(dM, M, D), p};
+    mxArray* lhs[1] = {nullptr};
+    if (call(1, lhs, rhs, err, errlen)) return 1;
+    *P = (int)mxGetM(lhs[0]);
+    if (mxGetN(lhs[0]) != 2 && *P) { snprintf(err, errlen, "getMatches returned %zu columns", mxGetN(lhs[0])); mxDestroyArray(lhs[0]); return 1; }
+    memcpy(pairs_colmajor, mxGetData(lhs[0]), (size_t)*P * 2 * 4);
+    mxDestroyArray(lhs[0]);
+    return 0;
+}
+
+int drv_align_points_knn(const double* pts, int n, int C1, int C2, double* aligned, double* coeff9, double* c3, char* err, int errlen) {
+    std::vector<mxArray*> rhs{mxCreateString("AlignPoints_KNN"), dmat(pts, n, 3), mxCreateDoubleScalar(C1), mxCreateDoubleScalar(C2)};
+    mxArray* lhs[3] = {nullptr, nullptr, nullptr};
+    if (call(3, lhs, rhs, err, errlen)) return 1;
+    memcpy(aligned, mxGetPr(lhs[0]), (size_t)n * 3 * 8); memcpy(coeff9, mxGetPr(lhs[1]), 72); memcpy(c3, mxGetPr(lhs[2]), 24);
+    for (mxArray* a : lhs) mxDestroyArray(a);
+    return 0;
+}
+
+// opts = {min_pts, max_pts, R, thVar1, thVar2, ALIGN_POINTS}; k is passed as the string 'all' like completeExperimentFast.m:303
+int drv_descriptors(const double* pts, int Pn, const double* kp, int S, const double* opts6, double* feat /* cap S x 3 col-major */,
+                    double* desc /* cap S x 980 col-major */, int* V, char* err, int errlen) {
+    mxArray* o = mxCreateStructMatrix(1, 1, 0, nullptr);
+    put(o, "min_pts", opts6[0]); put(o, "max_pts", opts6[1]); put(o, "R", opts6[2]);
+    const double tv[2] = {opts6[3], opts6[4]};
+    mxSetField(o, 0, "thVar", dmat(tv, 1, 2)); put(o, "ALIGN_POINTS", opts6[5]); mxSetField(o, 0, "k", mxCreateString("all")); put(o, "VERBOSE", 0);
+    std::vector<mxArray*> rhs{mxCreateString("getSpacialHistogramDescriptors"), dmat(pts, Pn, 3), dmat(kp, S, 3), o};
+    mxArray* lhs[2] = {nullptr, nullptr};
+    if (call(2, lhs, rhs, err, errlen)) return 1;
+    *V = (int)mxGetM(lhs[0]);
+    memcpy(feat, mxGetPr(lhs[0]), (size_t)*V * 3 * 8);
+    memcpy(desc, mxGetPr(lhs[1]), (size_t)*V * mxGetN(lhs[1]) * 8);
+    for (mxArray* a : lhs) mxDestroyArray(a);
+    return 0;
+}
+
+int drv_bad_command(char* err, int errlen) {
+    std::vector<mxArray*> rhs{mxCreateString("noSuchCommand")};
+    mxArray* lhs[1] = {nullptr};
+    return call(1, lhs, rhs, err, errlen);
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""ISA lint of the point-search kernel and of the micro-benchmark behind DESIGN.md's issue model (CPU test:
+hipcc cross-compiles gfx950 to assembly here).
+
+knn_mfma16.hip reads its A operands with inline-asm `ds_read_b128` and waits in a separate asm statement; the
+compiler believes an asm output is ready at once, so a register copy scheduled between the two would read the
+registers before the data lands (it happened once: DESIGN.md section 4.1).  Nothing at run time would tell on a
+lucky box, so the emitted ISA is checked:
+  * no instruction touches a ds_read_b128 destination between the load and its `s_waitcnt lgkmcnt(0)`;
+  * the hot body of the default kernel holds exactly 8 MFMAs (two sub-tiles x four query groups), no scratch
+    access, no long `s_nop` (the serial form's `s_nop 9` after every MFMA);
+  * scripts/ubench/mfma_f16_valu.hip really issues 8 distinct MFMAs per loop iteration in every MFMA mode (round 1's
+    version had them CSE'd into one, and a wrong conclusion was drawn from it).
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-math-errno", "-fno-honor-nans",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-S", "--cuda-device-only"]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _asm(src, tmp_path, extra=()):
+    out = str(tmp_path / (os.path.basename(src) + ".s"))
+    subprocess.check_call([HIPCC, *FLAGS, *extra, "-o", out, src], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _functions(text):
+    """name -> list of instruction lines (comments and directives dropped)."""
+    funcs, cur, name = {}, None, None
+    for ln in text.splitlines():
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            name, cur = m.group(1), []
+            funcs[name] = cur
+            continue
+        if cur is None:
+            continue
+        s = ln.split(";")[0].rstrip() if not ln.strip().startswith(";;#") else ln.strip()
+        if s.strip().startswith(".") and not s.strip().startswith(".LBB"):
+            if s.strip().startswith(".Lfunc_end"):
+                cur = None
+            continue
+        if s.strip():
+            cur.append(s.strip())
+    return funcs
+
+
+def _regs(operand_text):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operand_text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(x) for x in re.findall(r"\bv(\d+)\b", operand_text))
+    return out
+
+
+@pytest.fixture(scope="module")
+def knn_asm(tmp_path_factory):
+    return _functions(_asm(os.path.join(ROOT, "pcreg_amd", "csrc", "knn_mfma16.hip"), tmp_path_factory.mktemp("isa"),
+                           ["-I" + os.path.join(ROOT, "pcreg_amd", "csrc")]))
+
+
+def test_no_register_of_an_lds_load_is_touched_before_its_wait(knn_asm):
+    checked = 0
+    for name, ins in knn_asm.items():
+        if "knn_candidates_f16" not in name:
+            continue
+        for i, s in enumerate(ins):
+            if not s.startswith("ds_read_b128"):
+                continue
+            dst = _regs(s.split(",")[0])
+            for j in range(i + 1, len(ins)):
+                t = ins[j]
+                if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                    break
+                if t.startswith(";;#") or t.startswith(".LBB"):
+                    continue
+                assert not (dst & _regs(t.split(None, 1)[1] if " " in t else "")), f"{name}: `{t}` touches {s.split(',')[0]} before the wait"
+                assert not t.startswith(("s_endpgm", "s_barrier")), f"{name}: {s} is never waited for"
+            checked += 1
+    assert checked >= 4
+
+
+def _hot_body(ins):
+    """The default kernel's hot body: from the header of the loop that holds the steady-state MFMAs to the first
+    conditional scalar branch after it (the `any hit?` test)."""
+    mf = [i for i, s in enumerate(ins) if s.startswith("v_mfma")]
+    assert len(mf) >= 9
+    first = mf[1]                                   # mf[0] is the tile prologue's product
+    start = max(i for i in range(first) if ins[i].startswith(".LBB"))
+    end = next(i for i in range(first, len(ins)) if ins[i].startswith("s_cbranch_scc"))
+    return ins[start + 1:end]
+
+
+def test_hot_body_of_the_default_kernel(knn_asm):
+    name = next(n for n in knn_asm if "knn_candidates_f16_pipe_kernelILi4ELb0" in n)
+    body = [s for s in _hot_body(knn_asm[name]) if not s.startswith(";;#")]
+    assert sum(s.startswith("v_mfma_f32_32x32x16_f16") for s in body) == 8
+    assert not any(s.startswith("scratch_") for s in body), "spill inside the hot body"
+    for s in body:
+        if s.startswith("s_nop"):
+            assert int(s.split()[1]) <= 3, f"`{s}`: an MFMA result is waited for on the critical path"
+    # selection: per product 7 v_min3 + 1 v_min (VOP3 form) + 1 v_cmp, nothing else on the VALU but address arithmetic
+    assert sum(s.startswith("v_min3_f32") for s in body) == 56
+    assert sum(s.startswith("v_min_f32") for s in body) == 8
+    assert sum(s.startswith("v_cmp_lt_f32") for s in body) == 8
+    other = [s for s in body if s.startswith("v_") and not s.startswith(("v_mfma", "v_min3_f32", "v_min_f32", "v_cmp_lt_f32"))]
+    assert len(other) <= 4, other
+
+
+def test_ubench_issues_eight_distinct_mfmas_per_iteration(tmp_path):
+    funcs = _functions(_asm(os.path.join(ROOT, "scripts", "ubench", "mfma_f16_valu.hip"), tmp_path))
+    seen = 0
+    for mode in (0, 1, 2, 4, 5):
+        name = next(n for n in funcs if n.startswith(f"_Z1kILi{mode}E"))
+        ins = funcs[name]
+        # the kernel has ONE loop (not unrolled further) and no MFMA outside it: the static count is the per-iteration count
+        mf = [s for s in ins if s.startswith("v_mfma_f32_32x32x16_f16")]
+        assert len(mf) == 8, f"mode {mode}: {len(mf)} MFMAs in the loop body"
+        assert len({s.split()[1].rstrip(",") for s in mf}) >= 2 or mode == 1      # distinct accumulators (mode 1 is the serial form)
+        seen += 1
+    assert seen == 5

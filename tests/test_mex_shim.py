@@ -1,0 +1,126 @@
+"""mex/pcreg_mex.cpp through a compiler and through a driver that plays MATLAB.
+
+MATLAB's mex.h exists on no box, so the shim is built against tests/mexstub/mex.h (a minimal
+mxArray: test infrastructure, not a MATLAB-compatibility claim) with -Wall -Wextra -Werror and
+linked to libpcreg_hip.so; tests/mexstub/mex_driver.cpp builds the mxArrays matlab/*.m would pass
+and calls mexFunction.  CPU: the gateway compiles, links, dispatches, and raises pcreg:hip /
+pcreg:usage through mexErrMsgIdAndTxt.  GPU: one round trip per command equals the ctypes path
+(the same library underneath: any difference is the shim's transposes, struct unpacking or nlhs
+handling)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "mexstub", "libmexdrv.so")
+
+
+@pytest.fixture(scope="module")
+def drv():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "pcreg_amd", "libpcreg_hip.so")):
+        g.build()
+    srcs = [os.path.join(ROOT, "mex", "pcreg_mex.cpp"), os.path.join(ROOT, "tests", "mexstub", "mex_driver.cpp")]
+    newest = max(os.path.getmtime(p) for p in srcs + [os.path.join(ROOT, "include", "pcreg.h"), os.path.join(ROOT, "tests", "mexstub", "mex.h")])
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < newest:
+        # the shim itself must be warning-free; it is the only consumer of mex.h
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests", "mexstub"),
+                               "-I" + os.path.join(ROOT, "include"), srcs[0]])
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "tests", "mexstub"),
+                               "-I" + os.path.join(ROOT, "include"), *srcs, "-o", OUT, "-L" + os.path.join(ROOT, "pcreg_amd"), "-lpcreg_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "pcreg_amd")])
+    return C.CDLL(OUT)
+
+
+def _d(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _err():
+    return C.create_string_buffer(1024)
+
+
+def test_shim_compiles_and_raises_usage(drv):
+    e = _err()
+    assert drv.drv_bad_command(e, 1024) == 1
+    assert e.value.decode().startswith("pcreg:usage")
+    assert drv.drv_live_arrays() == 0
+
+
+def test_shim_reports_nodevice_through_mexerr(drv):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    p = _d(np.eye(4, 3))
+    T = np.zeros(16); empty = C.c_int(0); e = _err()
+    assert drv.drv_estimate_transform(_p(p), _p(p), 4, _p(T), C.byref(empty), e, 1024) == 1
+    assert e.value.decode().startswith("pcreg:hip") and "no CPU fallback" in e.value.decode()
+
+
+@pytest.mark.gpu
+def test_shim_round_trips_equal_the_ctypes_path(drv):
+    import pcreg_amd as pc
+    from conftest import rigid_case
+    e = _err()
+    # estimateTransform + calcDists
+    p1, p2, _ = rigid_case(40, 3, outlier_frac=0.0)
+    T = np.zeros(16); empty = C.c_int(-1)
+    assert drv.drv_estimate_transform(_p(_d(p1)), _p(_d(p2)), 40, _p(T), C.byref(empty), e, 1024) == 0, e.value
+    Tm = T.reshape(4, 4, order="F")
+    assert empty.value == 0 and np.array_equal(Tm, pc.estimateTransform(p1, p2))
+    d = np.zeros(40)
+    assert drv.drv_calc_dists(_p(_d(Tm)), _p(_d(p1)), _p(_d(p2)), 40, _p(d), e, 1024) == 0, e.value
+    assert np.array_equal(d, pc.calcDists(Tm, p1, p2).ravel())
+    # rank-deficient input -> []
+    z = np.zeros((5, 3))
+    assert drv.drv_estimate_transform(_p(_d(z)), _p(_d(z)), 5, _p(T), C.byref(empty), e, 1024) == 0 and empty.value == 1
+    # ransac with a MATLAB-shaped sample table (minPtNum x iterNum int32, one column per hypothesis)
+    p1, p2, _ = rigid_case(300, 5)
+    rng = np.random.default_rng(0)
+    iters = 200
+    tab = np.stack([rng.permutation(300)[:3] + 1 for _ in range(iters)]).astype(np.int32)     # [iterNum][3]
+    coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.3, REFINE=True, VERBOSE=0)
+    ref = pc.ransac(p1, p2, coef, pc.estimateTransform, pc.calcDists, sample_idx=tab)
+    coef5 = np.array([3, iters, 0.05, 0.3, 1], dtype=np.float64)
+    inl = np.zeros(300); ni, ns, mi, fl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    tabF = np.asfortranarray(tab.T)                                                           # 3 x iterNum column-major
+    assert drv.drv_ransac(_p(_d(p1)), _p(_d(p2)), 300, _p(coef5), _p(tabF, C.c_int32), C.c_double(0), _p(T), _p(inl),
+                          C.byref(ni), C.byref(ns), C.byref(mi), C.byref(fl), e, 1024) == 0, e.value
+    assert fl.value == 0 and np.array_equal(T.reshape(4, 4, order="F"), ref[0])
+    assert np.array_equal(inl[:ni.value], np.asarray(ref[1], dtype=np.float64).ravel()) and (ns.value, mi.value) == (ref[2], ref[3])
+    # getMatches (par struct with strings; P x 2 uint32 column-major out)
+    dS = rng.poisson(3.0, (60, 980)).astype(np.float64); dM = rng.poisson(3.0, (90, 980)).astype(np.float64)
+    dM[:40] = dS[:40] + (rng.random((40, 980)) < 0.02)
+    par = dict(Method="Approximate", Metric="SAD", MatchThreshold=10, MaxRatio=0.99, Unique=True, UNNORMALIZE=True, norm_factor=2.0,
+               CHANGE_METRIC=True, metric_factor=0.6, VERBOSE=0)
+    want = pc.getMatches(dS, dM, par)
+    par7 = np.array([10, 0.99, 1, 1, 2.0, 1, 0.6], dtype=np.float64)
+    pairs = np.zeros(60 * 2, dtype=np.uint32); P = C.c_int()
+    assert drv.drv_get_matches(_p(_d(dS)), 60, _p(_d(dM)), 90, 980, b"SAD", _p(par7), _p(pairs, C.c_uint32), C.byref(P), e, 1024) == 0, e.value
+    got = pairs[:2 * P.value].reshape(P.value, 2, order="F")
+    assert P.value == len(want) and np.array_equal(got, want)
+    # AlignPoints_KNN
+    X = rng.normal(size=(500, 3)) * [3.0, 1.5, 0.4] + 20
+    al = np.zeros((500, 3), order="F"); co = np.zeros(9); c3 = np.zeros(3)
+    assert drv.drv_align_points_knn(_p(_d(X)), 500, 0, 0, _p(al), _p(co), _p(c3), e, 1024) == 0, e.value
+    ral, rco, rc = pc.AlignPoints_KNN(X)
+    assert np.array_equal(al, ral) and np.array_equal(co.reshape(3, 3, order="F"), rco) and np.array_equal(c3, np.asarray(rc).ravel())
+    # getSpacialHistogramDescriptors (options struct with thVar vector and k = 'all')
+    cloud = rng.uniform(0, 12, (6000, 3)); kp = rng.uniform(3, 9, (12, 3))
+    opts = dict(min_pts=50, max_pts=6000, R=3.5, thVar=[1.0, 1.0], k="all", ALIGN_POINTS=True, VERBOSE=0)
+    rfeat, rdesc = pc.getSpacialHistogramDescriptors(cloud, kp, opts)
+    feat = np.zeros((12, 3), order="F"); desc = np.zeros((12, 980), order="F"); V = C.c_int()
+    o6 = np.array([50, 6000, 3.5, 1.0, 1.0, 1], dtype=np.float64)
+    assert drv.drv_descriptors(_p(_d(cloud)), 6000, _p(_d(kp)), 12, _p(o6), _p(feat), _p(desc), C.byref(V), e, 1024) == 0, e.value
+    v = V.value
+    assert v == len(rfeat) and v > 0
+    assert np.array_equal(feat.ravel(order="F")[:3 * v].reshape(v, 3, order="F"), rfeat)
+    assert np.array_equal(desc.ravel(order="F")[:980 * v].reshape(v, 980, order="F"), rdesc)
+    assert drv.drv_live_arrays() == 0
