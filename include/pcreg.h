@@ -318,6 +318,14 @@ int pcreg_dev_sphere_select(const double* feat, int V, const double centre[3], d
 int pcreg_dev_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap,
                               double* dst, void* stream);
 
+/* AlignPoints_KNN.m:17-59 for B supports resident in HBM (the device-tier form of
+ * pcreg_align_points_knn_batched; same layouts, every pointer is device memory): support b owns rows
+ * [offsets[b], offsets[b+1]) of pts / aligned (n x 3 column-major, ld >= total); max_n = the largest support;
+ * coeff 9*B, c 3*B, status B (0 ok, 1 = fewer than 2 points).  Enqueued on `stream`, nothing synchronises. */
+int pcreg_dev_align_points_knn_batched(const double* pts, int total, int ld, const int32_t* offsets, int B, int max_n,
+                                       int C1, int C2, double* aligned, double* coeff, double* c, int32_t* status,
+                                       void* stream);
+
 /* quickTF.m:5-7: out = [pts, 1] * T (first three columns).  pts/out n x 3 column-major on the
  * device, T 4x4 column-major in HOST memory (invertTF is a 16-number host operation). */
 int pcreg_dev_quick_tf(const double* pts, int n, int ld, const double T[16], double* out, int ldo, void* stream);
@@ -327,6 +335,34 @@ int pcreg_dev_quick_tf(const double* pts, int n, int ld, const double T[16], dou
  * empty), info[0] = number of inliers, info[1] = 1 if the transform is empty. */
 int pcreg_dev_refine_by_distance(const double* pts1, const double* pts2, const int32_t* n_dev, int cap, int ld,
                                  double maxDist, double* T16, int32_t* info, void* stream);
+
+/* ---- multi-GPU behind the C ABI (RCCL over xGMI inside the library; comm.hip) -----------------------------
+ * One process per GPU -- a MATLAB parfor / spmd worker each, the reference's own unit of parallelism
+ * (completeExperimentFast.m:134,201).  Worker 0 calls pcreg_comm_get_unique_id; the 128 bytes reach the other
+ * workers by the host language's own means (labBroadcast, a file); every worker calls pcreg_set_device and then
+ * pcreg_comm_init(rank, world, id).  The sharded calls are collective: every rank must make them, in the same
+ * order, and every rank gets the same result -- bit for bit the single-GPU one.  RCCL is dlopen'ed at
+ * pcreg_comm_init (PCREG_E_HIP with a message if librccl.so.1 is missing). */
+typedef struct pcreg_comm_id { char bytes[128]; } pcreg_comm_id;      /* an ncclUniqueId */
+int pcreg_comm_get_unique_id(pcreg_comm_id* id);
+int pcreg_comm_init(int rank, int world, const pcreg_comm_id* id);
+int pcreg_comm_rank(int* rank, int* world);
+int pcreg_comm_destroy(void);
+
+/* pcreg_match_points_f32 with the MODEL rows split over the ranks: this rank passes rows
+ * [m_lo, m_lo + M_local) of the M_total-row model and the whole (replicated) surface.  One all_gather of the
+ * per-rank top-2 lists + merge, filters on every rank, Unique by the owner of the model row, one integer
+ * all_reduce of the candidate table.  pairs: 1-based [surface row, GLOBAL model row], capacity Q. */
+int pcreg_match_points_sharded_f32(const float* q, int Q, int ldq, const float* m_local, int M_local, int ldm,
+                                   int m_lo, int M_total, float thr_abs, float max_ratio, int unique,
+                                   uint32_t* pairs, int* P);
+
+/* pcreg_ransac (built-in sampler, minPtNum 3) with the hypotheses of ONE registration split over the ranks:
+ * every rank passes the same pts1 / pts2, scores iterNum / world hypotheses, one all_gather of the 112-byte
+ * partial results agrees the first-maximum winner (ransac.m:70-72 on the GLOBAL hypothesis index). */
+int pcreg_ransac_sharded(const double* pts1, const double* pts2, int n, int ld, const pcreg_ransac_opts* opts,
+                         double T[16], int32_t* inlier_idx, int* n_inliers, int* num_success, int* max_inliers,
+                         int* failed);
 
 /* ---- on-disk formats of the drivers (host code, no device needed) --------------------------
  * .pcd clouds (pcread / pcwrite, completeExperimentFast.m:12-13,30,403): ascii, binary and

@@ -377,6 +377,15 @@ int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const i
     return PCREG_OK;
 }
 
+int pcreg_dev_align_points_knn_batched(const double* pts, int total, int ld, const int32_t* offsets, int B, int max_n,
+                                       int C1, int C2, double* aligned, double* coeff, double* c, int32_t* status,
+                                       void* stream) {
+    PCREG_ARG(pts && offsets && aligned && coeff && c && status && total >= 0 && ld >= total && B >= 0 && max_n >= 0);
+    GUARD();
+    if (B == 0) return PCREG_OK;
+    return launch_align_points_knn(pts, ld, offsets, B, max_n, C1, C2, aligned, ld, coeff, c, status, (hipStream_t)stream);
+}
+
 int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2, double* aligned, double coeff[9],
                            double c[3]) {
     PCREG_ARG(pts && aligned && coeff && c && n >= 2 && ld >= n);

@@ -56,3 +56,18 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.replace("the oracle", "").replace("oracle's", "").replace("oracle C", "").replace("oracle standing", "").replace("(oracle", "") or f.endswith((".hip", ".hpp")), f
                 assert "import oracle" not in txt and "from oracle" not in txt and "pcreg_oracle" not in txt, f
+
+
+def test_comm_entry_points_fail_cleanly_without_a_device():
+    """The multi-GPU entry points exist on every box; without a GPU pcreg_comm_init reports NODEVICE and the
+    sharded calls refuse to run without a communicator (no crash, no hang)."""
+    import torch
+    from pcreg_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    L = _lib.lib()
+    buf = (C.c_char * 128)()
+    assert L.pcreg_comm_init(0, 1, C.byref(buf)) == _lib.PCREG_E_NODEVICE
+    r, w = C.c_int(), C.c_int()
+    assert L.pcreg_comm_rank(C.byref(r), C.byref(w)) == _lib.PCREG_E_ARG
+    assert L.pcreg_comm_destroy() == 0

@@ -1,0 +1,123 @@
+"""BASELINE.json's configs at their REAL sizes on the GPU, with oracle spot checks (the pattern of
+test_search_at_full_size_spot_check: the oracle cannot redo 10^10 pairs, but every query / keypoint / crop is
+independent, so a random sample checked exhaustively on the host cores pins the whole run).
+
+  cfg 2  getMatches, D = 981 (980 counts + the UNNORMALIZE column), 50 k x 200 k, SAD, Unique
+  cfg 4  getSpacialHistogramDescriptors, 1 M keypoints on a 1 M-point cloud
+  cfg 5  64 crops x 50 k surface points vs one 1 M-point model, match + RANSAC per crop
+(cfg 3's 2 M-point model on one GPU is test_gpu_pipeline.py::test_search_at_full_size_spot_check; its 8-GPU form
+needs eight GPUs and is bench.py --gpus 8.)"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CORES = min(len(os.sched_getaffinity(0)), 16)
+
+
+def test_cfg2_get_matches_50k_x_200k_d981(oracle_c, oracle_py):
+    import pcreg_amd as pc
+    Q, M, D = 50_000, 200_000, 980
+    rng = np.random.default_rng(0)
+    dM = rng.poisson(3.0, (M, D)).astype(np.float64)
+    dS = rng.poisson(3.0, (Q, D)).astype(np.float64)
+    k = Q // 2                                                   # half of the surface rows are noisy copies of model rows
+    src = rng.choice(M, k, replace=False)
+    dS[:k] = dM[src] + rng.poisson(0.2, (k, D))
+    par = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate",
+               MatchThreshold=10, MaxRatio=0.99, Metric="SAD", Unique=True, VERBOSE=0)
+    pairs = pc.getMatches(dS, dM, par)                           # P x 2 uint32, 1-based, ascending in column 1
+    assert pairs.dtype == np.uint32 and pairs.shape[1] == 2 and len(pairs) > k // 2
+    assert np.all(np.diff(pairs[:, 0].astype(np.int64)) > 0)
+    assert len(np.unique(pairs[:, 1])) == len(pairs)             # Unique: a model row is matched at most once
+    # ---- oracle, 200 random surface rows against ALL model rows ----------------------------------------------
+    pS, pM = oracle_py.preprocess_descriptors(dS, dM, par)       # getMatches.m:22-37 on the full arrays (the constant is global)
+    del dS, dM
+    nS, nM = oracle_py._normalize_rows(pS), oracle_py._normalize_rows(pM)
+    del pS, pM
+    sel = np.sort(rng.choice(Q, 200, replace=False))
+    par_nu = dict(Metric="SAD", MatchThreshold=10, MaxRatio=0.99, Unique=False, Prenormalized=True)
+    cand, _ = oracle_c.matchFeatures(nS[sel], nM, par_nu, nthreads=CORES)          # forward matches of the sample
+    cand_of = {int(sel[i - 1]): int(j) - 1 for i, j in cand}
+    got_of = {int(i) - 1: int(j) - 1 for i, j in pairs if (int(i) - 1) in set(sel.tolist())}
+    n_unique_drop = 0
+    for i in sel.tolist():
+        if i in got_of:
+            assert cand_of.get(i) == got_of[i], f"surface row {i}: GPU matched {got_of[i]}, oracle forward match {cand_of.get(i)}"
+        if i in cand_of:                                          # the Unique rule for this candidate, over ALL 50 k queries
+            col = np.abs(nS - nM[cand_of[i]]).sum(axis=1)
+            best = int(np.argmin(col))
+            if best == i:
+                assert i in got_of, f"surface row {i} is the best query of model row {cand_of[i]} but the GPU dropped the pair"
+            else:
+                assert i not in got_of, f"surface row {i} is not the best query of model row {cand_of[i]} (row {best} is)"
+                n_unique_drop += 1
+        else:
+            assert i not in got_of
+    assert len(cand_of) >= 80                                     # the sample really exercises matches (half the rows are copies)
+
+
+def test_cfg4_descriptors_1m_keypoints(oracle_c):
+    from bench import _ridge_cloud
+    from pcreg_amd.device import DescriptorPipeline
+    P = S = 1_000_000
+    pts, kp = _ridge_cloud(P, S)
+    opt = dict(min_pts=500, max_pts=6000, R=3.5, thVar=[3, 1.5], k=0.85, ALIGN_POINTS=True, VERBOSE=0)
+    dev = torch.device("cuda", 0)
+    dp = DescriptorPipeline(dev)
+    tp = torch.from_numpy(np.ascontiguousarray(pts.T)).to(dev); tk = torch.from_numpy(np.ascontiguousarray(kp.T)).to(dev)
+    feat, desc, V = dp.describe(tp, tk, opt)
+    assert V > 0.9 * S
+    sums = desc[:V].sum(dim=1)
+    assert float(sums.min()) >= opt["min_pts"] and float(sums.max()) <= opt["max_pts"]     # every count row is a whole support
+    assert bool((desc[:V] >= 0).all()) and bool((desc[:V] == desc[:V].round()).all())
+    # ---- oracle on 200 random keypoints (two brute-force scans of the 1 M-point cloud each) -----------------------
+    sel = np.sort(np.random.default_rng(4).choice(S, 200, replace=False))
+    rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(pts, kp[sel], opt, nthreads=CORES)
+    featc = feat[:V].cpu().numpy()
+    # surviving keypoints keep the input order: row v of the GPU output is the v-th survivor; find the sample's rows by
+    # their coordinates (exact copies of the input keypoints)
+    key = {tuple(r): v for v, r in enumerate(map(tuple, featc.tolist()))} if V < S else None
+    rows = []
+    for r in rfeat:
+        v = key[tuple(r.tolist())] if key is not None else None
+        rows.append(v)
+    if key is None:
+        assert len(rfeat) == len(sel)
+        rows = sel.tolist()
+    got = desc[torch.tensor(rows, device=dev)].cpu().numpy()
+    np.testing.assert_array_equal(featc[rows], rfeat)
+    np.testing.assert_array_equal(got, rdesc)                     # all 980 counts of all sampled keypoints
+
+
+def test_cfg5_batch_of_64_crops_vs_1m_model(oracle_c):
+    from bench import BBOX, MATCH_RATIO, MATCH_THR_ABS, RANSAC_COEF, make_crop
+    from pcreg_amd.batch import BatchRegistration
+    from pcreg_amd.device import soa
+    M, Q, n_crops = 1_000_000, 50_000, 64
+    rng = np.random.default_rng(10)
+    model = rng.random((M, 3), dtype=np.float32) * BBOX.astype(np.float32)
+    dev = torch.device("cuda", 0)
+    ms = soa(torch.from_numpy(model).to(dev))
+    crops = [make_crop(model, Q, c) for c in range(n_crops)]
+    qs = [soa(torch.from_numpy(c).to(dev)) for c in crops]
+    br = BatchRegistration(ms, Q, n_streams=2, device=dev)
+    res = br.run(qs, MATCH_THR_ABS, MATCH_RATIO, RANSAC_COEF, seed=7)
+    assert [r["crop"] for r in res] == list(range(n_crops))
+    assert sum(r["failed"] for r in res) == 0
+    assert min(r["n_inliers"] for r in res) > 0.5 * Q and all(r["n_inliers"] == r["maxInliers"] for r in res)
+    for c in (0, 41):                                             # two crops end to end against the oracle
+        ref_pairs = oracle_c.match_points_f32(crops[c], model, MATCH_THR_ABS, MATCH_RATIO, True, nthreads=CORES)
+        assert res[c]["n_pairs"] == len(ref_pairs)
+        rp1 = crops[c][ref_pairs[:, 0] - 1].astype(np.float64); rp2 = model[ref_pairs[:, 1] - 1].astype(np.float64)
+        coef = dict(RANSAC_COEF, iterNum=RANSAC_COEF["iterNum"] if c == 0 else 1500)
+        if c != 0:                                                # a second crop at a shorter hypothesis count (oracle time): rerun it alone
+            r1 = BatchRegistration(ms, Q, n_streams=1, device=dev).run([qs[c]], MATCH_THR_ABS, MATCH_RATIO, coef, seed=7)[0]
+        else:
+            r1 = res[c]
+        ref = oracle_c.ransac(rp1, rp2, coef, seed=7)
+        assert not r1["failed"] and r1["numSuccess"] == ref["numSuccess"] and r1["maxInliers"] == ref["maxInliers"]
+        assert r1["n_inliers"] == len(ref["inlierIdx"])
+        assert np.linalg.norm(r1["T"] - ref["T"]) < 1e-5

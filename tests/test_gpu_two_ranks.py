@@ -25,7 +25,7 @@ def test_one_rank_rccl_rehearsal_of_every_collective():
     both all_gathers, the MAX / SUM all_reduces of the matcher and the three of the hypothesis-split RANSAC.
     The registration it finds must be the one the plain single-GPU step finds."""
     import json
-    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--model-points", "200000", "--surface-points", "20000"]
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--model-points", "200000", "--surface-points", "20000"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCREG_FORCE_COLLECTIVES="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py")] + common,
