@@ -150,6 +150,13 @@ int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const i
                                    int B, int C1, int C2, double* aligned, double* coeff,
                                    double* c, int32_t* status);
 
+/* The same for `single` clouds (pcread gives single: upsampleMesh.m:21, GetPointcloudFromModel.m:269;
+ * completeExperimentFast.m:291,309 feeds them on): inputs are widened to double exactly, the double kernels run,
+ * outputs come back as float -- the class MATLAB would return.  MATLAB's own single arithmetic may decide a
+ * borderline K-th-nearest / sign vote differently: documented in INTEGRATION.md, not reproduced. */
+int pcreg_align_points_knn_f32(const float* pts, int n, int ld, int C1, int C2,
+                               float* aligned, float coeff[9], float c[3]);
+
 /* `options` of getSpacialHistogramDescriptors.m:18-27 (completeExperimentFast.m:299-304). */
 typedef struct pcreg_desc_opts {
     int32_t min_pts;       /* options.min_pts                                            */
@@ -170,6 +177,12 @@ typedef struct pcreg_desc_opts {
  * The O(S*P) brute-force radius search of the reference is replaced by a uniform grid. */
 int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
                                         const pcreg_desc_opts* options, double* feat, double* desc, int* V);
+
+/* `single` cloud and keypoints (completeExperimentFast.m:309): widened exactly, double kernels, feat / desc
+ * returned as float (keypoint coordinates and integer counts: both exact).  Support membership `dists < R`
+ * and the bin edges are evaluated in double where MATLAB would use single. */
+int pcreg_spatial_histogram_descriptors_f32(const float* pts, int P, int ld, const float* sample_pts, int S, int lds,
+                                            const pcreg_desc_opts* options, float* feat, float* desc, int* V);
 
 /* ---- device tier ------------------------------------------------------------------
  * All pointers are device memory on the current device; `stream` is a hipStream_t.

@@ -111,10 +111,14 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nrhs != 4) usage = "AlignPoints_KNN: pts, C1, C2";
         else {
             int n = (int)mxGetM(prhs[1]);
-            plhs[0] = mxCreateDoubleMatrix(n, 3, mxREAL);
-            mxArray* co = mxCreateDoubleMatrix(3, 3, mxREAL); mxArray* c = mxCreateDoubleMatrix(1, 3, mxREAL);
-            rc = pcreg_align_points_knn(mxGetPr(prhs[1]), n, n, (int)mxGetScalar(prhs[2]), (int)mxGetScalar(prhs[3]),
-                                        mxGetPr(plhs[0]), mxGetPr(co), mxGetPr(c));
+            const bool sgl = mxIsSingle(prhs[1]);                // single in -> single out, like MATLAB's own function
+            const mxClassID cls = sgl ? mxSINGLE_CLASS : mxDOUBLE_CLASS;
+            plhs[0] = mxCreateNumericMatrix(n, 3, cls, mxREAL);
+            mxArray* co = mxCreateNumericMatrix(3, 3, cls, mxREAL); mxArray* c = mxCreateNumericMatrix(1, 3, cls, mxREAL);
+            if (sgl) rc = pcreg_align_points_knn_f32((const float*)mxGetData(prhs[1]), n, n, (int)mxGetScalar(prhs[2]), (int)mxGetScalar(prhs[3]),
+                                                     (float*)mxGetData(plhs[0]), (float*)mxGetData(co), (float*)mxGetData(c));
+            else rc = pcreg_align_points_knn(mxGetPr(prhs[1]), n, n, (int)mxGetScalar(prhs[2]), (int)mxGetScalar(prhs[3]),
+                                             mxGetPr(plhs[0]), mxGetPr(co), mxGetPr(c));
             if (nlhs > 1) plhs[1] = co; else mxDestroyArray(co);
             if (nlhs > 2) plhs[2] = c; else mxDestroyArray(c);
         }
@@ -131,16 +135,25 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             const mxArray* kk = mxGetField(p, 0, "k");
             o.k = (!kk || mxIsChar(kk)) ? 1.0 : mxGetScalar(kk);           // 'all' -> 1
             int P = (int)mxGetM(prhs[1]), S = (int)mxGetM(prhs[2]);
-            mxArray* f = mxCreateDoubleMatrix(3, S > 0 ? S : 1, mxREAL);     // row-major V x 3 == 3 x V column-major
-            mxArray* d = mxCreateDoubleMatrix(PCREG_DESC_LEN, S > 0 ? S : 1, mxREAL);
+            const bool sgl = mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]);     // the wrapper casts a mixed pair to double
+            const mxClassID cls = sgl ? mxSINGLE_CLASS : mxDOUBLE_CLASS;
+            mxArray* f = mxCreateNumericMatrix(3, S > 0 ? S : 1, cls, mxREAL);     // row-major V x 3 == 3 x V column-major
+            mxArray* d = mxCreateNumericMatrix(PCREG_DESC_LEN, S > 0 ? S : 1, cls, mxREAL);
             int V = 0;
-            rc = pcreg_spatial_histogram_descriptors(mxGetPr(prhs[1]), P, P, mxGetPr(prhs[2]), S, S, &o, mxGetPr(f), mxGetPr(d), &V);
+            if (sgl) rc = pcreg_spatial_histogram_descriptors_f32((const float*)mxGetData(prhs[1]), P, P, (const float*)mxGetData(prhs[2]), S, S, &o,
+                                                                  (float*)mxGetData(f), (float*)mxGetData(d), &V);
+            else rc = pcreg_spatial_histogram_descriptors(mxGetPr(prhs[1]), P, P, mxGetPr(prhs[2]), S, S, &o, mxGetPr(f), mxGetPr(d), &V);
             if (rc == PCREG_OK) {      // transpose into MATLAB's V x 3 / V x 980
-                plhs[0] = mxCreateDoubleMatrix(V, 3, mxREAL);
-                for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) mxGetPr(plhs[0])[v + (size_t)c * V] = mxGetPr(f)[c + 3 * (size_t)v];
-                if (nlhs > 1) {
-                    plhs[1] = mxCreateDoubleMatrix(V, PCREG_DESC_LEN, mxREAL);
-                    for (int v = 0; v < V; ++v) for (int c = 0; c < PCREG_DESC_LEN; ++c) mxGetPr(plhs[1])[v + (size_t)c * V] = mxGetPr(d)[c + PCREG_DESC_LEN * (size_t)v];
+                plhs[0] = mxCreateNumericMatrix(V, 3, cls, mxREAL);
+                if (nlhs > 1) plhs[1] = mxCreateNumericMatrix(V, PCREG_DESC_LEN, cls, mxREAL);
+                if (sgl) {
+                    const float* fs = (const float*)mxGetData(f); const float* ds = (const float*)mxGetData(d);
+                    float* fo = (float*)mxGetData(plhs[0]);
+                    for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) fo[v + (size_t)c * V] = fs[c + 3 * (size_t)v];
+                    if (nlhs > 1) { float* dd = (float*)mxGetData(plhs[1]); for (int v = 0; v < V; ++v) for (int c = 0; c < PCREG_DESC_LEN; ++c) dd[v + (size_t)c * V] = ds[c + PCREG_DESC_LEN * (size_t)v]; }
+                } else {
+                    for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) mxGetPr(plhs[0])[v + (size_t)c * V] = mxGetPr(f)[c + 3 * (size_t)v];
+                    if (nlhs > 1) for (int v = 0; v < V; ++v) for (int c = 0; c < PCREG_DESC_LEN; ++c) mxGetPr(plhs[1])[v + (size_t)c * V] = mxGetPr(d)[c + PCREG_DESC_LEN * (size_t)v];
                 }
             }
             mxDestroyArray(f); mxDestroyArray(d);

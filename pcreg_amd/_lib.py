@@ -53,7 +53,8 @@ SYMBOLS = [
     "pcreg_last_error", "pcreg_version", "pcreg_device_count", "pcreg_set_device", "pcreg_device_name",
     "pcreg_estimate_transform", "pcreg_calc_dists", "pcreg_ransac", "pcreg_ransac_batched",
     "pcreg_knn2_points_f32", "pcreg_match_points_f32", "pcreg_match_features", "pcreg_get_matches",
-    "pcreg_align_points_knn", "pcreg_align_points_knn_batched", "pcreg_spatial_histogram_descriptors",
+    "pcreg_align_points_knn", "pcreg_align_points_knn_f32", "pcreg_align_points_knn_batched", "pcreg_spatial_histogram_descriptors",
+    "pcreg_spatial_histogram_descriptors_f32",
     "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32", "pcreg_dev_merge_top2_strided_f32", "pcreg_dev_cand_table_f32",
     "pcreg_dev_filter_top2_f32", "pcreg_dev_unique_points_f32_workspace", "pcreg_dev_unique_points_f32",
     "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",

@@ -338,6 +338,13 @@ def AlignPoints_KNN(pts, *varargin):
     """[pts_aligned, coeff_unambig, c] = AlignPoints_KNN(pts[, C1, C2])  (AlignPoints_KNN.m:1-60).
     Like the reference, C1/C2 are honoured only when BOTH are given (:8-14)."""
     C1, C2 = (bool(varargin[0]), bool(varargin[1])) if len(varargin) == 2 else (False, False)
+    if getattr(pts, "dtype", None) == np.float32:          # class-preserving, like MATLAB: single in -> single out
+        p = _fcol(np.asarray(pts).reshape(-1, 3), np.float32)
+        n = p.shape[0]
+        aligned = np.zeros((n, 3), dtype=np.float32, order="F"); coeff = np.zeros(9, np.float32); c = np.zeros(3, np.float32)
+        check(lib().pcreg_align_points_knn_f32(_ptr(p, C.c_float), C.c_int(n), C.c_int(n), C.c_int(int(C1)), C.c_int(int(C2)),
+                                               _ptr(aligned, C.c_float), _ptr(coeff, C.c_float), _ptr(c, C.c_float)))
+        return np.ascontiguousarray(aligned), coeff.reshape(3, 3, order="F").copy(), c.reshape(1, 3)
     p = _pts3(pts, "pts")
     n = p.shape[0]
     aligned = np.zeros((n, 3), order="F")
@@ -384,6 +391,18 @@ def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
             raise KeyError(f"options.{k} is required (getSpacialHistogramDescriptors.m:18-23)")
     import time
     t0 = time.time()
+    if getattr(pts, "dtype", None) == np.float32 and getattr(sample_pts, "dtype", None) == np.float32:
+        # `single` clouds (pcread; completeExperimentFast.m:309): single feat / desc back, arithmetic in double
+        p = _fcol(np.asarray(pts).reshape(-1, 3), np.float32); s = _fcol(np.asarray(sample_pts).reshape(-1, 3), np.float32)
+        P, S = p.shape[0], s.shape[0]
+        o = _desc_opts(options)
+        feat = np.zeros((max(S, 1), 3), np.float32); desc = np.zeros((max(S, 1), 980), np.float32)
+        V = C.c_int(0)
+        check(lib().pcreg_spatial_histogram_descriptors_f32(_ptr(p, C.c_float), C.c_int(P), C.c_int(P), _ptr(s, C.c_float), C.c_int(S),
+                                                            C.c_int(S), C.byref(o), _ptr(feat, C.c_float), _ptr(desc, C.c_float), C.byref(V)))
+        if options.get("VERBOSE", 1):
+            print("Calculated descriptors in %0.1f seconds..." % (time.time() - t0))
+        return feat[:V.value].copy(), desc[:V.value].copy()
     p, s = _pts3(pts, "pts"), _pts3(sample_pts, "sample_pts")
     P, S = p.shape[0], s.shape[0]
     o = _desc_opts(options)

@@ -434,6 +434,37 @@ int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const 
 }
 
 // ------------------------------------------------------------------ device tier
+// ---- `single` inputs (clouds read by pcread are single: upsampleMesh.m:21, GetPointcloudFromModel.m:269) ----------------
+// The float -> double widening is exact; the arithmetic is the double kernels'; outputs are rounded once to float
+// (counts are integers: exact).  MATLAB itself would evaluate the support test, the LRF and the binning in single
+// arithmetic for single inputs: points within rounding of a sphere / bin boundary may land on the other side
+// ("Differences a user can observe").  Class-preserving drop-in, not bit parity with single MATLAB.
+int pcreg_align_points_knn_f32(const float* pts, int n, int ld, int C1, int C2, float* aligned, float coeff[9], float c[3]) {
+    PCREG_ARG(pts && aligned && coeff && c && n >= 2 && ld >= n);
+    std::vector<double> in((size_t)n * 3), out((size_t)n * 3);
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < n; ++i) in[(size_t)k * n + i] = (double)pts[(size_t)k * ld + i];
+    double co[9], cc[3];
+    TRY(pcreg_align_points_knn(in.data(), n, n, C1, C2, out.data(), co, cc));
+    for (size_t i = 0; i < (size_t)n * 3; ++i) aligned[i] = (float)out[i];
+    for (int i = 0; i < 9; ++i) coeff[i] = (float)co[i];
+    for (int i = 0; i < 3; ++i) c[i] = (float)cc[i];
+    return PCREG_OK;
+}
+
+int pcreg_spatial_histogram_descriptors_f32(const float* pts, int P, int ld, const float* sample_pts, int S, int lds,
+                                            const pcreg_desc_opts* options, float* feat, float* desc, int* V) {
+    PCREG_ARG(pts && sample_pts && options && feat && desc && V && P >= 0 && S >= 0 && ld >= P && lds >= S);
+    std::vector<double> p((size_t)P * 3), k((size_t)S * 3), f((size_t)(S > 0 ? S : 1) * 3), d((size_t)(S > 0 ? S : 1) * PCREG_DESC_LEN);
+    for (int c = 0; c < 3; ++c) {
+        for (int i = 0; i < P; ++i) p[(size_t)c * P + i] = (double)pts[(size_t)c * ld + i];
+        for (int i = 0; i < S; ++i) k[(size_t)c * S + i] = (double)sample_pts[(size_t)c * lds + i];
+    }
+    TRY(pcreg_spatial_histogram_descriptors(p.data(), P, P, k.data(), S, S, options, f.data(), d.data(), V));
+    for (size_t i = 0; i < (size_t)*V * 3; ++i) feat[i] = (float)f[i];                 // exact: they are the input keypoints
+    for (size_t i = 0; i < (size_t)*V * PCREG_DESC_LEN; ++i) desc[i] = (float)d[i];     // exact: integer counts <= max_pts
+    return PCREG_OK;
+}
+
 size_t pcreg_dev_knn2_points_f32_workspace(int Q, int M) { return knn2_points_workspace_bytes(Q, M); }
 
 int pcreg_dev_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,

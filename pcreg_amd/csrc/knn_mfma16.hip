@@ -38,8 +38,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kT16 = 512;                     // model points per tile: [2 k-halves][512 points][8 f16] = 16 KiB
 constexpr int kRefresh = 16;                  // tiles between two looks at the shared threshold words
 
+// The error-free split needs ONE f16 rounding of ONE fp32 value: the stored high part and the high part the
+// residual is taken against must be the same number.  hipcc folds `(_Float16)fma(a, b, c)` into v_fma_mixlo_f16 (the
+// product-sum rounded ONCE, straight to f16) where the value feeds a conversion, while a second use of the same
+// expression goes through the fp32 result (rounded twice): at an f16 rounding midpoint the two differ by one f16 ulp
+// -- |m~|^2 = 216.9375 came out 0.125 too small, the point dropped out of its group's minimum, and 6 of 50 000
+// queries of cfg 5's crop 0 got a wrong 2nd neighbour WITH a passing certificate (round 1 had the same bug; the
+// full-size test tests/test_gpu_fullsize.py found it).  The empty asm makes the value opaque: no fold, one rounding.
+__device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
-    h = (_Float16)x; l = (_Float16)(x - (float)h);
+    x = opaque_f32(x);
+    h = (_Float16)x; l = (_Float16)opaque_f32(x - (float)h);
 }
 
 // model -> tiles of f16 operands; R_m^2 (unscaled) by atomicMax on the float bits
@@ -56,11 +65,11 @@ __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __r
             float x = m[i] - cx, y = m[i + (size_t)ldm] - cy, z = m[i + 2 * (size_t)ldm] - cz;     // the m~ of the fp32 path
             mx = fmaxf(mx, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
             x *= sg; y *= sg; z *= sg;                                                         // exact
-            const float w = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));                 // <= 3 * 64^2
+            const float w = opaque_f32(__builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));    // <= 3 * 64^2; opaque: see split2
             _Float16 xh, xl, yh, yl, zh, zl;
             split2(x, xh, xl); split2(y, yh, yl); split2(z, zh, zl);
-            const _Float16 wh = (_Float16)w; const float w1 = w - (float)wh;
-            const _Float16 wm = (_Float16)w1; const _Float16 wl = (_Float16)(w1 - (float)wm);
+            const _Float16 wh = (_Float16)w; const float w1 = opaque_f32(w - (float)wh);
+            const _Float16 wm = (_Float16)w1; const _Float16 wl = (_Float16)opaque_f32(w1 - (float)wm);
             lo.v = f16x8{xh, xl, xh, xl, yh, yl, yh, yl};
             hi.v = f16x8{zh, zl, zh, zl, wh, wm, wl, (_Float16)0.0f};
         } else {                                   // padding: score +inf, never a candidate

@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-typedef enum { mxDOUBLE_CLASS, mxINT32_CLASS, mxUINT32_CLASS, mxCHAR_CLASS, mxSTRUCT_CLASS } mxClassID;
+typedef enum { mxDOUBLE_CLASS, mxSINGLE_CLASS, mxINT32_CLASS, mxUINT32_CLASS, mxCHAR_CLASS, mxSTRUCT_CLASS } mxClassID;
 typedef enum { mxREAL, mxCOMPLEX } mxComplexity;
 typedef size_t mwSize;
 
@@ -35,7 +35,7 @@ struct MexError {
 
 extern int g_mex_live_arrays;                        /* leak check: arrays created minus destroyed */
 
-inline size_t mx_elem_size(mxClassID c) { return c == mxDOUBLE_CLASS ? 8 : (c == mxINT32_CLASS || c == mxUINT32_CLASS) ? 4 : 1; }
+inline size_t mx_elem_size(mxClassID c) { return c == mxDOUBLE_CLASS ? 8 : (c == mxINT32_CLASS || c == mxUINT32_CLASS || c == mxSINGLE_CLASS) ? 4 : 1; }
 inline mxArray* mxCreateNumericMatrix(size_t m, size_t n, mxClassID c, mxComplexity) {
     mxArray* a = new mxArray; a->cls = c; a->m = m; a->n = n; a->data.assign(m * n * mx_elem_size(c), 0); ++g_mex_live_arrays; return a;
 }
@@ -49,6 +49,7 @@ inline void mxDestroyArray(mxArray* a) { if (a) { --g_mex_live_arrays; delete a;
 inline bool mxIsStruct(const mxArray* a) { return a && a->cls == mxSTRUCT_CLASS; }
 inline bool mxIsChar(const mxArray* a) { return a && a->cls == mxCHAR_CLASS; }
 inline bool mxIsInt32(const mxArray* a) { return a && a->cls == mxINT32_CLASS; }
+inline bool mxIsSingle(const mxArray* a) { return a && a->cls == mxSINGLE_CLASS; }
 inline bool mxIsEmpty(const mxArray* a) { return !a || a->m * a->n == 0; }
 inline size_t mxGetM(const mxArray* a) { return a->m; }
 inline size_t mxGetN(const mxArray* a) { return a->n; }
@@ -61,6 +62,7 @@ inline mxArray* mxGetField(const mxArray* s, size_t, const char* name) {
 inline double mxGetScalar(const mxArray* a) {
     if (!a || a->data.empty()) return 0.0;
     if (a->cls == mxDOUBLE_CLASS) { double v; memcpy(&v, a->data.data(), 8); return v; }
+    if (a->cls == mxSINGLE_CLASS) { float v; memcpy(&v, a->data.data(), 4); return v; }
     if (a->cls == mxINT32_CLASS) { int32_t v; memcpy(&v, a->data.data(), 4); return v; }
     if (a->cls == mxUINT32_CLASS) { uint32_t v; memcpy(&v, a->data.data(), 4); return v; }
     return 0.0;

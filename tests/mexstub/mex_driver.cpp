@@ -105,6 +105,35 @@ int drv_descriptors(const double* pts, int Pn, const double* kp, int S, const do
     return 0;
 }
 
+// `single` inputs: what matlab/AlignPoints_KNN.m and getSpacialHistogramDescriptors.m pass for pcread clouds
+static mxArray* fmat(const float* p, size_t m, size_t n) { mxArray* a = mxCreateNumericMatrix(m, n, mxSINGLE_CLASS, mxREAL); if (m * n > 0) memcpy(mxGetData(a), p, m * n * 4); return a; }
+
+int drv_align_points_knn_f32(const float* pts, int n, float* aligned, float* coeff9, float* c3, char* err, int errlen) {
+    std::vector<mxArray*> rhs{mxCreateString("AlignPoints_KNN"), fmat(pts, n, 3), mxCreateDoubleScalar(0), mxCreateDoubleScalar(0)};
+    mxArray* lhs[3] = {nullptr, nullptr, nullptr};
+    if (call(3, lhs, rhs, err, errlen)) return 1;
+    if (!mxIsSingle(lhs[0]) || !mxIsSingle(lhs[1]) || !mxIsSingle(lhs[2])) { snprintf(err, errlen, "outputs are not single"); return 1; }
+    memcpy(aligned, mxGetData(lhs[0]), (size_t)n * 3 * 4); memcpy(coeff9, mxGetData(lhs[1]), 36); memcpy(c3, mxGetData(lhs[2]), 12);
+    for (mxArray* a : lhs) mxDestroyArray(a);
+    return 0;
+}
+
+int drv_descriptors_f32(const float* pts, int Pn, const float* kp, int S, const double* opts6, float* feat, float* desc, int* V, char* err, int errlen) {
+    mxArray* o = mxCreateStructMatrix(1, 1, 0, nullptr);
+    put(o, "min_pts", opts6[0]); put(o, "max_pts", opts6[1]); put(o, "R", opts6[2]);
+    const double tv[2] = {opts6[3], opts6[4]};
+    mxSetField(o, 0, "thVar", dmat(tv, 1, 2)); put(o, "ALIGN_POINTS", opts6[5]); mxSetField(o, 0, "k", mxCreateString("all")); put(o, "VERBOSE", 0);
+    std::vector<mxArray*> rhs{mxCreateString("getSpacialHistogramDescriptors"), fmat(pts, Pn, 3), fmat(kp, S, 3), o};
+    mxArray* lhs[2] = {nullptr, nullptr};
+    if (call(2, lhs, rhs, err, errlen)) return 1;
+    if (!mxIsSingle(lhs[0]) || !mxIsSingle(lhs[1])) { snprintf(err, errlen, "outputs are not single"); return 1; }
+    *V = (int)mxGetM(lhs[0]);
+    memcpy(feat, mxGetData(lhs[0]), (size_t)*V * 3 * 4);
+    memcpy(desc, mxGetData(lhs[1]), (size_t)*V * mxGetN(lhs[1]) * 4);
+    for (mxArray* a : lhs) mxDestroyArray(a);
+    return 0;
+}
+
 int drv_bad_command(char* err, int errlen) {
     std::vector<mxArray*> rhs{mxCreateString("noSuchCommand")};
     mxArray* lhs[1] = {nullptr};

@@ -121,3 +121,19 @@ def test_cfg5_batch_of_64_crops_vs_1m_model(oracle_c):
         assert not r1["failed"] and r1["numSuccess"] == ref["numSuccess"] and r1["maxInliers"] == ref["maxInliers"]
         assert r1["n_inliers"] == len(ref["inlierIdx"])
         assert np.linalg.norm(r1["T"] - ref["T"]) < 1e-5
+
+
+def test_f16_split_rounding_midpoints_regression(oracle_c):
+    """cfg 5's crop 0 holds six queries whose true 2nd neighbour has |m~|^2 exactly on an f16 rounding midpoint (216.9375,
+    328.375, 171.4375, ...).  Round 1's prep kernel rounded the stored high part and the residual's high part differently
+    there (v_fma_mixlo_f16 fold), the point's score came out one f16 ulp too large, it fell out of the candidates and the
+    certificate still passed.  The whole crop must now equal the exhaustive oracle, indices and distance bits."""
+    import pcreg_amd as pc
+    from bench import BBOX, make_crop
+    M, Q = 1_000_000, 50_000
+    model = np.random.default_rng(10).random((M, 3), dtype=np.float32) * BBOX.astype(np.float32)
+    crop = make_crop(model, Q, 0)
+    gi, gd = pc.knn2_points(crop, model)
+    oi, od = oracle_c.knn2_points_f32(crop, model, nthreads=CORES)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd, od)

@@ -87,6 +87,14 @@ def test_no_register_of_an_lds_load_is_touched_before_its_wait(knn_asm):
     assert checked >= 4
 
 
+def test_no_mixed_precision_fma_in_the_f16_split(knn_asm):
+    """v_fma_mixlo_f16 = `(_Float16)fma(a, b, c)` rounded once; next to a second use of the fp32 value (rounded twice)
+    it breaks the error-free split at f16 rounding midpoints (knn_mfma16.hip, split2): 6 wrong second neighbours in
+    50 000 queries with a passing certificate.  The sources make the values opaque; the ISA must show no such fold."""
+    for name, ins in knn_asm.items():
+        assert not any(s.startswith("v_fma_mix") for s in ins), f"{name} holds a mixed-precision FMA"
+
+
 def _hot_body(ins):
     """The default kernel's hot body: from the header of the loop that holds the steady-state MFMAs to the first
     conditional scalar branch after it (the `any hit?` test)."""

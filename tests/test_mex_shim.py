@@ -124,3 +124,23 @@ def test_shim_round_trips_equal_the_ctypes_path(drv):
     assert np.array_equal(feat.ravel(order="F")[:3 * v].reshape(v, 3, order="F"), rfeat)
     assert np.array_equal(desc.ravel(order="F")[:980 * v].reshape(v, 980, order="F"), rdesc)
     assert drv.drv_live_arrays() == 0
+    # `single` inputs keep their class (pcread clouds: completeExperimentFast.m:309) and equal the widened double run, rounded once
+    Xs = X.astype(np.float32)
+    al32 = np.zeros((500, 3), np.float32, order="F"); co32 = np.zeros(9, np.float32); c32 = np.zeros(3, np.float32)
+    assert drv.drv_align_points_knn_f32(_p(np.asfortranarray(Xs), C.c_float), 500, _p(al32, C.c_float), _p(co32, C.c_float), _p(c32, C.c_float), e, 1024) == 0, e.value
+    wal, wco, wc = pc.AlignPoints_KNN(Xs.astype(np.float64))
+    assert np.array_equal(al32, wal.astype(np.float32)) and np.array_equal(co32.reshape(3, 3, order="F"), wco.astype(np.float32))
+    pal, pco, pcc = pc.AlignPoints_KNN(Xs)                                      # the Python mirror dispatches on the class too
+    assert pal.dtype == np.float32 and np.array_equal(pal, al32) and np.array_equal(pcc.ravel(), c32)
+    cl32, kp32 = cloud.astype(np.float32), kp.astype(np.float32)
+    f32 = np.zeros((12, 3), np.float32, order="F"); d32 = np.zeros((12, 980), np.float32, order="F")
+    assert drv.drv_descriptors_f32(_p(np.asfortranarray(cl32), C.c_float), 6000, _p(np.asfortranarray(kp32), C.c_float), 12, _p(o6), _p(f32, C.c_float),
+                                   _p(d32, C.c_float), C.byref(V), e, 1024) == 0, e.value
+    wf, wd = pc.getSpacialHistogramDescriptors(cl32.astype(np.float64), kp32.astype(np.float64), opts)
+    v = V.value
+    assert v == len(wf) and v > 0
+    assert np.array_equal(f32.ravel(order="F")[:3 * v].reshape(v, 3, order="F"), wf.astype(np.float32))
+    assert np.array_equal(d32.ravel(order="F")[:980 * v].reshape(v, 980, order="F"), wd.astype(np.float32))
+    pf, pd = pc.getSpacialHistogramDescriptors(cl32, kp32, opts)
+    assert pf.dtype == np.float32 and pd.dtype == np.float32 and np.array_equal(pd, wd.astype(np.float32))
+    assert drv.drv_live_arrays() == 0
