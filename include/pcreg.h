@@ -331,6 +331,28 @@ int pcreg_dev_sphere_select(const double* feat, int V, const double centre[3], d
 int pcreg_dev_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap,
                               double* dst, void* stream);
 
+/* The batched sphere sweep (completeExperimentFast.m:166-224 for ALL spheres in one enqueue chain, no host round trip
+ * between the per-sphere getMatches calls and the per-trial ransac calls -- the reference runs both under parfor).
+ * pcreg_dev_sweep_plan:   trial = find(num_putative > putative_thresh) (:175) in sphere order -> trial_idx [S] (-1 past
+ *                         n_trials), offsets [S+1] of each trial's pairs in the packed arrays, *n_trials.
+ * pcreg_dev_sweep_gather: pts1 = featSurface(matches(:,1),:), pts2 = featuresM(matches(:,2),:) (:205-206) for every trial,
+ *                         packed at offsets[t] (n x 3 column-major, leading dimension ld).  pairs_all [S][VS][2] are the
+ *                         1-based pairs of pcreg_dev_get_matches per sphere, featCur_all the spheres' gathered keypoints
+ *                         ([rows][3]) back to back, sphere i starting at row row_off[i].
+ * pcreg_dev_ransac_batched: pcreg_ransac_batched on device buffers: registration b owns rows [offsets[b], offsets[b+1])
+ *                         (offsets on the DEVICE: sizes need not be known on the host), built-in sampler seeded seed + b;
+ *                         empty registrations report failed = 1.  out [B], inlier_idx has the rows' layout. */
+int pcreg_dev_sweep_plan(const int32_t* n_pairs, int S, int putative_thresh, int32_t* trial_idx, int32_t* offsets,
+                         int32_t* n_trials, void* stream);
+int pcreg_dev_sweep_gather(const uint32_t* pairs_all, int VS, const int32_t* n_pairs, const int32_t* trial_idx,
+                           const int32_t* offsets, const int32_t* n_trials, int S, const double* featSurface,
+                           const double* featCur_all, const int64_t* row_off, double* pts1, double* pts2, int ld,
+                           void* stream);
+size_t pcreg_dev_ransac_batched_workspace(int n_cap, int iterNum, int B);
+int pcreg_dev_ransac_batched(const double* pts1, const double* pts2, int ld, const int32_t* offsets, int B, int n_cap,
+                             const pcreg_ransac_opts* opts, pcreg_dev_ransac_result* out, int32_t* inlier_idx,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* AlignPoints_KNN.m:17-59 for B supports resident in HBM (the device-tier form of
  * pcreg_align_points_knn_batched; same layouts, every pointer is device memory): support b owns rows
  * [offsets[b], offsets[b+1]) of pts / aligned (n x 3 column-major, ld >= total); max_n = the largest support;

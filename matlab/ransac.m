@@ -14,13 +14,21 @@ function [T, varargout] = ransac(pts1, pts2, ransacCoef, funcFindTransf, funcDis
     ptNum = size(pts1, 1);
     if onGpu
         iterNum = ransacCoef.iterNum; minPtNum = ransacCoef.minPtNum;
-        sampleIdx = zeros(minPtNum, iterNum, 'int32');          % one COLUMN per hypothesis
-        for p = 1:iterNum
-            r = randperm(ptNum);                                 % same stream consumption as ransac.m:42
-            sampleIdx(:, p) = r(1:minPtNum);
+        if isfield(ransacCoef, 'SAMPLER') && strcmp(ransacCoef.SAMPLER, 'device')
+            % the fast path: the library's counter-based sampler (reproducible by ransacCoef.seed, NOT MATLAB's stream).
+            % Drawing iterNum permutations of ptNum below costs seconds at n = 32 k, iterNum = 1e4; the kernel takes 0.7 ms.
+            sampleIdx = [];
+            if isfield(ransacCoef, 'seed'), seed = ransacCoef.seed; else, seed = 0; end
+        else
+            sampleIdx = zeros(minPtNum, iterNum, 'int32');      % one COLUMN per hypothesis
+            for p = 1:iterNum
+                r = randperm(ptNum);                             % same stream consumption as ransac.m:42
+                sampleIdx(:, p) = r(1:minPtNum);
+            end
+            seed = 0;
         end
         [T, inlierIdx, numSuccess, maxInliers, failed] = pcreg_mex('ransac', double(pts1), double(pts2), ...
-                                                                   ransacCoef, sampleIdx, 0);
+                                                                   ransacCoef, sampleIdx, seed);
         if failed
             if VERBOSE, fprintf('RANSAC could not find an appropriate transformation\n'); end
         elseif VERBOSE

@@ -7,6 +7,9 @@
 //   'getMatches', descSurface, descModel, par            -> matches (P x 2 uint32)
 //   'AlignPoints_KNN', pts, C1, C2                       -> pts_aligned, coeff_unambig, c
 //   'getSpacialHistogramDescriptors', pts, sample_pts, options -> feat (V x 3), desc (V x 980)
+//   'setDevice', ordinal | 'commId' -> id | 'commInit', rank, world, id | 'commDestroy'     (one worker per GPU)
+//   'matchPointsSharded', surface, modelRows, m_lo, M_total, thrAbs, maxRatio, unique     -> pairs (P x 2 uint32, global model rows)
+//   'ransacSharded', pts1, pts2, coef, seed                -> T, inlierIdx, numSuccess, maxInliers, failed
 // The shim only unpacks mxArrays: MATLAB's column-major doubles go straight through
 // (ld = number of rows).  It never throws with C++ objects alive:
 // errors are collected as codes and raised by one mexErrMsgIdAndTxt at the very end.
@@ -157,6 +160,63 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                 }
             }
             mxDestroyArray(f); mxDestroyArray(d);
+        }
+    } else if (!strcmp(cmd, "setDevice")) {                   // one GPU per parfor / spmd worker: pcreg_mex('setDevice', labindex - 1)
+        if (nrhs != 2) usage = "setDevice: ordinal";
+        else rc = pcreg_set_device((int)mxGetScalar(prhs[1]));
+    } else if (!strcmp(cmd, "commId")) {                      // id = pcreg_mex('commId') on worker 1; labBroadcast it
+        if (nrhs != 1) usage = "commId: no arguments";
+        else {
+            pcreg_comm_id id;
+            rc = pcreg_comm_get_unique_id(&id);
+            if (rc == PCREG_OK) { plhs[0] = mxCreateNumericMatrix(1, sizeof id, mxUINT8_CLASS, mxREAL); memcpy(mxGetData(plhs[0]), &id, sizeof id); }
+        }
+    } else if (!strcmp(cmd, "commInit")) {                    // pcreg_mex('commInit', rank, world, id)
+        if (nrhs != 4 || mxGetM(prhs[3]) * mxGetN(prhs[3]) != sizeof(pcreg_comm_id) || !mxIsUint8(prhs[3])) usage = "commInit: rank, world, id (1 x 128 uint8)";
+        else { pcreg_comm_id id; memcpy(&id, mxGetData(prhs[3]), sizeof id); rc = pcreg_comm_init((int)mxGetScalar(prhs[1]), (int)mxGetScalar(prhs[2]), &id); }
+    } else if (!strcmp(cmd, "commDestroy")) {
+        rc = pcreg_comm_destroy();
+    } else if (!strcmp(cmd, "matchPointsSharded")) {          // pairs = pcreg_mex('matchPointsSharded', surface, modelRows, m_lo, M_total, thrAbs, maxRatio, unique)
+        if (nrhs != 8 || !mxIsSingle(prhs[1]) || !mxIsSingle(prhs[2])) usage = "matchPointsSharded: surface (single Q x 3), model rows (single M_local x 3), m_lo, M_total, thrAbs, maxRatio, unique";
+        else {
+            int Q = (int)mxGetM(prhs[1]), Ml = (int)mxGetM(prhs[2]);
+            mxArray* buf = mxCreateNumericMatrix(2, Q > 0 ? Q : 1, mxUINT32_CLASS, mxREAL);
+            int P = 0;
+            rc = pcreg_match_points_sharded_f32((const float*)mxGetData(prhs[1]), Q, Q, (const float*)mxGetData(prhs[2]), Ml, Ml > 0 ? Ml : 1,
+                                                (int)mxGetScalar(prhs[3]), (int)mxGetScalar(prhs[4]), (float)mxGetScalar(prhs[5]), (float)mxGetScalar(prhs[6]),
+                                                (int)mxGetScalar(prhs[7]), (uint32_t*)mxGetData(buf), &P);
+            if (rc == PCREG_OK) {
+                plhs[0] = mxCreateNumericMatrix(P, 2, mxUINT32_CLASS, mxREAL);
+                const uint32_t* src = (const uint32_t*)mxGetData(buf); uint32_t* dst = (uint32_t*)mxGetData(plhs[0]);
+                for (int k = 0; k < P; ++k) { dst[k] = src[2 * k]; dst[k + P] = src[2 * k + 1]; }
+            }
+            mxDestroyArray(buf);
+        }
+    } else if (!strcmp(cmd, "ransacSharded")) {               // [T, inlierIdx, numSuccess, maxInliers, failed] = pcreg_mex('ransacSharded', pts1, pts2, coef, seed)
+        if (nrhs != 5) usage = "ransacSharded: pts1, pts2, coef, seed";
+        else {
+            const mxArray* c = prhs[3];
+            pcreg_ransac_opts o;
+            o.minPtNum = (int)field(c, "minPtNum", 3); o.iterNum = (int)field(c, "iterNum", 1000);
+            o.thDist = field(c, "thDist", 0.5); o.thInlrRatio = field(c, "thInlrRatio", 0.1);
+            o.REFINE = (int)field(c, "REFINE", 1); o.VERBOSE = 0; o.seed = (uint64_t)mxGetScalar(prhs[4]);
+            int n = (int)mxGetM(prhs[1]);
+            mxArray* inl = mxCreateNumericMatrix(n > 0 ? n : 1, 1, mxINT32_CLASS, mxREAL);
+            double T[16]; int ni = 0, ns = 0, mi = 0, fl = 1;
+            rc = pcreg_ransac_sharded(mxGetPr(prhs[1]), mxGetPr(prhs[2]), n, n, &o, T, (int32_t*)mxGetData(inl), &ni, &ns, &mi, &fl);
+            if (rc == PCREG_OK) {
+                plhs[0] = fl ? mxCreateDoubleMatrix(0, 0, mxREAL) : mxCreateDoubleMatrix(4, 4, mxREAL);
+                if (!fl) memcpy(mxGetPr(plhs[0]), T, sizeof T);
+                if (nlhs > 1) {
+                    plhs[1] = mxCreateDoubleMatrix(fl ? 0 : ni, fl ? 0 : 1, mxREAL);
+                    const int32_t* src = (const int32_t*)mxGetData(inl);
+                    for (int k = 0; k < (fl ? 0 : ni); ++k) mxGetPr(plhs[1])[k] = (double)src[k];
+                }
+                if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(ns);
+                if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(mi);
+                if (nlhs > 4) plhs[4] = mxCreateDoubleScalar(fl);
+            }
+            mxDestroyArray(inl);
         }
     } else {
         usage = "unknown command";

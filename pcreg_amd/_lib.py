@@ -63,7 +63,8 @@ SYMBOLS = [
     "pcreg_dev_spatial_histogram_descriptors_workspace", "pcreg_dev_spatial_histogram_descriptors",
     "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
     "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select",
-    "pcreg_dev_gather_rows_f64", "pcreg_dev_align_points_knn_batched", "pcreg_dev_quick_tf", "pcreg_dev_refine_by_distance",
+    "pcreg_dev_gather_rows_f64", "pcreg_dev_sweep_plan", "pcreg_dev_sweep_gather", "pcreg_dev_ransac_batched_workspace",
+    "pcreg_dev_ransac_batched", "pcreg_dev_align_points_knn_batched", "pcreg_dev_quick_tf", "pcreg_dev_refine_by_distance",
     "pcreg_comm_get_unique_id", "pcreg_comm_init", "pcreg_comm_rank", "pcreg_comm_destroy",
     "pcreg_match_points_sharded_f32", "pcreg_ransac_sharded",
     "pcreg_pcd_info", "pcreg_pcd_read", "pcreg_pcd_write", "pcreg_mat_read_double",
@@ -92,7 +93,7 @@ def lib() -> C.CDLL:
         L.pcreg_version.restype = C.c_char_p
         for name in ("pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_unique_points_f32_workspace",
                      "pcreg_dev_ransac_workspace", "pcreg_dev_spatial_histogram_descriptors_workspace",
-                     "pcreg_dev_get_matches_workspace", "pcreg_dev_sphere_select_workspace"):
+                     "pcreg_dev_get_matches_workspace", "pcreg_dev_sphere_select_workspace", "pcreg_dev_ransac_batched_workspace"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

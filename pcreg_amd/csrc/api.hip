@@ -651,6 +651,29 @@ int pcreg_dev_gather_rows_f64(const double* src, int D, const int32_t* idx, cons
     GUARD();
     return launch_gather_rows_f64(src, D, idx, n, cap, dst, (hipStream_t)stream);
 }
+int pcreg_dev_sweep_plan(const int32_t* n_pairs, int S, int putative_thresh, int32_t* trial_idx, int32_t* offsets, int32_t* n_trials, void* stream) {
+    PCREG_ARG(n_pairs && trial_idx && offsets && n_trials && S >= 0);
+    GUARD();
+    return launch_sweep_plan(n_pairs, S, putative_thresh, trial_idx, offsets, n_trials, (hipStream_t)stream);
+}
+int pcreg_dev_sweep_gather(const uint32_t* pairs_all, int VS, const int32_t* n_pairs, const int32_t* trial_idx, const int32_t* offsets,
+                           const int32_t* n_trials, int S, const double* featSurface, const double* featCur_all, const int64_t* row_off,
+                           double* pts1, double* pts2, int ld, void* stream) {
+    PCREG_ARG(pairs_all && n_pairs && trial_idx && offsets && n_trials && featSurface && featCur_all && row_off && pts1 && pts2 && S >= 0 && VS >= 0 && ld >= 0);
+    GUARD();
+    return launch_sweep_gather(pairs_all, VS, n_pairs, trial_idx, offsets, n_trials, S, featSurface, featCur_all, row_off, pts1, pts2, ld, (hipStream_t)stream);
+}
+size_t pcreg_dev_ransac_batched_workspace(int n_cap, int iterNum, int B) { return ransac_workspace_bytes(iterNum, B > 0 ? B : 1, n_cap); }
+int pcreg_dev_ransac_batched(const double* pts1, const double* pts2, int ld, const int32_t* offsets, int B, int n_cap,
+                             const pcreg_ransac_opts* opts, pcreg_dev_ransac_result* out, int32_t* inlier_idx,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(pts1 && pts2 && offsets && opts && out && inlier_idx && workspace && B >= 1 && n_cap >= 0 && ld >= 0);
+    PCREG_ARG(opts->minPtNum == 3);                    // the built-in sampler, seed + b for registration b
+    GUARD();
+    return launch_ransac(pts1, pts2, ld, offsets, nullptr, n_cap, B, *opts, nullptr, out, inlier_idx, nullptr, nullptr,
+                         workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int pcreg_dev_quick_tf(const double* pts, int n, int ld, const double T[16], double* out, int ldo, void* stream) {
     PCREG_ARG(pts && T && out && n >= 0 && ld >= n && ldo >= n);
     GUARD();

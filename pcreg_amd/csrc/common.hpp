@@ -113,6 +113,10 @@ int launch_refine_by_distance(const double* p1, const double* p2, const int32_t*
 void knn_f16_timing_enable(bool on);
 int knn_f16_timing_read(float* mean_ms, int* launches);
 int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st);
+int launch_sweep_plan(const int32_t* n_pairs, int S, int thresh, int32_t* trial_idx, int32_t* offsets, int32_t* n_trials, hipStream_t st);
+int launch_sweep_gather(const uint32_t* pairs_all, int VS, const int32_t* n_pairs, const int32_t* trial_idx, const int32_t* offsets,
+                        const int32_t* n_trials, int S, const double* featS, const double* featCur_all, const int64_t* row_off,
+                        double* p1, double* p2, int ld, hipStream_t st);
 int launch_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featS, const double* featM,
                                double* pts1, double* pts2, hipStream_t st);
 

@@ -68,6 +68,45 @@ __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double* __re
     }
 }
 
+// ---- the batched sweep (completeExperimentFast.m:166-224 for all spheres at once) -----------------------------------
+// trial = find(num_putative > putative_thresh) (:175), in sphere order; offsets = where trial t's pairs start in the
+// packed correspondence arrays.  One thread: S is a few hundred.  Entries past n_trials are empty registrations
+// (offsets[t] == offsets[t+1]), so the batched ransac can be launched on the capacity S without a host round trip.
+__global__ void sweep_plan_kernel(const int32_t* __restrict__ n_pairs, int S, int thresh, int32_t* __restrict__ trial_idx,
+                                  int32_t* __restrict__ offsets /*S + 1*/, int32_t* __restrict__ n_trials) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int t = 0, off = 0;
+    for (int i = 0; i < S; ++i) {
+        if (n_pairs[i] > thresh) { trial_idx[t] = i; offsets[t] = off; off += n_pairs[i]; ++t; }
+    }
+    for (int k = t; k <= S; ++k) offsets[k] = off;
+    for (int k = t; k < S; ++k) trial_idx[k] = -1;
+    *n_trials = t;
+}
+
+// pts1 = featSurface(matches(:,1), :), pts2 = featuresM(matches(:,2), :) (:205-206) for every trial sphere, packed at
+// offsets[t]: SoA columns with leading dimension ld.  pairs_all [S][VS][2] 1-based; featCur_all holds the spheres'
+// gathered keypoints back to back, sphere i's rows starting at row_off[i].
+__global__ __launch_bounds__(256) void sweep_gather_kernel(const uint32_t* __restrict__ pairs_all, int VS, const int32_t* __restrict__ n_pairs,
+                                                           const int32_t* __restrict__ trial_idx, const int32_t* __restrict__ offsets,
+                                                           const int32_t* __restrict__ n_trials, const double* __restrict__ featS,
+                                                           const double* __restrict__ featCur_all, const int64_t* __restrict__ row_off,
+                                                           double* __restrict__ p1, double* __restrict__ p2, int ld) {
+    const int t = blockIdx.y;
+    if (t >= *n_trials) return;
+    const int i = trial_idx[t], n = n_pairs[i], off = offsets[t];
+    const uint32_t* pr = pairs_all + (size_t)i * VS * 2;
+    const double* fc = featCur_all + (size_t)row_off[i] * 3;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        const size_t a = (size_t)pr[2 * k] - 1, b = (size_t)pr[2 * k + 1] - 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            p1[(size_t)c * ld + off + k] = featS[a * 3 + c];
+            p2[(size_t)c * ld + off + k] = fc[b * 3 + c];
+        }
+    }
+}
+
 struct TF16 { double t[16]; };
 // pts_tf = [pts, 1] * TF (column-major 4x4), first three columns; pts n x 3 column-major
 __global__ void quick_tf_kernel(const double* __restrict__ pts, int n, int ld, TF16 T, double* __restrict__ out, int ldo) {
@@ -109,6 +148,21 @@ int launch_sphere_select(const double* feat, int V, const double c[3], double R,
 int launch_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap, double* dst, hipStream_t st) {
     if (cap <= 0 || D <= 0) return PCREG_OK;
     hipLaunchKernelGGL(gather_rows_f64_kernel, dim3(std::min(cap, 8192)), dim3(256), 0, st, src, D, idx, n, cap, dst);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+int launch_sweep_plan(const int32_t* n_pairs, int S, int thresh, int32_t* trial_idx, int32_t* offsets, int32_t* n_trials, hipStream_t st) {
+    hipLaunchKernelGGL(sweep_plan_kernel, dim3(1), dim3(64), 0, st, n_pairs, S, thresh, trial_idx, offsets, n_trials);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+int launch_sweep_gather(const uint32_t* pairs_all, int VS, const int32_t* n_pairs, const int32_t* trial_idx, const int32_t* offsets,
+                        const int32_t* n_trials, int S, const double* featS, const double* featCur_all, const int64_t* row_off,
+                        double* p1, double* p2, int ld, hipStream_t st) {
+    if (S <= 0 || VS <= 0) return PCREG_OK;
+    hipLaunchKernelGGL(sweep_gather_kernel, dim3((VS + 255) / 256, S), dim3(256), 0, st, pairs_all, VS, n_pairs, trial_idx, offsets, n_trials,
+                       featS, featCur_all, row_off, p1, p2, ld);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

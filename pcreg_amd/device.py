@@ -220,18 +220,22 @@ class DescriptorPipeline:
             raise ValueError(f"a support holds {overflow} points: more than an LDS-resident support may have (lower max_pts)")
         return feat, desc, V
 
-    def match(self, descS: torch.Tensor, VS: int, descM: torch.Tensor, VM: int, par: dict):
-        """-> (pairs [VS,2] int32 1-based, n_pairs device int32)."""
+    def match(self, descS: torch.Tensor, VS: int, descM: torch.Tensor, VM: int, par: dict, pairs_out: torch.Tensor | None = None,
+              n_pairs_out: torch.Tensor | None = None, ws_cap: tuple | None = None):
+        """-> (pairs [VS,2] int32 1-based, n_pairs device int32).  pairs_out / n_pairs_out: write into the caller's
+        buffers (the batched sweep); ws_cap = (VS, VM) sizes the workspace once for a series of calls."""
         from .api import _match_opts
         L = lib()
         o = _match_opts(par)
-        pairs = torch.empty((max(VS, 1), 2), dtype=torch.int32, device=self.dev)
+        pairs = pairs_out if pairs_out is not None else torch.empty((max(VS, 1), 2), dtype=torch.int32, device=self.dev)
+        n_pairs = n_pairs_out if n_pairs_out is not None else self.n_pairs
         D = descS.shape[1]
-        ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(VS, VM, D))
+        cap = ws_cap or (VS, VM)
+        ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(cap[0], cap[1], D))
         check(L.pcreg_dev_get_matches(_p(descS), VS, D, _p(descM), VM, D, D, _l.LAYOUT_ROW_MAJOR,
-                                      C.byref(o), _p(pairs), None, _p(self.n_pairs), _p(ws), C.c_size_t(ws.numel()),
+                                      C.byref(o), _p(pairs), None, _p(n_pairs), _p(ws), C.c_size_t(ws.numel()),
                                       _stream()))
-        return pairs, self.n_pairs
+        return pairs, n_pairs
 
     def ransac(self, pairs: torch.Tensor, featS: torch.Tensor, featM: torch.Tensor, coef: dict, seed: int = 0):
         """ransac on featS(pairs(:,1),:) / featM(pairs(:,2),:); result via fetch_result()."""

@@ -1,11 +1,11 @@
 """The sphere-sweep driver of completeExperimentFast.m:46-225 and its final stage (:291, :356-394)
 as a device-resident pipeline.
 
-Host logic (loops, thresholds, the stats arrays) mirrors the .m script line by line; everything that
-touches descriptors or points runs through the device tier of include/pcreg.h on resident buffers:
-the model's keypoints and descriptors are uploaded once, each sphere is an index list + a row gather
-on the device, `getMatches` and `ransac` consume those buffers in place, and only counts and the
-per-sphere results (pairs, 4x4 transforms) come back.
+Everything that touches descriptors or points runs through the device tier of include/pcreg.h on resident
+buffers: the model's keypoints and descriptors are uploaded once, each sphere is an index list + a row gather
+on the device, `getMatches` and `ransac` consume those buffers in place.  `SphereSweep.run` is the batched form
+(the reference's two parfor loops as one enqueue chain, TWO host synchronisations for the whole sweep);
+`run_serial` walks the spheres one at a time like the script's inner loops and is kept as its cross-check.
 """
 from __future__ import annotations
 
@@ -86,9 +86,10 @@ class SphereSweep:
         self.pipe.ransac(m["pairs"], self.featS, m["featCur"], options, seed=seed)
         return self.pipe.fetch_result()
 
-    def run(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
-            putative_thresh: int = 170, seed: int = 0) -> dict:
-        """completeExperimentFast.m:46-224: centres, num_desc, num_putative, matches, model_rows, trial and the stats arrays."""
+    def run_serial(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
+                   putative_thresh: int = 170, seed: int = 0) -> dict:
+        """The script's loops one sphere at a time (two host reads per sphere): kept as the plain reading of
+        completeExperimentFast.m:46-224 and as the cross-check of run()."""
         centres = self.sphere_centres(d_spheres)
         valid, _ = self.valid_spheres(centres, R_desc, min_pts)
         centres = centres[valid]
@@ -107,6 +108,104 @@ class SphereSweep:
                     matches=[m["pairs"][:m["num_putative"]].cpu().numpy().astype(np.uint32) for m in per],
                     model_rows=[m["rows"].cpu().numpy().astype(np.int64) for m in per], trial=trial,
                     statsPutative=np.array(sp, dtype=np.int64), statsSuccess=np.array(ss, dtype=np.int64),
+                    statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
+
+    def run(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
+            putative_thresh: int = 170, seed: int = 0, n_streams: int = 4) -> dict:
+        """completeExperimentFast.m:46-224 as ONE enqueue chain with TWO host synchronisations for the whole sweep.
+
+        The reference runs the per-sphere getMatches under parfor (:131-149) and the per-trial ransac under a second
+        parfor (:201-216).  Here: (sync 1) the descriptor counts of all candidate centres, which fix the valid spheres
+        and every buffer size (:52-64); then, with nothing read back in between, for every valid sphere -- round-robin on
+        `n_streams` HIP streams so that the latency-sized kernels of different spheres overlap -- getDescriptorMask as an
+        index list, the row gathers and getMatches (:109-149); then on the main stream the putative threshold as a device
+        list of trial spheres (:175, pcreg_dev_sweep_plan), the matched keypoints of all trials packed back to back
+        (:205-206, pcreg_dev_sweep_gather) and ONE batched ransac launch over the trial capacity
+        (pcreg_dev_ransac_batched, seed + trial ordinal); (sync 2) counts, pairs, rows and the result structs come back
+        together.  Same outputs as run_serial()."""
+        from ._lib import DevRansacResult
+        L = lib()
+        dev = self.dev
+        centres = self.sphere_centres(d_spheres)
+        valid, counts = self.valid_spheres(centres, R_desc, min_pts)                     # ---- sync 1
+        centres = centres[valid]
+        num_desc = counts[valid].astype(np.int64)
+        S = len(centres)
+        empty = dict(centres=centres, num_desc=num_desc, num_putative=np.zeros(0, np.int64), matches=[], model_rows=[], trial=np.zeros(0, np.int64),
+                     statsPutative=np.zeros(0, np.int64), statsSuccess=np.zeros(0, np.int64), statsInliers=np.zeros(0, np.int64),
+                     statsRatio=np.zeros(0), transforms=[])
+        if S == 0:
+            return empty
+        i32, f64 = torch.int32, torch.float64
+        row_off = np.zeros(S + 1, dtype=np.int64); row_off[1:] = np.cumsum(num_desc)
+        tot = int(row_off[-1]); n_max = int(num_desc.max())
+        rows_all = torch.empty(tot, dtype=i32, device=dev)
+        feat_all = torch.empty((tot, 3), dtype=f64, device=dev)
+        desc_all = torch.empty((tot, self.D), dtype=f64, device=dev)
+        n_sel = torch.zeros(S, dtype=i32, device=dev)
+        pairs_all = torch.zeros((S, max(self.VS, 1), 2), dtype=i32, device=dev)
+        n_pairs = torch.zeros(S, dtype=i32, device=dev)
+        ns = max(1, min(n_streams, S))
+        if not hasattr(self, "_lanes") or len(self._lanes) < ns:
+            self._lanes = [(torch.cuda.Stream(device=dev), DescriptorPipeline(dev),
+                            torch.empty(max(L.pcreg_dev_sphere_select_workspace(self.VM), 256), dtype=torch.uint8, device=dev)) for _ in range(ns)]
+        cur = torch.cuda.current_stream(dev)
+        for st, _, _ in self._lanes[:ns]:
+            st.wait_stream(cur)
+        for i in range(S):
+            st, pipe, ws_sel = self._lanes[i % ns]
+            lo, n = int(row_off[i]), int(num_desc[i])
+            cc = (C.c_double * 3)(*[float(v) for v in centres[i]])
+            with torch.cuda.stream(st):
+                sp = C.c_void_p(st.cuda_stream)
+                rows = rows_all[lo:lo + n]
+                check(L.pcreg_dev_sphere_select(_p(self.featM), self.VM, cc, C.c_double(R_desc), _p(rows), _p(n_sel[i:i + 1]), _p(ws_sel),
+                                                C.c_size_t(ws_sel.numel()), sp))                                         # getDescriptorMask, :118
+                check(L.pcreg_dev_gather_rows_f64(_p(self.descM), self.D, _p(rows), _p(n_sel[i:i + 1]), n, _p(desc_all[lo:lo + n]), sp))   # :121-125
+                check(L.pcreg_dev_gather_rows_f64(_p(self.featM), 3, _p(rows), _p(n_sel[i:i + 1]), n, _p(feat_all[lo:lo + n]), sp))
+                pipe.match(self.descS, self.VS, desc_all[lo:lo + n], n, par, pairs_out=pairs_all[i], n_pairs_out=n_pairs[i:i + 1],
+                           ws_cap=(self.VS, n_max))                                                                       # getMatches, :141
+        for st, _, _ in self._lanes[:ns]:
+            cur.wait_stream(st)
+        # ---- :166-224 on the main stream
+        sp = _stream()
+        trial_idx = torch.empty(S, dtype=i32, device=dev); offsets = torch.empty(S + 1, dtype=i32, device=dev)
+        n_trials = torch.zeros(1, dtype=i32, device=dev)
+        check(L.pcreg_dev_sweep_plan(_p(n_pairs), S, int(putative_thresh), _p(trial_idx), _p(offsets), _p(n_trials), sp))
+        ld = S * max(self.VS, 1)                                    # capacity of the packed correspondences (Unique: <= VS pairs per sphere)
+        p1 = torch.zeros((3, ld), dtype=f64, device=dev); p2 = torch.zeros((3, ld), dtype=f64, device=dev)
+        roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
+        check(L.pcreg_dev_sweep_gather(_p(pairs_all), self.VS, _p(n_pairs), _p(trial_idx), _p(offsets), _p(n_trials), S, _p(self.featS),
+                                       _p(feat_all), _p(roff_dev), _p(p1), _p(p2), ld, sp))
+        o = RansacOpts(int(options["minPtNum"]), int(options["iterNum"]), float(options["thDist"]), float(options["thInlrRatio"]),
+                       int(bool(options["REFINE"])), 0, int(seed))
+        rs = C.sizeof(DevRansacResult)
+        results = torch.zeros((S, rs), dtype=torch.uint8, device=dev)
+        inliers = torch.empty(ld, dtype=i32, device=dev)
+        wsb = L.pcreg_dev_ransac_batched_workspace(self.VS, o.iterNum, S)
+        ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+        check(L.pcreg_dev_ransac_batched(_p(p1), _p(p2), ld, _p(offsets), S, self.VS, C.byref(o), _p(results), _p(inliers), _p(ws),
+                                         C.c_size_t(ws.numel()), sp))
+        # ---- sync 2: everything comes back together
+        npr = n_pairs.cpu().numpy().astype(np.int64)
+        nt = int(n_trials.item())
+        trial = trial_idx[:nt].cpu().numpy().astype(np.int64)
+        raw = results[:max(nt, 1)].cpu().numpy()
+        pairs_host = pairs_all.cpu().numpy()
+        rows_host = rows_all.cpu().numpy().astype(np.int64)
+        nsel = n_sel.cpu().numpy()
+        assert np.array_equal(nsel, num_desc), "sphere_select disagrees with sphere_counts"
+        sp_, ss, si, sr, tf = [], [], [], [], []
+        for t in range(nt):
+            r = DevRansacResult.from_buffer_copy(raw[t].tobytes())
+            P = int(npr[trial[t]])
+            sp_.append(P); ss.append(r.num_success); si.append(r.max_inliers)
+            sr.append(100.0 * r.max_inliers / P if not r.failed else 0.0)
+            tf.append(None if r.failed else np.array(r.T[:]).reshape(4, 4, order="F"))
+        return dict(centres=centres, num_desc=num_desc, num_putative=npr,
+                    matches=[pairs_host[i, :npr[i]].astype(np.uint32) for i in range(S)],
+                    model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)], trial=trial,
+                    statsPutative=np.array(sp_, dtype=np.int64), statsSuccess=np.array(ss, dtype=np.int64),
                     statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
 
 

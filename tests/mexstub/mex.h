@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-typedef enum { mxDOUBLE_CLASS, mxSINGLE_CLASS, mxINT32_CLASS, mxUINT32_CLASS, mxCHAR_CLASS, mxSTRUCT_CLASS } mxClassID;
+typedef enum { mxDOUBLE_CLASS, mxSINGLE_CLASS, mxINT32_CLASS, mxUINT32_CLASS, mxUINT8_CLASS, mxCHAR_CLASS, mxSTRUCT_CLASS } mxClassID;
 typedef enum { mxREAL, mxCOMPLEX } mxComplexity;
 typedef size_t mwSize;
 
@@ -50,6 +50,7 @@ inline bool mxIsStruct(const mxArray* a) { return a && a->cls == mxSTRUCT_CLASS;
 inline bool mxIsChar(const mxArray* a) { return a && a->cls == mxCHAR_CLASS; }
 inline bool mxIsInt32(const mxArray* a) { return a && a->cls == mxINT32_CLASS; }
 inline bool mxIsSingle(const mxArray* a) { return a && a->cls == mxSINGLE_CLASS; }
+inline bool mxIsUint8(const mxArray* a) { return a && a->cls == mxUINT8_CLASS; }
 inline bool mxIsEmpty(const mxArray* a) { return !a || a->m * a->n == 0; }
 inline size_t mxGetM(const mxArray* a) { return a->m; }
 inline size_t mxGetN(const mxArray* a) { return a->n; }

@@ -134,6 +134,42 @@ int drv_descriptors_f32(const float* pts, int Pn, const float* kp, int S, const 
     return 0;
 }
 
+// one-worker rehearsal of the spmd block of INTEGRATION.md section 3: setDevice, commId, commInit, matchPointsSharded,
+// ransacSharded, commDestroy -- all through the gateway
+int drv_comm_round_trip(const float* surf, int Q, const float* model, int M, float thr, float ratio, uint32_t* pairs_colmajor, int* P,
+                        const double* coef5, double seed, double* T16, double* inlier_idx, int* n_inl, int* num_success, int* max_inl, int* failed,
+                        const double* p1, const double* p2, int n, char* err, int errlen) {
+    mxArray* lhs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    { std::vector<mxArray*> rhs{mxCreateString("setDevice"), mxCreateDoubleScalar(0)}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    { std::vector<mxArray*> rhs{mxCreateString("commId")}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* id = lhs[0]; lhs[0] = nullptr;
+    if (!mxIsUint8(id) || mxGetN(id) != 128) { snprintf(err, errlen, "commId is not 1 x 128 uint8"); return 1; }
+    { std::vector<mxArray*> rhs{mxCreateString("commInit"), mxCreateDoubleScalar(0), mxCreateDoubleScalar(1), id}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    int rc = 0;
+    {
+        std::vector<mxArray*> rhs{mxCreateString("matchPointsSharded"), fmat(surf, Q, 3), fmat(model, M, 3), mxCreateDoubleScalar(0), mxCreateDoubleScalar(M),
+                                  mxCreateDoubleScalar(thr), mxCreateDoubleScalar(ratio), mxCreateDoubleScalar(1)};
+        rc = call(1, lhs, rhs, err, errlen);
+        if (!rc) { *P = (int)mxGetM(lhs[0]); memcpy(pairs_colmajor, mxGetData(lhs[0]), (size_t)*P * 2 * 4); mxDestroyArray(lhs[0]); lhs[0] = nullptr; }
+    }
+    if (!rc) {
+        mxArray* c = mxCreateStructMatrix(1, 1, 0, nullptr);
+        put(c, "minPtNum", coef5[0]); put(c, "iterNum", coef5[1]); put(c, "thDist", coef5[2]); put(c, "thInlrRatio", coef5[3]); put(c, "REFINE", coef5[4]);
+        std::vector<mxArray*> rhs{mxCreateString("ransacSharded"), dmat(p1, n, 3), dmat(p2, n, 3), c, mxCreateDoubleScalar(seed)};
+        rc = call(5, lhs, rhs, err, errlen);
+        if (!rc) {
+            *failed = (int)mxGetScalar(lhs[4]);
+            if (!*failed) memcpy(T16, mxGetPr(lhs[0]), 128);
+            *n_inl = (int)(mxGetM(lhs[1]) * mxGetN(lhs[1]));
+            if (*n_inl) memcpy(inlier_idx, mxGetPr(lhs[1]), (size_t)*n_inl * 8);
+            *num_success = (int)mxGetScalar(lhs[2]); *max_inl = (int)mxGetScalar(lhs[3]);
+            for (mxArray*& a : lhs) { mxDestroyArray(a); a = nullptr; }
+        }
+    }
+    { char e2[256]; std::vector<mxArray*> rhs{mxCreateString("commDestroy")}; call(0, lhs, rhs, e2, sizeof e2); }
+    return rc;
+}
+
 int drv_bad_command(char* err, int errlen) {
     std::vector<mxArray*> rhs{mxCreateString("noSuchCommand")};
     mxArray* lhs[1] = {nullptr};

@@ -32,7 +32,13 @@ def test_sphere_sweep_equals_oracle_driver(oracle_c, oracle_py):
     ref = oracle_py.sphere_sweep(featM, descM, featS, descS, PAR, OPT, get_matches=oracle_c.getMatches,
                                  run_ransac=oracle_c.ransac, **kw)
     assert len(ref["centres"]) >= 4 and len(ref["trial"]) >= 1          # the scene exercises both stages
-    got = SphereSweep(featM, descM, featS, descS).run(PAR, OPT, **kw)
+    sw = SphereSweep(featM, descM, featS, descS)
+    got = sw.run(PAR, OPT, **kw)                                            # batched: two host syncs for the whole sweep
+    ser = sw.run_serial(PAR, OPT, **kw)                                     # one sphere at a time
+    for k in ("num_desc", "num_putative", "trial", "statsPutative", "statsSuccess", "statsInliers"):
+        np.testing.assert_array_equal(got[k], ser[k])
+    for a, b in zip(got["transforms"], ser["transforms"]):
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
     np.testing.assert_array_equal(got["centres"], ref["centres"])
     np.testing.assert_array_equal(got["num_desc"], ref["num_desc"])
     np.testing.assert_array_equal(got["num_putative"], ref["num_putative"])
@@ -105,3 +111,22 @@ def test_quicktf_inverttf_and_distance_refine(oracle_py):
     assert (Tg3 is None) == (Tref3 is None)
     if Tg3 is not None:
         assert np.linalg.norm(Tg3 - Tref3) < 1e-9
+
+
+def test_batched_sweep_counts_its_host_syncs(monkeypatch):
+    """The batched driver's contract: no device-to-host read between the first sphere's select and the batched
+    ransac launch.  torch.Tensor.cpu / .item are the only ways sweep.py reads the device; they are counted per phase."""
+    import torch
+    from pcreg_amd import sweep as sw_mod
+    featM, descM, featS, descS = _scene(seed=2, VM=5000, VS=200, D=64)
+    sw = sw_mod.SphereSweep(featM, descM, featS, descS)
+    calls = []
+    real_plan = sw_mod.lib().pcreg_dev_sweep_plan
+    orig_cpu, orig_item = torch.Tensor.cpu, torch.Tensor.item
+    monkeypatch.setattr(torch.Tensor, "cpu", lambda self, *a, **k: (calls.append("cpu"), orig_cpu(self, *a, **k))[1])
+    monkeypatch.setattr(torch.Tensor, "item", lambda self, *a, **k: (calls.append("item"), orig_item(self, *a, **k))[1])
+    out = sw.run(PAR, OPT, R_desc=9.0, d_spheres=6.0, min_pts=400, putative_thresh=50, seed=1)
+    S = len(out["centres"])
+    assert S >= 4
+    # sync 1 = featM (once, cached) + the counts; sync 2 = the final block of reads; nothing scales with S
+    assert len(calls) <= 10, calls

@@ -144,3 +144,31 @@ def test_shim_round_trips_equal_the_ctypes_path(drv):
     pf, pd = pc.getSpacialHistogramDescriptors(cl32, kp32, opts)
     assert pf.dtype == np.float32 and pd.dtype == np.float32 and np.array_equal(pd, wd.astype(np.float32))
     assert drv.drv_live_arrays() == 0
+
+
+@pytest.mark.gpu
+def test_shim_multi_gpu_commands_one_worker(drv):
+    """The spmd block of INTEGRATION.md section 3 with one worker, through the gateway: setDevice, commId (1 x 128 uint8),
+    commInit, matchPointsSharded, ransacSharded, commDestroy; results equal the single-GPU entry points."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(8)
+    model = (rng.random((30000, 3)) * [100, 56, 99]).astype(np.float32)
+    pick = rng.choice(30000, 4000, replace=False)
+    surf = (model[pick] + rng.normal(0, 0.03, (4000, 3))).astype(np.float32)
+    want = pc.match_points(surf, model, 0.25, 0.8, True)
+    p1 = surf[want[:, 0] - 1].astype(np.float64); p2 = model[want[:, 1] - 1].astype(np.float64)
+    n = len(want)
+    coef5 = np.array([3, 1500, 0.3, 0.08, 1], dtype=np.float64)
+    pairs = np.zeros(4000 * 2, dtype=np.uint32); P = C.c_int()
+    T = np.zeros(16); inl = np.zeros(n); ni, ns, mi, fl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    e = _err()
+    rc = drv.drv_comm_round_trip(_p(np.asfortranarray(surf), C.c_float), 4000, _p(np.asfortranarray(model), C.c_float), 30000, C.c_float(0.25), C.c_float(0.8),
+                                 _p(pairs, C.c_uint32), C.byref(P), _p(coef5), C.c_double(5), _p(T), _p(inl), C.byref(ni), C.byref(ns), C.byref(mi), C.byref(fl),
+                                 _p(_d(p1)), _p(_d(p2)), n, e, 1024)
+    assert rc == 0, e.value
+    assert np.array_equal(pairs[:2 * P.value].reshape(P.value, 2, order="F"), want)
+    coef = dict(minPtNum=3, iterNum=1500, thDist=0.3, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    Tr, inr, nsr, mir, _ = pc.ransac(p1, p2, coef, pc.estimateTransform, pc.calcDists, seed=5)
+    assert fl.value == 0 and (ns.value, mi.value) == (nsr, mir) and np.array_equal(inl[:ni.value], np.asarray(inr, dtype=np.float64).ravel())
+    assert np.linalg.norm(T.reshape(4, 4, order="F") - Tr) < 1e-12
+    assert drv.drv_live_arrays() == 0
