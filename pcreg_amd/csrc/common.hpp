@@ -1,5 +1,6 @@
 // pcreg_amd/csrc/common.hpp -- shared host-side helpers of libpcreg_hip (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -45,6 +46,23 @@ Scratch& scratch();
 // device-tier temporaries: one Scratch per stream, so that calls on different streams may overlap
 // (a stream runs its own kernels in order, which makes the reuse within it safe)
 Scratch& stream_scratch(hipStream_t st);
+
+// Environment switches.  Two kinds:
+//  * result-preserving A/B switches (PCREG_KNN_EXACT, PCREG_UNIQUE_MODE, PCREG_MATCH_EXACT, PCREG_MATCH_FORCE_FALLBACK,
+//    PCREG_RANSAC_FUSED / _NOLANE / _F64SCORE): always available, read per call (the tests flip them inside one process);
+//    every setting gives the same indices and counts;
+//  * experiment / debug switches that change the launch shape, print, synchronise, write files or INVALIDATE results
+//    (timing-only kernels): they exist only in a build with -DPCREG_EXPERIMENTS (`make EXPERIMENTS=1`); the default
+//    library compiles them to their default value, so a stray variable in a user's environment cannot change anything.
+static inline int pcreg_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline const char* pcreg_env_str(const char* name) { return getenv(name); }
+#ifdef PCREG_EXPERIMENTS
+#define PCREG_EXP_ENV(name, dflt) pcreg_env_int(name, dflt)
+#define PCREG_EXP_STR(name) pcreg_env_str(name)
+#else
+#define PCREG_EXP_ENV(name, dflt) (dflt)
+#define PCREG_EXP_STR(name) ((const char*)nullptr)
+#endif
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

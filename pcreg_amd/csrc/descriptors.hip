@@ -709,7 +709,7 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     size_t lds = (size_t)cap * sizeof(int);
     PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(desc_kernel, dim3(S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, perm, S, ldk, o,
-                       ed, cap, getenv("PCREG_DESC_STOP") ? atoi(getenv("PCREG_DESC_STOP")) : 0, rows, valid, err_dev);
+                       ed, cap, PCREG_EXP_ENV("PCREG_DESC_STOP", 0), rows, valid, err_dev);
     PCREG_HIP(hipGetLastError());
     const int nbs = (S + 255) / 256;
     hipLaunchKernelGGL(desc_count_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt);

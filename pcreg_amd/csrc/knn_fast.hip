@@ -771,8 +771,8 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     if (Q == 0) return PCREG_OK;
     size_t need = knn2_points_fast_workspace_bytes(Q, M);
     if (ws_bytes < need) { set_error("knn (fast) workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
-    static const int target_env = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : 0;
-    static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 40;
+    const int target_env = PCREG_EXP_ENV("PCREG_KNN_BLOCKS", 0);
+    const int variant = PCREG_EXP_ENV("PCREG_KNN_VARIANT", 40);
     const bool use_mfma = variant >= 5 && variant < 10;
     size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
     char* w = (char*)ws;
@@ -799,7 +799,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2, n_flag);
     int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0, group16 = 0;
     bool sparse_lists = false;
-    static const bool no_seed = getenv("PCREG_KNN_NOSEED") && atoi(getenv("PCREG_KNN_NOSEED")) != 0;
+    const bool no_seed = PCREG_EXP_ENV("PCREG_KNN_NOSEED", 0) != 0;
     if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)
         PCREG_HIP(hipMemsetAsync(seed_cnt, 0, seed_cells * 4, st));
         int fb = (M + kBlock - 1) / kBlock; if (fb > 16384) fb = 16384;     // one point per thread: the atomics want parallelism
@@ -871,7 +871,7 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
         hipLaunchKernelGGL(knn_finalize_kernel<64>, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
                            part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)nullptr, 0);
     PCREG_HIP(hipGetLastError());
-    if (getenv("PCREG_KNN_DEBUG")) {
+    if (PCREG_EXP_ENV("PCREG_KNN_DEBUG", 0)) {
         int32_t nf = 0;
         PCREG_HIP(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, st)); PCREG_HIP(hipStreamSynchronize(st));
         fprintf(stderr, "[pcreg] knn fast: Q=%d M=%d variant=%d S=%d kc=%d unproven=%d\n", Q, M, variant, S, kc, nf);

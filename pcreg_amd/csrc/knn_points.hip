@@ -481,8 +481,8 @@ static int knn2_exact_impl(const float* q, int Q, int ldq, const float* m, int M
     if (Q == 0) return PCREG_OK;
     size_t need = knn2_points_exact_workspace_bytes(Q, M);
     if (ws_bytes < need) { set_error("knn workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
-    static const int variant = getenv("PCREG_KNN_VARIANT") ? atoi(getenv("PCREG_KNN_VARIANT")) : 0;
-    static const int target = getenv("PCREG_KNN_BLOCKS") ? atoi(getenv("PCREG_KNN_BLOCKS")) : 2048;
+    const int variant = PCREG_EXP_ENV("PCREG_KNN_POINTS_VARIANT", 0);
+    const int target = PCREG_EXP_ENV("PCREG_KNN_BLOCKS", 2048);
     const int qpt = (variant == 2) ? 8 : (variant == 3 ? 2 : 4);
     int n_tiles = (Q + kBlock * qpt - 1) / (kBlock * qpt);
     int S = pick_splits(n_tiles, M > 0 ? M : 1, target);
@@ -516,7 +516,7 @@ int launch_knn2_points_exact_list(const float* q, int Q, int ldq, const float* m
 
 // PCREG_KNN_EXACT=1 forces the direct-form kernel (tuning / A-B runs); the default is the
 // certified fast path of knn_fast.hip, which returns the same bits.
-static bool use_exact_only() { static const bool v = getenv("PCREG_KNN_EXACT") && atoi(getenv("PCREG_KNN_EXACT")) != 0; return v; }
+static bool use_exact_only() { return pcreg_env_int("PCREG_KNN_EXACT", 0) != 0; }
 
 size_t knn2_points_workspace_bytes(int Q, int M) {
     size_t a = knn2_points_exact_workspace_bytes(Q, M), b = knn2_points_fast_workspace_bytes(Q, M);
@@ -573,7 +573,7 @@ int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int
     if (Q == 0) return PCREG_OK;
     size_t need = unique_points_workspace_bytes(Q);
     if (ws_bytes < need) { set_error("unique workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
-    static const int unique_mode = getenv("PCREG_UNIQUE_MODE") ? atoi(getenv("PCREG_UNIQUE_MODE")) : 0;   // 1: second search
+    const int unique_mode = pcreg_env_int("PCREG_UNIQUE_MODE", 0);   // 1: second search
     if (!use_exact_only() && Q >= 4096 && unique_mode == 0) {
         // grid of the queries + exact range-emptiness test per candidate (see ug_* above)
         char* w = (char*)ws;

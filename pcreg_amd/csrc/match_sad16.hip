@@ -542,8 +542,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     {
         // cost ~ (row tiles per chunk) x (workgroups on the fullest CU); one workgroup alone on a CU runs
         // at about 2/3 of the per-workgroup speed of a full CU (measured sweep: scripts/sad_split_sweep.sh)
-        const char* fs = getenv("PCREG_SAD_SPLITS");            // experiment override
-        const int forced = fs ? atoi(fs) : 0;
+        const int forced = PCREG_EXP_ENV("PCREG_SAD_SPLITS", 0);            // experiment override
         long best_cost = -1;
         for (int s_try = 1; s_try <= kMaxSplit && s_try <= row_tiles; ++s_try) {
             if (forced > 0 && s_try != std::min(forced, std::min(kMaxSplit, row_tiles))) continue;
@@ -554,9 +553,9 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
         }
     }
     unsigned long long* dbg = nullptr;
-    const char* tl = getenv("PCREG_SAD_TIMELINE");      // debug: dump per-block (start, end, HW_ID, XCC_ID) to this file
+    const char* tl = PCREG_EXP_STR("PCREG_SAD_TIMELINE");      // debug: dump per-block (start, end, HW_ID, XCC_ID) to this file
     if (tl) PCREG_HIP(hipMalloc(&dbg, (size_t)n_tiles * S * 4 * sizeof(unsigned long long)));
-    if (getenv("PCREG_SAD_DRY"))      // timing experiment only: list maintenance compiled out, results invalid
+    if (PCREG_EXP_ENV("PCREG_SAD_DRY", 0))      // timing experiment only: list maintenance compiled out, results invalid
         hipLaunchKernelGGL(sad16_candidates_kernel<true>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live);
     else
         hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live);
@@ -578,7 +577,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     hipLaunchKernelGGL(sad16_finalize_kernel, dim3((nA + 3) / 4), dim3(kBlock), 0, st, At, nA, Bt, nB, D, range,
                        part_idx, part_s, S, idx, dist, flag_list, n_flag, force, nA_live);
     PCREG_HIP(hipGetLastError());
-    if (getenv("PCREG_MATCH_DEBUG")) {                       // the only host round trip of the call, debugging only
+    if (PCREG_EXP_ENV("PCREG_MATCH_DEBUG", 0)) {                       // the only host round trip of the call, debugging only
         int32_t nf = 0;
         PCREG_HIP(hipMemcpyAsync(&nf, n_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         PCREG_HIP(hipStreamSynchronize(st));
