@@ -447,6 +447,33 @@ __global__ void gather_scatter_kernel(const float* __restrict__ q, int Q, int ld
     }
 }
 
+// the same in ONE launch for capacities up to kCompactMax (select.hpp): one 1024-thread workgroup, contiguous runs
+__global__ __launch_bounds__(kCompactThreads) void gather_compact_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
+                                                                         const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
+                                                                         const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
+                                                                         uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2,
+                                                                         int32_t* __restrict__ n_pairs) {
+    __shared__ int s_wave[kCompactThreads / 64];
+    const int P = min(*n_cand, Q);
+    const int per = (P + kCompactThreads - 1) / kCompactThreads;
+    const int lo = min(P, (int)threadIdx.x * per), hi = min(P, lo + per);
+    int cnt = 0;
+    for (int k = lo; k < hi; ++k) cnt += (keep == nullptr || keep[k] != 0);
+    int total;
+    int o = block_exclusive_scan_1024(cnt, s_wave, &total);
+    for (int k = lo; k < hi; ++k) {
+        if (keep != nullptr && keep[k] == 0) continue;
+        const int qi = cand_q[k], mj = cand_m[k];
+        if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)mj + 1u; }
+        if (pts1) {
+            pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
+            pts2[o] = (double)m[mj]; pts2[o + (size_t)Q] = (double)m[mj + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[mj + 2 * (size_t)ldm];
+        }
+        ++o;
+    }
+    if (threadIdx.x == 0) *n_pairs = total;
+}
+
 // number of model chunks so that the grid has ~>= 8 workgroups per CU
 int pick_splits(int n_tiles, int M, int target = 2048) {
     int S = (target + n_tiles - 1) / n_tiles;
@@ -633,6 +660,11 @@ int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int 
                             double* pts1, double* pts2, int32_t* n_pairs, hipStream_t st) {
     PCREG_ARG((pts1 == nullptr) == (pts2 == nullptr));
     if (Q <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
+    if (Q <= kCompactMax) {
+        hipLaunchKernelGGL(gather_compact_kernel, dim3(1), dim3(kCompactThreads), 0, st, q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand, pairs, pts1, pts2, n_pairs);
+        PCREG_HIP(hipGetLastError());
+        return PCREG_OK;
+    }
     const int nb = (Q + 255) / 256;                   // capacity launch: the kernels read the real count
     void* tmp = nullptr;
     int rc = stream_scratch(st).get(21, ((size_t)nb + 1) * sizeof(int32_t), &tmp);
