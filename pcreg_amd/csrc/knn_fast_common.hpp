@@ -54,5 +54,19 @@ __device__ __forceinline__ void cand_insert(Cand& c, float s, int j) {
 }
 
 
+// The same insertion without a branch: a four-stage compare-exchange chain that carries (score, index) down the sorted
+// list; `pred` false (or s >= c.s[3]) leaves the list as it is.  Straight-line code for the rare list update of the
+// pipelined f16 kernel: the nested branches of cand_insert cost a lone wave ~3 scalar branch latencies per level.
+__device__ __forceinline__ void cand_insert_branchless(Cand& c, float s, int j, bool pred) {
+    float x = pred ? s : INFINITY; int xi = j;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+        const bool lt = x < c.s[k];                 // strict: an earlier equal entry keeps its place
+        const float lo = lt ? x : c.s[k], hi = lt ? c.s[k] : x;
+        const int loi = lt ? xi : c.i[k], hii = lt ? c.i[k] : xi;
+        c.s[k] = lo; c.i[k] = loi; x = hi; xi = hii;
+    }
+}
+
 }  // namespace
 }  // namespace pcreg

@@ -233,8 +233,9 @@ __global__ __launch_bounds__(kBlock, 4) void knn_candidates_f16_pipe_kernel(
                 for (int g = 0; g < QG; ++g) {
 #pragma unroll
                     for (int ss = 0; ss < 2; ++ss) {
-                        if (hit[ss][g] != 0) {
-                            if (mnk[ss][g] < thr[g]) { cand_insert(cand[g], mnk[ss][g], jt + (sub + ss) * 32); thr[g] = fminf(thr[g], cand[g].s[3]); }
+                        if (hit[ss][g] != 0) {           // scalar test; the insertion itself is straight-line code
+                            cand_insert_branchless(cand[g], mnk[ss][g], jt + (sub + ss) * 32, mnk[ss][g] < thr[g]);
+                            thr[g] = fminf(thr[g], cand[g].s[3]);
                         }
                     }
                 }
@@ -333,7 +334,8 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
     }
 #define PCREG_F16_PIPE(DRYV) hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<QG, DRYV>), dim3(q_blocks * grid_chunks), dim3(kBlock), 0, st, q, Q, ldq, \
                            (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map, S)
-    if (dry) PCREG_F16_PIPE(true); else PCREG_F16_PIPE(false);
+    if (dry) PCREG_F16_PIPE(true);
+    else PCREG_F16_PIPE(false);
 #undef PCREG_F16_PIPE
     if (ev1) PCREG_HIP(hipEventRecord(ev1, st));
     PCREG_HIP(hipGetLastError());
