@@ -137,3 +137,52 @@ def test_f16_split_rounding_midpoints_regression(oracle_c):
     oi, od = oracle_c.knn2_points_f32(crop, model, nthreads=CORES)
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd, od)
+
+
+def _midpoint_points(rng, want=400):
+    """Scaled model points (x, y, z) whose fp32 value w = fma(z, z, fma(y, y, x * x)) is EXACTLY an f16 rounding
+    midpoint while the exact product-sum is not: the case in which `(_Float16)fma(..)` rounded once (v_fma_mixlo_f16)
+    and rounded twice (through fp32) give different f16 values."""
+    f32 = np.float32
+    out = []
+    while len(out) < want:
+        h = np.float16(rng.uniform(70, 800))
+        ulp = float(np.spacing(h))
+        W = float(h) + (ulp / 2 if rng.random() < 0.5 else -ulp / 2)                 # exactly representable in fp32
+        xs, ys = f32(rng.integers(1, 4 * 6) / 4.0), f32(rng.integers(1, 4 * 6) / 4.0)
+        s2 = float(ys) * float(ys) + float(xs) * float(xs)                           # exact, and exact in fp32
+        if s2 >= W - 1:
+            continue
+        z0 = f32(np.sqrt(W - s2))
+        for d in (0, 1, -1, 2, -2):
+            z = np.nextafter(z0, f32(np.inf if d > 0 else -np.inf)) if d else z0
+            if abs(d) == 2:
+                z = np.nextafter(z, f32(np.inf if d > 0 else -np.inf))
+            exact = float(z) * float(z) + s2                                          # float64: exact enough (48 + a few bits)
+            if f32(exact) == f32(W) and exact != W:
+                out.append((float(xs), float(ys), float(z)))
+                break
+    return np.array(out, dtype=np.float32)
+
+
+def test_f16_split_midpoints_by_construction(oracle_c):
+    """Model points whose sigma^2 |m - c|^2, AS COMPUTED IN fp32, is exactly an f16 rounding midpoint while the exact
+    product-sum is not (see _midpoint_points): the box is pinned to [-64, 64]^3 by two corner points (centre 0,
+    sigma = 1/2, both exact).  Queries sit next to such points so that they are first or second neighbours.  With round
+    1's prep kernel the stored high part of |m~|^2 and the residual's high part were rounded differently there, the
+    point's score came out one f16 ulp off, second neighbours went missing and the certificate still passed (verified:
+    this test fails on that build); the search must equal the oracle exactly."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(12)
+    ties = _midpoint_points(rng) * np.float32(2.0)                                     # unscaled: sigma = 1/2, exact doubling
+    ties = (ties * rng.choice([-1.0, 1.0], ties.shape).astype(np.float32))[:, rng.permutation(3)]
+    assert np.abs(ties).max() < 64
+    filler = rng.uniform(-60, 60, (30000, 3)).astype(np.float32)
+    corners = np.array([[-64, -64, -64], [64, 64, 64]], dtype=np.float32)
+    model = np.vstack([corners, ties, filler]).astype(np.float32)
+    model = model[rng.permutation(len(model))]
+    q = np.vstack([ties + rng.normal(0, 0.3, ties.shape).astype(np.float32), rng.uniform(-60, 60, (2000, 3)).astype(np.float32)]).astype(np.float32)
+    gi, gd = pc.knn2_points(q, model)
+    oi, od = oracle_c.knn2_points_f32(q, model, nthreads=CORES)
+    np.testing.assert_array_equal(gi, oi)
+    np.testing.assert_array_equal(gd, od)
