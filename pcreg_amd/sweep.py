@@ -111,7 +111,7 @@ class SphereSweep:
                     statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
 
     def run(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
-            putative_thresh: int = 170, seed: int = 0, n_streams: int = 4) -> dict:
+            putative_thresh: int = 170, seed: int = 0, n_streams: int = 8) -> dict:
         """completeExperimentFast.m:46-224 as ONE enqueue chain with TWO host synchronisations for the whole sweep.
 
         The reference runs the per-sphere getMatches under parfor (:131-149) and the per-trial ransac under a second

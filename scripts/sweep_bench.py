@@ -22,12 +22,13 @@ par = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.
 opt = dict(minPtNum=3, iterNum=10000, thDist=0.3, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
 kw = dict(R_desc=9.0, d_spheres=5.0, min_pts=1400, putative_thresh=170, seed=0)
 sw = SphereSweep(featM, descM, featS, descS, device=dev)
-out = sw.run(par, opt, **kw)                       # warm-up (allocations)
-torch.cuda.synchronize(); t0 = time.perf_counter(); out = sw.run(par, opt, **kw); torch.cuda.synchronize(); tb = time.perf_counter() - t0
+NS = int(os.environ.get("SWEEP_STREAMS", "8"))
+out = sw.run(par, opt, n_streams=NS, **kw)                       # warm-up (allocations)
+torch.cuda.synchronize(); t0 = time.perf_counter(); out = sw.run(par, opt, n_streams=NS, **kw); torch.cuda.synchronize(); tb = time.perf_counter() - t0
 torch.cuda.synchronize(); t0 = time.perf_counter(); ser = sw.run_serial(par, opt, **kw); torch.cuda.synchronize(); ts = time.perf_counter() - t0
 same = all(np.array_equal(out[k], ser[k]) for k in ("num_putative", "trial", "statsSuccess", "statsInliers"))
 S = len(out["centres"])
 print(json.dumps({"workload": f"sphere sweep: {S} valid spheres (of a {VM}-keypoint model, {int(out['num_desc'].mean())} descriptors per sphere on average), "
                               f"surface {VS} keypoints, D {D}, {len(out['trial'])} trial spheres x RANSAC(3,1e4,0.3,0.08,REFINE)",
                   "batched_ms": round(tb * 1e3, 1), "batched_spheres_per_s": round(S / tb, 1), "serial_ms": round(ts * 1e3, 1),
-                  "serial_spheres_per_s": round(S / ts, 1), "same_results": bool(same), "host_syncs_batched": 2}), flush=True)
+                  "serial_spheres_per_s": round(S / ts, 1), "same_results": bool(same), "host_syncs_batched": 2, "streams": NS}), flush=True)

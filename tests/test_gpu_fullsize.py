@@ -132,11 +132,12 @@ def test_f16_split_rounding_midpoints_regression(oracle_c):
     from bench import BBOX, make_crop
     M, Q = 1_000_000, 50_000
     model = np.random.default_rng(10).random((M, 3), dtype=np.float32) * BBOX.astype(np.float32)
-    crop = make_crop(model, Q, 0)
-    gi, gd = pc.knn2_points(crop, model)
-    oi, od = oracle_c.knn2_points_f32(crop, model, nthreads=CORES)
-    np.testing.assert_array_equal(gi, oi)
-    np.testing.assert_array_equal(gd, od)
+    for c in (0, 17, 41):                         # crop 0 holds the six known cases; two more crops, every query checked
+        crop = make_crop(model, Q, c)
+        gi, gd = pc.knn2_points(crop, model)
+        oi, od = oracle_c.knn2_points_f32(crop, model, nthreads=CORES)
+        np.testing.assert_array_equal(gi, oi)
+        np.testing.assert_array_equal(gd, od)
 
 
 def _midpoint_points(rng, want=400):
