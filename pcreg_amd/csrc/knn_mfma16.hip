@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __r
 // is never loop-carried in flight; it is waited for inside the iteration that issued it and only waited values
 // cross the back edge (tests/test_isa_lint.py checks the emitted ISA for a VGPR read between load and wait).
 template <int QG, bool DRY>   // DRY: timing only (no compare, no lists; PCREG_KNN_VARIANT=41)
-__global__ __launch_bounds__(kBlock, QG <= 4 ? 4 : 2) void knn_candidates_f16_pipe_kernel(
+__global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_candidates_f16_pipe_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr, uint2* __restrict__ cand_ent, int32_t* __restrict__ cand_cnt,
     int cap, int q_blocks, int xcd_map, int n_chunks) {
@@ -308,12 +308,11 @@ size_t knn_f16_prep_bytes(int M) { return (size_t)((M > 0 ? M : 1) + kT16 - 1) /
 int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
                               unsigned* rm2, void* mtiles, unsigned* gthr, void* cand_ent, int32_t* cand_cnt,
                               int target_blocks, int max_S, bool dry, int* S_out, int* group16_out, hipStream_t st) {
-    // experiment (EXPERIMENTS build): 8 query groups per wave at 2 waves per SIMD -- timing-only form 1.37 ms, real 1.69 vs 1.61
-    const int QG = PCREG_EXP_ENV("PCREG_KNN_F16_QG", 4) == 8 ? 8 : 4;
+    const int QGe = PCREG_EXP_ENV("PCREG_KNN_F16_QG", 4), QG = QGe == 8 ? 8 : (QGe == 2 ? 2 : 4);
     *group16_out = 1;                       // list entries are groups of 16 model points (knn_finalize_kernel expands them)
     const int n_tiles = (M + kT16 - 1) / kT16;
     const int q_blocks = (Q + (kBlock / 64) * QG * 32 - 1) / ((kBlock / 64) * QG * 32);
-    int S = (QG == 8 ? target_blocks / 2 : target_blocks) / q_blocks; if (S < 1) S = 1;
+    int S = (QG == 8 ? target_blocks / 2 : (QG == 2 ? target_blocks * 5 / 4 : target_blocks)) / q_blocks; if (S < 1) S = 1;
     if (S > max_S) S = max_S;
     if (S > n_tiles) S = n_tiles > 0 ? n_tiles : 1;
     int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
@@ -333,13 +332,17 @@ int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, in
         ev0 = g_time_ev[g_time_used].first; ev1 = g_time_ev[g_time_used].second; ++g_time_used;
         PCREG_HIP(hipEventRecord(ev0, st));
     }
-#define PCREG_F16_PIPE(DRYV) if (QG == 8) hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<8, DRYV>), dim3(q_blocks * grid_chunks), dim3(kBlock), 0, st, q, Q, ldq, \
-                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map, S); \
-                             else hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<4, DRYV>), dim3(q_blocks * grid_chunks), dim3(kBlock), 0, st, q, Q, ldq, \
+#define PCREG_F16_LAUNCH(QGV, DRYV) hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<QGV, DRYV>), dim3(q_blocks * grid_chunks), dim3(kBlock), 0, st, q, Q, ldq, \
                            (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map, S)
-    if (dry) { PCREG_F16_PIPE(true); }
-    else { PCREG_F16_PIPE(false); }
-#undef PCREG_F16_PIPE
+#ifdef PCREG_EXPERIMENTS
+    // measured and not kept: 8 query groups per wave at 2 waves per SIMD (timing-only form 1.37 ms, real 1.69 vs 1.61);
+    // 2 groups per wave at 5 waves per SIMD (88 VGPRs; 1.86-1.90 vs 1.58)
+    if (QG == 2) { if (dry) PCREG_F16_LAUNCH(2, true); else PCREG_F16_LAUNCH(2, false); }
+    else if (QG == 8) { if (dry) PCREG_F16_LAUNCH(8, true); else PCREG_F16_LAUNCH(8, false); }
+    else
+#endif
+    { if (dry) PCREG_F16_LAUNCH(4, true); else PCREG_F16_LAUNCH(4, false); }
+#undef PCREG_F16_LAUNCH
     if (ev1) PCREG_HIP(hipEventRecord(ev1, st));
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
