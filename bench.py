@@ -435,6 +435,7 @@ def main() -> None:
     ap.add_argument("--surface-points", type=int, default=50_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only")
+    ap.add_argument("--crops", type=int, default=64, help="crops of the cfg 5 batch")
     args = ap.parse_args()
 
     import torch
@@ -446,16 +447,23 @@ def main() -> None:
         sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PCREG_BENCH_SHARE_GPU=1 (tests only): every rank on cuda:0 with gloo carrying the collectives -- RCCL refuses two ranks
+    # on one device; this rehearses the whole N > 1 control flow of this file on the one-GPU box.  Its timings mean nothing.
+    share = os.environ.get("PCREG_BENCH_SHARE_GPU") == "1"
+    ordinal = 0 if share else local_rank
+    torch.cuda.set_device(ordinal)
+    dev = torch.device("cuda", ordinal)
     force = os.environ.get("PCREG_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ     # one-rank RCCL rehearsal
     collective = world > 1 or force
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     from pcreg_amd._lib import lib, check
-    check(lib().pcreg_set_device(local_rank))
-    torch.cuda.set_device(local_rank)
+    check(lib().pcreg_set_device(ordinal))
+    torch.cuda.set_device(ordinal)
     ctx = Ctx(rank, world, dev, collective)
 
     Q, M_total = args.surface_points, args.model_points
@@ -477,7 +485,7 @@ def main() -> None:
             more["cfg3_model_2M"] = {"workload": f"{Q} surface pts vs 2000000 model pts on one GPU (the 1-GPU point of cfg 3's strong-scaling curve)",
                                      "scaling": "strong", "ms_per_step": round(r["ms_per_step"], 4), "value": round(r["value"], 2), "unit": "Gpairs/s",
                                      "search_call_ms": round(r["search_call_ms"], 4), "ransac": r["ransac"], "steps": extra_steps}
-        more["cfg5_batch"] = run_batch_cfg5(ctx, 64, 1_000_000, Q)
+        more["cfg5_batch"] = run_batch_cfg5(ctx, args.crops, 1_000_000, Q)
 
     if rank == 0:
         rows = head["rows_per_gpu"]

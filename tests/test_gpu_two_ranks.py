@@ -37,3 +37,29 @@ def test_one_rank_rccl_rehearsal_of_every_collective():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     plain = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert forced["ransac"] == plain["ransac"] and not plain["ransac"]["failed"] and plain["ransac"]["n_pairs"] > 1000
+
+
+def test_bench_n2_control_flow_on_one_gpu():
+    """bench.py --gpus 2 end to end with both ranks on cuda:0 and gloo carrying the collectives (RCCL refuses two ranks on
+    one device): the strong-scaling headline on the FIXED model, cfg 3's 2 M model, the weak-scaling run and cfg 5's batch
+    dealt over two ranks all run and agree with the one-rank line where they must (same registration found)."""
+    import json
+    small = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--model-points", "200000", "--surface-points", "20000", "--crops", "4"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCREG_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small,
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["model_points_total"] == 200000
+    assert "100000 rows per GPU" in two["config"]["workload"]
+    for k in ("cfg3_model_2M", "weak_1M_per_gpu", "cfg5_batch"):
+        assert k in two, k
+    assert two["cfg3_model_2M"]["scaling"] == "strong" and two["weak_1M_per_gpu"]["scaling"] == "weak"
+    assert two["cfg5_batch"]["failed"] == 0 and two["cfg5_batch"]["n_gpus"] == 2
+    env1 = {k: v for k, v in os.environ.items() if k not in ("PCREG_BENCH_SHARE_GPU", "PCREG_FORCE_COLLECTIVES")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-extras"] + small, capture_output=True, text=True,
+                       env=env1, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    one = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["ransac"] == one["ransac"] and not one["ransac"]["failed"]          # the sharded run finds the single-GPU registration
