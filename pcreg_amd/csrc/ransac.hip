@@ -311,6 +311,62 @@ __device__ __forceinline__ void mom_accumulate(double (&mom)[27], const double (
     mom_gram(mom, p);
 }
 
+// The same decision with the eigenvectors of the two smaller singular values and a flag: a singular value below ~1e-7
+// sigma_max lies under the noise floor of the Gram matrix (forming A'A squares the condition number), MATLAB's tolerance
+// N eps(sigma_max) is ~1e-12 sigma_max, so in between the Gram cannot tell.  The caller that still has the points settles
+// it with one more pass: the 2 x 2 Gram of the points projected on span(vmid, vmin) holds sigma_2^2 and sigma_3^2 free of
+// the cancellation against sigma_1^2 (the span is accurate to ~eps even when the split inside it is noise); see
+// rank_from_projection, estimate_transform_kernel (estimateTransform.m:11).
+__device__ bool rank_gram_probe(const double (&g)[6], int N, int need, double (&vmid)[3], double (&vmin)[3], double& tol,
+                                bool& ambiguous) {
+    ambiguous = false; tol = 0.0;
+    vmid[0] = vmid[1] = vmid[2] = vmin[0] = vmin[1] = vmin[2] = 0.0;
+    double tr = g[0] + g[3] + g[5];
+    if (!(tr > 0.0)) return false;
+    double A[3][3] = {{g[0], g[1], g[2]}, {g[1], g[3], g[4]}, {g[2], g[4], g[5]}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off <= 1e-300 || off <= 1e-19 * tr) break;
+#define PCREG_JROT(P, Q)                                                                    \
+        if (A[P][Q] != 0.0) {                                                               \
+            double th = (A[Q][Q] - A[P][P]) / (2.0 * A[P][Q]);                              \
+            double t = copysign(1.0, th) / (fabs(th) + sqrt(fma(th, th, 1.0)));             \
+            double c = 1.0 / sqrt(fma(t, t, 1.0)), s = c * t;                               \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[k][P], b = A[k][Q]; A[k][P] = c*a - s*b; A[k][Q] = s*a + c*b; } \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[P][k], b = A[Q][k]; A[P][k] = c*a - s*b; A[Q][k] = s*a + c*b; } \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = V[k][P], b = V[k][Q]; V[k][P] = c*a - s*b; V[k][Q] = s*a + c*b; } \
+        }
+        PCREG_JROT(0, 1) PCREG_JROT(0, 2) PCREG_JROT(1, 2)
+#undef PCREG_JROT
+    }
+    double sv[3] = {sqrt(fmax(A[0][0], 0.0)), sqrt(fmax(A[1][1], 0.0)), sqrt(fmax(A[2][2], 0.0))};
+    int od[3] = {0, 1, 2};                                   // descending
+    if (sv[od[1]] > sv[od[0]]) { int t = od[0]; od[0] = od[1]; od[1] = t; }
+    if (sv[od[2]] > sv[od[0]]) { int t = od[0]; od[0] = od[2]; od[2] = t; }
+    if (sv[od[2]] > sv[od[1]]) { int t = od[1]; od[1] = od[2]; od[2] = t; }
+    const double smax = sv[od[0]];
+    tol = (double)(N > 3 ? N : 3) * ulp_at(smax);
+    const int kd = need >= 3 ? od[2] : od[1];                // the singular value that decides rank >= need
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { if (c == od[1]) a = V[k][c]; if (c == od[2]) b = V[k][c]; }
+        vmid[k] = a; vmin[k] = b;
+    }
+    ambiguous = sv[kd] <= 1e-7 * smax;
+    return ((sv[0] > tol) + (sv[1] > tol) + (sv[2] > tol)) >= need;
+}
+// sigma_2 (need = 2) or sigma_3 (need = 3) from the projected 2 x 2 Gram [aa ab; ab bb], compared with MATLAB's tolerance
+__device__ bool rank_from_projection(double aa, double ab, double bb, int need, double tol) {
+    const double h = 0.5 * (aa - bb), lmax = 0.5 * (aa + bb) + sqrt(fma(h, h, ab * ab));
+    if (!(lmax > 0.0)) return false;
+    if (need < 3) return sqrt(lmax) > tol;
+    const double w = ab * ab, det = fma(aa, bb, -w) + fma(-ab, ab, w);      // aa bb - ab^2 with the product's rounding undone
+    return sqrt(fmax(det, 0.0) / lmax) > tol;
+}
+
 // estimateTransform for N > 3 correspondences given their moments.
 __device__ bool fit_moments(int N, const double (&mom)[27], const double (&o)[6], double (&T)[12], bool rank_certified = false) {
     if (N < 4) return false;
@@ -1679,7 +1735,27 @@ __global__ __launch_bounds__(64) void estimate_transform_kernel(const double* p1
         for (int i = lane; i < n; i += 64) { double q[6]; P.load(i, q); mom_accumulate(acc, q, o); }
 #pragma unroll
         for (int k = 0; k < 27; ++k) mom[k] = wave_sum(acc[k]);
-        ok = fit_moments(n, mom, o, T);
+        // rank(pts1) >= 3 and rank(pts2) >= 2 (estimateTransform.m:11): from the Grams where they can tell, from the points
+        // themselves (one more pass along the deciding eigenvector) where the Gram's noise floor hides the answer
+        const double g1[6] = {mom[15], mom[16], mom[17], mom[18], mom[19], mom[20]};
+        const double g2[6] = {mom[21], mom[22], mom[23], mom[24], mom[25], mom[26]};
+        double u1[3], w1[3], u2[3], w2[3], tol1, tol2; bool amb1, amb2;
+        bool r1 = rank_gram_probe(g1, n, 3, u1, w1, tol1, amb1), r2 = rank_gram_probe(g2, n, 2, u2, w2, tol2, amb2);
+        if (amb1 || amb2) {
+            double e[6] = {0, 0, 0, 0, 0, 0};
+            for (int i = lane; i < n; i += 64) {
+                double q[6]; P.load(i, q);
+                const double a1 = fma(q[2], u1[2], fma(q[1], u1[1], q[0] * u1[0])), b1 = fma(q[2], w1[2], fma(q[1], w1[1], q[0] * w1[0]));
+                const double a2 = fma(q[5], u2[2], fma(q[4], u2[1], q[3] * u2[0])), b2 = fma(q[5], w2[2], fma(q[4], w2[1], q[3] * w2[0]));
+                e[0] = fma(a1, a1, e[0]); e[1] = fma(a1, b1, e[1]); e[2] = fma(b1, b1, e[2]);
+                e[3] = fma(a2, a2, e[3]); e[4] = fma(a2, b2, e[4]); e[5] = fma(b2, b2, e[5]);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) e[k] = wave_sum(e[k]);
+            if (amb1) r1 = rank_from_projection(e[0], e[1], e[2], 3, tol1);
+            if (amb2) r2 = rank_from_projection(e[3], e[4], e[5], 2, tol2);
+        }
+        ok = r1 && r2 && fit_moments(n, mom, o, T, true);
     }
     if (lane < 16) {
         int k = lane & 3, j = lane >> 2;

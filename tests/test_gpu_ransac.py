@@ -340,3 +340,36 @@ def test_hypotheses_split_in_shares_equal_the_single_run(n, iters, world):
     assert not single[4]
     for a, b in zip(single, split):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("ratio", [0.0, 1e-13, 1e-11, 1e-9, 1e-6])
+@pytest.mark.parametrize("n", [5, 50, 5000])
+def test_estimate_transform_rank_decision_near_planar(n, ratio):
+    """estimateTransform.m:11 -- rank(pts1) < 3 -> [].  A rotated plane through the origin with thickness
+    ratio * extent: MATLAB's tolerance is N * eps(sigma_max), far below what a Gram matrix can resolve
+    (sigma^2 drowns at ~1e-8); the public entry decides it from the points themselves."""
+    import pcreg_amd as pc
+    from oracle import pcreg_oracle as o
+    rng = np.random.default_rng(n)
+    flat = rng.uniform(-40, 40, size=(n, 3)); flat[:, 2] = rng.standard_normal(n) * ratio * 40.0
+    R = o.eul2rotm([0.7, -0.4, 1.1])
+    p1 = flat @ R
+    Rt = o.eul2rotm([0.3, 0.2, -0.5]); p2 = p1 @ Rt + np.array([3.0, -2.0, 5.0])
+    want = o.estimateTransform(p1, p2)                      # None stands for MATLAB's []
+    assert (want is None) == (o.matlab_rank(p1) < 3)
+    got = pc.estimateTransform(p1, p2)
+    assert (got.size == 0) == (want is None), (o.matlab_rank(p1), np.linalg.svd(p1, compute_uv=False))
+    if want is not None:
+        # estimateTransform.m:62 has no reflection fix: the third singular pair of H (~ratio^2 of the first) picks rotation
+        # or mirror image, and below ~1e-8 rounding noise picks it -- in LAPACK as much as here.  Both map the plane onto
+        # itself, so compare T where the data decide and the residual everywhere.
+        if ratio >= 1e-6:
+            assert np.abs(got - want).max() < 1e-5
+        res = np.hstack([p2, np.ones((n, 1))]) @ got
+        assert np.abs(res[:, :3] - p1).max() < 1e-5 + 200.0 * ratio and np.abs(got[:3, :3] @ got[:3, :3].T - np.eye(3)).max() < 1e-12
+    # and on the model side: rank(pts2) < 2 (a line through the origin) -> []
+    line = np.outer(rng.uniform(-40, 40, n), R[0]) + np.outer(rng.standard_normal(n) * ratio * 40.0, R[1])
+    want = o.estimateTransform(rng.uniform(-40, 40, size=(n, 3)), line)
+    got = pc.estimateTransform(rng.uniform(-40, 40, size=(n, 3)), line)
+    if want is None or ratio >= 1e-11:      # below ~1e-12 H has ONE usable singular pair: MATLAB returns a T made of rounding
+        assert (got.size == 0) == (want is None)    # noise there, this library [] (DESIGN.md section 3)
