@@ -21,6 +21,7 @@
 //   compact      order-preserving compaction of the surviving rows into feat / desc (double).
 // The dominant traffic is the 980-count row per keypoint: HBM-write-bound.
 #include "common.hpp"
+#include "wave_math.hpp"
 #include "select.hpp"
 #include "select_kth.hpp"
 #include <cfloat>
@@ -203,63 +204,29 @@ __global__ void kp_scatter_kernel(const int32_t* __restrict__ kcell, int S, cons
 }
 
 // ---- per-keypoint descriptor ------------------------------------------------------------------
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ double bsum(double v, double* s_red) {
-    v = wsum(v);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
-    __syncthreads();
-    return t;
-}
-// N sums at once: the same per-value order as bsum (wave butterfly, then ((w0+w1)+w2)+w3), one barrier pair
+// block-wide sums of a 256-thread workgroup: DPP wave sums (wave_math.hpp: no LDS crossbar), then every wave adds the
+// four wave partials the same way, so all threads hold the same bits; one barrier pair per call
 template <int N>
 __device__ __forceinline__ void bsum_n(double (&v)[N], double* s_redn /*[4][N]*/) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wsum(v[k]);
-    if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(v[k]);
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < N; ++k) s_redn[(threadIdx.x >> 6) * N + k] = v[k];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = ((s_redn[k] + s_redn[N + k]) + s_redn[2 * N + k]) + s_redn[3 * N + k];
+    for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(lane < 4 ? s_redn[lane * N + k] : 0.0);
     __syncthreads();
 }
 __device__ __forceinline__ int bsum_i(int v, int* s_red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = wave_sum_dpp_i(v);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     int t = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     __syncthreads();
     return t;
-}
-__device__ void jacobi3(double (&A)[3][3], double (&V)[3][3]) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) V[r][c] = r == c ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        double dia = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
-        if (off <= 1e-300 || off <= DBL_EPSILON * 1e-3 * dia) break;
-#define PCREG_JROT(P_, Q_)                                                                  \
-        if (A[P_][Q_] != 0.0) {                                                             \
-            double th = (A[Q_][Q_] - A[P_][P_]) / (2.0 * A[P_][Q_]);                        \
-            double t = copysign(1.0, th) / (fabs(th) + sqrt(th * th + 1.0));                \
-            double c = 1.0 / sqrt(t * t + 1.0), s = c * t;                                  \
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[k][P_], b = A[k][Q_]; A[k][P_] = c*a - s*b; A[k][Q_] = s*a + c*b; } \
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = A[P_][k], b = A[Q_][k]; A[P_][k] = c*a - s*b; A[Q_][k] = s*a + c*b; } \
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { double a = V[k][P_], b = V[k][Q_]; V[k][P_] = c*a - s*b; V[k][Q_] = s*a + c*b; } \
-        }
-        PCREG_JROT(0, 1) PCREG_JROT(0, 2) PCREG_JROT(1, 2)
-#undef PCREG_JROT
-    }
 }
 // histcounts bin (histcn.m:108): e[k-1] <= x < e[k], last bin closed, 0 = outside / NaN
 template <int NE>
@@ -290,6 +257,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     __shared__ int s_nsmall, s_bin, s_below, s_nless, s_neq;
     __shared__ int s_ok;
     __shared__ double s_m[9];
+    __shared__ double s_V[9];
 
     const Grid g = *gp;
     const int s = perm[blockIdx.x];
@@ -432,11 +400,9 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         // distance), then an exact rank inside the bin that holds it; bisection only if that bin is crowded
         unsigned long long lo = ~0ull, hi = 0ull;
         PCREG_MY_KEYS(lo = k < lo ? k : lo; hi = k > hi ? k : hi;)
-#pragma unroll
-        for (int ofs = 32; ofs > 0; ofs >>= 1) {
-            const unsigned long long a2 = __shfl_xor(lo, ofs), b2 = __shfl_xor(hi, ofs);
-            lo = a2 < lo ? a2 : lo; hi = b2 > hi ? b2 : hi;
-        }
+        // the keys are bit patterns of non-negative doubles: reduce them as doubles (DPP, wave_math.hpp)
+        lo = kth_key(wave_min_dpp(lo == ~0ull ? DBL_MAX : __longlong_as_double((long long)lo)));
+        hi = kth_key(wave_max_dpp(__longlong_as_double((long long)hi)));
         if (lane == 0) { s_u64[wave] = lo; s_u64[4 + wave] = hi; }
         for (int i = tid; i < 256; i += kBlock) s_hist[i] = 0;
         if (tid == 0) { s_nsmall = 0; s_vk = 0ull; s_nless = 0; s_neq = 0; }
@@ -536,10 +502,9 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
 #pragma unroll
     for (int k = 0; k < 6; ++k) cv[k] = cv[k] / (double)(K - 1);
     if (tid == 0) {
-        double A[3][3] = {{cv[0], cv[1], cv[2]}, {cv[1], cv[3], cv[4]}, {cv[2], cv[4], cv[5]}};
-        double V[3][3];
-        jacobi3(A, V);
-        double ev[3] = {A[0][0], A[1][1], A[2][2]};
+        double a[6] = {cv[0], cv[1], cv[2], cv[3], cv[4], cv[5]};
+        jacobi_sym3(a, s_V);
+        double ev[3] = {a[0], a[3], a[5]};
         int od[3] = {0, 1, 2};
         if (ev[od[1]] > ev[od[0]]) { int t = od[0]; od[0] = od[1]; od[1] = t; }
         if (ev[od[2]] > ev[od[0]]) { int t = od[0]; od[0] = od[2]; od[2] = t; }
@@ -547,8 +512,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         double v0 = ev[od[0]], v1 = ev[od[1]], v2 = ev[od[2]];
         s_ok = !((v0 / v1 < o.thVar[0]) || (v1 / v2 < o.thVar[1]));        // :118-121
         for (int col = 0; col < 3; ++col) {
-            double a0 = 0, a1 = 0, a2 = 0;
-            for (int k = 0; k < 3; ++k) if (od[col] == k) { a0 = V[0][k]; a1 = V[1][k]; a2 = V[2][k]; }
+            const double a0 = s_V[od[col]], a1 = s_V[3 + od[col]], a2 = s_V[6 + od[col]];
             double big = a0;
             if (fabs(a1) > fabs(big)) big = a1;
             if (fabs(a2) > fabs(big)) big = a2;

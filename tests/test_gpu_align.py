@@ -21,8 +21,18 @@ def test_align_points_knn(n, C1, C2, oracle_c):
     al, co, c = pc.AlignPoints_KNN(X, C1, C2)
     ral, rco, rc = oracle_c.AlignPoints_KNN(X, C1, C2)
     assert np.abs(c.ravel() - rc).max() < TOL
-    assert np.abs(co - rco).max() < TOL
-    assert np.abs(al - ral).max() < TOL
+    if n >= 20:
+        assert np.abs(co - rco).max() < TOL
+        assert np.abs(al - ral).max() < TOL
+        return
+    # n = 2, 3: the covariance of the K kept points is singular.  The principal axis is defined (and must agree);
+    # the basis of the null space (n = 2) and the sign of the plane's normal (n = 3: the vote of :45-50 counts
+    # projections that are zero up to rounding) are whatever the eigen-solver's rounding makes them -- in MATLAB's
+    # LAPACK as in the oracle's Jacobi -- so compare what the input determines
+    assert np.abs(co[:, 0] - rco[:, 0]).max() < TOL and np.abs(al[:, 0] - ral[:, 0]).max() < TOL
+    assert np.abs(co.T @ co - np.eye(3)).max() < TOL and np.abs(al - X @ co).max() < TOL
+    if n == 3:
+        assert np.abs(np.abs(co) - np.abs(rco)).max() < TOL
 
 
 def test_align_points_knn_ties_and_varargin(oracle_c):
