@@ -40,7 +40,9 @@ struct Grid {
     double ox, oy, oz, inv;                // origin and 1 / cell edge
     int nx, ny, nz, ncells;
 };
-struct Edges { double r[NR + 1], t[NT + 1], p[NP + 1], ct[NT + 1]; };   // ct = cos(t)
+// ct = cos(t); r2ge[k] = the smallest d2 with sqrt(d2) >= r[k], r2gt = the smallest d2 with sqrt(d2) > r[NR] (the radial
+// bin of a point follows from its SQUARED distance, exactly); cts[k] = ct[k] |ct[k]| (theta's bin from z |z| vs cts d2)
+struct Edges { double r[NR + 1], t[NT + 1], p[NP + 1], ct[NT + 1], r2ge[NR + 1], r2gt, cts[NT + 1]; };
 
 __device__ __forceinline__ int cell_coord(double v, double o, double inv, int n) {
     int c = (int)floor((v - o) * inv);
@@ -242,11 +244,11 @@ __device__ __forceinline__ int hist_loc(double x, const double (&e)[NE]) {
 __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ sz,
     const int32_t* __restrict__ sorted_idx, const int32_t* __restrict__ cell_start, const Grid* __restrict__ gp,
-    const double* __restrict__ kp, const int32_t* __restrict__ perm, int S, int ldk, pcreg_desc_opts o, Edges ed, int cap, int dbg_stop,
+    const double* __restrict__ kp, const int32_t* __restrict__ perm, int S, int ldk, pcreg_desc_opts o, Edges ed, double R2T, int cap, int dbg_stop, int xcd_chunk,
     uint32_t* __restrict__ rows /*[S][ND]*/, int32_t* __restrict__ valid, int32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* lpos = reinterpret_cast<int*>(smem);                           // [cap] position in the sorted arrays (+ a "kept" flag bit)
-    __shared__ double s_redn[4 * 6];
+    __shared__ double s_redn[4 * 9];
     __shared__ int s_redi[4];
     __shared__ unsigned s_cnt[ND];
     __shared__ unsigned long long s_u64[8];
@@ -260,10 +262,15 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     __shared__ double s_V[9];
 
     const Grid g = *gp;
-    const int s = perm[blockIdx.x];
+    // workgroups are dealt round-robin over the 8 XCDs: XCD x walks its own eighth of the cell-ordered keypoints, so its
+    // L2 holds the few cells its ~128 concurrent keypoints share instead of a slice of everybody's (PCREG_DESC_XCD=0: off)
+    int slot = blockIdx.x;
+    if (xcd_chunk > 0) { slot = (blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3); if ((int)(blockIdx.x >> 3) >= xcd_chunk || slot >= S) return; }
+    const int s = perm[slot];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double cx = kp[s], cy = kp[s + (size_t)ldk], cz = kp[s + 2 * (size_t)ldk];
-    const double R = o.R;
+    // sqrt(d2) < R (getLocalPoints.m:23-25) <=> d2 < R2T, R2T = the smallest double whose correctly rounded square root
+    // is >= R (found by the launcher): the same decision for every d2, without ~25 fp64 instructions per candidate
     if (tid == 0) valid[s] = 0;
     for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
     __syncthreads();
@@ -296,8 +303,9 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     auto in_sphere = [&](int j, int end) -> bool {
         if (j >= end) return false;
         const double x = sx[j] - cx, y = sy[j] - cy, z = sz[j] - cz;
-        return sqrt(x * x + y * y + z * z) < R;                             // getLocalPoints.m:23-25
+        return x * x + y * y + z * z < R2T;                                 // getLocalPoints.m:23-25 (see R2T)
     };
+    double a3[3] = {0, 0, 0};
     {
         int ch = 0;                                  // running chunk number of this wave
 #pragma unroll
@@ -314,7 +322,8 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
                 for (int u = 0; u < 4; ++u) {
                     if (j0 + u * 64 < re[r]) {       // wave-uniform
                         const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
-                        const bool in = (j0 + u * 64 + lane < re[r]) && sqrt(x * x + y * y + z * z) < R;
+                        const bool in = (j0 + u * 64 + lane < re[r]) && x * x + y * y + z * z < R2T;
+                        if (in) { a3[0] += x; a3[1] += y; a3[2] += z; }        // the local centroid's sums ride along (:80)
                         const unsigned long long bal = __ballot(in);
                         if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
                         ++ch;
@@ -375,9 +384,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     const bool all = o.k >= 1.0;
     const int K = all ? n : (int)floor(n * o.k + 0.5);
     if (K < 2) return;
-    double a3[3] = {0, 0, 0};
-    PCREG_MY_PTS(a3[0] += px; a3[1] += py; a3[2] += pz;)
-    bsum_n<3>(a3, s_redn);
+    bsum_n<3>(a3, s_redn);                          // summed while the candidates streamed by (collection pass 1)
     const double gx = a3[0] / n, gy = a3[1] / n, gz = a3[2] / n;
     if (!all) {
 #define PCREG_KEY(px, py, pz) kth_key(sqrt(((px) - gx) * ((px) - gx) + ((py) - gy) * ((py) - gy) + ((pz) - gz) * ((pz) - gz)))
@@ -488,17 +495,20 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
 
     if (dbg_stop == 2) return;
     // ---- pca(pts_k, 'eig') (:91) ----
-    double b3[3] = {0, 0, 0};
-    PCREG_MY_PTS(if (psel) { b3[0] += px; b3[1] += py; b3[2] += pz; })
-    bsum_n<3>(b3, s_redn);
-    const double mx = b3[0] / K, my = b3[1] / K, mz = b3[2] / K;
-    double cv[6] = {0, 0, 0, 0, 0, 0};
+    // ONE pass for the mean and the covariance of the K kept points: first and second moments of q = p - g about the
+    // local centroid g (known since the selection; the kept points are the K nearest to it, so their mean is a small
+    // fraction of their spread away and cov = (sum q q' - K d d') / (K - 1), d = sum q / K, loses nothing to cancellation)
+    double mo[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     PCREG_MY_PTS(
         if (psel) {
-            const double x = px - mx, y = py - my, z = pz - mz;
-            cv[0] += x * x; cv[1] += x * y; cv[2] += x * z; cv[3] += y * y; cv[4] += y * z; cv[5] += z * z;
+            const double x = px - gx, y = py - gy, z = pz - gz;
+            mo[0] += x; mo[1] += y; mo[2] += z;
+            mo[3] += x * x; mo[4] += x * y; mo[5] += x * z; mo[6] += y * y; mo[7] += y * z; mo[8] += z * z;
         })
-    bsum_n<6>(cv, s_redn);
+    bsum_n<9>(mo, s_redn);
+    const double dx = mo[0] / K, dy = mo[1] / K, dz = mo[2] / K;
+    const double mx = gx + dx, my = gy + dy, mz = gz + dz;
+    double cv[6] = {mo[3] - K * dx * dx, mo[4] - K * dx * dy, mo[5] - K * dx * dz, mo[6] - K * dy * dy, mo[7] - K * dy * dz, mo[8] - K * dz * dz};
 #pragma unroll
     for (int k = 0; k < 6; ++k) cv[k] = cv[k] / (double)(K - 1);
     if (tid == 0) {
@@ -544,26 +554,46 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     }
     if (dbg_stop == 3) return;
     // ---- spherical histogram over ALL local points (:150-171, histcn.m:108-131) ----
+    // Per point: r = |p|, theta = acos(z / r), phi = atan2(y, y) (sic, :152), then histcounts on each.  None of the three
+    // needs its transcendental -- or even the square root and the division -- for the bin:
+    //  * r's bin from d2 = x^2 + y^2 + z^2 against the exact squared images of the edges (Edges::r2ge);
+    //  * phi only depends on the sign of y (two constants, binned once);
+    //  * theta's bin from z |z| against cos(edge) |cos(edge)| d2, both monotone images of z / r and cos(edge), unless the
+    //    two are within 1e-12 d2 of each other (then |z / r - cos(edge)| could be below the 1e-13 that keeps the computed
+    //    acos on its side of the edge, |acos'| >= 1) or the point is within 1e-6 rad of the z axis: those points, and
+    //    any with y == 0, take the literal path (sqrt, division, fp64 acos / atan2).
     const double ph_pos = atan2(1.0, 1.0), ph_neg = atan2(-1.0, -1.0);
+    const int lp_pos = hist_loc<NP + 1>(ph_pos, ed.p), lp_neg = hist_loc<NP + 1>(ph_neg, ed.p);
     PCREG_MY_PTS(
         double x = px; double y = py; double z = pz;
         if (o.ALIGN_POINTS) { x = px * cu[0] + py * cu[3] + pz * cu[6]; y = px * cu[1] + py * cu[4] + pz * cu[7]; z = px * cu[2] + py * cu[5] + pz * cu[8]; }
-        const double r = sqrt(x * x + y * y + z * z); const double u = z / r;
-        // phi = atan2(y, y) (sic, :152) only depends on the sign of y; theta's bin follows from comparing
-        // cos(theta) = z/r with the cosines of the edges unless it is within 1e-13 of one (|acos'| >= 1, so the
-        // computed acos cannot cross that edge); only those points pay for the fp64 acos / atan2
-        const double ph = y > 0.0 ? ph_pos : (y < 0.0 ? ph_neg : atan2(y, y));
-        bool safe = (1.0 - u) > 1e-13 && (u + 1.0) > 1e-13;
+        const double xy2 = x * x + y * y; const double d2 = xy2 + z * z;
+        const double zs = z * fabs(z);
+        bool safe = xy2 > 1e-12 * d2 && y != 0.0;
         int lt = 1;
-        _Pragma("unroll") for (int jj = 1; jj < NT; ++jj) { const double dl = u - ed.ct[jj]; safe = safe && fabs(dl) > 1e-13; lt += dl < 0.0; }
-        if (!safe) lt = hist_loc<NT + 1>(acos(u), ed.t);
-        const int lr = hist_loc<NR + 1>(r, ed.r); const int lp = hist_loc<NP + 1>(ph, ed.p);
+        _Pragma("unroll") for (int jj = 1; jj < NT; ++jj) { const double dl = zs - ed.cts[jj] * d2; safe = safe && fabs(dl) > 1e-12 * d2; lt += dl < 0.0; }
+        int lr = 0;
+        if (d2 < ed.r2gt) { lr = 1; _Pragma("unroll") for (int jj = 1; jj < NR; ++jj) lr += d2 >= ed.r2ge[jj]; if (!(d2 >= ed.r2ge[0])) lr = 0; }
+        int lp = y > 0.0 ? lp_pos : lp_neg;
+        if (!safe) {
+            const double r = sqrt(d2); const double u = z / r;
+            lt = hist_loc<NT + 1>(acos(u), ed.t); lr = hist_loc<NR + 1>(r, ed.r); lp = hist_loc<NP + 1>(atan2(y, y), ed.p);
+        }
         if (lr > 0 && lt > 0 && lp > 0) atomicAdd(&s_cnt[(lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1)], 1u);)
     __syncthreads();
     uint32_t* row = rows + (size_t)s * ND;
     for (int i = tid; i < ND; i += kBlock) row[i] = s_cnt[i];
     if (tid == 0) valid[s] = 1;
 #undef PCREG_MY_PTS
+}
+
+// the smallest double t with sqrt(t) >= r under IEEE round-to-nearest (host; r > 0 finite): sqrt(d2) < r <=> d2 < t
+static double sqrt_threshold(double r) {
+    if (!(r > 0.0) || !std::isfinite(r)) return r > 0.0 ? r : 0.0;       // r <= 0 or NaN: nothing is inside; +inf: everything finite
+    double t = r * r;
+    while (t > 0.0 && std::sqrt(t) >= r) t = std::nextafter(t, 0.0);
+    while (std::sqrt(t) < r) t = std::nextafter(t, INFINITY);
+    return t;
 }
 
 // ---- compaction of the surviving rows (:177-179) ----------------------------------------------
@@ -666,14 +696,18 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     Edges ed;
     const double r3 = o.R * o.R * o.R, pi = 3.14159265358979323846;
     for (int k = 0; k <= NR; ++k) ed.r[k] = cbrt(k * (r3 / NR));                 // nthroot(0:R^3/10:R^3, 3)
-    for (int k = 0; k <= NT; ++k) { ed.t[k] = k * (pi / NT); ed.ct[k] = cos(ed.t[k]); }   // 0:pi/7:pi
+    for (int k = 0; k <= NT; ++k) { ed.t[k] = k * (pi / NT); ed.ct[k] = cos(ed.t[k]); ed.cts[k] = ed.ct[k] * fabs(ed.ct[k]); }   // 0:pi/7:pi
+    for (int k = 0; k <= NR; ++k) ed.r2ge[k] = sqrt_threshold(ed.r[k]);
+    ed.r2gt = sqrt_threshold(std::nextafter(ed.r[NR], INFINITY));
     for (int k = 0; k <= NP; ++k) ed.p[k] = -pi + k * (2 * pi / NP);             // -pi:2*pi/14:pi
     int cap = o.max_pts < 8190 ? o.max_pts + 1 : 8191;
     if (cap < 64) cap = 64;
     size_t lds = (size_t)cap * sizeof(int);
     PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(desc_kernel, dim3(S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, perm, S, ldk, o,
-                       ed, cap, PCREG_EXP_ENV("PCREG_DESC_STOP", 0), rows, valid, err_dev);
+    const int xcd_chunk = PCREG_EXP_ENV("PCREG_DESC_XCD", 1) ? (S + 7) / 8 : 0;
+    const double R2T = sqrt_threshold(o.R);
+    hipLaunchKernelGGL(desc_kernel, dim3(xcd_chunk ? 8 * xcd_chunk : S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, perm, S, ldk, o,
+                       ed, R2T, cap, PCREG_EXP_ENV("PCREG_DESC_STOP", 0), xcd_chunk, rows, valid, err_dev);
     PCREG_HIP(hipGetLastError());
     const int nbs = (S + 255) / 256;
     hipLaunchKernelGGL(desc_count_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt);
