@@ -37,7 +37,8 @@ constexpr int kMaxCells = 1 << 16;
 constexpr int NR = 10, NT = 7, NP = 14, ND = NR * NT * NP;
 
 struct Grid {
-    double ox, oy, oz, inv;                // origin and 1 / cell edge
+    double ox, oy, oz, inv;                // origin and 1 / cell edge (y, z)
+    double invx, h;                        // 1 / cell edge along x (a fraction of h: see grid_setup_kernel), h = y/z edge
     int nx, ny, nz, ncells;
 };
 // ct = cos(t); r2ge[k] = the smallest d2 with sqrt(d2) >= r[k], r2gt = the smallest d2 with sqrt(d2) > r[NR] (the radial
@@ -49,7 +50,7 @@ __device__ __forceinline__ int cell_coord(double v, double o, double inv, int n)
     return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 __device__ __forceinline__ int cell_of(const Grid& g, double x, double y, double z) {
-    return (cell_coord(z, g.oz, g.inv, g.nz) * g.ny + cell_coord(y, g.oy, g.inv, g.ny)) * g.nx + cell_coord(x, g.ox, g.inv, g.nx);
+    return (cell_coord(z, g.oz, g.inv, g.nz) * g.ny + cell_coord(y, g.oy, g.inv, g.ny)) * g.nx + cell_coord(x, g.ox, g.invx, g.nx);
 }
 
 // ---- grid: bounding box -> cell size ------------------------------------------------------
@@ -87,7 +88,14 @@ __global__ void grid_setup_kernel(const double* __restrict__ part, int nparts, d
         if (nx * ny * nz <= (double)kMaxCells) { g->nx = (int)nx; g->ny = (int)ny; g->nz = (int)nz; break; }
         cell *= 1.26;                      // ~ halve the cell count
     }
-    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2]; g->inv = 1.0 / cell;
+    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2]; g->inv = 1.0 / cell; g->h = cell;
+    // Cells are thinner along x (edge h / fx, as many as fit): a keypoint's nine (dz, dy) rows stay contiguous runs, but each
+    // is cut to the x interval the sphere can reach in that row -- about half the candidates of the 3 x 3 x 3 block, and the
+    // kept points sit twice as densely in the runs the later passes gather from
+    int fx = 8;
+    while (fx > 1 && (floor((hi[0] - lo[0]) * fx / cell) + 1) * g->ny * g->nz > (double)kMaxCells) fx >>= 1;
+    g->invx = fx / cell;
+    g->nx = (int)(floor((hi[0] - lo[0]) * g->invx) + 1);
     g->ncells = g->nx * g->ny * g->nz;
 }
 
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     const int s = perm[slot];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double cx = kp[s], cy = kp[s + (size_t)ldk], cz = kp[s + 2 * (size_t)ldk];
+    const double R = o.R;
     // sqrt(d2) < R (getLocalPoints.m:23-25) <=> d2 < R2T, R2T = the smallest double whose correctly rounded square root
     // is >= R (found by the launcher): the same decision for every d2, without ~25 fp64 instructions per candidate
     if (tid == 0) valid[s] = 0;
@@ -280,9 +289,8 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     // row is cut into four wave segments; pass 1 only counts, one barrier turns the 36 counts into list
     // offsets, pass 2 re-tests and writes -- the list order (row, then ascending position) is the same
     // as a serial scan's, with two barriers instead of three per 256 candidates.
-    const int kx = cell_coord(cx, g.ox, g.inv, g.nx), ky = cell_coord(cy, g.oy, g.inv, g.ny), kz = cell_coord(cz, g.oz, g.inv, g.nz);
-    // a keypoint outside the cloud's box by more than one cell has no neighbours: the clamped
-    // cell is then farther than R along that axis and the distance test rejects everything
+    const int ky = cell_coord(cy, g.oy, g.inv, g.ny), kz = cell_coord(cz, g.oz, g.inv, g.nz);
+    // a keypoint outside the cloud's box by more than one cell has no neighbours: its rows are then farther than R
     __shared__ int s_seg[9][4];
     int rb[9], re[9];                               // this wave's segment of every row
 #pragma unroll
@@ -290,8 +298,16 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         const int zz = kz + r / 3 - 1, yy = ky + r % 3 - 1;
         int b = 0, e = 0;
         if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
-            const int x0 = max(kx - 1, 0), x1 = min(kx + 1, g.nx - 1);
-            b = cell_start[(zz * g.ny + yy) * g.nx + x0]; e = cell_start[(zz * g.ny + yy) * g.nx + x1 + 1];   // x-adjacent cells are contiguous
+            // the row's slab in y and z keeps every point at least (gy, gz) away from the keypoint: what is left of R^2
+            // bounds |x - cx|.  Margins of 1e-9 (cell edges are products rounded once, cell_coord is monotone in x).
+            const double ylo = g.oy + yy * g.h, zlo = g.oz + zz * g.h;
+            const double gy = fmax(0.0, fmax(ylo - cy, cy - (ylo + g.h)) - 1e-9 * g.h), gz = fmax(0.0, fmax(zlo - cz, cz - (zlo + g.h)) - 1e-9 * g.h);
+            const double w2 = R * R - gy * gy - gz * gz;
+            if (w2 >= 0.0) {
+                const double w = sqrt(w2) + 1e-9 * R;
+                const int x0 = cell_coord(cx - w, g.ox, g.invx, g.nx), x1 = cell_coord(cx + w, g.ox, g.invx, g.nx);
+                b = cell_start[(zz * g.ny + yy) * g.nx + x0]; e = cell_start[(zz * g.ny + yy) * g.nx + x1 + 1];   // x-adjacent cells are contiguous
+            }
         }
         const int seg = (((e - b) + 3) / 4 + 63) / 64 * 64;
         rb[r] = min(e, b + wave * seg); re[r] = min(e, b + (wave + 1) * seg);
@@ -423,8 +439,10 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
             const int bb = (int)((__longlong_as_double((long long)k) - dlo) * scale);
             return bb > 255 ? 255 : bb;
         };
+        if (dbg_stop == 4) return;
         PCREG_MY_KEYS(atomicAdd(&s_hist[bin_of(k)], 1);)
         __syncthreads();
+        if (dbg_stop == 5) return;
         if (wave == 0) {                             // the bin of the K-th and the number of entries below that bin
             int c4[4], run = 0;
 #pragma unroll
@@ -468,6 +486,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
             PCREG_MY_KEYS(c1 += k < vK; c2 += k == vK;)
             n_less = bsum_i(c1, s_redi); n_eq = bsum_i(c2, s_redi);
         }
+        if (dbg_stop == 6) return;
         const int take_eq = K - n_less;
         // ties at the K-th distance: the stable sort keeps the lowest ORIGINAL indices
         unsigned sm = 0u;
