@@ -268,6 +268,9 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     __shared__ int s_ok;
     __shared__ double s_m[9];
     __shared__ double s_V[9];
+    constexpr int kDef = 128;
+    __shared__ int s_def[kDef];
+    __shared__ int s_ndef;
 
     const Grid g = *gp;
     // workgroups are dealt round-robin over the 8 XCDs: XCD x walks its own eighth of the cell-ordered keypoints, so its
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     const double R = o.R;
     // sqrt(d2) < R (getLocalPoints.m:23-25) <=> d2 < R2T, R2T = the smallest double whose correctly rounded square root
     // is >= R (found by the launcher): the same decision for every d2, without ~25 fp64 instructions per candidate
-    if (tid == 0) valid[s] = 0;
+    if (tid == 0) { valid[s] = 0; s_ndef = 0; }
     for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
     __syncthreads();
 
@@ -554,25 +557,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     double cu[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) cu[k] = s_m[k];
-    if (o.ALIGN_POINTS) {                                                   // :128-145, vote over the K rows
-        int vx = 0, vz = 0;
-        PCREG_MY_PTS(
-            if (psel) {
-                const double x = px - mx, y = py - my, z = pz - mz;
-                vx += (x * cu[0] + y * cu[3] + z * cu[6]) > 0;
-                vz += (x * cu[2] + y * cu[5] + z * cu[8]) > 0;
-            })
-        vx = bsum_i(vx, s_redi); vz = bsum_i(vz, s_redi);
-        double xs = (2.0 * vx >= (double)K) ? 1.0 : -1.0, zs = (2.0 * vz >= (double)K) ? 1.0 : -1.0;
-        double M[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { M[r * 3] = cu[r * 3] * xs; M[r * 3 + 1] = cu[r * 3 + 1]; M[r * 3 + 2] = cu[r * 3 + 2] * zs; }
-        double ys = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { cu[r * 3] = cu[r * 3] * xs; cu[r * 3 + 1] = cu[r * 3 + 1] * ys; cu[r * 3 + 2] = cu[r * 3 + 2] * zs; }
-    }
-    if (dbg_stop == 3) return;
-    // ---- spherical histogram over ALL local points (:150-171, histcn.m:108-131) ----
+    // ---- sign vote (:128-145) and spherical histogram over ALL local points (:150-171, histcn.m:108-131) ----
     // Per point: r = |p|, theta = acos(z / r), phi = atan2(y, y) (sic, :152), then histcounts on each.  None of the three
     // needs its transcendental -- or even the square root and the division -- for the bin:
     //  * r's bin from d2 = x^2 + y^2 + z^2 against the exact squared images of the edges (Edges::r2ge);
@@ -581,27 +566,95 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     //    two are within 1e-12 d2 of each other (then |z / r - cos(edge)| could be below the 1e-13 that keeps the computed
     //    acos on its side of the edge, |acos'| >= 1) or the point is within 1e-6 rad of the z axis: those points, and
     //    any with y == 0, take the literal path (sqrt, division, fp64 acos / atan2).
+    // With ALIGN_POINTS the vote and the histogram share ONE pass.  The vote only flips signs: column 0 by xs, column 2
+    // by zs, and column 1 is scaled by ys = det(the flipped matrix) (:53) = xs zs det(the unflipped one) -- every term of
+    // the determinant holds one entry of each column, so the flips factor out of the rounded expression exactly.  The
+    // pass therefore bins every point in the frame (c0, c1 det0, c2), whose coordinates are the final ones up to the
+    // signs (xs, xs zs, zs), bit for bit, and the row is written through the permutation the signs induce: theta's bins
+    // mirror (the edges are symmetric to rounding, which the 1e-12 band covers), phi's two populated bins swap.  Points
+    // that are not safe are deferred and binned literally in the final frame.
     const double ph_pos = atan2(1.0, 1.0), ph_neg = atan2(-1.0, -1.0);
     const int lp_pos = hist_loc<NP + 1>(ph_pos, ed.p), lp_neg = hist_loc<NP + 1>(ph_neg, ed.p);
-    PCREG_MY_PTS(
-        double x = px; double y = py; double z = pz;
-        if (o.ALIGN_POINTS) { x = px * cu[0] + py * cu[3] + pz * cu[6]; y = px * cu[1] + py * cu[4] + pz * cu[7]; z = px * cu[2] + py * cu[5] + pz * cu[8]; }
+    auto bin_fast = [&](double x, double y, double z, bool& safe) -> int {
         const double xy2 = x * x + y * y; const double d2 = xy2 + z * z;
-        const double zs = z * fabs(z);
-        bool safe = xy2 > 1e-12 * d2 && y != 0.0;
+        const double zq = z * fabs(z);
+        safe = xy2 > 1e-12 * d2 && y != 0.0;
         int lt = 1;
-        _Pragma("unroll") for (int jj = 1; jj < NT; ++jj) { const double dl = zs - ed.cts[jj] * d2; safe = safe && fabs(dl) > 1e-12 * d2; lt += dl < 0.0; }
+#pragma unroll
+        for (int jj = 1; jj < NT; ++jj) { const double dl = zq - ed.cts[jj] * d2; safe = safe && fabs(dl) > 1e-12 * d2; lt += dl < 0.0; }
         int lr = 0;
-        if (d2 < ed.r2gt) { lr = 1; _Pragma("unroll") for (int jj = 1; jj < NR; ++jj) lr += d2 >= ed.r2ge[jj]; if (!(d2 >= ed.r2ge[0])) lr = 0; }
-        int lp = y > 0.0 ? lp_pos : lp_neg;
-        if (!safe) {
-            const double r = sqrt(d2); const double u = z / r;
-            lt = hist_loc<NT + 1>(acos(u), ed.t); lr = hist_loc<NR + 1>(r, ed.r); lp = hist_loc<NP + 1>(atan2(y, y), ed.p);
+        if (d2 < ed.r2gt) {
+            lr = 1;
+#pragma unroll
+            for (int jj = 1; jj < NR; ++jj) lr += d2 >= ed.r2ge[jj];
+            if (!(d2 >= ed.r2ge[0])) lr = 0;
         }
-        if (lr > 0 && lt > 0 && lp > 0) atomicAdd(&s_cnt[(lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1)], 1u);)
-    __syncthreads();
+        const int lp = y > 0.0 ? lp_pos : lp_neg;
+        return (lr > 0 && lp > 0) ? (lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1) : -1;
+    };
+    auto bin_literal = [&](double x, double y, double z) -> int {
+        const double d2 = x * x + y * y + z * z;
+        const double r = sqrt(d2); const double u = z / r;
+        const int lt = hist_loc<NT + 1>(acos(u), ed.t), lr = hist_loc<NR + 1>(r, ed.r), lp = hist_loc<NP + 1>(atan2(y, y), ed.p);
+        return (lr > 0 && lt > 0 && lp > 0) ? (lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1) : -1;
+    };
     uint32_t* row = rows + (size_t)s * ND;
-    for (int i = tid; i < ND; i += kBlock) row[i] = s_cnt[i];
+    bool permuted = false;
+    if (o.ALIGN_POINTS) {
+        const double det0 = cu[0] * (cu[4] * cu[8] - cu[5] * cu[7]) - cu[1] * (cu[3] * cu[8] - cu[5] * cu[6]) + cu[2] * (cu[3] * cu[7] - cu[4] * cu[6]);
+        const double c1x = cu[1] * det0, c1y = cu[4] * det0, c1z = cu[7] * det0;
+        int votes = 0;                              // vx | vz << 16 (K <= n <= 8191)
+        PCREG_MY_PTS(
+            if (psel) {
+                const double x = px - mx, y = py - my, z = pz - mz;
+                votes += ((x * cu[0] + y * cu[3] + z * cu[6]) > 0 ? 1 : 0) + ((x * cu[2] + y * cu[5] + z * cu[8]) > 0 ? 1 << 16 : 0);
+            }
+            const double x0 = px * cu[0] + py * cu[3] + pz * cu[6], y0 = px * c1x + py * c1y + pz * c1z, z0 = px * cu[2] + py * cu[5] + pz * cu[8];
+            bool safe; const int bb = bin_fast(x0, y0, z0, safe);
+            if (safe) { if (bb >= 0) atomicAdd(&s_cnt[bb], 1u); }
+            else { const int q = atomicAdd(&s_ndef, 1); if (q < kDef) s_def[q] = i; })
+        votes = bsum_i(votes, s_redi);              // its barriers also complete s_cnt and s_ndef
+        const int vx = votes & 0xFFFF, vz = votes >> 16;
+        double xs = (2.0 * vx >= (double)K) ? 1.0 : -1.0, zs = (2.0 * vz >= (double)K) ? 1.0 : -1.0;
+        double M[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { M[r * 3] = cu[r * 3] * xs; M[r * 3 + 1] = cu[r * 3 + 1]; M[r * 3 + 2] = cu[r * 3 + 2] * zs; }
+        double ys = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { cu[r * 3] = cu[r * 3] * xs; cu[r * 3 + 1] = cu[r * 3 + 1] * ys; cu[r * 3 + 2] = cu[r * 3 + 2] * zs; }
+        if (dbg_stop == 3) return;
+        const int ndef = s_ndef;
+        if (ndef <= kDef) {
+            permuted = true;
+            for (int i = tid; i < ND; i += kBlock) {
+                const int lr1 = i % NR, lt1 = (i / NR) % NT, lp1 = i / (NR * NT);
+                const int st = zs < 0.0 ? NT - 1 - lt1 : lt1;
+                int sp = lp1;
+                if (xs * zs < 0.0) sp = lp1 == lp_pos - 1 ? lp_neg - 1 : (lp1 == lp_neg - 1 ? lp_pos - 1 : lp1);
+                row[i] = s_cnt[lr1 + NR * st + NR * NT * sp];
+            }
+            __syncthreads();
+            for (int q = tid; q < ndef; q += kBlock) {
+                const int j = lpos[s_def[q]];
+                const double px = sx[j] - cx, py = sy[j] - cy, pz = sz[j] - cz;
+                const int bb = bin_literal(px * cu[0] + py * cu[3] + pz * cu[6], px * cu[1] + py * cu[4] + pz * cu[7], px * cu[2] + py * cu[5] + pz * cu[8]);
+                if (bb >= 0) atomicAdd(&row[bb], 1u);
+            }
+        } else {                                    // too many deferred points: bin everything again in the final frame
+            for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
+            __syncthreads();
+        }
+    }
+    if (!permuted) {
+        PCREG_MY_PTS(
+            double x = px; double y = py; double z = pz;
+            if (o.ALIGN_POINTS) { x = px * cu[0] + py * cu[3] + pz * cu[6]; y = px * cu[1] + py * cu[4] + pz * cu[7]; z = px * cu[2] + py * cu[5] + pz * cu[8]; }
+            bool safe; int bb = bin_fast(x, y, z, safe);
+            if (!safe) bb = bin_literal(x, y, z);
+            if (bb >= 0) atomicAdd(&s_cnt[bb], 1u);)
+        __syncthreads();
+        for (int i = tid; i < ND; i += kBlock) row[i] = s_cnt[i];
+    }
     if (tid == 0) valid[s] = 1;
 #undef PCREG_MY_PTS
 }
