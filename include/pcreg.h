@@ -292,6 +292,12 @@ size_t pcreg_dev_spatial_histogram_descriptors_workspace(int P, int S);
 int pcreg_dev_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
                                             const pcreg_desc_opts* options, double* feat, double* desc,
                                             int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the 980 counts of a row as uint16 (getSpacialHistogramDescriptors.m:166-171 produces integer counts
+ * <= the support size): 1.96 KB per keypoint instead of 7.84 KB, what a resident pipeline wants to keep and hand to
+ * pcreg_dev_get_matches_u16.  options->max_pts must be <= 65535 (else PCREG_E_ARG).  Same workspace. */
+int pcreg_dev_spatial_histogram_descriptors_u16(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                                const pcreg_desc_opts* options, double* feat, uint16_t* desc,
+                                                int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
 
 /* getMatches.m:21-59 on device buffers.  layout: PCREG_LAYOUT_FEATURE_MAJOR = MATLAB's
  * column-major n x D (ld >= n); PCREG_LAYOUT_ROW_MAJOR = dense [n][D] (ld == D), what the
@@ -305,6 +311,12 @@ size_t pcreg_dev_get_matches_workspace(int Q, int M, int D);
 int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M, int ldM, int D,
                           int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric,
                           int32_t* n_pairs, void* workspace, size_t workspace_bytes, void* stream);
+/* The same on dense uint16 rows [n][D] (pcreg_dev_spatial_histogram_descriptors_u16's output): the counts are widened
+ * to double, exactly, on the way into getMatches.m:24-37's private copies -- pairs and metric are those of the double
+ * entry.  Same workspace. */
+int pcreg_dev_get_matches_u16(const uint16_t* descSurface, int Q, const uint16_t* descModel, int M, int D,
+                              const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* completeExperimentFast.m:205-206: pts1 = featSurface(matches(:,1),:), pts2 =
  * featModel(matches(:,2),:) as n x 3 column-major with ld = cap -- the input of

@@ -61,6 +61,7 @@ SYMBOLS = [
     "pcreg_dev_ransac_partial", "pcreg_dev_ransac_finish", "pcreg_dev_ransac_finish_parts",
     "pcreg_dev_search_kernel_timing", "pcreg_dev_search_kernel_ms",
     "pcreg_dev_spatial_histogram_descriptors_workspace", "pcreg_dev_spatial_histogram_descriptors",
+    "pcreg_dev_spatial_histogram_descriptors_u16", "pcreg_dev_get_matches_u16",
     "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
     "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select",
     "pcreg_dev_gather_rows_f64", "pcreg_dev_sweep_plan", "pcreg_dev_sweep_gather", "pcreg_dev_ransac_batched_workspace",

@@ -420,7 +420,7 @@ int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const 
     int32_t* dV = (int32_t*)dcnt; int32_t* dErr = dV + 1;
     TRY(upload_cols(pts, P, ld, 3, (double*)dp, g_stream));
     TRY(upload_cols(sample_pts, S, lds, 3, (double*)dk, g_stream));
-    TRY(launch_descriptors((double*)dp, P, P, (double*)dk, S, S, *options, (double*)dfeat, (double*)ddesc, dV, dErr, ws, wsb, g_stream));
+    TRY(launch_descriptors((double*)dp, P, P, (double*)dk, S, S, *options, (double*)dfeat, ddesc, false, dV, dErr, ws, wsb, g_stream));
     int32_t hv[2] = {0, 0};
     PCREG_HIP(hipMemcpyAsync(hv, dcnt, sizeof hv, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipStreamSynchronize(g_stream));
@@ -574,10 +574,20 @@ int pcreg_dev_spatial_histogram_descriptors(const double* pts, int P, int ld, co
                                             void* workspace, size_t workspace_bytes, void* stream) {
     PCREG_ARG(pts && sample_pts && options && feat && desc && counters && workspace && P >= 1 && S >= 1 && ld >= P && lds >= S);
     GUARD();
-    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, feat, desc, counters, counters + 1, workspace,
+    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, feat, desc, false, counters, counters + 1, workspace,
                               workspace_bytes, (hipStream_t)stream);
 }
 
+int pcreg_dev_spatial_histogram_descriptors_u16(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                                const pcreg_desc_opts* options, double* feat, uint16_t* desc, int32_t* counters,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(pts && sample_pts && options && feat && desc && counters && workspace && P >= 1 && S >= 1 && ld >= P && lds >= S);
+    GUARD();
+    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, feat, desc, true, counters, counters + 1, workspace,
+                              workspace_bytes, (hipStream_t)stream);
+}
+
+static constexpr int kLayoutRowMajorU16 = 1000;      // internal: dense uint16 rows (pcreg_dev_get_matches_u16)
 static size_t dev_get_matches_layout(int Q, int M, int D, int Dp, size_t off[6]) {
     size_t q = (size_t)(Q > 0 ? Q : 1), m = (size_t)(M > 0 ? M : 1), b = 0;
     off[0] = b; b += align_up(q * D * sizeof(double), 256);            // raw surface, feature-major
@@ -593,15 +603,9 @@ size_t pcreg_dev_get_matches_workspace(int Q, int M, int D) {
     return dev_get_matches_layout(Q, M, D, D + 1, off);
 }
 
-int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M, int ldM, int D,
-                          int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-    PCREG_ARG(descSurface && descModel && par && pairs && n_pairs && workspace && Q >= 0 && M >= 0 && D >= 1);
-    PCREG_ARG(layout == PCREG_LAYOUT_FEATURE_MAJOR || layout == PCREG_LAYOUT_ROW_MAJOR);
-    PCREG_ARG(layout == PCREG_LAYOUT_ROW_MAJOR ? (ldS >= D && ldM >= D) : (ldS >= Q && ldM >= M));
-    PCREG_ARG(par->metric == PCREG_METRIC_SAD || par->metric == PCREG_METRIC_SSD);
-    GUARD();
-    hipStream_t st = (hipStream_t)stream;
+static int dev_get_matches_impl(const void* descSurface, int Q, int ldS, const void* descModel, int M, int ldM, int D,
+                                int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
+                                void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (Q == 0 || M == 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
     const int Dp = D + (par->unnormalize ? 1 : 0);
     size_t off[6];
@@ -609,12 +613,16 @@ int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const doubl
     if (workspace_bytes < need) { set_error("get_matches workspace too small: %zu < %zu", workspace_bytes, need); return PCREG_E_WORKSPACE; }
     char* w = (char*)workspace;
     double *rawS = (double*)(w + off[0]), *rawM = (double*)(w + off[1]), *fS = (double*)(w + off[2]), *fM = (double*)(w + off[3]);
-    const double *inS = descSurface, *inM = descModel;
+    const double *inS = (const double*)descSurface, *inM = (const double*)descModel;
     int ls = ldS, lm = ldM;
     if (layout == PCREG_LAYOUT_ROW_MAJOR) {        // [row][D] (ld = row pitch) -> feature-major
         if (ldS != D || ldM != D) { set_error("row-major descriptors must be dense (ld == D)"); return PCREG_E_ARG; }
-        TRY(launch_transpose_rows(descSurface, D, D, Q, rawS, st));
-        TRY(launch_transpose_rows(descModel, D, D, M, rawM, st));
+        TRY(launch_transpose_rows((const double*)descSurface, D, D, Q, rawS, st));
+        TRY(launch_transpose_rows((const double*)descModel, D, D, M, rawM, st));
+        inS = rawS; inM = rawM; ls = Q; lm = M;
+    } else if (layout == kLayoutRowMajorU16) {     // dense u16 rows (counts) -> feature-major doubles, exactly
+        TRY(launch_widen_rows_u16((const uint16_t*)descSurface, Q, D, rawS, st));
+        TRY(launch_widen_rows_u16((const uint16_t*)descModel, M, D, rawM, st));
         inS = rawS; inM = rawM; ls = Q; lm = M;
     }
     // getMatches.m:24-37 always works on private copies (the caller's descriptors stay untouched)
@@ -623,6 +631,28 @@ int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const doubl
         TRY(launch_normalize_rows2(fS, Q, Q, fM, M, M, Dp, st));
     }
     return launch_match_features(fS, Q, Q, fM, M, M, Dp, *par, pairs, metric, n_pairs, w + off[5], workspace_bytes - off[5], st);
+}
+
+int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M, int ldM, int D,
+                          int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(descSurface && descModel && par && pairs && n_pairs && workspace && Q >= 0 && M >= 0 && D >= 1);
+    PCREG_ARG(layout == PCREG_LAYOUT_FEATURE_MAJOR || layout == PCREG_LAYOUT_ROW_MAJOR);
+    PCREG_ARG(layout == PCREG_LAYOUT_ROW_MAJOR ? (ldS >= D && ldM >= D) : (ldS >= Q && ldM >= M));
+    PCREG_ARG(par->metric == PCREG_METRIC_SAD || par->metric == PCREG_METRIC_SSD);
+    GUARD();
+    return dev_get_matches_impl(descSurface, Q, ldS, descModel, M, ldM, D, layout, par, pairs, metric, n_pairs, workspace,
+                                workspace_bytes, (hipStream_t)stream);
+}
+
+int pcreg_dev_get_matches_u16(const uint16_t* descSurface, int Q, const uint16_t* descModel, int M, int D,
+                              const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(descSurface && descModel && par && pairs && n_pairs && workspace && Q >= 0 && M >= 0 && D >= 1);
+    PCREG_ARG(par->metric == PCREG_METRIC_SAD || par->metric == PCREG_METRIC_SSD);
+    GUARD();
+    return dev_get_matches_impl(descSurface, Q, D, descModel, M, D, D, kLayoutRowMajorU16, par, pairs, metric, n_pairs, workspace,
+                                workspace_bytes, (hipStream_t)stream);
 }
 
 int pcreg_dev_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featSurface,

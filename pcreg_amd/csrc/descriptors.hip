@@ -691,15 +691,16 @@ __global__ void desc_slot_kernel(const int32_t* __restrict__ valid, int S, const
     for (int w = 0; w < wave; ++w) base += s_c[w];
     if (s < S) slot[s] = kp ? base + __popcll(b & ((1ull << lane) - 1ull)) : -1;
 }
+template <typename OutT>
 __global__ __launch_bounds__(kBlock) void desc_emit_kernel(const uint32_t* __restrict__ rows, const int32_t* __restrict__ slot,
                                                            const double* __restrict__ kp, int S, int ldk,
-                                                           double* __restrict__ feat, double* __restrict__ desc) {
+                                                           double* __restrict__ feat, OutT* __restrict__ desc) {
     const int s = blockIdx.x;
     const int v = slot[s];
     if (v < 0) return;
     const uint32_t* row = rows + (size_t)s * ND;
-    double* out = desc + (size_t)v * ND;
-    for (int i = threadIdx.x; i < ND; i += kBlock) out[i] = (double)row[i];
+    OutT* out = desc + (size_t)v * ND;
+    for (int i = threadIdx.x; i < ND; i += kBlock) out[i] = (OutT)row[i];     // counts <= max_pts: exact in either type
     if (threadIdx.x < 3) feat[(size_t)v * 3 + threadIdx.x] = kp[s + (size_t)threadIdx.x * ldk];
 }
 
@@ -718,9 +719,10 @@ size_t descriptors_workspace_bytes(int P, int S) {
 }
 
 int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o,
-                       double* feat, double* desc, int32_t* V_dev, int32_t* err_dev, void* ws, size_t ws_bytes,
+                       double* feat, void* desc, bool desc_u16, int32_t* V_dev, int32_t* err_dev, void* ws, size_t ws_bytes,
                        hipStream_t st) {
     PCREG_ARG(P >= 0 && S >= 0 && o.R > 0 && o.k > 0 && o.min_pts >= 0);
+    if (desc_u16 && o.max_pts > 65535) { set_error("u16 descriptor rows need max_pts <= 65535 (a count can reach max_pts)"); return PCREG_E_ARG; }
     PCREG_HIP(hipMemsetAsync(V_dev, 0, sizeof(int32_t), st));
     PCREG_HIP(hipMemsetAsync(err_dev, 0, sizeof(int32_t), st));
     if (S == 0 || P == 0) return PCREG_OK;
@@ -785,7 +787,8 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     hipLaunchKernelGGL(desc_count_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bcnt, nbs, V_dev);
     hipLaunchKernelGGL(desc_slot_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt, slot);
-    hipLaunchKernelGGL(desc_emit_kernel, dim3(S), dim3(kBlock), 0, st, rows, slot, kp, S, ldk, feat, desc);
+    if (desc_u16) hipLaunchKernelGGL(desc_emit_kernel<uint16_t>, dim3(S), dim3(kBlock), 0, st, rows, slot, kp, S, ldk, feat, (uint16_t*)desc);
+    else hipLaunchKernelGGL(desc_emit_kernel<double>, dim3(S), dim3(kBlock), 0, st, rows, slot, kp, S, ldk, feat, (double*)desc);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

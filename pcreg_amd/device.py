@@ -202,19 +202,20 @@ class DescriptorPipeline:
             t = self._ws[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.dev)
         return t
 
-    def describe(self, pts: torch.Tensor, sample_pts: torch.Tensor, options: dict):
-        """-> (feat [S,3], desc [S,980], V): rows < V are the surviving keypoints in sample order."""
+    def describe(self, pts: torch.Tensor, sample_pts: torch.Tensor, options: dict, compact: bool = False):
+        """-> (feat [S,3], desc [S,980], V): rows < V are the surviving keypoints in sample order.
+        compact: the counts as uint16 (a quarter of the bytes; `match` takes either)."""
         from .api import _desc_opts
         L = lib()
         o = _desc_opts(options)
         P, S = pts.shape[1], sample_pts.shape[1]
         feat = torch.empty((S, 3), dtype=torch.float64, device=self.dev)
-        desc = torch.empty((S, self.ND), dtype=torch.float64, device=self.dev)
+        desc = torch.empty((S, self.ND), dtype=torch.uint16 if compact else torch.float64, device=self.dev)
         counters = torch.zeros(2, dtype=torch.int32, device=self.dev)
         ws = self._workspace("desc", L.pcreg_dev_spatial_histogram_descriptors_workspace(P, S))
-        check(L.pcreg_dev_spatial_histogram_descriptors(_p(pts), P, pts.stride(0), _p(sample_pts), S, sample_pts.stride(0),
-                                                        C.byref(o), _p(feat), _p(desc), _p(counters), _p(ws),
-                                                        C.c_size_t(ws.numel()), _stream()))
+        entry = L.pcreg_dev_spatial_histogram_descriptors_u16 if compact else L.pcreg_dev_spatial_histogram_descriptors
+        check(entry(_p(pts), P, pts.stride(0), _p(sample_pts), S, sample_pts.stride(0), C.byref(o), _p(feat), _p(desc), _p(counters), _p(ws),
+                    C.c_size_t(ws.numel()), _stream()))
         V, overflow = (int(v) for v in counters.cpu())
         if overflow:
             raise ValueError(f"a support holds {overflow} points: more than an LDS-resident support may have (lower max_pts)")
@@ -232,9 +233,15 @@ class DescriptorPipeline:
         D = descS.shape[1]
         cap = ws_cap or (VS, VM)
         ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(cap[0], cap[1], D))
-        check(L.pcreg_dev_get_matches(_p(descS), VS, D, _p(descM), VM, D, D, _l.LAYOUT_ROW_MAJOR,
-                                      C.byref(o), _p(pairs), None, _p(n_pairs), _p(ws), C.c_size_t(ws.numel()),
-                                      _stream()))
+        if descS.dtype == torch.uint16:                 # compact descriptors (describe(..., compact=True)) on both sides
+            if descM.dtype != torch.uint16:
+                raise TypeError("compact (uint16) descriptors on one side only")
+            check(L.pcreg_dev_get_matches_u16(_p(descS), VS, _p(descM), VM, D, C.byref(o), _p(pairs), None, _p(n_pairs), _p(ws),
+                                              C.c_size_t(ws.numel()), _stream()))
+        else:
+            check(L.pcreg_dev_get_matches(_p(descS), VS, D, _p(descM), VM, D, D, _l.LAYOUT_ROW_MAJOR,
+                                          C.byref(o), _p(pairs), None, _p(n_pairs), _p(ws), C.c_size_t(ws.numel()),
+                                          _stream()))
         return pairs, n_pairs
 
     def ransac(self, pairs: torch.Tensor, featS: torch.Tensor, featM: torch.Tensor, coef: dict, seed: int = 0):

@@ -57,3 +57,32 @@ def test_align_points_knn_batched(oracle_c):
             continue
         ral, rco, rc = oracle_c.AlignPoints_KNN(X)
         assert np.abs(co[b] - rco).max() < TOL and np.abs(al[b] - ral).max() < TOL and np.abs(c[b] - rc).max() < TOL
+
+
+@pytest.mark.parametrize("n", [1024, 1025, 2048, 2049, 3000, 3072, 3073, 4096, 4097, 8192])
+def test_align_points_knn_every_kernel_variant(n, oracle_c):
+    """The register-resident kernel is instantiated per support size (points per thread x threads): both sides of
+    every switch point, up to the largest support it takes."""
+    import pcreg_amd as pc
+    X = _support(n, 9000 + n)
+    al, co, c = pc.AlignPoints_KNN(X)
+    ral, rco, rc = oracle_c.AlignPoints_KNN(X)
+    assert np.abs(c.ravel() - rc).max() < TOL and np.abs(co - rco).max() < TOL and np.abs(al - ral).max() < TOL
+
+
+def test_align_points_knn_support_too_large_fails_loudly():
+    import pcreg_amd as pc
+    from pcreg_amd._lib import PcregError
+    with pytest.raises(PcregError):
+        pc.AlignPoints_KNN(_support(8193, 1))
+
+
+def test_align_points_knn_ties_in_large_support(oracle_c):
+    """Equal distances at the K-th boundary in a support that spans several rows of points per thread (the tie
+    ranking walks rows, then threads)."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(5)
+    X = rng.integers(-6, 7, (3000, 3)).astype(float)
+    al, co, c = pc.AlignPoints_KNN(X)
+    ral, rco, rc = oracle_c.AlignPoints_KNN(X)
+    assert np.abs(co - rco).max() < TOL and np.abs(al - ral).max() < TOL

@@ -98,3 +98,31 @@ def test_dev_get_matches_feature_major_layout_and_empty(oracle_c):
     rc = L.pcreg_dev_get_matches(_p(tS), 300, 300, _p(tM), 900, 900, 64, _lib.LAYOUT_FEATURE_MAJOR, C.byref(o),
                                  _p(pairs), None, _p(n), _p(ws), C.c_size_t(1024), _stream())
     assert rc == _lib.PCREG_E_WORKSPACE
+
+
+def test_compact_u16_descriptors_give_the_same_chain(oracle_c):
+    """pcreg_dev_spatial_histogram_descriptors_u16 -> pcreg_dev_get_matches_u16: the counts as uint16 rows (a quarter
+    of the bytes) equal the double rows value for value, and the pairs are those of the double chain and the oracle."""
+    import torch
+    from pcreg_amd.device import DescriptorPipeline, soa
+    from pcreg_amd._lib import PcregError
+    model, surface, kpM, kpS = _scene(23)
+    fM, dM = oracle_c.getSpacialHistogramDescriptors(model, kpM, OPT)
+    fS, dS = oracle_c.getSpacialHistogramDescriptors(surface, kpS, OPT)
+    ref_pairs = oracle_c.getMatches(dS, dM, PAR)
+    dev = torch.device("cuda", 0)
+    pipe = DescriptorPipeline(dev)
+    t = lambda a: soa(torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+    featM, descM, VM = pipe.describe(t(model), t(kpM), OPT, compact=True)
+    featS, descS, VS = pipe.describe(t(surface), t(kpS), OPT, compact=True)
+    assert descM.dtype == torch.uint16 and (VM, VS) == (len(fM), len(fS))
+    np.testing.assert_array_equal(descM[:VM].cpu().numpy().astype(np.float64), dM)
+    np.testing.assert_array_equal(descS[:VS].cpu().numpy().astype(np.float64), dS)
+    np.testing.assert_array_equal(featS[:VS].cpu().numpy(), fS)
+    pairs, n_pairs = pipe.match(descS, VS, descM, VM, PAR)
+    n = int(n_pairs.item())
+    assert n == len(ref_pairs) >= 3
+    np.testing.assert_array_equal(pairs[:n].cpu().numpy().astype(np.uint32), ref_pairs)
+    # a count can reach max_pts: a u16 row cannot promise more than 65535
+    with pytest.raises(PcregError):
+        pipe.describe(t(model), t(kpM), dict(OPT, max_pts=70000), compact=True)
