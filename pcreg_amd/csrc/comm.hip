@@ -155,7 +155,6 @@ int pcreg_match_points_sharded_f32(const float* q, int Q, int ldq, const float* 
     // 2. threshold + ratio test, redundantly on every rank
     CTRY(pcreg_dev_filter_top2_f32((int32_t*)didx, (float*)ddist, Q, M_total, thr_abs, max_ratio, (int32_t*)dcq, (int32_t*)dcm, n_cand, st));
     // 3. Unique verdict by the rank that owns the candidate's model row; 4. one integer SUM publishes verdicts + coordinates
-    PCREG_HIP(hipMemsetAsync(dkeep, 0, q4, st));
     if (unique)
         CTRY(pcreg_dev_unique_points_f32((float*)dq, Q, Q, (float*)dm, M_local, M_local > 0 ? M_local : 1, m_lo, (int32_t*)dcq, (int32_t*)dcm, n_cand,
                                          (int32_t*)dkeep, wsu, wsu_b, st));

@@ -40,7 +40,10 @@ namespace {
 // ---- 1a. bounding box of model + queries (two-stage, deterministic) -----------------
 __global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __restrict__ m, int M, int ldm,
                                                               const float* __restrict__ q, int Q, int ldq,
-                                                              float* __restrict__ part /*[grid][12]: model lo/hi, query lo/hi*/) {
+                                                              float* __restrict__ part /*[grid][12]: model lo/hi, query lo/hi*/,
+                                                              int32_t* __restrict__ zero_me, int n_zero) {
+    // the seeding grid's cell counters are cleared here (saves a memset launch; nothing reads them before seed_fill)
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_zero; i += gridDim.x * kBlock) zero_me[i] = 0;
     float lo[2][3], hi[2][3];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -800,13 +803,13 @@ int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, 
     size_t ews_bytes = ws_bytes - (size_t)(w - (char*)ws);
 
     int nb = (M + Q + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart);
+    const bool no_seed = PCREG_EXP_ENV("PCREG_KNN_NOSEED", 0) != 0;
+    const bool seeded = M >= kSeedMinM && !no_seed;
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart, seed_cnt, seeded ? (int)seed_cells : 0);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2, n_flag);
     int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0, group16 = 0;
     bool sparse_lists = false;
-    const bool no_seed = PCREG_EXP_ENV("PCREG_KNN_NOSEED", 0) != 0;
-    if (M >= kSeedMinM && !no_seed) {           // first thresholds from the grid (stage 1c)
-        PCREG_HIP(hipMemsetAsync(seed_cnt, 0, seed_cells * 4, st));
+    if (seeded) {                               // first thresholds from the grid (stage 1c)
         int fb = (M + kBlock - 1) / kBlock; if (fb > 16384) fb = 16384;     // one point per thread: the atomics want parallelism
         hipLaunchKernelGGL(seed_fill_kernel, dim3(fb), dim3(kBlock), 0, st, m, M, ldm, prep, seed_cnt, seed_slots);
         hipLaunchKernelGGL(seed_query_kernel, dim3((Q * 8 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, q, Q, ldq, m, ldm, prep,

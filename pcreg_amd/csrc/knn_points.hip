@@ -262,7 +262,8 @@ __device__ __forceinline__ int ug_cell1(float x, float x0, float inv_c, int n) {
 }
 
 __global__ __launch_bounds__(1024) void ug_bbox_kernel(const float* __restrict__ q, int Q, int ldq, int cells_cap,
-                                                       UgPrep* __restrict__ prep, int32_t* __restrict__ n_flag) {
+                                                       UgPrep* __restrict__ prep, int32_t* __restrict__ n_flag, int32_t* __restrict__ cnt) {
+    for (int i = threadIdx.x; i < cells_cap; i += 1024) cnt[i] = 0;       // the grid's counters (saves a memset launch)
     __shared__ float s_lo[3][16], s_hi[3][16];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i0 = threadIdx.x; i0 < Q; i0 += 4 * 1024) {
@@ -424,17 +425,19 @@ __global__ void gather_count_kernel(const int32_t* __restrict__ keep, const int3
 __global__ void gather_scatter_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
                                       const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
                                       const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
-                                      const int32_t* __restrict__ block_off, uint32_t* __restrict__ pairs,
-                                      double* __restrict__ pts1, double* __restrict__ pts2) {
+                                      const int32_t* __restrict__ block_off, int self_prefix, int32_t* __restrict__ n_pairs,
+                                      uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2) {
     const int P = *n_cand;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     bool kp = k < P && (keep == nullptr || keep[k] != 0);
     __shared__ int s_cnt[4];
+    __shared__ int s_pre[4];
+    const int pre = self_prefix ? block_self_prefix_256(block_off, blockIdx.x, gridDim.x, s_pre, n_pairs) : block_off[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long b = __ballot(kp);
     if (lane == 0) s_cnt[wave] = __popcll(b);
     __syncthreads();
-    int base = block_off[blockIdx.x];
+    int base = pre;
     for (int w = 0; w < wave; ++w) base += s_cnt[w];
     if (kp) {
         int o = base + __popcll(b & ((1ull << lane) - 1ull));
@@ -610,8 +613,7 @@ int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int
         int32_t* cnt = (int32_t*)w;         w += align_up(cells * 4, 256);
         float4* slots = (float4*)w;         w += align_up(cells * kUgSlots * 16, 256);
         int32_t* flag_list = (int32_t*)w;
-        PCREG_HIP(hipMemsetAsync(cnt, 0, cells * 4, st));
-        hipLaunchKernelGGL(ug_bbox_kernel, dim3(1), dim3(1024), 0, st, q, Q, ldq, (int)cells, prep, n_flag);
+        hipLaunchKernelGGL(ug_bbox_kernel, dim3(1), dim3(1024), 0, st, q, Q, ldq, (int)cells, prep, n_flag, cnt);
         hipLaunchKernelGGL(ug_fill_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, q, Q, ldq, prep, cnt, slots);
         hipLaunchKernelGGL(ug_check_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo, cand_q, cand_m, n_cand,
                            prep, cnt, slots, keep, flag_list, n_flag);
@@ -671,9 +673,10 @@ int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int 
     if (rc) return rc;
     int32_t* bc = (int32_t*)tmp;
     hipLaunchKernelGGL(gather_count_kernel, dim3(nb), dim3(256), 0, st, keep, n_cand, bc);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_pairs);
+    const int self_prefix = nb <= kSelfPrefixMax;
+    if (!self_prefix) hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_pairs);
     hipLaunchKernelGGL(gather_scatter_kernel, dim3(nb), dim3(256), 0, st, q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand,
-                       bc, pairs, pts1, pts2);
+                       bc, self_prefix, n_pairs, pairs, pts1, pts2);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -88,17 +88,37 @@ static __global__ void scan_blocks_kernel(int32_t* __restrict__ block_cnt, int n
     if (threadIdx.x == 0) *total = carry;
 }
 
+// The offset of workgroup b = the sum of the RAW counts of the workgroups before it, which every workgroup of a scatter
+// kernel can add up itself (a few hundred ints): the compaction chains then need no scan launch in between.  Used up to
+// kSelfPrefixMax workgroups (the reads grow with the square); the last workgroup also publishes the total.
+constexpr int kSelfPrefixMax = 2048;
+__device__ __forceinline__ int block_self_prefix_256(const int32_t* __restrict__ block_cnt, int b, int nblocks, int* s4 /*[4]*/,
+                                                     int32_t* __restrict__ total) {
+    int v = 0;
+    for (int i = threadIdx.x; i < b; i += 256) v += block_cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const int base = s4[0] + s4[1] + s4[2] + s4[3];
+    if (total && b == nblocks - 1 && threadIdx.x == 0) *total = base + block_cnt[b];
+    __syncthreads();
+    return base;
+}
+
 static __global__ void filter_scatter_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ flag, int Q,
-                                             const int32_t* __restrict__ block_off, int32_t* __restrict__ cand_q,
-                                             int32_t* __restrict__ cand_m) {
+                                             const int32_t* __restrict__ block_off, int self_prefix, int32_t* __restrict__ n_cand,
+                                             int32_t* __restrict__ cand_q, int32_t* __restrict__ cand_m) {
     int qi = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = qi < Q && flag[qi];
     __shared__ int s_cnt[4];
+    __shared__ int s_pre[4];
+    const int pre = self_prefix ? block_self_prefix_256(block_off, blockIdx.x, gridDim.x, s_pre, n_cand) : block_off[blockIdx.x];
     unsigned long long b = __ballot(keep);
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) s_cnt[wave] = __popcll(b);
     __syncthreads();
-    int base = block_off[blockIdx.x];
+    int base = pre;
     for (int w = 0; w < wave; ++w) base += s_cnt[w];
     if (keep) {
         int o = base + __popcll(b & ((1ull << lane) - 1ull));
@@ -169,8 +189,9 @@ int run_filter_top2(const int32_t* idx, const T* dist, int Q, int M_total, T thr
     int nb = (Q + 255) / 256;
     int32_t* flag = tmp; int32_t* bc = tmp + Q;
     hipLaunchKernelGGL(filter_flag_kernel_t<T>, dim3(nb), dim3(256), 0, st, idx, dist, Q, M_total, thr, ratio, flag, bc);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_cand);
-    hipLaunchKernelGGL(filter_scatter_kernel, dim3(nb), dim3(256), 0, st, idx, flag, Q, bc, cand_q, cand_m);
+    const int self_prefix = nb <= kSelfPrefixMax;
+    if (!self_prefix) hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_cand);
+    hipLaunchKernelGGL(filter_scatter_kernel, dim3(nb), dim3(256), 0, st, idx, flag, Q, bc, self_prefix, n_cand, cand_q, cand_m);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

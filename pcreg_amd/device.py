@@ -72,7 +72,7 @@ class HipOps:
         return self.cand_q, self.cand_m, self.n_cand
 
     def unique_local(self, q, model, m_lo, cand_q, cand_m, n_cand):
-        self.keep.zero_()
+        # keep[k] is written for every candidate of this shard and read for no other (include/pcreg.h): no clearing
         check(lib().pcreg_dev_unique_points_f32(_p(q), self.Q, q.shape[1], _p(model), model.shape[1], model.shape[1],
                                                 C.c_int32(m_lo), _p(cand_q), _p(cand_m), _p(n_cand), _p(self.keep),
                                                 _p(self.ws_unq), C.c_size_t(self.ws_unq.numel()), _stream()))
