@@ -191,8 +191,11 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int sub = 0; sub < kSubs; sub += 2) {
-            unsigned long long hit[2][QG];
-            float mnk[2][QG];
+            // ONE threshold test per two sub-tiles: the first step only keeps its minimum (mn0), the second folds it into
+            // its tree as the 17th value (8 v_min3, the 16 scores alone take 7 v_min3 + 1 v_min) and tests min(mn0, mn1);
+            // the rare path gets mn1 back by issuing that one product again (same operands, same bits)
+            unsigned long long hit[QG];
+            float mn0[QG];
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 // the next sub-tile's A operand: issued now, waited for in this half's last step (after sub 15 it
@@ -214,10 +217,13 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
                     const float m0 = fminf(fminf(d[0], d[1]), d[2]), m1 = fminf(fminf(d[3], d[4]), d[5]);
                     const float m2 = fminf(fminf(d[6], d[7]), d[8]), m3 = fminf(fminf(d[9], d[10]), d[11]);
                     const float m4 = fminf(fminf(d[12], d[13]), d[14]);
-                    const float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
-                    if (DRY) { asm volatile("" :: "v"(mn)); hit[ss][g] = 0; }
-                    else hit[ss][g] = __builtin_amdgcn_ballot_w64(mn < thr[g]);
-                    mnk[ss][g] = mn;
+                    if (ss == 0) {
+                        mn0[g] = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
+                    } else {
+                        const float mn = fminf(fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15])), mn0[g]);
+                        if (DRY) { asm volatile("" :: "v"(mn)); hit[g] = 0; }
+                        else hit[g] = __builtin_amdgcn_ballot_w64(mn < thr[g]);
+                    }
                     dprev = dnext;
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // the MFMA first, the selection under it
                     __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
@@ -227,16 +233,23 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
             }
             unsigned long long any = 0;
 #pragma unroll
-            for (int g = 0; g < QG; ++g) any |= hit[0][g] | hit[1][g];
+            for (int g = 0; g < QG; ++g) any |= hit[g];
             if (!DRY && any != 0) {        // wave-uniform, rare
+                u32x4 a1;                  // the second sub-tile's A operand again (av already holds the next pair's)
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(a1) : "v"(cur + (unsigned)(sub + 1) * 512u) : "memory");
+                const f16x8 av1 = __builtin_bit_cast(f16x8, a1);
 #pragma unroll
                 for (int g = 0; g < QG; ++g) {
-#pragma unroll
-                    for (int ss = 0; ss < 2; ++ss) {
-                        if (hit[ss][g] != 0) {           // scalar test; the insertion itself is straight-line code
-                            cand_insert_branchless(cand[g], mnk[ss][g], jt + (sub + ss) * 32, mnk[ss][g] < thr[g]);
-                            thr[g] = fminf(thr[g], cand[g].s[3]);
-                        }
+                    if (hit[g] != 0) {               // scalar test; the insertions themselves are straight-line code
+                        const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(av1, bq[g], zero, 0, 0, 0);
+                        const float m0 = fminf(fminf(d[0], d[1]), d[2]), m1 = fminf(fminf(d[3], d[4]), d[5]);
+                        const float m2 = fminf(fminf(d[6], d[7]), d[8]), m3 = fminf(fminf(d[9], d[10]), d[11]);
+                        const float m4 = fminf(fminf(d[12], d[13]), d[14]);
+                        const float mn1 = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
+                        cand_insert_branchless(cand[g], mn0[g], jt + sub * 32, mn0[g] < thr[g]);
+                        thr[g] = fminf(thr[g], cand[g].s[3]);
+                        cand_insert_branchless(cand[g], mn1, jt + (sub + 1) * 32, mn1 < thr[g]);
+                        thr[g] = fminf(thr[g], cand[g].s[3]);
                     }
                 }
             }
