@@ -263,7 +263,10 @@ __device__ __forceinline__ int ug_cell1(float x, float x0, float inv_c, int n) {
 
 __global__ __launch_bounds__(1024) void ug_bbox_kernel(const float* __restrict__ q, int Q, int ldq, int cells_cap,
                                                        UgPrep* __restrict__ prep, int32_t* __restrict__ n_flag, int32_t* __restrict__ cnt) {
-    for (int i = threadIdx.x; i < cells_cap; i += 1024) cnt[i] = 0;       // the grid's counters (saves a memset launch)
+    if (blockIdx.x > 0) {                     // workgroups 1.. clear the grid's counters (saves a memset launch); 0 finds the box
+        for (int i = (blockIdx.x - 1) * 1024 + threadIdx.x; i < cells_cap; i += (gridDim.x - 1) * 1024) cnt[i] = 0;
+        return;
+    }
     __shared__ float s_lo[3][16], s_hi[3][16];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i0 = threadIdx.x; i0 < Q; i0 += 4 * 1024) {
@@ -613,7 +616,7 @@ int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int
         int32_t* cnt = (int32_t*)w;         w += align_up(cells * 4, 256);
         float4* slots = (float4*)w;         w += align_up(cells * kUgSlots * 16, 256);
         int32_t* flag_list = (int32_t*)w;
-        hipLaunchKernelGGL(ug_bbox_kernel, dim3(1), dim3(1024), 0, st, q, Q, ldq, (int)cells, prep, n_flag, cnt);
+        hipLaunchKernelGGL(ug_bbox_kernel, dim3(1 + (unsigned)std::min<size_t>(64, (cells + 4095) / 4096)), dim3(1024), 0, st, q, Q, ldq, (int)cells, prep, n_flag, cnt);
         hipLaunchKernelGGL(ug_fill_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, q, Q, ldq, prep, cnt, slots);
         hipLaunchKernelGGL(ug_check_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo, cand_q, cand_m, n_cand,
                            prep, cnt, slots, keep, flag_list, n_flag);
