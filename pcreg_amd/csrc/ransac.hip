@@ -1198,6 +1198,7 @@ __device__ __forceinline__ float sqdist32(const float (&p)[6], const float (&T)[
 // rs_score_kernel with the fp32 screen in front: same grid, same partial counts, same masks.  No branch per slot:
 // the eight slots of a hypothesis are screened straight through, the "somebody is in the band" masks are OR-ed,
 // and only then does the wave decide whether to redo the hypothesis in fp64.
+typedef int rs_i32x16 __attribute__((ext_vector_type(16)));
 template <bool EMIT>
 __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, const double* __restrict__ TT,
                                                               const float* __restrict__ T32,
@@ -1217,62 +1218,74 @@ __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, con
     }
     __syncthreads();
     for (int pb = blockIdx.x; pb * kSPts < n; pb += gridDim.x) {       // normally one trip
-        float q[kSS][6]; unsigned long long actb[kSS];
+        float q[kSS][6];
         const int ibase = pb * kSPts + wave * kSS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < kSS; ++s) {
             const int i = ibase + s * 64;
             const bool act = i < n;
-            actb[s] = __ballot(act);
             const int ii = act ? i : 0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) q[s][c] = sa.c32[(size_t)c * sa.n32 + ii];
+            // a lane past the end scores NaN: neither screen test holds for it, so the hot loop carries no activity masks
+            if (!act) q[s][0] = __builtin_nanf("");
         }
-        for (int h = h0; h < h1; ++h) {
-            if (!((vmask[(h - h0) >> 6] >> ((h - h0) & 63)) & 1ull)) continue;   // wave-uniform
-            float T[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) T[k] = T32[(size_t)h * 16 + k];         // uniform address: scalar loads
-            const float thlo = T32[(size_t)h * 16 + 12], thhi = T32[(size_t)h * 16 + 13];
-            unsigned long long b[kSS], band = 0ull;
-#pragma unroll
-            for (int s = 0; s < kSS; ++s) {
-                const float d = sqdist32(q[s], T);
-                b[s] = __ballot(d < thlo) & actb[s];
-                band |= __ballot(d <= thhi) & actb[s] & ~b[s];                    // NaN: neither test holds
-            }
-            if (band != 0ull) {                         // rare: the whole hypothesis again, fp64 on the raw coordinates
-                double T64[12];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) T64[k] = TT[(size_t)h * 12 + k];
-#pragma unroll 1
-                for (int s = 0; s < kSS; ++s) {
-                    const int i = ibase + s * 64;
-                    const bool act = (actb[s] >> lane) & 1ull;
-                    const int ii = act ? i : 0;
-                    double p[6];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { p[c] = a.p1[ii + (size_t)c * a.ld]; p[3 + c] = a.p2[ii + (size_t)c * a.ld]; }
-                    const unsigned long long bb = __ballot((sqdist(p, T64) < th) & act);
-#pragma unroll
-                    for (int s2 = 0; s2 < kSS; ++s2) if (s2 == s) b[s2] = bb;
-                }
-            }
-            int cnt = 0;
-            int mine_lo = 0, mine_hi = 0;
-#pragma unroll
-            for (int s = 0; s < kSS; ++s) {
-                cnt += __popcll(b[s]);
-                if (EMIT) {                 // ballot s into lane s
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_lo) : "s"((int)(unsigned)b[s]), "n"(s));
-                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_hi) : "s"((int)(unsigned)(b[s] >> 32)), "n"(s));
-                }
-            }
-            if (lane == 0) s_cnt[wave][h - h0] += cnt;
-            if (EMIT && lane < kSS)         // one 64-byte row segment per (wave, hypothesis)
-                sa.masks[(size_t)h * sa.nslots_cap + (size_t)pb * (kSPts / 64) + wave * kSS + lane] =
-                    ((unsigned long long)(unsigned)mine_hi << 32) | (unsigned)mine_lo;
+        // One hypothesis = one 64-byte row of T32 (R, t', thlo, thhi), wave-uniform: a scalar load -- and a COLD one (every
+        // row is read once per workgroup), ~2000 cycles that five or six waves per SIMD do not cover.  The rows are
+        // therefore fetched one hypothesis ahead, into two alternating sets of 16 SGPRs (written as asm: the compiler
+        // waits for a scalar load where it issues it).
+        rs_i32x16 RA, RB;
+#define PCREG_ROW_LOAD(R, H) { const float* rp_ = T32 + (size_t)min((H), h1 - 1) * 16; asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(R) : "s"(rp_)); }
+#define PCREG_ROW_WAIT(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R))
+#define PCREG_SCORE_HYP(H, R)                                                                                      \
+        if ((vmask[((H) - h0) >> 6] >> (((H) - h0) & 63)) & 1ull) {               /* wave-uniform */                 \
+            float T[12];                                                                                           \
+            _Pragma("unroll") for (int k = 0; k < 12; ++k) { const int w_ = R[k]; T[k] = __int_as_float(w_); }                 \
+            const int wlo_ = R[12], whi_ = R[13]; const float thlo = __int_as_float(wlo_), thhi = __int_as_float(whi_);          \
+            unsigned long long b[kSS], band = 0ull;                                                                \
+            _Pragma("unroll") for (int s = 0; s < kSS; ++s) {                                                      \
+                const float d = sqdist32(q[s], T);                                                                 \
+                b[s] = __ballot(d < thlo);                                                                         \
+                band |= __ballot(d <= thhi) ^ b[s];     /* nested sets: they differ iff somebody is in the band */  \
+            }                                                                                                      \
+            if (band != 0ull) {                         /* rare: the whole hypothesis again, fp64 on the raw coordinates */ \
+                double T64[12];                                                                                    \
+                _Pragma("unroll") for (int k = 0; k < 12; ++k) T64[k] = TT[(size_t)(H) * 12 + k];                  \
+                _Pragma("unroll 1") for (int s = 0; s < kSS; ++s) {                                                \
+                    const int i = ibase + s * 64;                                                                  \
+                    const bool act = i < n;                                                                        \
+                    const int ii = act ? i : 0;                                                                    \
+                    double p[6];                                                                                   \
+                    _Pragma("unroll") for (int c = 0; c < 3; ++c) { p[c] = a.p1[ii + (size_t)c * a.ld]; p[3 + c] = a.p2[ii + (size_t)c * a.ld]; } \
+                    const unsigned long long bb = __ballot((sqdist(p, T64) < th) & act);                           \
+                    _Pragma("unroll") for (int s2 = 0; s2 < kSS; ++s2) if (s2 == s) b[s2] = bb;                    \
+                }                                                                                                  \
+            }                                                                                                      \
+            int cnt = 0;                                                                                           \
+            int mine_lo = 0, mine_hi = 0;                                                                          \
+            _Pragma("unroll") for (int s = 0; s < kSS; ++s) {                                                      \
+                cnt += __popcll(b[s]);                                                                             \
+                if (EMIT) {                 /* ballot s into lane s */                                              \
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_lo) : "s"((int)(unsigned)b[s]), "n"(s)); \
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mine_hi) : "s"((int)(unsigned)(b[s] >> 32)), "n"(s)); \
+                }                                                                                                  \
+            }                                                                                                      \
+            if (lane == 0) s_cnt[wave][(H) - h0] += cnt;                                                           \
+            if (EMIT && lane < kSS)         /* one 64-byte row segment per (wave, hypothesis) */                   \
+                sa.masks[(size_t)(H) * sa.nslots_cap + (size_t)pb * (kSPts / 64) + wave * kSS + lane] =            \
+                    ((unsigned long long)(unsigned)mine_hi << 32) | (unsigned)mine_lo;                             \
         }
+        PCREG_ROW_LOAD(RA, h0)
+        for (int h = h0; h < h1; h += 2) {
+            PCREG_ROW_WAIT(RA); PCREG_ROW_LOAD(RB, h + 1)
+            PCREG_SCORE_HYP(h, RA)
+            PCREG_ROW_WAIT(RB); PCREG_ROW_LOAD(RA, h + 2)
+            if (h + 1 < h1) { PCREG_SCORE_HYP(h + 1, RB) }
+        }
+        PCREG_ROW_WAIT(RA);                               // drain the last prefetch
+#undef PCREG_SCORE_HYP
+#undef PCREG_ROW_WAIT
+#undef PCREG_ROW_LOAD
     }
     __syncthreads();
     for (int hl = threadIdx.x; hl < h1 - h0; hl += kSW * 64) {
