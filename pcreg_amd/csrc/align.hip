@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NT, PT <= 8 ? 4 : 2) void align_points_knn_reg_kern
     __shared__ unsigned long long s_small[kSmall];
     __shared__ int s_hist[256];
     __shared__ unsigned long long s_vk;
-    __shared__ int s_nsmall, s_bin, s_below, s_nless, s_neq;
+    __shared__ int s_nsmall, s_nless, s_neq;
 
     const int b = blockIdx.x;
     const int off = offsets[b];
@@ -128,22 +128,25 @@ __global__ __launch_bounds__(NT, PT <= 8 ? 4 : 2) void align_points_knn_reg_kern
     auto bin_of = [&](double d) -> int { const int bb = (int)((d - dlo) * scale); return bb > 255 ? 255 : bb; };
     PCREG_RG(atomicAdd(&s_hist[bin_of(D[r])], 1);)
     __syncthreads();
-    if (wave == 0) {
+    int bstar, below;
+    {   // every wave finds the bin of the K-th and the number of entries below that bin itself (no broadcast through LDS)
         int c4[4], run = 0;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) { c4[q4] = s_hist[lane * 4 + q4]; run += c4[q4]; }
         int incl = run;
 #pragma unroll
         for (int ofs = 1; ofs < 64; ofs <<= 1) { const int t = __shfl_up(incl, ofs); if (lane >= ofs) incl += t; }
-        int before = incl - run;
+        int before = incl - run, mybin = -1, mybelow = 0;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            if (before < K && K <= before + c4[q4]) { s_bin = lane * 4 + q4; s_below = before; }
+            if (before < K && K <= before + c4[q4]) { mybin = lane * 4 + q4; mybelow = before; }
             before += c4[q4];
         }
+        const unsigned long long has = __ballot(mybin >= 0);           // exactly one lane: 1 <= K <= n = the histogram's total
+        const int src = has ? __ffsll((long long)has) - 1 : 0;
+        bstar = __shfl(mybin, src); below = __shfl(mybelow, src);
+        if (bstar < 0) bstar = 0;
     }
-    __syncthreads();
-    const int bstar = s_bin, below = s_below;
     PCREG_RG(if (bin_of(D[r]) == bstar) { const int q = atomicAdd(&s_nsmall, 1); if (q < kSmall) s_small[q] = kth_key(D[r]); })
     __syncthreads();
     const int m = s_nsmall, Kp = K - below;
@@ -206,6 +209,8 @@ __global__ __launch_bounds__(NT, PT <= 8 ? 4 : 2) void align_points_knn_reg_kern
         mx = a3[0] / K; my = a3[1] / K; mz = a3[2] / K;
     }
     PCREG_AL_STAMP(3)
+    // (one pass for both moments, as in the descriptor kernel, was measured too: nine sums at once spill at 128 VGPRs
+    // and the kernel is 3 % slower)
     double cv[6] = {0, 0, 0, 0, 0, 0};
     const double cxc = opaque_f64(cx), cyc = opaque_f64(cy), czc = opaque_f64(cz);
     PCREG_RG(if ((sel >> r) & 1u) {
@@ -214,8 +219,6 @@ __global__ __launch_bounds__(NT, PT <= 8 ? 4 : 2) void align_points_knn_reg_kern
     double dof = C1 ? (double)K : (double)(K - 1);
     if (dof < 1.0) dof = 1.0;
     block_sum_nw<NW>(cv, s_redn);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cv[k] = cv[k] / dof;
     PCREG_AL_STAMP(4)
     if (tid == 0) {
         double a[6];
