@@ -145,7 +145,9 @@ int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2,
 /* B supports in one launch (the per-keypoint loop of
  * getSpacialHistogramDescriptors.m:64-145 calls the same LRF per support):
  * support b owns rows [offsets[b], offsets[b+1]) of pts / aligned; coeff 9*B, c 3*B;
- * status[b] = 0 ok, 1 = support too small (n < 2). */
+ * status[b] = 0 ok, 1 = support too small (n < 2).  A support may hold at most 8192 points (it is kept in the
+ * registers of one workgroup); larger -> PCREG_E_ARG.  The reference's supports hold 500 ... 6000
+ * (completeExperimentFast.m:300-302). */
 int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const int32_t* offsets,
                                    int B, int C1, int C2, double* aligned, double* coeff,
                                    double* c, int32_t* status);
