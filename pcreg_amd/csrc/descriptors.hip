@@ -37,9 +37,11 @@ constexpr int kMaxCells = 1 << 16;
 constexpr int NR = 10, NT = 7, NP = 14, ND = NR * NT * NP;
 
 struct Grid {
-    double ox, oy, oz, inv;                // origin and 1 / cell edge (y, z)
-    double invx, h;                        // 1 / cell edge along x (a fraction of h: see grid_setup_kernel), h = y/z edge
+    double ox, oy, oz;                     // origin
+    double invx, invy, invz;               // 1 / cell edge per axis: the edges are fractions of h (see grid_setup_kernel)
+    double hy, hz;                         // cell edges along y and z
     int nx, ny, nz, ncells;
+    int fx, fy, fz;                        // h / edge per axis: a sphere of radius R <= h reaches at most f cells to either side
 };
 // ct = cos(t); r2ge[k] = the smallest d2 with sqrt(d2) >= r[k], r2gt = the smallest d2 with sqrt(d2) > r[NR] (the radial
 // bin of a point follows from its SQUARED distance, exactly); cts[k] = ct[k] |ct[k]| (theta's bin from z |z| vs cts d2)
@@ -50,7 +52,7 @@ __device__ __forceinline__ int cell_coord(double v, double o, double inv, int n)
     return c < 0 ? 0 : (c >= n ? n - 1 : c);
 }
 __device__ __forceinline__ int cell_of(const Grid& g, double x, double y, double z) {
-    return (cell_coord(z, g.oz, g.inv, g.nz) * g.ny + cell_coord(y, g.oy, g.inv, g.ny)) * g.nx + cell_coord(x, g.ox, g.invx, g.nx);
+    return (cell_coord(z, g.oz, g.invz, g.nz) * g.ny + cell_coord(y, g.oy, g.invy, g.ny)) * g.nx + cell_coord(x, g.ox, g.invx, g.nx);
 }
 
 // ---- grid: bounding box -> cell size ------------------------------------------------------
@@ -76,26 +78,34 @@ __global__ __launch_bounds__(kBlock) void bbox_partial_d_kernel(const double* __
         part[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
-__global__ void grid_setup_kernel(const double* __restrict__ part, int nparts, double R, Grid* __restrict__ g) {
+__global__ void grid_setup_kernel(const double* __restrict__ part, int nparts, double R, Grid* __restrict__ g, int force_opt) {
     if (threadIdx.x != 0) return;
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = 0; b < nparts; ++b)
         for (int c = 0; c < 3; ++c) { lo[c] = fmin(lo[c], part[b * 6 + c]); hi[c] = fmax(hi[c], part[b * 6 + 3 + c]); }
     if (!(hi[0] >= lo[0])) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = 0; }
-    double cell = R;                       // >= R so that a sphere touches at most 3 cells per axis
+    double cell = R;                       // h >= R: a sphere reaches at most one h to either side along every axis
     for (;;) {
         double nx = floor((hi[0] - lo[0]) / cell) + 1, ny = floor((hi[1] - lo[1]) / cell) + 1, nz = floor((hi[2] - lo[2]) / cell) + 1;
-        if (nx * ny * nz <= (double)kMaxCells) { g->nx = (int)nx; g->ny = (int)ny; g->nz = (int)nz; break; }
+        if (nx * ny * nz <= (double)kMaxCells) break;
         cell *= 1.26;                      // ~ halve the cell count
     }
-    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2]; g->inv = 1.0 / cell; g->h = cell;
-    // Cells are thinner along x (edge h / fx, as many as fit): a keypoint's nine (dz, dy) rows stay contiguous runs, but each
-    // is cut to the x interval the sphere can reach in that row -- about half the candidates of the 3 x 3 x 3 block, and the
-    // kept points sit twice as densely in the runs the later passes gather from
-    int fx = 8;
-    while (fx > 1 && (floor((hi[0] - lo[0]) * fx / cell) + 1) * g->ny * g->nz > (double)kMaxCells) fx >>= 1;
-    g->invx = fx / cell;
-    g->nx = (int)(floor((hi[0] - lo[0]) * g->invx) + 1);
+    // The cells are a fraction of h wide: a keypoint's neighbourhood is then (2 fy + 1)(2 fz + 1) rows of x-contiguous
+    // cells, each cut to the x interval the sphere can reach given the row's slab gaps.  Candidate volume per keypoint
+    // (Monte Carlo over keypoint positions, in R^3; the sphere itself is 4.19): (1,1,1) 20.6, (8,1,1) 13.5, (4,2,1) 11.5,
+    // (2,2,2) 10.5, (4,2,2) 9.2 -- the finest subdivision that fits the cell budget is taken.
+    const int opts[7][3] = {{4, 2, 2}, {2, 2, 2}, {4, 2, 1}, {8, 1, 1}, {4, 1, 1}, {2, 1, 1}, {1, 1, 1}};
+    int pick = 6;
+    for (int k = force_opt >= 0 ? force_opt : 0; k < 7; ++k) {
+        double cnt = 1.0;
+        for (int c = 0; c < 3; ++c) cnt *= floor((hi[c] - lo[c]) * (opts[k][c] / cell)) + 1;     // the very expression that sizes the grid below
+        if (cnt <= (double)kMaxCells) { pick = k; break; }
+    }
+    g->fx = opts[pick][0]; g->fy = opts[pick][1]; g->fz = opts[pick][2];
+    g->ox = lo[0]; g->oy = lo[1]; g->oz = lo[2];
+    g->invx = g->fx / cell; g->invy = g->fy / cell; g->invz = g->fz / cell;
+    g->hy = cell / g->fy; g->hz = cell / g->fz;
+    g->nx = (int)(floor((hi[0] - lo[0]) * g->invx) + 1); g->ny = (int)(floor((hi[1] - lo[1]) * g->invy) + 1); g->nz = (int)(floor((hi[2] - lo[2]) * g->invz) + 1);
     g->ncells = g->nx * g->ny * g->nz;
 }
 
@@ -287,24 +297,26 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
     __syncthreads();
 
-    // ---- getLocalPoints: |p - c| < R (strict), from the <= 27 cells around c ----
-    // Nine (dz, dy) rows of three x-adjacent cells each are contiguous runs of the sorted arrays.  Every
-    // row is cut into four wave segments; pass 1 only counts, one barrier turns the 36 counts into list
-    // offsets, pass 2 re-tests and writes -- the list order (row, then ascending position) is the same
-    // as a serial scan's, with two barriers instead of three per 256 candidates.
-    const int ky = cell_coord(cy, g.oy, g.inv, g.ny), kz = cell_coord(cz, g.oz, g.inv, g.nz);
-    // a keypoint outside the cloud's box by more than one cell has no neighbours: its rows are then farther than R
-    __shared__ int s_seg[9][4];
-    int rb[9], re[9];                               // this wave's segment of every row
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int zz = kz + r / 3 - 1, yy = ky + r % 3 - 1;
+    // ---- getLocalPoints: |p - c| < R (strict), from the cells around c ----
+    // The grid's cells are a fraction of R wide (Grid::fx, fy, fz per axis).  A ROW = the cells of one (z, y) slab pair,
+    // contiguous along x in the sorted arrays: at most (2 fy + 1)(2 fz + 1) <= kRowsMax rows can hold points of the sphere,
+    // and each is cut to the x interval the sphere can reach given the row's slab gaps.  Rows are split into chunks of
+    // 64 consecutive points; wave w takes the chunks w, w + 4, ... of the whole sequence (balanced whatever the row
+    // lengths), the list is wave-major (all of wave 0's points, then wave 1's, ...): deterministic, and the later
+    // passes do not care -- ties go by ORIGINAL index.
+    constexpr int kRowsMax = 25;
+    __shared__ int s_rowb[kRowsMax], s_rowe[kRowsMax], s_cp[kRowsMax + 1], s_wtot[4];
+    const int nyo = g.fy, nzo = g.fz, wy = 2 * nyo + 1, nrows = wy * (2 * nzo + 1);
+    if (tid < nrows) {
+        const int ky = cell_coord(cy, g.oy, g.invy, g.ny), kz = cell_coord(cz, g.oz, g.invz, g.nz);
+        const int zz = kz + tid / wy - nzo, yy = ky + tid % wy - nyo;
         int b = 0, e = 0;
+        // a keypoint outside the cloud's box by more than R has no neighbours: all its rows are then farther than R
         if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
             // the row's slab in y and z keeps every point at least (gy, gz) away from the keypoint: what is left of R^2
             // bounds |x - cx|.  Margins of 1e-9 (cell edges are products rounded once, cell_coord is monotone in x).
-            const double ylo = g.oy + yy * g.h, zlo = g.oz + zz * g.h;
-            const double gy = fmax(0.0, fmax(ylo - cy, cy - (ylo + g.h)) - 1e-9 * g.h), gz = fmax(0.0, fmax(zlo - cz, cz - (zlo + g.h)) - 1e-9 * g.h);
+            const double ylo = g.oy + yy * g.hy, zlo = g.oz + zz * g.hz;
+            const double gy = fmax(0.0, fmax(ylo - cy, cy - (ylo + g.hy)) - 1e-9 * g.hy), gz = fmax(0.0, fmax(zlo - cz, cz - (zlo + g.hz)) - 1e-9 * g.hz);
             const double w2 = R * R - gy * gy - gz * gz;
             if (w2 >= 0.0) {
                 const double w = sqrt(w2) + 1e-9 * R;
@@ -312,13 +324,25 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
                 b = cell_start[(zz * g.ny + yy) * g.nx + x0]; e = cell_start[(zz * g.ny + yy) * g.nx + x1 + 1];   // x-adjacent cells are contiguous
             }
         }
-        const int seg = (((e - b) + 3) / 4 + 63) / 64 * 64;
-        rb[r] = min(e, b + wave * seg); re[r] = min(e, b + (wave + 1) * seg);
+        s_rowb[tid] = b; s_rowe[tid] = e;
     }
+    __syncthreads();
+    if (tid == 0) {                                  // chunk prefix over the rows
+        int run = 0;
+        for (int r = 0; r < nrows; ++r) { s_cp[r] = run; run += (s_rowe[r] - s_rowb[r] + 63) >> 6; }
+        s_cp[nrows] = run;
+    }
+    __syncthreads();
+    const int n_chunks = s_cp[nrows];
     // pass 1 streams the candidates ONCE (four 64-point chunks = twelve loads in flight per wave) and keeps
     // every chunk's ballot; pass 2 replays the ballots, so it touches no global memory
     constexpr int kMaskCap = 160;                   // chunks per wave whose ballot is kept (beyond: re-tested)
     __shared__ unsigned long long s_mask[4][kMaskCap];
+    // chunk c -> (first position, end of its row); the row pointer only moves forward (chunks are visited in order)
+    auto chunk_range = [&](int c, int& rp, int& j0, int& end) {
+        while (c >= s_cp[rp + 1]) ++rp;
+        j0 = s_rowb[rp] + ((c - s_cp[rp]) << 6); end = s_rowe[rp];
+    };
     auto in_sphere = [&](int j, int end) -> bool {
         if (j >= end) return false;
         const double x = sx[j] - cx, y = sy[j] - cy, z = sz[j] - cz;
@@ -326,52 +350,47 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     };
     double a3[3] = {0, 0, 0};
     {
-        int ch = 0;                                  // running chunk number of this wave
+        int rp = 0, cnt = 0, ch = 0;                 // ch: running chunk number of this wave
+        for (int c0 = wave; c0 < n_chunks; c0 += 16) {
+            double X[4], Y[4], Z[4]; int J0[4], E[4];
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            int c = 0;
-            for (int j0 = rb[r]; j0 < re[r]; j0 += 256) {
-                double X[4], Y[4], Z[4];
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 4 * u;
+                J0[u] = 0; E[u] = 0;
+                if (c < n_chunks) chunk_range(c, rp, J0[u], E[u]);           // wave-uniform
+                const int j = max(min(J0[u] + lane, E[u] - 1), 0);
+                X[u] = sx[j]; Y[u] = sy[j]; Z[u] = sz[j];
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = min(j0 + u * 64 + lane, re[r] - 1);
-                    X[u] = sx[j]; Y[u] = sy[j]; Z[u] = sz[j];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (j0 + u * 64 < re[r]) {       // wave-uniform
-                        const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
-                        const bool in = (j0 + u * 64 + lane < re[r]) && x * x + y * y + z * z < R2T;
-                        if (in) { a3[0] += x; a3[1] += y; a3[2] += z; }        // the local centroid's sums ride along (:80)
-                        const unsigned long long bal = __ballot(in);
-                        if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
-                        ++ch;
-                        c += __popcll(bal);
-                    }
+            for (int u = 0; u < 4; ++u) {
+                if (c0 + 4 * u < n_chunks) {         // wave-uniform
+                    const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
+                    const bool in = (J0[u] + lane < E[u]) && x * x + y * y + z * z < R2T;
+                    if (in) { a3[0] += x; a3[1] += y; a3[2] += z; }        // the local centroid's sums ride along (:80)
+                    const unsigned long long bal = __ballot(in);
+                    if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
+                    ++ch;
+                    cnt += __popcll(bal);
                 }
             }
-            if (lane == 0) s_seg[r][wave] = c;
         }
+        if (lane == 0) s_wtot[wave] = cnt;
     }
     __syncthreads();
-    int n_total = 0, my_base[9];
+    int n_total = 0, my_base = 0;
 #pragma unroll
-    for (int r = 0; r < 9; ++r)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { if (w == wave) my_base[r] = n_total; n_total += s_seg[r][w]; }
+    for (int w = 0; w < 4; ++w) { if (w == wave) my_base = n_total; n_total += s_wtot[w]; }
     const int n = n_total;
     if (n < 1 || n < o.min_pts || n > o.max_pts) return;                   // getLocalPoints.m:17,31
     if (n > cap) { if (tid == 0) atomicMax(err, n); return; }              // support larger than the LDS list
     {
-        int ch = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            int pos = my_base[r];
-            for (int j0 = rb[r]; j0 < re[r]; j0 += 64, ++ch) {
-                const unsigned long long bal = ch < kMaskCap ? s_mask[wave][ch] : __ballot(in_sphere(j0 + lane, re[r]));
-                if ((bal >> lane) & 1ull) lpos[pos + __popcll(bal & ((1ull << lane) - 1ull))] = j0 + lane;
-                pos += __popcll(bal);
-            }
+        int rp = 0, ch = 0, pos = my_base;
+        for (int c = wave; c < n_chunks; c += 4, ++ch) {
+            int j0, end;
+            chunk_range(c, rp, j0, end);
+            const unsigned long long bal = ch < kMaskCap ? s_mask[wave][ch] : __ballot(in_sphere(j0 + lane, end));
+            if ((bal >> lane) & 1ull) lpos[pos + __popcll(bal & ((1ull << lane) - 1ull))] = j0 + lane;
+            pos += __popcll(bal);
         }
     }
     __syncthreads();
@@ -753,7 +772,7 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
 
     int nb = (P + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
     hipLaunchKernelGGL(bbox_partial_d_kernel, dim3(nb), dim3(kBlock), 0, st, pts, P, ld, bpart);
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, st, bpart, nb, o.R, grid);
+    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(64), 0, st, bpart, nb, o.R, grid, PCREG_EXP_ENV("PCREG_DESC_SUBDIV", -1));
     PCREG_HIP(hipMemsetAsync(counts, 0, (size_t)tiles * kMaxCells * 4, st));
     hipLaunchKernelGGL(grid_count_kernel, dim3(tiles), dim3(kBlock), 0, st, pts, P, ld, grid, cell_id, counts);
     hipLaunchKernelGGL(grid_cell_prefix_kernel, dim3((kMaxCells + 1 + 255) / 256), dim3(256), 0, st, counts, tiles, grid, cell_total);
