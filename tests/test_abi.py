@@ -71,3 +71,13 @@ def test_comm_entry_points_fail_cleanly_without_a_device():
     r, w = C.c_int(), C.c_int()
     assert L.pcreg_comm_rank(C.byref(r), C.byref(w)) == _lib.PCREG_E_ARG
     assert L.pcreg_comm_destroy() == 0
+
+
+def test_default_library_carries_no_experiment_switches():
+    """The experiment / debug environment switches (timing-only kernels, early returns, launch-shape overrides) exist only
+    in `make EXPERIMENTS=1` builds: the library `__graft_entry__.build()` produces must not even contain their names
+    (the objects depend on the flag string, so a default `make` after an experiments build relinks everything)."""
+    from pcreg_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"PCREG_KNN_VARIANT", b"PCREG_DESC_STOP", b"PCREG_SAD_DRY", b"PCREG_KNN_F16_QG", b"PCREG_ALIGN_TIMES", b"PCREG_DESC_SUBDIV"):
+        assert name not in blob, name.decode()
