@@ -162,3 +162,25 @@ def test_unique_grid_check_equals_oracle(kind, Q, M, thr, ratio, oracle_c):
     assert len(ref) > 0
     if kind in ("duplicates", "clusters"):
         assert len(ref) < len(loose)             # Unique really removed something
+
+
+def test_getDescDist_known_answer_on_the_hip_path(oracle_py):
+    """GPU twin of tests/test_oracle_kat.py::test_getDescDist_known_answer: pcreg_match_features' matchMetric output, on rows
+    prepared with visualizeGTMatches.m:390-410's constant, equals the reference's own scalar restatement of the metric;
+    pcreg_get_matches (which computes the constant itself, getMatches.m:24) returns the same pairs."""
+    import pcreg_amd as pc
+    from test_oracle_kat import desc_rows_l1_1600, getDescDist_literal
+    D = 980
+    dM = desc_rows_l1_1600(300, D, 11)
+    dS = dM[np.random.default_rng(12).permutation(300)[:120]].copy()
+    to = np.random.default_rng(13).integers(0, D, 120)
+    for r in range(120):
+        dS[r, int(np.argmax(dS[r]))] -= 3; dS[r, to[r]] += 3
+    par = dict(Method="Exhaustive", Metric="SAD", MatchThreshold=100.0, MaxRatio=1.0, Unique=False, UNNORMALIZE=True,
+               norm_factor=2, CHANGE_METRIC=True, metric_factor=0.45, VERBOSE=0)
+    pS, pM = oracle_py.preprocess_descriptors(dS, dM, par)         # appended 3200, power 0.45
+    pairs, met = pc.matchFeatures(pS, pM, Method="Exhaustive", MatchThreshold=100.0, MaxRatio=1.0, Metric="SAD", Unique=False)
+    assert len(pairs) == 120
+    for (i, j), d in zip(pairs.astype(int), met):
+        assert abs(d - getDescDist_literal(dS[i - 1], dM[j - 1])) < 1e-13, (i, j)
+    np.testing.assert_array_equal(pc.getMatches(dS, dM, par), pairs)

@@ -241,3 +241,60 @@ def test_descriptors_numpy_vs_c(oracle_py, oracle_c):
             # only 2 of the 14 phi slabs can be populated (y > 0 -> pi/4, y < 0 -> -3pi/4)
             slabs = d1.reshape(len(d1), 14, 7, 10).sum(axis=(2, 3))
             assert (np.count_nonzero(slabs, axis=1) <= 2).all()
+
+
+# ---- the one restatement of the match metric the reference itself holds ------------------------------------------
+def getDescDist_literal(desc1, desc2):
+    """visualizeGTMatches.m:390-410, line by line: append `unnorm*avg_desc_len` (2 * 1600), raise to 0.45,
+    L2-normalise, L1 distance.  The order append -> power -> L2-normalise -> SAD is what getMatches.m:22-56 +
+    matchFeatures('Metric','SAD') must reproduce."""
+    change_metric, unnorm, avg_desc_len = 0.45, 2, 1600            # :392-394
+    d1 = np.concatenate([desc1, [unnorm * avg_desc_len]])           # :397
+    d2 = np.concatenate([desc2, [unnorm * avg_desc_len]])           # :398
+    d1 = d1 ** change_metric                                        # :401
+    d2 = d2 ** change_metric                                        # :402
+    d1 = d1 / np.sqrt(np.sum(d1 * d1))                              # :405  norm(desc1, 2)
+    d2 = d2 / np.sqrt(np.sum(d2 * d2))                              # :406
+    return np.sum(np.abs(d1 - d2))                                  # :409  vecnorm(desc1 - desc2, 1)
+
+
+def desc_rows_l1_1600(n, D, seed):
+    """Non-negative integer count rows whose L1 norm is exactly 1600 each, so that getMatches.m:24's
+    mean(vecnorm([descSurface; descModel], 1, 2)) is exactly getDescDist's avg_desc_len."""
+    rng = np.random.default_rng(seed)
+    rows = rng.multinomial(1600, rng.dirichlet(np.full(D, 0.3)), size=n).astype(np.float64)
+    assert (rows.sum(axis=1) == 1600).all()
+    return rows
+
+
+def test_getDescDist_known_answer(oracle_py, oracle_c):
+    """visualizeGTMatches.m:390-410 pins the metric getMatches hands to matchFeatures: for every matched pair the
+    oracle's matchMetric must equal the reference's own scalar restatement."""
+    D = 60
+    dM = desc_rows_l1_1600(40, D, 1)
+    dS = dM[np.random.default_rng(2).permutation(40)[:25]].copy()
+    to = np.random.default_rng(3).integers(0, D, 25)
+    for r in range(25):                                   # move three counts out of the fullest bin: L1 stays 1600
+        dS[r, int(np.argmax(dS[r]))] -= 3; dS[r, to[r]] += 3
+    assert (dS.sum(axis=1) == 1600).all()
+    par = dict(Method="Exhaustive", Metric="SAD", MatchThreshold=100.0, MaxRatio=1.0, Unique=False, UNNORMALIZE=True,
+               norm_factor=2, CHANGE_METRIC=True, metric_factor=0.45)
+    # (a) the preprocessing alone: appended constant == unnorm * avg_desc_len == 3200, then the power
+    pS, pM = oracle_py.preprocess_descriptors(dS, dM, par)
+    assert pS.shape[1] == D + 1 and np.all(pS[:, -1] == 3200.0 ** 0.45) and np.all(pM[:, -1] == 3200.0 ** 0.45)
+    # (b) the per-pair metric of the numpy oracle, all 25 x best-of-40
+    pairs, met, allr = oracle_py.matchFeatures(pS, pM, Method="Exhaustive", MatchThreshold=100.0, MaxRatio=1.0,
+                                               Metric="SAD", Unique=False, return_all=True)
+    assert len(pairs) == 25
+    for (i, j), d in zip(pairs.astype(int), met):
+        assert abs(d - getDescDist_literal(dS[i - 1], dM[j - 1])) < 1e-15 * 8, (i, j)
+        # and it is the minimum of the literal distance over the model rows (first index on ties)
+        lit = np.array([getDescDist_literal(dS[i - 1], dM[k]) for k in range(40)])
+        assert j - 1 == int(np.argmin(np.round(lit, 13))) or abs(lit[j - 1] - lit.min()) < 1e-14
+    # (c) the C oracle: same pairs, same metric
+    pc, mc = oracle_c.matchFeatures(pS, pM, dict(par, UNNORMALIZE=False, CHANGE_METRIC=False))
+    assert np.array_equal(pc, pairs) and np.abs(mc - met).max() < 1e-14
+    assert np.array_equal(oracle_c.getMatches(dS, dM, par), oracle_py.getMatches(dS, dM, par))
+    # (d) the second-best distances too (what the ratio test divides by)
+    for i in range(25):
+        assert abs(allr["d2"][i] - getDescDist_literal(dS[i], dM[allr["i2"][i]])) < 1e-14
