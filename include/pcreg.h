@@ -124,6 +124,14 @@ int pcreg_match_points_f32(const float* q, int Q, int ldq, const float* m, int M
                            float thr_abs, float max_ratio, int unique,
                            uint32_t* pairs, int* P);
 
+/* The same against a model that is uploaded and prepared ONCE (host tier of the handle below): MATLAB keeps the
+ * handle as a uint64 and matches any number of surfaces against it (completeExperimentFast.m:131-149). */
+typedef struct pcreg_model pcreg_model;
+int pcreg_model_create(const float* m, int M, int ldm, pcreg_model** model);
+int pcreg_model_destroy(pcreg_model* model);
+int pcreg_model_match_points_f32(pcreg_model* model, const float* q, int Q, int ldq, float thr_abs, float max_ratio,
+                                 int unique, uint32_t* pairs, int* P);
+
 /* getMatches.m:51  matchFeatures(features1, features2, 'Method',..,'MatchThreshold',..,
  * 'MaxRatio',..,'Metric',..,'Unique',..) on Q x D / M x D double features (exact
  * search; 'Approximate' is answered exactly).  Only the matchFeatures fields of opts
@@ -198,6 +206,44 @@ int pcreg_dev_knn2_points_f32(const float* q, int Q, int ldq, const float* m, in
                               int32_t idx_base, int32_t* idx, float* dist,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- a PREPARED MODEL: one model, many surfaces (completeExperimentFast.m:131-149 matches every candidate sphere,
+ * :201-216 registers every promising one, against the same model; BASELINE cfg 5: 64 crops vs one CT model) ----------
+ * Everything that depends on the model alone -- its bounding box, the tiles of matrix-core operands, the model-wide
+ * seeding grid -- is computed once; a search against the handle is four launches, the match stage one.
+ * pcreg_dev_model_create enqueues the preparation on `stream` and returns at once; the model's points (`m`, n x 3
+ * column-major, ldm) are NOT copied and must stay valid and unchanged while the handle lives.  A handle may be used
+ * from several streams at once as long as each call has its own workspace.  Reported rows are idx_base + local row. */
+typedef struct pcreg_dev_model pcreg_dev_model;
+int pcreg_dev_model_create(const float* m, int M, int ldm, void* stream, pcreg_dev_model** model);
+int pcreg_dev_model_destroy(pcreg_dev_model* model);
+/* Top-2 of every query over the prepared model (pcreg_dev_knn2_points_f32's contract and bits).  The workspace also
+ * receives a uniform grid over the queries, which pcreg_dev_model_match_f32 / _match_table_f32 need for Unique: pass
+ * the SAME workspace to them, with no other search on it in between. */
+size_t pcreg_dev_model_search_workspace(int Q, int M);
+int pcreg_dev_model_search_f32(const pcreg_dev_model* model, const float* q, int Q, int ldq, int32_t idx_base,
+                               int32_t* idx, float* dist, void* workspace, size_t workspace_bytes, void* stream);
+/* matchFeatures' filter chain on that top-2 in ONE launch: threshold, ratio test, Unique back-check, ordered compaction
+ * into 1-based pairs [k][2] and the matched coordinates pts1 / pts2 (n x 3 column-major doubles, ld = Q; both NULL to
+ * skip) -- completeExperimentFast.m:205-206.  The handle holds the WHOLE model (one rank). */
+int pcreg_dev_model_match_f32(const pcreg_dev_model* model, const float* q, int Q, int ldq, const int32_t* idx,
+                              const float* dist, float thr_abs, float max_ratio, int unique, void* workspace,
+                              size_t workspace_bytes, uint32_t* pairs, double* pts1, double* pts2, int32_t* n_pairs,
+                              void* stream);
+/* The same split around the multi-GPU exchange (idx / dist are the MERGED global top-2):
+ * _match_table_f32: this rank's contribution to a [4][Q] table of 4-byte words, column = query: rows 0-2 the coordinate
+ *   bits of the query's nearest model point, row 3 its Unique verdict (1 when Unique is off), written by the rank whose
+ *   shard [m_lo, m_lo + M) holds that point and only for queries that pass the filters; zero elsewhere.  An integer
+ *   all_reduce(SUM) over the ranks assembles the table exactly (one contributor per column).
+ * pcreg_dev_match_from_table_f32: filters again (deterministic), verdicts and coordinates from the summed table, ordered
+ *   compaction.  `workspace`: any search workspace of this Q (only its counters are used). */
+int pcreg_dev_model_match_table_f32(const pcreg_dev_model* model, int32_t m_lo, int M_total, const float* q, int Q, int ldq,
+                                    const int32_t* idx, const float* dist, float thr_abs, float max_ratio, int unique,
+                                    void* workspace, size_t workspace_bytes, int32_t* table, void* stream);
+int pcreg_dev_match_from_table_f32(const float* q, int Q, int ldq, int M_total, const int32_t* idx, const float* dist,
+                                   float thr_abs, float max_ratio, const int32_t* table, void* workspace,
+                                   size_t workspace_bytes, uint32_t* pairs, double* pts1, double* pts2, int32_t* n_pairs,
+                                   void* stream);
+
 /* Merge R candidate lists (e.g. the all-gathered per-shard results, laid out
  * [R][Q][2]) into one top-2 per query, ordering by (dist, idx). */
 int pcreg_dev_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q,
@@ -206,38 +252,6 @@ int pcreg_dev_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R,
  * carry a rank's indices and distances in a single buffer. */
 int pcreg_dev_merge_top2_strided_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, size_t rank_stride,
                                      int32_t* idx, float* dist, void* stream);
-
-/* Threshold + ratio test on a merged top-2: cand_q/cand_m (capacity Q, 0-based,
- * ascending query) and *n_cand (device int32). */
-int pcreg_dev_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total,
-                              float thr_abs, float max_ratio, int32_t* cand_q, int32_t* cand_m,
-                              int32_t* n_cand, void* stream);
-
-/* Unique back-check for the candidates whose model row lies in this shard
- * [m_lo, m_lo+M): keep[k] = 1 if cand_q[k] is the first-best query of model row
- * cand_m[k] over all Q queries, 0 if not, untouched if the row is in another shard.
- * n_cand is read from device memory; capacity = Q. */
-size_t pcreg_dev_unique_points_f32_workspace(int Q);
-int pcreg_dev_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
-                                int32_t m_lo, const int32_t* cand_q, const int32_t* cand_m,
-                                const int32_t* n_cand, int32_t* keep,
-                                void* workspace, size_t workspace_bytes, void* stream);
-
-/* Multi-GPU: this rank's contribution to the [4][Q] candidate table of 4-byte words (rows 0-2: coordinate bits of
- * the candidates whose model row is in this shard [m_lo, m_lo + M); row 3: their Unique verdict, 1 if keep is NULL;
- * zero elsewhere).  An integer all_reduce(SUM) over the ranks assembles the table exactly; rows 0-2 then serve as
- * the `m` of pcreg_dev_gather_pairs_f32 (ldm = Q, identity cand_m) and row 3 as its keep. */
-int pcreg_dev_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
-                             const int32_t* n_cand, int Q, int32_t* table, void* stream);
-
-/* Compact the kept candidates into 1-based pairs (row-major [k][2]) and gather the
- * matched coordinates as double n x 3 (ld = Q): pts1 = surface(query) rows, pts2 =
- * model rows (completeExperimentFast.m:205-206).  m is the FULL model here (or any
- * array indexable by the global model row). */
-int pcreg_dev_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm,
-                               const int32_t* cand_q, const int32_t* cand_m, const int32_t* keep,
-                               const int32_t* n_cand, uint32_t* pairs, double* pts1, double* pts2,
-                               int32_t* n_pairs, void* stream);
 
 /* Device-resident ransac: n is read from device memory (*n_dev <= n_cap), so the
  * match stage can feed it without a host round trip.  Results land in `out`
@@ -252,7 +266,7 @@ int pcreg_dev_ransac(const double* pts1, const double* pts2, const int32_t* n_de
                      pcreg_dev_ransac_result* out, int32_t* inlier_idx,
                      void* workspace, size_t workspace_bytes, void* stream);
 
-/* Measurement aid: with timing enabled, the candidates kernel of every (large) point search is
+/* Measurement aid: with timing enabled, the candidates kernel of every point search the CALLER asks for (any size) is
  * bracketed by two HIP events on its launch stream; pcreg_dev_search_kernel_ms returns the mean
  * duration over the launches since the previous call (it waits for them) and their number. */
 int pcreg_dev_search_kernel_timing(int enable);
@@ -395,6 +409,10 @@ int pcreg_dev_refine_by_distance(const double* pts1, const double* pts2, const i
 typedef struct pcreg_comm_id { char bytes[128]; } pcreg_comm_id;      /* an ncclUniqueId */
 int pcreg_comm_get_unique_id(pcreg_comm_id* id);
 int pcreg_comm_init(int rank, int world, const pcreg_comm_id* id);
+/* The same communicator over HOST-STAGED exchanges instead of RCCL: the ranks meet in the POSIX shared-memory segment
+ * `name` ("/something", unique per group; every rank passes the same).  For workers that share one GPU (RCCL refuses two
+ * ranks on a device) and for boxes without RCCL; the messages of this path are latency-sized (<= 16 Q bytes). */
+int pcreg_comm_init_host_staged(int rank, int world, const char* name);
 int pcreg_comm_rank(int* rank, int* world);
 int pcreg_comm_destroy(void);
 

@@ -53,11 +53,13 @@ SYMBOLS = [
     "pcreg_last_error", "pcreg_version", "pcreg_device_count", "pcreg_set_device", "pcreg_device_name",
     "pcreg_estimate_transform", "pcreg_calc_dists", "pcreg_ransac", "pcreg_ransac_batched",
     "pcreg_knn2_points_f32", "pcreg_match_points_f32", "pcreg_match_features", "pcreg_get_matches",
+    "pcreg_model_create", "pcreg_model_destroy", "pcreg_model_match_points_f32",
+    "pcreg_dev_model_create", "pcreg_dev_model_destroy", "pcreg_dev_model_search_workspace", "pcreg_dev_model_search_f32",
+    "pcreg_dev_model_match_f32", "pcreg_dev_model_match_table_f32", "pcreg_dev_match_from_table_f32",
     "pcreg_align_points_knn", "pcreg_align_points_knn_f32", "pcreg_align_points_knn_batched", "pcreg_spatial_histogram_descriptors",
     "pcreg_spatial_histogram_descriptors_f32",
-    "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32", "pcreg_dev_merge_top2_strided_f32", "pcreg_dev_cand_table_f32",
-    "pcreg_dev_filter_top2_f32", "pcreg_dev_unique_points_f32_workspace", "pcreg_dev_unique_points_f32",
-    "pcreg_dev_gather_pairs_f32", "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
+    "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32", "pcreg_dev_merge_top2_strided_f32",
+    "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
     "pcreg_dev_ransac_partial", "pcreg_dev_ransac_finish", "pcreg_dev_ransac_finish_parts",
     "pcreg_dev_search_kernel_timing", "pcreg_dev_search_kernel_ms",
     "pcreg_dev_spatial_histogram_descriptors_workspace", "pcreg_dev_spatial_histogram_descriptors",
@@ -66,7 +68,7 @@ SYMBOLS = [
     "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select",
     "pcreg_dev_gather_rows_f64", "pcreg_dev_sweep_plan", "pcreg_dev_sweep_gather", "pcreg_dev_ransac_batched_workspace",
     "pcreg_dev_ransac_batched", "pcreg_dev_align_points_knn_batched", "pcreg_dev_quick_tf", "pcreg_dev_refine_by_distance",
-    "pcreg_comm_get_unique_id", "pcreg_comm_init", "pcreg_comm_rank", "pcreg_comm_destroy",
+    "pcreg_comm_get_unique_id", "pcreg_comm_init", "pcreg_comm_init_host_staged", "pcreg_comm_rank", "pcreg_comm_destroy",
     "pcreg_match_points_sharded_f32", "pcreg_ransac_sharded",
     "pcreg_pcd_info", "pcreg_pcd_read", "pcreg_pcd_write", "pcreg_mat_read_double",
 ]
@@ -92,7 +94,7 @@ def lib() -> C.CDLL:
         L = C.CDLL(LIB_PATH)
         L.pcreg_last_error.restype = C.c_char_p
         L.pcreg_version.restype = C.c_char_p
-        for name in ("pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_unique_points_f32_workspace",
+        for name in ("pcreg_dev_model_search_workspace", "pcreg_dev_knn2_points_f32_workspace",
                      "pcreg_dev_ransac_workspace", "pcreg_dev_spatial_histogram_descriptors_workspace",
                      "pcreg_dev_get_matches_workspace", "pcreg_dev_sphere_select_workspace", "pcreg_dev_ransac_batched_workspace"):
             getattr(L, name).restype = C.c_size_t

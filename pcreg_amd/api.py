@@ -321,6 +321,46 @@ def knn2_points(query, model):
     return idx[:Q], dist[:Q]
 
 
+class Model:
+    """A model cloud uploaded and prepared ONCE (pcreg_model_create), matched against any number of surfaces: the host-tier
+    handle a MATLAB caller keeps across the sphere loop of completeExperimentFast.m:131-149.  Use as a context manager or
+    call close()."""
+
+    def __init__(self, model):
+        m = _fcol(model, np.float32)
+        self.M = m.shape[0]
+        self._h = C.c_void_p()
+        check(lib().pcreg_model_create(_ptr(m, C.c_float), C.c_int(self.M), C.c_int(max(self.M, 1)), C.byref(self._h)))
+
+    def match_points(self, query, thr_abs: float, max_ratio: float, unique: bool = True) -> np.ndarray:
+        if not self._h.value:
+            raise ValueError("the model handle is closed")
+        q = _fcol(query, np.float32)
+        Q = q.shape[0]
+        pairs = np.zeros((max(Q, 1), 2), dtype=np.uint32)
+        P = C.c_int(0)
+        check(lib().pcreg_model_match_points_f32(self._h, _ptr(q, C.c_float), C.c_int(Q), C.c_int(max(Q, 1)), C.c_float(thr_abs),
+                                                 C.c_float(max_ratio), C.c_int(int(unique)), _ptr(pairs, C.c_uint32), C.byref(P)))
+        return pairs[:P.value].copy()
+
+    def close(self):
+        if self._h.value:
+            lib().pcreg_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def match_points(query, model, thr_abs: float, max_ratio: float, unique: bool = True) -> np.ndarray:
     """matchFeatures' filter chain on raw 3-D fp32 points -> P x 2 uint32 (1-based)."""
     q, m = _fcol(query, np.float32), _fcol(model, np.float32)

@@ -58,14 +58,15 @@ class BatchRegistration:
 
     def __init__(self, model_soa: torch.Tensor, Q_cap: int, n_streams: int = 2, group=None,
                  device: torch.device | None = None):
-        from .device import RegistrationPipeline
+        from .device import RegistrationPipeline, as_prepared
         self.dev = device or model_soa.device
-        self.model = model_soa
+        with torch.cuda.device(self.dev):
+            self.model = as_prepared(model_soa)             # ONE prepared model for every crop and every stream
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.Q_cap = Q_cap
-        M = model_soa.shape[1]
+        M = self.model.M
         self.pipes = [RegistrationPipeline(Q_cap, M, device=self.dev, replica=True) for _ in range(max(1, n_streams))]
         self.streams = [torch.cuda.Stream(device=self.dev) for _ in self.pipes]
         self.rows = None

@@ -249,44 +249,137 @@ int pcreg_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M,
     return PCREG_OK;
 }
 
-int pcreg_match_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, float thr_abs,
-                           float max_ratio, int unique, uint32_t* pairs, int* P) {
-    PCREG_ARG(q && m && pairs && P && Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+// ---- prepared models ---------------------------------------------------------------------------------------------
+}  // extern "C" (the handle types are C++ structs behind opaque C names)
+struct pcreg_dev_model { pcreg::ModelView v; void* block; };
+struct pcreg_model { pcreg_dev_model* dm; float* d_m; int M; };
+extern "C" {
+
+static int dev_model_create(const float* m, int M, int ldm, hipStream_t st, pcreg_dev_model** out) {
+    *out = nullptr;
+    void* block = nullptr;
+    PCREG_HIP(hipMalloc(&block, model_prep_bytes(M)));
+    pcreg_dev_model* h = new pcreg_dev_model{model_view(m, M, ldm, block), block};
+    int rc = launch_model_prepare(h->v, st);
+    if (rc) { (void)hipFree(block); delete h; return rc; }
+    *out = h;
+    return PCREG_OK;
+}
+
+int pcreg_dev_model_create(const float* m, int M, int ldm, void* stream, pcreg_dev_model** model) {
+    PCREG_ARG(model != nullptr && M >= 0 && ldm >= M && (M == 0 || m != nullptr));
     GUARD();
+    return dev_model_create(m, M, ldm, (hipStream_t)stream, model);
+}
+int pcreg_dev_model_destroy(pcreg_dev_model* model) {
+    if (!model) return PCREG_OK;
+    std::lock_guard<std::mutex> lock(g_mu);
+    (void)hipDeviceSynchronize();                 // searches that still read the prepared block
+    (void)hipFree(model->block);
+    delete model;
+    return PCREG_OK;
+}
+size_t pcreg_dev_model_search_workspace(int Q, int M) { return search_ws_bytes(Q, M); }
+int pcreg_dev_model_search_f32(const pcreg_dev_model* model, const float* q, int Q, int ldq, int32_t idx_base, int32_t* idx,
+                               float* dist, void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(model && q && idx && dist && workspace);
+    GUARD();
+    return launch_model_search(model->v, q, Q, ldq, idx_base, idx, dist, workspace, workspace_bytes, true, true, (hipStream_t)stream);
+}
+int pcreg_dev_model_match_f32(const pcreg_dev_model* model, const float* q, int Q, int ldq, const int32_t* idx, const float* dist,
+                              float thr_abs, float max_ratio, int unique, void* workspace, size_t workspace_bytes, uint32_t* pairs,
+                              double* pts1, double* pts2, int32_t* n_pairs, void* stream) {
+    PCREG_ARG(model && q && idx && dist && workspace && n_pairs);
+    GUARD();
+    return launch_match_finish(model->v, q, Q, ldq, idx, dist, thr_abs, max_ratio, unique, workspace, workspace_bytes, pairs, pts1, pts2,
+                               n_pairs, (hipStream_t)stream);
+}
+int pcreg_dev_model_match_table_f32(const pcreg_dev_model* model, int32_t m_lo, int M_total, const float* q, int Q, int ldq,
+                                    const int32_t* idx, const float* dist, float thr_abs, float max_ratio, int unique,
+                                    void* workspace, size_t workspace_bytes, int32_t* table, void* stream) {
+    PCREG_ARG(model && q && idx && dist && workspace && table);
+    GUARD();
+    return launch_match_table(model->v, m_lo, M_total, q, Q, ldq, idx, dist, thr_abs, max_ratio, unique, workspace, workspace_bytes, table,
+                              (hipStream_t)stream);
+}
+int pcreg_dev_match_from_table_f32(const float* q, int Q, int ldq, int M_total, const int32_t* idx, const float* dist, float thr_abs,
+                                   float max_ratio, const int32_t* table, void* workspace, size_t workspace_bytes, uint32_t* pairs,
+                                   double* pts1, double* pts2, int32_t* n_pairs, void* stream) {
+    PCREG_ARG(q && idx && dist && table && workspace && n_pairs);
+    GUARD();
+    return launch_match_from_table(q, Q, ldq, M_total, idx, dist, thr_abs, max_ratio, table, workspace, workspace_bytes, pairs, pts1, pts2,
+                                   n_pairs, (hipStream_t)stream);
+}
+
+// matchFeatures' chain on raw points against a prepared model: upload the surface, search (4 launches), match (1)
+static int match_points_on_view(const ModelView& v, const float* q, int Q, int ldq, float thr_abs, float max_ratio, int unique,
+                                uint32_t* pairs, int* P) {
     *P = 0;
-    if (Q == 0 || M == 0) return PCREG_OK;
-    void *dq, *dm, *di, *dd, *ws, *dcq, *dcm, *dkeep, *dcnt, *dpairs, *wsu;
-    size_t wsb = knn2_points_workspace_bytes(Q, M), wsu_b = unique_points_workspace_bytes(Q);
+    if (Q == 0 || v.M == 0) return PCREG_OK;
+    void *dq, *di, *dd, *ws, *dcnt, *dpairs;
+    const size_t wsb = search_ws_bytes(Q, v.M);
     TRY(scratch().get(0, sizeof(float) * 3 * (size_t)Q, &dq));
-    TRY(scratch().get(1, sizeof(float) * 3 * (size_t)M, &dm));
     TRY(scratch().get(2, sizeof(int32_t) * 2 * (size_t)Q, &di));
     TRY(scratch().get(3, sizeof(float) * 2 * (size_t)Q, &dd));
     TRY(scratch().get(4, wsb, &ws));
-    TRY(scratch().get(5, sizeof(int32_t) * (size_t)Q, &dcq));
-    TRY(scratch().get(6, sizeof(int32_t) * (size_t)Q, &dcm));
-    TRY(scratch().get(7, sizeof(int32_t) * (size_t)Q, &dkeep));
     TRY(scratch().get(8, 256, &dcnt));
     TRY(scratch().get(9, sizeof(uint32_t) * 2 * (size_t)Q, &dpairs));
-    TRY(scratch().get(10, wsu_b, &wsu));
-    int32_t* n_cand = (int32_t*)dcnt; int32_t* n_pairs = n_cand + 1;
+    int32_t* n_pairs = (int32_t*)dcnt;
     TRY(upload_cols(q, Q, ldq, 3, (float*)dq, g_stream));
-    TRY(upload_cols(m, M, ldm, 3, (float*)dm, g_stream));
-    TRY(launch_knn2_points_f32((float*)dq, Q, Q, (float*)dm, M, M, 0, (int32_t*)di, (float*)dd, ws, wsb, g_stream));
-    TRY(launch_filter_top2_f32((int32_t*)di, (float*)dd, Q, M, thr_abs, max_ratio, (int32_t*)dcq, (int32_t*)dcm, n_cand, g_stream));
-    const int32_t* keep = nullptr;
-    if (unique) {
-        TRY(launch_unique_points_f32((float*)dq, Q, Q, (float*)dm, M, M, 0, (int32_t*)dcq, (int32_t*)dcm, n_cand,
-                                     (int32_t*)dkeep, wsu, wsu_b, g_stream));
-        keep = (int32_t*)dkeep;
-    }
-    TRY(launch_gather_pairs_f32((float*)dq, Q, Q, (float*)dm, M, (int32_t*)dcq, (int32_t*)dcm, keep, n_cand,
-                                (uint32_t*)dpairs, nullptr, nullptr, n_pairs, g_stream));
+    TRY(launch_model_search(v, (float*)dq, Q, Q, 0, (int32_t*)di, (float*)dd, ws, wsb, true, true, g_stream));
+    TRY(launch_match_finish(v, (float*)dq, Q, Q, (int32_t*)di, (float*)dd, thr_abs, max_ratio, unique, ws, wsb, (uint32_t*)dpairs, nullptr,
+                            nullptr, n_pairs, g_stream));
     int32_t np = 0;
     PCREG_HIP(hipMemcpyAsync(&np, n_pairs, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipStreamSynchronize(g_stream));
     if (np > 0) PCREG_HIP(hipMemcpy(pairs, dpairs, sizeof(uint32_t) * 2 * (size_t)np, hipMemcpyDeviceToHost));
     *P = np;
     return PCREG_OK;
+}
+
+int pcreg_model_create(const float* m, int M, int ldm, pcreg_model** model) {
+    PCREG_ARG(model != nullptr && M >= 0 && ldm >= M && (M == 0 || m != nullptr));
+    GUARD();
+    *model = nullptr;
+    float* d_m = nullptr;
+    PCREG_HIP(hipMalloc((void**)&d_m, sizeof(float) * 3 * (size_t)(M > 0 ? M : 1)));
+    int rc = upload_cols(m, M, ldm, 3, d_m, g_stream);
+    pcreg_dev_model* dm = nullptr;
+    if (!rc) rc = dev_model_create(d_m, M, M > 0 ? M : 1, g_stream, &dm);
+    if (!rc && hipStreamSynchronize(g_stream) != hipSuccess) { set_error("model preparation failed"); rc = PCREG_E_HIP; }
+    if (rc) { if (dm) { (void)hipFree(dm->block); delete dm; } (void)hipFree(d_m); return rc; }
+    *model = new pcreg_model{dm, d_m, M};
+    return PCREG_OK;
+}
+int pcreg_model_destroy(pcreg_model* model) {
+    if (!model) return PCREG_OK;
+    std::lock_guard<std::mutex> lock(g_mu);
+    (void)hipDeviceSynchronize();
+    if (model->dm) { (void)hipFree(model->dm->block); delete model->dm; }
+    (void)hipFree(model->d_m);
+    delete model;
+    return PCREG_OK;
+}
+int pcreg_model_match_points_f32(pcreg_model* model, const float* q, int Q, int ldq, float thr_abs, float max_ratio, int unique,
+                                 uint32_t* pairs, int* P) {
+    PCREG_ARG(model && model->dm && q && pairs && P && Q >= 0 && ldq >= Q);
+    GUARD();
+    return match_points_on_view(model->dm->v, q, Q, ldq, thr_abs, max_ratio, unique, pairs, P);
+}
+
+int pcreg_match_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, float thr_abs,
+                           float max_ratio, int unique, uint32_t* pairs, int* P) {
+    PCREG_ARG(q && m && pairs && P && Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+    GUARD();
+    *P = 0;
+    if (Q == 0 || M == 0) return PCREG_OK;
+    void *dm, *block;
+    TRY(scratch().get(1, sizeof(float) * 3 * (size_t)M, &dm));
+    TRY(scratch().get(10, model_prep_bytes(M), &block));
+    TRY(upload_cols(m, M, ldm, 3, (float*)dm, g_stream));
+    const ModelView v = model_view((float*)dm, M, M, block);
+    TRY(launch_model_prepare(v, g_stream));
+    return match_points_on_view(v, q, Q, ldq, thr_abs, max_ratio, unique, pairs, P);
 }
 
 static int match_host(const double* f1, int Q, int ld1, const double* f2, int M, int ld2, int D,
@@ -486,40 +579,6 @@ int pcreg_dev_merge_top2_strided_f32(const int32_t* idx_in, const float* dist_in
     PCREG_ARG(idx_in && dist_in && idx && dist);
     GUARD();
     return launch_merge_top2_f32(idx_in, dist_in, R, Q, idx, dist, (hipStream_t)stream, rank_stride);
-}
-
-int pcreg_dev_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr_abs, float max_ratio,
-                              int32_t* cand_q, int32_t* cand_m, int32_t* n_cand, void* stream) {
-    PCREG_ARG(idx && dist && cand_q && cand_m && n_cand);
-    GUARD();
-    return launch_filter_top2_f32(idx, dist, Q, M_total, thr_abs, max_ratio, cand_q, cand_m, n_cand, (hipStream_t)stream);
-}
-
-size_t pcreg_dev_unique_points_f32_workspace(int Q) { return unique_points_workspace_bytes(Q); }
-
-int pcreg_dev_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t m_lo,
-                                const int32_t* cand_q, const int32_t* cand_m, const int32_t* n_cand, int32_t* keep,
-                                void* workspace, size_t workspace_bytes, void* stream) {
-    PCREG_ARG(q && m && cand_q && cand_m && n_cand && keep && workspace);
-    GUARD();
-    return launch_unique_points_f32(q, Q, ldq, m, M, ldm, m_lo, cand_q, cand_m, n_cand, keep, workspace, workspace_bytes,
-                                    (hipStream_t)stream);
-}
-
-int pcreg_dev_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
-                             const int32_t* n_cand, int Q, int32_t* table, void* stream) {
-    PCREG_ARG(m && cand_m && n_cand && table);
-    GUARD();
-    return launch_cand_table_f32(m, M, ldm, m_lo, cand_m, keep, n_cand, Q, table, (hipStream_t)stream);
-}
-
-int pcreg_dev_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm, const int32_t* cand_q,
-                               const int32_t* cand_m, const int32_t* keep, const int32_t* n_cand, uint32_t* pairs,
-                               double* pts1, double* pts2, int32_t* n_pairs, void* stream) {
-    PCREG_ARG(q && m && cand_q && cand_m && n_cand && n_pairs);
-    GUARD();
-    return launch_gather_pairs_f32(q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand, pairs, pts1, pts2, n_pairs,
-                                   (hipStream_t)stream);
 }
 
 size_t pcreg_dev_ransac_workspace(int n_cap, int iterNum) { return ransac_workspace_bytes(iterNum, 1, n_cap); }

@@ -8,16 +8,33 @@
 //     pcreg_ransac_sharded             every rank passes the same pairs; hypotheses are split over the ranks
 // return the SAME result on every rank, bit for bit the single-GPU one.  The protocol is pcreg_amd/sharded.py's
 // (which stays the test harness: gloo world-2 on CPU, two ranks on one GPU): per registration
-//     1 ncclAllGather  of the per-rank top-2 lists ([2][Q][2] 4-byte words)      + merge kernel
-//     1 ncclAllReduce  (int32 SUM) of the dense [4][Q] candidate table (one contributor per column: exact)
-//     1 ncclAllGather  of the 112-byte partial RANSAC results                    + finish kernel
-// RCCL is opened with dlopen at pcreg_comm_init (no link-time dependency: the library loads on boxes without
-// RCCL, and lives next to a torch that bundles its own copy); collectives run on the library's comm stream.
+//     1 all-gather  of the per-rank top-2 lists ([2][Q][2] 4-byte words)      + merge kernel
+//     1 all-reduce  (int32 SUM) of the dense [4][Q] table, column = query (one contributor per column: exact)
+//     1 all-gather  of the 112-byte partial RANSAC results                    + finish kernel
+// Two transports behind the same three calls:
+//   * RCCL over xGMI (pcreg_comm_init): opened with dlopen (no link-time dependency: the library loads on boxes
+//     without RCCL, and lives next to a torch that bundles its own copy);
+//   * host-staged (pcreg_comm_init_host_staged): every rank copies its buffer into a POSIX shared-memory segment,
+//     a sense-reversing barrier, every rank combines -- for workers that SHARE a GPU (RCCL refuses two ranks on one
+//     device) and for boxes without RCCL.  Latency-sized messages (<= 16 Q bytes), so PCIe is not the issue; it is
+//     also how the N > 1 path of this file is tested on the one-GPU box (tests/test_gpu_comm.py).
+// A communicator lives on the device that was current at init: its stream and scratch are created there and
+// released by pcreg_comm_destroy; calls from another device are refused.  Every argument check and every
+// allocation of a sharded call happens BEFORE its first collective, so a rank either fails before anybody waits
+// for it or goes through (a HIP launch failure in between is fatal for the whole group, as with any collective).
 #include "common.hpp"
 #include <rccl/rccl.h>          // types and prototypes only; the functions are resolved with dlsym
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace pcreg {
@@ -35,9 +52,61 @@ struct Rccl {
 Rccl g_rccl;
 std::mutex g_cmu;
 ncclComm_t g_comm = nullptr;
-int g_rank = 0, g_world = 0;
+int g_rank = 0, g_world = 0, g_cdev = -1;
+bool g_open = false;
 hipStream_t g_cstream = nullptr;
 Scratch g_cs;                       // the sharded entry points' own device buffers
+
+// ---- host-staged transport -----------------------------------------------------------------------------------------
+constexpr size_t kHsSlot = 64u << 20;               // bytes per rank (sparse: only touched pages exist)
+struct HsHeader { std::atomic<int> count; std::atomic<int> sense; std::atomic<int> attached; int world; };
+struct HostStaged {
+    bool on = false;
+    std::string name;
+    void* base = nullptr; size_t bytes = 0;
+    int local_sense = 0;
+    std::vector<char> tmp;
+    HsHeader* hdr() const { return (HsHeader*)base; }
+    char* slot(int r) const { return (char*)base + 4096 + (size_t)r * kHsSlot; }
+};
+HostStaged g_hs;
+
+int hs_barrier() {
+    HsHeader* h = g_hs.hdr();
+    g_hs.local_sense ^= 1;
+    if (h->count.fetch_add(1, std::memory_order_acq_rel) == g_world - 1) {
+        h->count.store(0, std::memory_order_relaxed);
+        h->sense.store(g_hs.local_sense, std::memory_order_release);
+        return PCREG_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (h->sense.load(std::memory_order_acquire) != g_hs.local_sense) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+            set_error("host-staged communicator: a rank did not arrive within 120 s"); return PCREG_E_HIP;
+        }
+    }
+    return PCREG_OK;
+}
+// every rank's `bytes` (device, on st) -> all ranks' blocks back to back in `all` (gather) or their int32 sum in `buf`
+int hs_exchange(void* buf, void* all, size_t bytes, bool sum, hipStream_t st) {
+    if (bytes > kHsSlot) { set_error("host-staged communicator: %zu bytes exceed the %zu-byte slot", bytes, kHsSlot); return PCREG_E_ARG; }
+    PCREG_HIP(hipMemcpyAsync(g_hs.slot(g_rank), buf, bytes, hipMemcpyDeviceToHost, st));
+    PCREG_HIP(hipStreamSynchronize(st));
+    int rc = hs_barrier(); if (rc) return rc;
+    if (sum) {
+        g_hs.tmp.assign(bytes, 0);
+        int32_t* acc = (int32_t*)g_hs.tmp.data();
+        for (int r = 0; r < g_world; ++r) { const int32_t* s = (const int32_t*)g_hs.slot(r); for (size_t k = 0; k < bytes / 4; ++k) acc[k] += s[k]; }
+        PCREG_HIP(hipMemcpyAsync(buf, g_hs.tmp.data(), bytes, hipMemcpyHostToDevice, st));
+    } else {
+        g_hs.tmp.resize(bytes * (size_t)g_world);
+        for (int r = 0; r < g_world; ++r) memcpy(g_hs.tmp.data() + (size_t)r * bytes, g_hs.slot(r), bytes);
+        PCREG_HIP(hipMemcpyAsync(all, g_hs.tmp.data(), bytes * (size_t)g_world, hipMemcpyHostToDevice, st));
+    }
+    PCREG_HIP(hipStreamSynchronize(st));
+    return hs_barrier();                     // nobody overwrites a slot that somebody still reads
+}
 
 int load_rccl() {
     if (g_rccl.handle) return PCREG_OK;
@@ -55,8 +124,34 @@ int load_rccl() {
 #define CTRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 
 int need_comm() {
-    if (!g_comm) { set_error("pcreg_comm_init has not been called on this process"); return PCREG_E_ARG; }
+    if (!g_open) { set_error("pcreg_comm_init has not been called on this process"); return PCREG_E_ARG; }
+    int dev = -1;
+    PCREG_HIP(hipGetDevice(&dev));
+    if (dev != g_cdev) { set_error("the communicator was opened on device %d, the calling thread is on device %d", g_cdev, dev); return PCREG_E_ARG; }
     return PCREG_OK;
+}
+// n int32 words per rank
+int all_gather_words(void* send, void* recv, size_t n, hipStream_t st) {
+    if (g_hs.on) return hs_exchange(send, recv, n * 4, false, st);
+    PCREG_NCCL(g_rccl.AllGather(send, recv, n, ncclInt32, g_comm, st));
+    return PCREG_OK;
+}
+int all_reduce_sum_words(void* buf, size_t n, hipStream_t st) {
+    if (g_hs.on) return hs_exchange(buf, nullptr, n * 4, true, st);
+    PCREG_NCCL(g_rccl.AllReduce(buf, buf, n, ncclInt32, ncclSum, g_comm, st));
+    return PCREG_OK;
+}
+int open_common(int rank, int world) {
+    CTRY(ensure_device());
+    PCREG_HIP(hipGetDevice(&g_cdev));
+    PCREG_HIP(hipStreamCreateWithFlags(&g_cstream, hipStreamNonBlocking));
+    g_rank = rank; g_world = world; g_open = true;
+    return PCREG_OK;
+}
+void close_common() {
+    if (g_cstream) { (void)hipStreamSynchronize(g_cstream); (void)hipStreamDestroy(g_cstream); g_cstream = nullptr; }
+    g_cs.release_all();
+    g_rank = 0; g_world = 0; g_cdev = -1; g_open = false;
 }
 
 }  // namespace
@@ -79,35 +174,57 @@ int pcreg_comm_get_unique_id(pcreg_comm_id* id) {
 
 int pcreg_comm_init(int rank, int world, const pcreg_comm_id* id) {
     PCREG_ARG(id != nullptr && world >= 1 && rank >= 0 && rank < world);
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-        (void)hipGetLastError();
-        set_error("no HIP device available; libpcreg_hip has no CPU fallback");
-        return PCREG_E_NODEVICE;
-    }
     std::lock_guard<std::mutex> lock(g_cmu);
-    if (g_comm) { set_error("pcreg_comm_init: a communicator is already open (pcreg_comm_destroy first)"); return PCREG_E_ARG; }
+    if (g_open) { set_error("pcreg_comm_init: a communicator is already open (pcreg_comm_destroy first)"); return PCREG_E_ARG; }
     CTRY(load_rccl());
+    CTRY(open_common(rank, world));
     ncclUniqueId u; memcpy(&u, id, sizeof u);
-    if (!g_cstream) PCREG_HIP(hipStreamCreateWithFlags(&g_cstream, hipStreamNonBlocking));
-    PCREG_NCCL(g_rccl.CommInitRank(&g_comm, world, u, rank));          // on the calling thread's current device (pcreg_set_device)
-    g_rank = rank; g_world = world;
+    ncclResult_t r = g_rccl.CommInitRank(&g_comm, world, u, rank);          // on the device recorded above (pcreg_set_device)
+    if (r != ncclSuccess) { set_error("RCCL: ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); g_comm = nullptr; close_common(); return PCREG_E_HIP; }
+    return PCREG_OK;
+}
+
+int pcreg_comm_init_host_staged(int rank, int world, const char* name) {
+    PCREG_ARG(name != nullptr && name[0] == '/' && strlen(name) < 200 && world >= 1 && rank >= 0 && rank < world);
+    std::lock_guard<std::mutex> lock(g_cmu);
+    if (g_open) { set_error("pcreg_comm_init_host_staged: a communicator is already open (pcreg_comm_destroy first)"); return PCREG_E_ARG; }
+    const size_t bytes = 4096 + (size_t)world * kHsSlot;
+    int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { set_error("shm_open(%s) failed", name); return PCREG_E_HIP; }
+    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); set_error("ftruncate(%s) failed", name); return PCREG_E_HIP; }     // a fresh segment is zero-filled
+    void* base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) { set_error("mmap(%s) failed", name); return PCREG_E_HIP; }
+    int rc = open_common(rank, world);
+    if (rc) { munmap(base, bytes); return rc; }
+    g_hs.on = true; g_hs.name = name; g_hs.base = base; g_hs.bytes = bytes; g_hs.local_sense = 0;
+    g_hs.hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
+    const auto t0 = std::chrono::steady_clock::now();                       // every rank is attached before anybody uses the barrier
+    while (g_hs.hdr()->attached.load(std::memory_order_acquire) < world) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { set_error("host-staged communicator: %d of %d ranks attached", g_hs.hdr()->attached.load(), world); return PCREG_E_HIP; }
+    }
     return PCREG_OK;
 }
 
 int pcreg_comm_rank(int* rank, int* world) {
     PCREG_ARG(rank && world);
     std::lock_guard<std::mutex> lock(g_cmu);
-    CTRY(need_comm());
+    if (!g_open) { set_error("pcreg_comm_init has not been called on this process"); return PCREG_E_ARG; }
     *rank = g_rank; *world = g_world;
     return PCREG_OK;
 }
 
 int pcreg_comm_destroy(void) {
     std::lock_guard<std::mutex> lock(g_cmu);
-    if (g_comm) { (void)hipStreamSynchronize(g_cstream); (void)g_rccl.CommDestroy(g_comm); g_comm = nullptr; }
-    g_cs.release_all();
-    g_rank = 0; g_world = 0;
+    if (g_cstream) (void)hipStreamSynchronize(g_cstream);
+    if (g_comm) { (void)g_rccl.CommDestroy(g_comm); g_comm = nullptr; }
+    if (g_hs.on) {
+        munmap(g_hs.base, g_hs.bytes);
+        if (g_rank == 0) shm_unlink(g_hs.name.c_str());
+        g_hs = HostStaged{};
+    }
+    close_common();
     return PCREG_OK;
 }
 
@@ -119,28 +236,25 @@ int pcreg_match_points_sharded_f32(const float* q, int Q, int ldq, const float* 
     std::lock_guard<std::mutex> lock(g_cmu);
     CTRY(need_comm());
     *P = 0;
-    if (Q == 0 || M_total == 0) return PCREG_OK;
+    if (Q == 0 || M_total == 0) return PCREG_OK;                 // the same on every rank: nobody enters a collective
     const int R = g_world;
     hipStream_t st = g_cstream;
     const size_t q4 = (size_t)Q * 4;
-    void *dq, *dm, *dpack, *dall, *didx, *ddist, *dcq, *dcm, *dkeep, *dcnt, *dtable, *dpairs, *ws, *wsu, *dident;
-    const size_t wsb = pcreg_dev_knn2_points_f32_workspace(Q, M_local), wsu_b = pcreg_dev_unique_points_f32_workspace(Q);
+    // every buffer of the call, before the first collective
+    void *dq, *dm, *dpack, *dall, *didx, *ddist, *dcnt, *dtable, *dpairs, *ws, *block;
+    const size_t wsb = search_ws_bytes(Q, M_local);
     CTRY(g_cs.get(0, sizeof(float) * 3 * (size_t)Q, &dq));
     CTRY(g_cs.get(1, sizeof(float) * 3 * (size_t)(M_local > 0 ? M_local : 1), &dm));
     CTRY(g_cs.get(2, q4 * 4, &dpack));                        // [2][Q][2] words: indices, then the distances' bit patterns
     CTRY(g_cs.get(3, q4 * 4 * (size_t)R, &dall));
     CTRY(g_cs.get(4, q4 * 2, &didx));
     CTRY(g_cs.get(5, q4 * 2, &ddist));
-    CTRY(g_cs.get(6, q4, &dcq));
-    CTRY(g_cs.get(7, q4, &dcm));
-    CTRY(g_cs.get(8, q4, &dkeep));
     CTRY(g_cs.get(9, 256, &dcnt));
     CTRY(g_cs.get(10, q4 * 4, &dtable));
     CTRY(g_cs.get(11, q4 * 2, &dpairs));
     CTRY(g_cs.get(12, wsb, &ws));
-    CTRY(g_cs.get(13, wsu_b, &wsu));
-    CTRY(g_cs.get(14, q4, &dident));
-    int32_t* n_cand = (int32_t*)dcnt; int32_t* n_pairs = n_cand + 1;
+    CTRY(g_cs.get(13, model_prep_bytes(M_local), &block));
+    int32_t* n_pairs = (int32_t*)dcnt;
     int32_t* idx_l = (int32_t*)dpack; float* dist_l = (float*)((int32_t*)dpack + 2 * (size_t)Q);
     if (ldq == Q) PCREG_HIP(hipMemcpyAsync(dq, q, sizeof(float) * 3 * (size_t)Q, hipMemcpyHostToDevice, st));
     else PCREG_HIP(hipMemcpy2DAsync(dq, sizeof(float) * (size_t)Q, q, sizeof(float) * (size_t)ldq, sizeof(float) * (size_t)Q, 3, hipMemcpyHostToDevice, st));
@@ -148,28 +262,23 @@ int pcreg_match_points_sharded_f32(const float* q, int Q, int ldq, const float* 
         if (ldm == M_local) PCREG_HIP(hipMemcpyAsync(dm, m_local, sizeof(float) * 3 * (size_t)M_local, hipMemcpyHostToDevice, st));
         else PCREG_HIP(hipMemcpy2DAsync(dm, sizeof(float) * (size_t)M_local, m_local, sizeof(float) * (size_t)ldm, sizeof(float) * (size_t)M_local, 3, hipMemcpyHostToDevice, st));
     }
-    // 1. local top-2 (global row numbers), all_gather, merge by (distance, index)
-    CTRY(pcreg_dev_knn2_points_f32((float*)dq, Q, Q, (float*)dm, M_local, M_local > 0 ? M_local : 1, m_lo, idx_l, dist_l, ws, wsb, st));
-    PCREG_NCCL(g_rccl.AllGather(dpack, dall, q4, ncclInt32, g_comm, st));
-    CTRY(pcreg_dev_merge_top2_strided_f32((int32_t*)dall, (float*)((int32_t*)dall + 2 * (size_t)Q), R, Q, q4, (int32_t*)didx, (float*)ddist, st));
-    // 2. threshold + ratio test, redundantly on every rank
-    CTRY(pcreg_dev_filter_top2_f32((int32_t*)didx, (float*)ddist, Q, M_total, thr_abs, max_ratio, (int32_t*)dcq, (int32_t*)dcm, n_cand, st));
-    // 3. Unique verdict by the rank that owns the candidate's model row; 4. one integer SUM publishes verdicts + coordinates
-    if (unique)
-        CTRY(pcreg_dev_unique_points_f32((float*)dq, Q, Q, (float*)dm, M_local, M_local > 0 ? M_local : 1, m_lo, (int32_t*)dcq, (int32_t*)dcm, n_cand,
-                                         (int32_t*)dkeep, wsu, wsu_b, st));
-    CTRY(pcreg_dev_cand_table_f32((float*)dm, M_local, M_local > 0 ? M_local : 1, m_lo, (int32_t*)dcm, unique ? (int32_t*)dkeep : nullptr, n_cand, Q,
-                                  (int32_t*)dtable, st));
-    PCREG_NCCL(g_rccl.AllReduce(dtable, dtable, q4, ncclInt32, ncclSum, g_comm, st));
-    // pair indices from the candidate lists, verdict from row 3 of the table
-    CTRY(pcreg_dev_gather_pairs_f32((float*)dq, Q, Q, (float*)dtable, Q, (int32_t*)dcq, (int32_t*)dcm, unique ? (int32_t*)dtable + 3 * (size_t)Q : nullptr,
-                                    n_cand, (uint32_t*)dpairs, nullptr, nullptr, n_pairs, st));
+    // 1. prepare this rank's shard, local top-2 (global row numbers) + the query grid, all-gather, merge by (distance, index)
+    const ModelView v = model_view((float*)dm, M_local, M_local > 0 ? M_local : 1, block);
+    CTRY(launch_model_prepare(v, st));
+    CTRY(launch_model_search(v, (float*)dq, Q, Q, m_lo, idx_l, dist_l, ws, wsb, true, true, st));
+    CTRY(all_gather_words(dpack, dall, q4, st));
+    CTRY(launch_merge_top2_f32((int32_t*)dall, (float*)((int32_t*)dall + 2 * (size_t)Q), R, Q, (int32_t*)didx, (float*)ddist, st, q4));
+    // 2. filters on every rank, the Unique verdict and the matched coordinates by the rank that owns the model row;
+    //    one integer SUM publishes both; 3. ordered compaction from the summed table
+    CTRY(launch_match_table(v, m_lo, M_total, (float*)dq, Q, Q, (int32_t*)didx, (float*)ddist, thr_abs, max_ratio, unique, ws, wsb, (int32_t*)dtable, st));
+    CTRY(all_reduce_sum_words(dtable, q4, st));
+    CTRY(launch_match_from_table((float*)dq, Q, Q, M_total, (int32_t*)didx, (float*)ddist, thr_abs, max_ratio, (int32_t*)dtable, ws, wsb,
+                                 (uint32_t*)dpairs, nullptr, nullptr, n_pairs, st));
     int32_t np = 0;
     PCREG_HIP(hipMemcpyAsync(&np, n_pairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     PCREG_HIP(hipStreamSynchronize(st));
     if (np > 0) PCREG_HIP(hipMemcpy(pairs, dpairs, sizeof(uint32_t) * 2 * (size_t)np, hipMemcpyDeviceToHost));
     *P = np;
-    (void)dident;
     return PCREG_OK;
 }
 
@@ -205,11 +314,11 @@ int pcreg_ransac_sharded(const double* pts1, const double* pts2, int n, int ld, 
     const int32_t nh = n;
     PCREG_HIP(hipMemcpyAsync(dn, &nh, sizeof nh, hipMemcpyHostToDevice, st));
     PCREG_HIP(hipMemsetAsync(dpart, 0, sizeof(pcreg_dev_ransac_part), st));
-    CTRY(pcreg_dev_ransac_partial((double*)d1, (double*)d2, (int32_t*)dn, cap, cap, opts, nullptr, begin, count, (pcreg_dev_ransac_part*)dpart, ws, wsb, st));
+    CTRY(launch_ransac_partial((double*)d1, (double*)d2, cap, (int32_t*)dn, cap, *opts, nullptr, begin, count, (pcreg_dev_ransac_part*)dpart, ws, wsb, st));
     static_assert(sizeof(pcreg_dev_ransac_part) == 112, "the gathered struct is 112 bytes");
-    PCREG_NCCL(g_rccl.AllGather(dpart, dall, sizeof(pcreg_dev_ransac_part) / 4, ncclInt32, g_comm, st));
-    CTRY(pcreg_dev_ransac_finish_parts((double*)d1, (double*)d2, (int32_t*)dn, cap, cap, opts, (pcreg_dev_ransac_part*)dall, R,
-                                       (pcreg_dev_ransac_result*)dres, (int32_t*)dinl, st));
+    CTRY(all_gather_words(dpart, dall, sizeof(pcreg_dev_ransac_part) / 4, st));
+    CTRY(launch_ransac_finish((double*)d1, (double*)d2, cap, (int32_t*)dn, cap, *opts, (pcreg_dev_ransac_part*)dall,
+                              (pcreg_dev_ransac_result*)dres, (int32_t*)dinl, st, R));
     pcreg_dev_ransac_result res;
     PCREG_HIP(hipMemcpyAsync(&res, dres, sizeof res, hipMemcpyDeviceToHost, st));
     if (n > 0) PCREG_HIP(hipMemcpyAsync(inlier_idx, dinl, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));

@@ -86,27 +86,42 @@ int launch_estimate_transform(const double* p1, const double* p2, int n, int ld,
 int launch_calc_dists(const double* T16_dev, const double* p1, const double* p2, int n, int ld,
                       double* d, hipStream_t st);
 
+// a prepared model (knn_fast.hip): pointers into one device block of model_prep_bytes(M) bytes + the caller's points
+struct ModelView {
+    const float* m; int M, ldm;
+    void* prep; unsigned* rm2; float* box_part; void* tiles; int32_t* seed_cnt; void* seed_slots; int seeded;
+};
+size_t model_prep_bytes(int M);
+ModelView model_view(const float* m, int M, int ldm, void* block);
+int launch_model_prepare(const ModelView& v, hipStream_t st);
+// the per-call workspace of a search and of the match stage that follows it
+struct SearchWs {
+    void* ctr; unsigned* gthr; int32_t* flag_list; int32_t* cand_cnt; void* cand_ent; int cap;
+    int32_t* tail_idx; float* tail_dist;
+    void* ug_prep; float* ug_part; int32_t* ug_cnt; void* ug_slots; int ug_cells, ug_nparts;
+};
+SearchWs search_ws_layout(int Q, int M, void* base, size_t* bytes);
+size_t search_ws_bytes(int Q, int M);
+int launch_model_search(const ModelView& v, const float* q, int Q, int ldq, int32_t idx_base, int32_t* idx, float* dist,
+                        void* ws, size_t ws_bytes, bool with_grid, bool timed, hipStream_t st);
+// the match stage on a finished search (knn_points.hip): threshold + ratio + Unique (query grid of the search's workspace)
+// + ordered compaction in ONE launch; the two halves around the multi-GPU table exchange
+int launch_match_finish(const ModelView& v, const float* q, int Q, int ldq, const int32_t* idx, const float* dist, float thr,
+                        float ratio, int unique, void* ws, size_t ws_bytes, uint32_t* pairs, double* pts1, double* pts2,
+                        int32_t* n_pairs, hipStream_t st);
+int launch_match_table(const ModelView& v, int32_t m_lo, int M_total, const float* q, int Q, int ldq, const int32_t* idx,
+                       const float* dist, float thr, float ratio, int unique, void* ws, size_t ws_bytes, int32_t* table,
+                       hipStream_t st);
+int launch_match_from_table(const float* q, int Q, int ldq, int M_total, const int32_t* idx, const float* dist, float thr,
+                            float ratio, const int32_t* table, void* ws, size_t ws_bytes, uint32_t* pairs, double* pts1,
+                            double* pts2, int32_t* n_pairs, hipStream_t st);
+
 size_t knn2_points_workspace_bytes(int Q, int M);
 int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
                            int32_t idx_base, int32_t* idx, float* dist, void* ws, size_t ws_bytes,
-                           hipStream_t st);
+                           hipStream_t st, bool timed = true);
 int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx,
                           float* dist, hipStream_t st, size_t rank_stride = 0);
-int launch_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
-                          const int32_t* n_cand, int Q, int32_t* table, hipStream_t st);
-int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr,
-                           float ratio, int32_t* cand_q, int32_t* cand_m, int32_t* n_cand,
-                           hipStream_t st);
-size_t unique_points_workspace_bytes(int Q);
-int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm,
-                             int32_t m_lo, const int32_t* cand_q, const int32_t* cand_m,
-                             const int32_t* n_cand, int32_t* keep, void* ws, size_t ws_bytes,
-                             hipStream_t st);
-int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm,
-                            const int32_t* cand_q, const int32_t* cand_m, const int32_t* keep,
-                            const int32_t* n_cand, uint32_t* pairs, double* pts1, double* pts2,
-                            int32_t* n_pairs, hipStream_t st);
-
 // generic-D descriptor matching (fp64)
 size_t match_features_workspace_bytes(int Q, int M, int D);
 int launch_preprocess(const double* dS, int Q, int ldS, const double* dM, int M, int ldM, int D,

@@ -1,31 +1,28 @@
-// pcreg_amd/csrc/knn_fast.hip -- certified fast path of the fp32 3-D point search.
+// pcreg_amd/csrc/knn_fast.hip -- certified fast path of the fp32 3-D point search against a PREPARED model.
 //
-// Same contract as knn2_points_kernel (knn_points.hip): for every query the two nearest
-// model points under d = fmaf(dz,dz, fmaf(dy,dy, dx*dx)), dx = q - m, ties to the lowest
-// index -- the bits the oracle produces.  The direct form costs 6 VALU per pair; this path
-// gets the same answer from ~3.6 VALU per pair:
+// Same contract as knn2_points_kernel (knn_points.hip): for every query the two nearest model points under
+// d = fmaf(dz,dz, fmaf(dy,dy, dx*dx)), dx = q - m, ties to the lowest index -- the bits the oracle produces.
 //
-//  1. prep      model -> float4 {x-c, y-c, z-c, |m-c|^2} about the bounding-box centre c
-//               (one streaming pass, 12 B in / 16 B out per point) and the radii R_m.
-//  2. candidates  s(q,m) = |m~|^2 - 2 q~.m~  (= |q~-m~|^2 - |q~|^2): THREE fma per pair.
-//               Every lane owns QPT queries with a sorted top-4 of s in registers; model
-//               tiles stream through LDS (16-B loads, broadcast ds_read_b128); one
-//               v_min tree + ONE compare per batch of 8 pairs guards the insertion code.
-//               The model is split in chunks over grid.y; all chunks of a query share one
-//               monotone threshold word in HBM (relaxed atomicMin of the ordered-uint image
-//               of the lane's 4th-best): it only prunes, results never depend on who
-//               published what first.
-//  3. finalize  one wave per query: exact fmaf-chain distances for the few union candidates
-//               that can still be in the top-2, wave-shuffle (dist,idx) top-2 reduction,
-//               and the CERTIFICATE: every point not in a candidate list has s >= G (the
-//               final threshold word), hence exact d >= G + |q~|^2 - E with the rounding
-//               bound E below; if that is > the exact 2nd-best the answer is proven.
-//  4. fallback  queries that fail the certificate (~0.2 % on the benchmark cloud, all of
-//               them when coordinates are so large that E swamps the spacing) are redone
-//               exactly: one workgroup per query when few, the tiled exact kernel when many.
+// The reference matches MANY surfaces against ONE model (completeExperimentFast.m:131-149,201-216), so everything that
+// depends on the model alone is done once (model_prepare):
+//   P1  model_bbox_partial/final_kernel   box of the model -> centre c, power-of-two scale sigma, seeding-grid geometry
+//   P2  prep_model_f16_kernel             model -> tiles of f16 matrix-core operands, R_m^2, and the seeding grid's cells
+// and a search is FOUR launches (round 2: eleven):
+//   S1  seed_query_kernel    a first threshold per query from the model-wide seeding grid; clears the call's counters
+//                            and the candidate lists; per-workgroup boxes of the queries (query grid, below)
+//   S2  knn_candidates_f16_pipe_kernel (knn_mfma16.hip)   all Q x M scores on the matrix cores + selection
+//   S3  knn_finalize_kernel  one 8-lane group per query: exact fmaf-chain distances of the listed candidates,
+//                            (distance, index) top-2, and the CERTIFICATE: every point outside the lists has
+//                            s >= G (the final threshold word), hence exact d >= G + |q~|^2 - E; proven answers are
+//                            written, the others are listed; fills the query grid
+//   S4  knn_tail_kernel      the listed queries again, exactly: slices of the model per query when few, the tiled
+//                            all-pairs form when many; per-query / per-tile arrival counters let the last workgroup
+//                            merge, so there is no second launch.  Idle (one read) when the list is empty.
+// By-product: a uniform grid over the QUERIES (boxes in S1, geometry by a surplus workgroup of S2, cells in S3), which
+// the Unique back-check of the match stage walks (knn_points.hip: match_finish_kernel) -- no launches of its own.
 //
-// Rounding bound (u = 2^-24, R_m = max|m~|, r = |q~|), derived in DESIGN.md section 5:
-//   E = u*(3 R_m^2 + 3.03 (R_m^2 + 2 r R_m) + 4.04 (r + R_m)^2) + 16 u (d2 + |G + r^2|)
+// Rounding bound (u = 2^-24, R_m = max|m~|, r = |q~|), derived in DESIGN.md section 4.1:
+//   E = u*(3 R_m^2 + 16 r R_m + 32.1 (R_m^2 + 2 r R_m) + 4.04 (r + R_m)^2) + 16 u (d2 + |G + r^2|)
 #include "common.hpp"
 #include "select.hpp"
 #include "knn_fast_common.hpp"
@@ -35,75 +32,58 @@
 #include <algorithm>
 
 namespace pcreg {
+
+size_t knn_f16_prep_bytes(int M);
+void knn_f16_shape(int Q, int M, int target_blocks, int* q_blocks, int* S, int* tiles_per_chunk);
+int launch_prep_model_f16(const float* m, int M, int ldm, const void* prep, unsigned* rm2, void* mtiles, int32_t* seed_cnt,
+                          void* seed_slots, hipStream_t st);
+int launch_knn_candidates_f16(const float* q, int Q, int ldq, int M, const void* prep, const void* mtiles, unsigned* gthr,
+                              void* cand_ent, int32_t* cand_cnt, int target_blocks, bool dry, bool timed, const float* ug_part,
+                              int ug_nparts, int ug_cells, void* ug_prep, int* S_out, hipStream_t st);
+
 namespace {
 
-// ---- 1a. bounding box of model + queries (two-stage, deterministic) -----------------
-__global__ __launch_bounds__(kBlock) void bbox_partial_kernel(const float* __restrict__ m, int M, int ldm,
-                                                              const float* __restrict__ q, int Q, int ldq,
-                                                              float* __restrict__ part /*[grid][12]: model lo/hi, query lo/hi*/,
-                                                              int32_t* __restrict__ zero_me, int n_zero) {
-    // the seeding grid's cell counters are cleared here (saves a memset launch; nothing reads them before seed_fill)
+// ---- P1. bounding box of the model (two-stage, deterministic) ----------------------------------------------------
+__global__ __launch_bounds__(kBlock) void model_bbox_partial_kernel(const float* __restrict__ m, int M, int ldm,
+                                                                    float* __restrict__ part /*[grid][6]: lo, hi*/,
+                                                                    int32_t* __restrict__ zero_me, int n_zero) {
+    // the seeding grid's cell counters are cleared here (saves a memset; nothing reads them before the fill)
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_zero; i += gridDim.x * kBlock) zero_me[i] = 0;
-    float lo[2][3], hi[2][3];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { lo[k][c] = INFINITY; hi[k][c] = -INFINITY; }
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < M + Q; i += gridDim.x * kBlock) {
-        const bool is_m = i < M;
-        const float* p = is_m ? m + i : q + (i - M);
-        size_t ld = is_m ? (size_t)ldm : (size_t)ldq;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = p[c * ld];
-            lo[0][c] = fminf(lo[0][c], is_m ? v : INFINITY); hi[0][c] = fmaxf(hi[0][c], is_m ? v : -INFINITY);
-            lo[1][c] = fminf(lo[1][c], is_m ? INFINITY : v); hi[1][c] = fmaxf(hi[1][c], is_m ? -INFINITY : v);
-        }
+        for (int c = 0; c < 3; ++c) { const float v = m[i + (size_t)c * ldm]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
     }
-    __shared__ float s[kBlock / 64][12];
+    __shared__ float s[kBlock / 64][6];
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { lo[k][c] = fminf(lo[k][c], __shfl_xor(lo[k][c], o)); hi[k][c] = fmaxf(hi[k][c], __shfl_xor(hi[k][c], o)); }
-        }
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+    }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { s[threadIdx.x >> 6][k * 6 + c] = lo[k][c]; s[threadIdx.x >> 6][k * 6 + 3 + c] = hi[k][c]; }
+        for (int c = 0; c < 3; ++c) { s[threadIdx.x >> 6][c] = lo[c]; s[threadIdx.x >> 6][3 + c] = hi[c]; }
     }
     __syncthreads();
-    if (threadIdx.x < 12) {
-        const bool is_lo = (threadIdx.x % 6) < 3;
+    if (threadIdx.x < 6) {
         float v = s[0][threadIdx.x];
-        for (int w = 1; w < kBlock / 64; ++w) v = is_lo ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
-        part[blockIdx.x * 12 + threadIdx.x] = v;
+        for (int w = 1; w < kBlock / 64; ++w) v = threadIdx.x < 3 ? fminf(v, s[w][threadIdx.x]) : fmaxf(v, s[w][threadIdx.x]);
+        part[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
-__global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, int M, int cell_cap, Prep* __restrict__ prep,
-                                  unsigned* __restrict__ rm2_bits, int32_t* __restrict__ n_flag) {
-    float lo2[2][3], hi2[2][3];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { lo2[k][c] = INFINITY; hi2[k][c] = -INFINITY; }
+__global__ void model_bbox_final_kernel(const float* __restrict__ part, int nparts, int M, int cell_cap, Prep* __restrict__ prep,
+                                        unsigned* __restrict__ rm2_bits) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = threadIdx.x; b < nparts; b += 64)              // launched with one wave
-        for (int k = 0; k < 2; ++k)
-            for (int c = 0; c < 3; ++c) { lo2[k][c] = fminf(lo2[k][c], part[b * 12 + k * 6 + c]); hi2[k][c] = fmaxf(hi2[k][c], part[b * 12 + k * 6 + 3 + c]); }
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], part[b * 6 + c]); hi[c] = fmaxf(hi[c], part[b * 6 + 3 + c]); }
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { lo2[k][c] = fminf(lo2[k][c], __shfl_xor(lo2[k][c], o)); hi2[k][c] = fmaxf(hi2[k][c], __shfl_xor(hi2[k][c], o)); }
-        }
+        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
+    }
     if (threadIdx.x == 0) {
-        float lo[3], hi[3];                                     // the joint box
-        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo2[0][c], lo2[1][c]); hi[c] = fmaxf(hi2[0][c], hi2[1][c]); }
         prep->cx = 0.5f * lo[0] + 0.5f * hi[0]; prep->cy = 0.5f * lo[1] + 0.5f * hi[1]; prep->cz = 0.5f * lo[2] + 0.5f * hi[2];
-        {   // an upper bound of max |m~|^2 (and |q~|^2) from the box itself: the seeding margin uses it
+        {   // an upper bound of max |m~|^2 from the box itself: the seeding margin uses it
             float ax = 0.5f * (hi[0] - lo[0]), ay = 0.5f * (hi[1] - lo[1]), az = 0.5f * (hi[2] - lo[2]);
             prep->rm2 = (ax * ax + ay * ay + az * az) * 1.0001f;
         }
@@ -112,80 +92,45 @@ __global__ void bbox_final_kernel(const float* __restrict__ part, int nparts, in
         if (H > 0.0f && H < INFINITY) sg = ldexpf(1.0f, 5 - ilogbf(H));        // sigma * H in [32, 64)
         prep->sigma = sg; prep->inv_sigma2 = 1.0f / (sg * sg);                 // powers of two: exact
         prep->pad0 = prep->pad1 = 0.0f;
-        // seeding grid: cells of about two model points (density of the MODEL box), laid over the QUERY box
-        // plus one cell of margin -- the only cells a query ever looks at; at most cell_cap cells
-        float mext[3], memax = 0.0f;
-        for (int c = 0; c < 3; ++c) { mext[c] = hi2[0][c] - lo2[0][c]; memax = fmaxf(memax, mext[c]); }
+        // seeding grid: cells of about two model points over the model's box plus one cell of margin on every side (a
+        // query outside looks at the border cells); at most cell_cap cells
+        float ext[3], emax = 0.0f;
+        for (int c = 0; c < 3; ++c) { ext[c] = hi[c] - lo[c]; emax = fmaxf(emax, ext[c]); }
         int n[3] = {1, 1, 1};
         float h = 1.0f, g0[3] = {lo[0], lo[1], lo[2]};
-        const bool have_q = lo2[1][0] <= hi2[1][0];
-        if (memax > 0.0f && memax < INFINITY && have_q) {
-            for (int c = 0; c < 3; ++c) mext[c] = fmaxf(mext[c], memax * 1e-3f);
-            h = cbrtf(mext[0] * mext[1] * mext[2] / fmaxf((float)M * 0.5f, 1.0f));
+        if (emax > 0.0f && emax < INFINITY) {
+            float e2[3];
+            for (int c = 0; c < 3; ++c) e2[c] = fmaxf(ext[c], emax * 1e-3f);
+            h = cbrtf(e2[0] * e2[1] * e2[2] / fmaxf((float)M * 0.5f, 1.0f));
             for (int it = 0; it < 64; ++it) {
                 long tot = 1;
                 for (int c = 0; c < 3; ++c) {
-                    // clip the query box to the model box grown by one cell: cells farther out hold no model point
-                    const float a = fmaxf(lo2[1][c], lo2[0][c] - h), b = fminf(hi2[1][c], hi2[0][c] + h);
-                    g0[c] = a - h;
-                    n[c] = (int)fminf(ceilf(fmaxf(b - a, 0.0f) / h) + 2.0f, 2048.0f); if (n[c] < 1) n[c] = 1; tot *= n[c];
+                    g0[c] = lo[c] - h;
+                    n[c] = (int)fminf(ceilf(ext[c] / h) + 2.0f, 2048.0f); if (n[c] < 1) n[c] = 1; tot *= n[c];
                 }
                 if (tot <= cell_cap) break;
                 h *= 1.2f;
             }
+            if ((long)n[0] * n[1] * n[2] > cell_cap) { n[0] = n[1] = n[2] = 1; g0[0] = lo[0]; g0[1] = lo[1]; g0[2] = lo[2]; h = emax * 2.0f; }
         }
         prep->gx0 = g0[0]; prep->gy0 = g0[1]; prep->gz0 = g0[2]; prep->inv_h = 1.0f / h;
         prep->nx = n[0]; prep->ny = n[1]; prep->nz = n[2]; prep->ncell = n[0] * n[1] * n[2];
         *rm2_bits = 0u;
-        *n_flag = 0;                                   // (saves a memset launch)
     }
-}
-// ---- 1b. model -> {m~, |m~|^2}; R_m^2 by atomicMax on the (non-negative) float bits ----
-__global__ __launch_bounds__(kBlock) void prep_model_kernel(const float* __restrict__ m, int M, int ldm,
-                                                            const Prep* __restrict__ prep, float4* __restrict__ out,
-                                                            unsigned* __restrict__ rm2_bits) {
-    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
-    float mx = 0.0f;
-    const int Mpad = (M + kMTile - 1) / kMTile * kMTile;   // whole LDS tiles; padding has w = +inf, never a candidate
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < Mpad; i += gridDim.x * kBlock) {
-        if (i >= M) { out[i] = make_float4(0.0f, 0.0f, 0.0f, INFINITY); continue; }
-        float x = m[i] - cx, y = m[i + (size_t)ldm] - cy, z = m[i + 2 * (size_t)ldm] - cz;
-        float w = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
-        out[i] = make_float4(x, y, z, w);
-        mx = fmaxf(mx, w);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(rm2_bits, __float_as_uint(mx));     // max is order-independent
 }
 
-// ---- 1c. seeding: a first threshold per query from a coarse grid of the model ------------------
-// The candidate kernels only touch their sorted lists when a score beats the query's threshold, and a
-// wave pays that slow path whenever ANY of its lanes does.  Starting from +inf every lane does so
-// O(log n) times; starting from "the 4th-nearest of a few model points around the query" almost never.
-// The grid remembers up to kSeedSlots points per cell (whoever arrives first: the threshold is a hint,
-// results never depend on it); a query looks at its 27 cells, takes the 4th-smallest EXACT distance d4
-// and publishes s-space threshold d4 - |q~|^2 plus twice the score error bound, so that its true four
-// nearest are still below it.  Every point that is later skipped was compared with a word >= the final
-// word G, which is all the certificate needs.
+// ---- S1. seeding: a first threshold per query from the model-wide grid ------------------------------------------
+// The candidate kernel only touches its sorted lists when a score beats the query's threshold, and a wave pays that
+// slow path whenever ANY of its lanes does.  Starting from +inf every lane does so O(log n) times; starting from "the
+// 4th-nearest of a few model points around the query" almost never.  The grid remembers up to kSeedSlots points per
+// cell (whoever arrived first: the threshold is a hint, results never depend on it); a query looks at the 27 cells
+// around its own (clamped into the grid: any model point's exact distance is a valid upper bound), takes the
+// 4th-smallest EXACT distance d4 and publishes the s-space threshold d4 - |q~|^2 plus twice the score error bound, so
+// that its true four nearest are still below it.  Every point that is later skipped was compared with a word >= the
+// final word G, which is all the certificate needs.
 __device__ __forceinline__ int seed_cell(float v, float lo, float inv_h, int n) {
     int c = (int)floorf((v - lo) * inv_h);
     return c < 0 ? 0 : (c >= n ? n - 1 : c);
-}
-__global__ __launch_bounds__(kBlock) void seed_fill_kernel(const float* __restrict__ m, int M, int ldm, const Prep* __restrict__ prep,
-                                                           int32_t* __restrict__ cnt, float4* __restrict__ slots) {
-    const float gx0 = prep->gx0, gy0 = prep->gy0, gz0 = prep->gz0, ih = prep->inv_h;
-    const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < M; i += gridDim.x * kBlock) {
-        const float x = m[i], y = m[i + (size_t)ldm], z = m[i + 2 * (size_t)ldm];
-        // the grid covers the query box plus a margin: model points outside it are never looked at
-        const float fx = floorf((x - gx0) * ih), fy = floorf((y - gy0) * ih), fz = floorf((z - gz0) * ih);
-        if (!(fx >= 0.0f && fx < (float)nx && fy >= 0.0f && fy < (float)ny && fz >= 0.0f && fz < (float)nz)) continue;
-        int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-        int cell = (cz * ny + cy) * nx + cx;
-        int k = atomicAdd(&cnt[cell], 1);
-        if (k < kSeedSlots) slots[(size_t)cell * kSeedSlots + k] = make_float4(x, y, z, 0.0f);   // the point itself: one 64-B line per cell
-    }
 }
 // eight lanes per query: lane k of the group looks at cells k, k + 8, k + 16, k + 24 of the 27, keeps its
 // own sorted four smallest distances, and three xor-shuffle rounds merge the eight lists
@@ -194,14 +139,39 @@ __device__ __forceinline__ void sort4(float (&d)[4]) {
     PCREG_CS(0, 1) PCREG_CS(2, 3) PCREG_CS(0, 2) PCREG_CS(1, 3) PCREG_CS(1, 2)
 #undef PCREG_CS
 }
-__global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
-                                                            const Prep* __restrict__ prep,
-                                                            const int32_t* __restrict__ cnt, const float4* __restrict__ slots,
-                                                            int e_mode, unsigned* __restrict__ gthr, int rank) {
+__global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restrict__ q, int Q, int ldq,
+                                                            const Prep* __restrict__ prep, const int32_t* __restrict__ cnt,
+                                                            const float4* __restrict__ slots, int seeded, unsigned* __restrict__ gthr,
+                                                            int32_t* __restrict__ cand_cnt, SearchCounters* __restrict__ ctr,
+                                                            float* __restrict__ ug_part, int32_t* __restrict__ ug_cnt, int ug_cells) {
+    // housekeeping for the launches that follow
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < (int)(sizeof(SearchCounters) / 4); i += gridDim.x * kBlock) ((int32_t*)ctr)[i] = 0;
+    if (ug_cnt) for (int i = blockIdx.x * kBlock + threadIdx.x; i < ug_cells; i += gridDim.x * kBlock) ug_cnt[i] = 0;
     const int qi = (blockIdx.x * kBlock + threadIdx.x) >> 3, sub = threadIdx.x & 7;
     const bool live = qi < Q;
     const int qq = live ? qi : 0;
     const float qx = q[qq], qy = q[qq + (size_t)ldq], qz = q[qq + 2 * (size_t)ldq];
+    if (ug_part) {                  // box of this workgroup's queries (the query grid's geometry follows from all of them)
+        __shared__ float s_box[kBlock / 64][6];
+        float v[6] = {live ? qx : INFINITY, live ? qy : INFINITY, live ? qz : INFINITY, live ? qx : -INFINITY, live ? qy : -INFINITY, live ? qz : -INFINITY};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { v[c] = fminf(v[c], __shfl_xor(v[c], o)); v[3 + c] = fmaxf(v[3 + c], __shfl_xor(v[3 + c], o)); }
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s_box[threadIdx.x >> 6][c] = v[c];
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            float r = s_box[0][threadIdx.x];
+            for (int w = 1; w < kBlock / 64; ++w) r = threadIdx.x < 3 ? fminf(r, s_box[w][threadIdx.x]) : fmaxf(r, s_box[w][threadIdx.x]);
+            ug_part[(size_t)blockIdx.x * 6 + threadIdx.x] = r;
+        }
+    }
+    if (live && sub == 0) cand_cnt[qi] = 0;                   // the query's candidate list starts empty
+    if (!seeded) { if (live && sub == 0) gthr[qi] = 0xFFFFFFFFu; return; }       // +inf: no hint
     const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
     const int cx = seed_cell(qx, prep->gx0, prep->inv_h, nx), cy = seed_cell(qy, prep->gy0, prep->inv_h, ny), cz = seed_cell(qz, prep->gz0, prep->inv_h, nz);
     float d[KC] = {INFINITY, INFINITY, INFINITY, INFINITY};
@@ -239,15 +209,13 @@ __global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restr
     }
     if (!live || sub != 0) return;
     unsigned word = 0xFFFFFFFFu;                           // +inf: no hint
-    // The `rank`-th smallest exact distance of the sample bounds the true rank-th nearest distance from above, and any
-    // rank >= 2 keeps both true neighbours under the threshold.  Default 4; 2 makes the candidate kernel collect ~2.5
-    // points per query instead of ~5.6 and was measured (EXPERIMENTS build, PCREG_KNN_SEED_RANK): the kernel's time does
-    // not move (1.568-1.578 vs 1.576-1.581 ms), so the number of list updates is not what it waits for.
-    const float dk = rank <= 2 ? d[1] : (rank == 3 ? d[2] : d[3]);
+    // The 4th-smallest exact distance of the sample bounds the true 4th-nearest distance from above; any rank >= 2 keeps
+    // both true neighbours under the threshold (rank 2 was measured in round 2: the kernel's time does not move).
+    const float dk = d[3];
     if (dk < INFINITY) {
         const float tx = qx - prep->cx, ty = qy - prep->cy, tz = qz - prep->cz;
         const double r2 = (double)tx * tx + (double)ty * ty + (double)tz * tz;
-        const double E = score_error_bound(e_mode, (double)prep->rm2, sqrt(r2));
+        const double E = score_error_bound(1, (double)prep->rm2, sqrt(r2));
         const double u = 5.9604644775390625e-08;
         const double t = (double)dk - r2 + 2.0 * E + 16.0 * u * ((double)dk + fabs((double)dk - r2));
         word = f2ord(nextafterf((float)t, INFINITY));
@@ -255,339 +223,38 @@ __global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restr
     gthr[qi] = word;
 }
 
-template <int QPT_, int UB_, bool DRY = false>
-__global__ __launch_bounds__(kBlock) void knn_candidates_kernel(
-    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk, int chunk_stride,
-    const Prep* __restrict__ prep, unsigned* __restrict__ gthr /*[Q] ordered-uint thresholds*/,
-    int32_t* __restrict__ part_idx /*[S][Q][KC]*/, float* __restrict__ part_s) {
-    __shared__ float4 tile[kMTile];
-    // Query coefficients live in LDS and are re-read once per tile as 128-bit tuples {az, ax, ay, -}:
-    // a ds_read_b128 result is an aligned VGPR quad, and with this component order no coefficient
-    // shares a VGPR bank (register number mod 4) with the model component it multiplies -- an fma
-    // whose src0 sits in the bank of another VGPR source issues at half rate on gfx950
-    // (scripts/ubench/vgpr_bank.hip).
-    __shared__ float4 qcoef[QPT_][kBlock];
-    const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * (kBlock * QPT_);
-    const int sidx = blockIdx.y;
-    const int m_begin = min(M, sidx * chunk_stride), m_end = min(M, m_begin + chunk);
-    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
-
-    float thr[QPT_];
-    unsigned gseen[QPT_];
-    Cand cand[QPT_];
-#pragma unroll
-    for (int r = 0; r < QPT_; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        bool ok = qi < Q;
-        float x = ok ? q[qi] - cx : 0.0f, y = ok ? q[qi + (size_t)ldq] - cy : 0.0f, z = ok ? q[qi + 2 * (size_t)ldq] - cz : 0.0f;
-        qcoef[r][tid] = make_float4(-2.0f * z, -2.0f * x, -2.0f * y, 0.0f);       // exact scaling
-#pragma unroll
-        for (int k = 0; k < KC; ++k) { cand[r].s[k] = INFINITY; cand[r].i[k] = -1; }
-        thr[r] = INFINITY; gseen[r] = 0xFFFFFFFFu;
-    }
-
-    for (int t0 = m_begin; t0 < m_end; t0 += kMTile) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kMTile / kBlock; ++k) {
-            int j = t0 + k * kBlock + tid;
-            tile[k * kBlock + tid] = j < m_end ? mp[j] : make_float4(0.0f, 0.0f, 0.0f, INFINITY);   // s = +inf: never a candidate
-        }
-        // pick up what the other chunks of these queries have already proven
-#pragma unroll
-        for (int r = 0; r < QPT_; ++r) {
-            int qi = q0 + r * kBlock + tid;
-            if (qi < Q) {
-                unsigned g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gseen[r] = g;
-                thr[r] = fminf(cand[r].s[3], ord2f(g));
-            }
-        }
-        __syncthreads();
-        float4 qc[QPT_];
-#pragma unroll
-        for (int r = 0; r < QPT_; ++r) qc[r] = qcoef[r][tid];
-        const int cnt = min(kMTile, m_end - t0);
-        const int nb = (cnt + UB_ - 1) / UB_ * UB_;
-        for (int jb = 0; jb < nb; jb += UB_) {
-            float4 p[UB_];
-#pragma unroll
-            for (int u = 0; u < UB_; ++u) p[u] = tile[jb + u];
-#pragma unroll
-            for (int r = 0; r < QPT_; ++r) {
-                float s[UB_];
-#pragma unroll
-                for (int u = 0; u < UB_; ++u)
-                    s[u] = __builtin_fmaf(qc[r].y, p[u].x, __builtin_fmaf(qc[r].z, p[u].y, __builtin_fmaf(qc[r].x, p[u].z, p[u].w)));
-                // min/max/compare issue at HALF the FMA rate on gfx950 (scripts/ubench/op_rates.hip):
-                // fold three values per v_min3 -> 4 selection ops per 8 scores instead of 7
-                float mn;
-                if (UB_ == 8) {
-                    float m1 = fminf(fminf(s[0], s[1]), s[2]);
-                    float m2 = fminf(fminf(s[3 % UB_], s[4 % UB_]), s[5 % UB_]);
-                    float m3 = fminf(fminf(s[6 % UB_], s[7 % UB_]), m1);
-                    mn = fminf(m2, m3);
-                } else {
-                    mn = fminf(fminf(fminf(s[0], s[1]), s[2]), s[3]);
-                }
-                if (DRY) { asm volatile("" :: "v"(mn)); }   // timing-only build: hot loop without insertions
-                else if (mn < thr[r]) {
-                    const int j0 = t0 + jb;
-#pragma unroll
-                    for (int u = 0; u < UB_; ++u) if (s[u] < thr[r]) cand_insert(cand[r], s[u], j0 + u);
-                    thr[r] = fminf(thr[r], cand[r].s[3]);
-                }
-            }
-        }
-        // publish a tighter bound (relaxed: a late or lost update only costs pruning)
-#pragma unroll
-        for (int r = 0; r < QPT_; ++r) {
-            int qi = q0 + r * kBlock + tid;
-            if (qi < Q && cand[r].s[3] < INFINITY) {
-                unsigned k = f2ord(cand[r].s[3]);
-                if (k < gseen[r]) { atomicMin(&gthr[qi], k); gseen[r] = k; }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < QPT_; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        if (qi < Q && part_idx != nullptr) {          // the seeding pass only publishes thresholds
-            size_t o = ((size_t)sidx * Q + qi) * KC;
-            *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[r].i[0], cand[r].i[1], cand[r].i[2], cand[r].i[3]);
-            *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[r].s[0], cand[r].s[1], cand[r].s[2], cand[r].s[3]);
-        }
-    }
-}
-
-// ---- 2a'. the same kernel with LDS-DMA double buffering ------------------------------------
-// Tile t+1 is copied global -> LDS by `global_load_lds_dwordx4` (no VGPR staging: each wave
-// instruction lands 64 x 16 B contiguously) into the other buffer while tile t is scored;
-// one barrier per tile instead of two and the L2 latency disappears behind the arithmetic.
-// The prepared model is padded with w = +inf to a whole number of tiles, so no tail code.
-template <int QPT_, int UB_>
-__global__ __launch_bounds__(kBlock) void knn_candidates_dma_kernel(
-    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk, int chunk_stride,
-    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx, float* __restrict__ part_s) {
-    __shared__ __attribute__((aligned(16))) float4 tile[2][kMTile];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * (kBlock * QPT_);
-    const int sidx = blockIdx.y;
-    const int m_begin = min(M, sidx * chunk_stride), m_end = min(M, m_begin + chunk);
-    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
-
-    float ax[QPT_], ay[QPT_], az[QPT_], thr[QPT_];
-    unsigned gseen[QPT_];
-    Cand cand[QPT_];
-#pragma unroll
-    for (int r = 0; r < QPT_; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        bool ok = qi < Q;
-        float x = ok ? q[qi] - cx : 0.0f, y = ok ? q[qi + (size_t)ldq] - cy : 0.0f, z = ok ? q[qi + 2 * (size_t)ldq] - cz : 0.0f;
-        ax[r] = -2.0f * x; ay[r] = -2.0f * y; az[r] = -2.0f * z;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) { cand[r].s[k] = INFINITY; cand[r].i[k] = -1; }
-        thr[r] = INFINITY; gseen[r] = 0xFFFFFFFFu;
-    }
-    // wave w copies the 1-KiB segments w, w+4, w+8, w+12 of a 16-KiB tile
-    auto dma_tile = [&](int t0, int buf) {
-#pragma unroll
-        for (int k = 0; k < kMTile / kBlock; ++k) {
-            const int seg = k * (kBlock / 64) + wave;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(mp + t0 + seg * 64 + lane),
-                                             (__attribute__((address_space(3))) void*)(&tile[buf][seg * 64]), 16, 0, 0);
-        }
-    };
-    const int ntile = (m_end - m_begin + kMTile - 1) / kMTile;
-    if (ntile > 0) dma_tile(m_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
-        const int t0 = m_begin + t * kMTile;
-        if (t + 1 < ntile) dma_tile(t0 + kMTile, (t + 1) & 1);
-#pragma unroll
-        for (int r = 0; r < QPT_; ++r) {
-            int qi = q0 + r * kBlock + tid;
-            if (qi < Q) {
-                if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
-                unsigned g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gseen[r] = g;
-                thr[r] = fminf(cand[r].s[3], ord2f(g));
-            }
-        }
-        const float4* cur = tile[t & 1];
-        const int cnt = min(kMTile, m_end - t0);
-        const int nb = (cnt + UB_ - 1) / UB_ * UB_;
-        for (int jb = 0; jb < nb; jb += UB_) {
-            float4 p[UB_];
-#pragma unroll
-            for (int u = 0; u < UB_; ++u) p[u] = cur[jb + u];
-#pragma unroll
-            for (int r = 0; r < QPT_; ++r) {
-                float s[UB_];
-#pragma unroll
-                for (int u = 0; u < UB_; ++u)
-                    s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, p[u].w)));
-                // min/max/compare issue at HALF the FMA rate on gfx950 (scripts/ubench/op_rates.hip):
-                // fold three values per v_min3 -> 4 selection ops per 8 scores instead of 7
-                float mn;
-                if (UB_ == 8) {
-                    float m1 = fminf(fminf(s[0], s[1]), s[2]);
-                    float m2 = fminf(fminf(s[3 % UB_], s[4 % UB_]), s[5 % UB_]);
-                    float m3 = fminf(fminf(s[6 % UB_], s[7 % UB_]), m1);
-                    mn = fminf(m2, m3);
-                } else {
-                    mn = fminf(fminf(fminf(s[0], s[1]), s[2]), s[3]);
-                }
-                if (mn < thr[r]) {
-                    const int j0 = t0 + jb;
-#pragma unroll
-                    for (int u = 0; u < UB_; ++u) if (s[u] < thr[r] && j0 + u < m_end) cand_insert(cand[r], s[u], j0 + u);
-                    thr[r] = fminf(thr[r], cand[r].s[3]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile has landed
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < QPT_; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        if (qi < Q) {
-            if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
-            if (part_idx != nullptr) {
-                size_t o = ((size_t)sidx * Q + qi) * KC;
-                *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[r].i[0], cand[r].i[1], cand[r].i[2], cand[r].i[3]);
-                *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[r].s[0], cand[r].s[1], cand[r].s[2], cand[r].s[3]);
-            }
-        }
-    }
-}
-
-// ---- 2c. candidate generation with the model in SCALAR registers ------------------------
-// The model point of a batch is the same for every lane, so it does not need LDS (or VGPRs)
-// at all: the prepared float4 stream is read with s_load_dwordx8 through the scalar cache and
-// used as the SGPR operand of the FMAs (one SGPR per VOP3 on gfx9: |m~|^2 goes through one
-// v_mov per point, shared by the lane's QPT queries).  No LDS, no barriers, ~35 fewer VGPRs
-// than the LDS-tiled kernel -> more waves per SIMD.  The next batch is requested before the
-// current one is consumed (scalar loads return out of order; one s_waitcnt per batch).
-template <int QPT_>
-__global__ __launch_bounds__(kBlock) void knn_candidates_sgpr_kernel(
-    const float* __restrict__ q, int Q, int ldq, const float4* __restrict__ mp, int M, int chunk,
-    const Prep* __restrict__ prep, unsigned* __restrict__ gthr, int32_t* __restrict__ part_idx, float* __restrict__ part_s) {
-    constexpr int UB = 8;
-    const int tid = threadIdx.x;
-    const int q0 = blockIdx.x * (kBlock * QPT_);
-    const int sidx = blockIdx.y;
-    const int m_begin = min(M, sidx * chunk), m_end = min(M, m_begin + chunk);
-    const float cx = prep->cx, cy = prep->cy, cz = prep->cz;
-
-    float ax[QPT_], ay[QPT_], az[QPT_], thr[QPT_];
-    unsigned gseen[QPT_];
-    Cand cand[QPT_];
-#pragma unroll
-    for (int r = 0; r < QPT_; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        bool ok = qi < Q;
-        float x = ok ? q[qi] - cx : 0.0f, y = ok ? q[qi + (size_t)ldq] - cy : 0.0f, z = ok ? q[qi + 2 * (size_t)ldq] - cz : 0.0f;
-        ax[r] = -2.0f * x; ay[r] = -2.0f * y; az[r] = -2.0f * z;
-#pragma unroll
-        for (int k = 0; k < KC; ++k) { cand[r].s[k] = INFINITY; cand[r].i[k] = -1; }
-        thr[r] = INFINITY; gseen[r] = 0xFFFFFFFFu;
-    }
-    // the prepared array is padded to a multiple of 16 points with w = +inf, so whole batches
-    // can be read past m_end without a tail loop (a padded point is never a candidate)
-    const int nb = (m_end - m_begin + UB - 1) / UB;
-    float4 pn[UB];
-#pragma unroll
-    for (int u = 0; u < UB; ++u) pn[u] = mp[m_begin + u];
-    for (int b = 0; b < nb; ++b) {
-        const int j0 = m_begin + b * UB;
-        float4 p[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) p[u] = pn[u];
-        if (b + 1 < nb) {
-#pragma unroll
-            for (int u = 0; u < UB; ++u) pn[u] = mp[j0 + UB + u];
-        }
-        if ((b & 127) == 0) {      // every 1024 points: exchange thresholds with the other chunks
-#pragma unroll
-            for (int r = 0; r < QPT_; ++r) {
-                int qi = q0 + r * kBlock + tid;
-                if (qi < Q) {
-                    if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
-                    unsigned g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    gseen[r] = g;
-                    thr[r] = fminf(cand[r].s[3], ord2f(g));
-                }
-            }
-        }
-        float w[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) w[u] = (j0 + u < m_end) ? p[u].w : INFINITY;
-#pragma unroll
-        for (int r = 0; r < QPT_; ++r) {
-            float s[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-                s[u] = __builtin_fmaf(ax[r], p[u].x, __builtin_fmaf(ay[r], p[u].y, __builtin_fmaf(az[r], p[u].z, w[u])));
-            float mn = fminf(fminf(fminf(s[0], s[1]), fminf(s[2], s[3])), fminf(fminf(s[4], s[5]), fminf(s[6], s[7])));
-            if (mn < thr[r]) {
-#pragma unroll
-                for (int u = 0; u < UB; ++u) if (s[u] < thr[r]) cand_insert(cand[r], s[u], j0 + u);
-                thr[r] = fminf(thr[r], cand[r].s[3]);
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < QPT_; ++r) {
-        int qi = q0 + r * kBlock + tid;
-        if (qi < Q) {
-            if (cand[r].s[3] < INFINITY) { unsigned k = f2ord(cand[r].s[3]); if (k < gseen[r]) atomicMin(&gthr[qi], k); }
-            size_t o = ((size_t)sidx * Q + qi) * KC;
-            *reinterpret_cast<int4*>(part_idx + o) = make_int4(cand[r].i[0], cand[r].i[1], cand[r].i[2], cand[r].i[3]);
-            *reinterpret_cast<float4*>(part_s + o) = make_float4(cand[r].s[0], cand[r].s[1], cand[r].s[2], cand[r].s[3]);
-        }
-    }
-}
-
-}  // namespace
-size_t knn_f16_prep_bytes(int M);
-int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
-                              unsigned* rm2, void* mtiles, unsigned* gthr, void* cand_ent, int32_t* cand_cnt,
-                              int target_blocks, int max_S, bool dry, int* S_out, int* group16_out, hipStream_t st);
-namespace {
-// ---- 3. exact re-rank + certificate: one wave per query ------------------------------------
+// ---- S3. exact re-rank + certificate: one 8-lane group per query --------------------------------------------------
 __device__ __forceinline__ bool lex_lt_f(float da, int ia, float db, int ib) {
     return da < db || (da == db && (unsigned)ia < (unsigned)ib);
 }
-template <int LPQ>      // lanes per query: 64 for the dense lists (S * kc entries), 8 for the short per-query lists
+// A list entry is (first row jb, minimum score) of the 16 model points jb + 8 (r / 4) + r % 4, r = 0..15, that one lane
+// of knn_candidates_f16_pipe_kernel scored together; pass 2 expands every entry that can still matter.  Points past M
+// (tile padding) are skipped.  A query's list: cand_cnt[qi] entries at ent[(size_t)qi * cap + e].
+constexpr int LPQ = 8;
 __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
     const Prep* __restrict__ prep, const unsigned* __restrict__ rm2_bits, const unsigned* __restrict__ gthr,
-    const int32_t* __restrict__ part_idx, const float* __restrict__ part_s, int S, int kc, int idx_base,
-    int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int e_mode,
-    const int32_t* __restrict__ cand_cnt, int group16) {
-    // group16 (sparse lists of the pipelined f16 kernel): an entry is (first row jb, minimum score) of the 16 model
-    // points jb + 8 (r / 4) + r % 4, r = 0..15, that one lane of knn_candidates_f16_pipe_kernel scored together;
-    // pass 2 expands every entry that can still matter.  Points past M (tile padding) are skipped.
+    const uint2* __restrict__ ent_all, const int32_t* __restrict__ cand_cnt, int cap, int idx_base,
+    int32_t* __restrict__ idx, float* __restrict__ dist, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag,
+    const UgPrep* __restrict__ ug_prep, int32_t* __restrict__ ug_cnt, float4* __restrict__ ug_slots) {
     const int lane = threadIdx.x & (LPQ - 1);
     const int qi = blockIdx.x * (kBlock / LPQ) + (threadIdx.x / LPQ);
     if (qi >= Q) return;
     const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
-    // cand_cnt == nullptr: dense lists, kc candidates per (chunk, query) at [chunk][query][kc] (VALU / fp32-MFMA paths).
-    // cand_cnt != nullptr: one list per query, cand_cnt[qi] (index, score-bits) pairs at part_idx[(qi * S * kc + e) * 2].
-    const bool sparse = cand_cnt != nullptr;
-    const int total = sparse ? min(cand_cnt[qi], S * kc) : S * kc;
-    const uint2* ent = reinterpret_cast<const uint2*>(part_idx) + (size_t)qi * S * kc;
+    if (ug_prep && lane == 0) {                // the query grid of the Unique back-check (knn_points.hip): this query's cell
+        const UgPrep P = *ug_prep;
+        const int cell = (ug_cell1(qz, P.z0, P.inv_c, P.nz) * P.ny + ug_cell1(qy, P.y0, P.inv_c, P.ny)) * P.nx + ug_cell1(qx, P.x0, P.inv_c, P.nx);
+        const int s = atomicAdd(&ug_cnt[cell], 1);
+        if (s < kUgSlots) ug_slots[(size_t)cell * kUgSlots + s] = make_float4(qx, qy, qz, __int_as_float(qi));
+    }
+    const int total = min(cand_cnt[qi], cap);
+    const uint2* ent = ent_all + (size_t)qi * cap;
     // pass 1: the two smallest approximate scores of the union (values only)
     float a1 = INFINITY, a2 = INFINITY;
     for (int e = lane; e < total; e += LPQ) {
-        int j; float s;
-        if (sparse) { const uint2 v = ent[e]; j = (int)v.x; s = __uint_as_float(v.y); }
-        else { size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc); j = part_idx[o]; s = part_s[o]; }
-        if (j >= 0) { if (s < a2) { if (s < a1) { a2 = a1; a1 = s; } else a2 = s; } }
+        const uint2 v = ent[e];
+        const float s = __uint_as_float(v.y);
+        if ((int)v.x >= 0) { if (s < a2) { if (s < a1) { a2 = a1; a1 = s; } else a2 = s; } }
     }
 #pragma unroll
     for (int o = LPQ / 2; o > 0; o >>= 1) {
@@ -598,27 +265,26 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     }
     // rounding bound (double arithmetic on the fp32 quantities the candidate kernel used)
     const double u = 5.9604644775390625e-08;                     // 2^-24
-    const float cxf = prep->cx, cyf = prep->cy, czf = prep->cz;
+    const float cxf = prep->cx, cyf = prep->cy, czf = prep->cz, sg = prep->sigma;
     const float tx = qx - cxf, ty = qy - cyf, tz = qz - czf;       // the same q~ the candidate kernel formed
+    const bool scored = fabsf(sg * tx) <= kQueryScaledMax && fabsf(sg * ty) <= kQueryScaledMax && fabsf(sg * tz) <= kQueryScaledMax;
     const double r2 = (double)tx * tx + (double)ty * ty + (double)tz * tz;
     const double r = sqrt(r2);
     const double Rm2 = (double)__uint_as_float(*rm2_bits);
-    // e_mode 0: scores from the fp32 fma chain.  e_mode 1: scores from the f16-split matrix-core product
-    // (knn_mfma16.hip): 16 u r R_m for the two-term f16 representations of Q and m (2^-22 relative each) and
-    // 32.1 u (R_m^2 + 2 r R_m) for sixteen fp32 accumulation steps of at most one ulp each.
-    const double Eab = score_error_bound(e_mode, Rm2, r);
+    // scores from the f16-split matrix-core product (knn_mfma16.hip): 16 u r R_m for the two-term f16 representations
+    // of Q and m (2^-22 relative each) and 32.1 u (R_m^2 + 2 r R_m) for sixteen fp32 accumulation steps of at most
+    // one ulp each.
+    const double Eab = score_error_bound(1, Rm2, r);
     // pass 2: exact distances of every candidate that can still reach the top-2
     const float cut = (float)((double)a2 + 2.0 * Eab + 16.0 * u * fabs((double)a2 + r2));
     const float cut_up = nextafterf(cut, INFINITY);              // float rounding of the cut must not exclude anything
     float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
     for (int e = lane; e < total; e += LPQ) {
-        int j; float sc;
-        if (sparse) { const uint2 v = ent[e]; j = (int)v.x; sc = __uint_as_float(v.y); }
-        else { size_t o = ((size_t)(e / kc) * Q + qi) * kc + (e % kc); j = part_idx[o]; sc = part_s[o]; }
+        const uint2 v = ent[e];
+        const int j = (int)v.x; const float sc = __uint_as_float(v.y);
         if (j >= 0 && (sc <= cut_up || !(a2 < INFINITY))) {
-            const int nr = group16 ? 16 : 1;
-            for (int r = 0; r < nr; ++r) {
-                const int jj = group16 ? j + 8 * (r >> 2) + (r & 3) : j;
+            for (int rr = 0; rr < 16; ++rr) {
+                const int jj = j + 8 * (rr >> 2) + (rr & 3);
                 if (jj >= M) continue;
                 float dx = qx - m[jj], dy = qy - m[jj + (size_t)ldm], dz = qz - m[jj + 2 * (size_t)ldm];
                 float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -628,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
             }
         }
     }
-    // wave-shuffle top-2 reduction ordered by (dist, idx); empty slots are (+inf, -1 -> max uint)
+    // group-shuffle top-2 reduction ordered by (dist, idx); empty slots are (+inf, -1 -> max uint)
 #pragma unroll
     for (int o = LPQ / 2; o > 0; o >>= 1) {
         float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
@@ -645,7 +311,8 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     const unsigned gword = gthr[qi];
     const float G = ord2f(gword);
     bool ok;
-    if (M <= 2) ok = (i1 >= 0) && (M < 2 || i2 >= 0);          // nothing outside the lists when M <= KC (handled below too)
+    if (!scored) ok = false;                                     // never scored on the matrix cores: redo exactly
+    else if (M <= 2) ok = (i1 >= 0) && (M < 2 || i2 >= 0);       // nothing outside the lists when M <= KC
     else if (gword == 0xFFFFFFFFu) ok = true;                    // never published, never seeded: nothing was skipped, every point is a candidate
     else if (!(G < INFINITY)) ok = false;                        // a published +inf (scores overflowed): no bound, redo exactly
     else {
@@ -664,231 +331,299 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
     }
 }
 
-// ---- 4a. exact fallback, few queries: kFbSlices workgroups per flagged query + a merge ------------
+// ---- S4. the unproven queries again, exactly: ONE launch --------------------------------------------------------
+// few (<= kFew): work item = (listed query, slice of the model); all threads of a workgroup stride over the slice.
+// many: work item = (tile of kTailQ listed queries, chunk of the model); a lane owns four queries, the chunk streams
+// through LDS -- knn2_points_kernel's loop (6 VALU per pair, the oracle's bits).
+// Either way the workgroup that delivers the LAST partial of a query / tile (an arrival counter, cleared by S1) merges
+// the partials by (distance, index) and writes the result.
 constexpr int kFew = 1024, kFbSlices = 32;
-__global__ __launch_bounds__(kBlock) void knn_fallback_slice_kernel(
-    const float* __restrict__ q, int ldq, const float* __restrict__ m, int M, int ldm,
-    const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag,
-    int32_t* __restrict__ fb_idx /*[kFew][kFbSlices][2]*/, float* __restrict__ fb_dist) {
-    const int nf = *n_flag;
-    if (nf > kFew) return;                                       // the tiled kernel handles big lists
+constexpr int kTailGrid = 2048, kTailQ = 4 * kBlock;              // tiled form: 1024 queries per tile
+struct Top2 { float d1, d2; int i1, i2; };
+__device__ __forceinline__ void top2_insert(Top2& t, float d, int j) {
+    // candidates arrive in ascending j, so strict '<' keeps the lowest index
+    if (d < t.d2) {
+        if (d < t.d1) { t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = j; }
+        else { t.d2 = d; t.i2 = j; }
+    }
+}
+__device__ __forceinline__ void top2_wave_merge(float& d1, float& d2, int& i1, int& i2) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+        int j1s = __shfl_xor(i1, o), j2s = __shfl_xor(i2, o);
+        bool first_mine = lex_lt_f(d1, i1, e1, j1s);
+        float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1s;
+        float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;
+        float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1s : j2s;
+        bool sec_mine = lex_lt_f(x2, y2, x3, y3);
+        d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
+    }
+}
+__global__ __launch_bounds__(kBlock) void knn_tail_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ m, int M, int ldm, int idx_base,
+    const int32_t* __restrict__ flag_list, SearchCounters* __restrict__ ctr,
+    int32_t* __restrict__ part_idx, float* __restrict__ part_dist /* few: [kFew][kFbSlices][2]; many: [S][tiles * kTailQ][2] */,
+    int32_t* __restrict__ idx, float* __restrict__ dist) {
+    const int nf = ctr->n_flag;
+    if (nf <= 0) return;
     __shared__ float sd[kBlock / 64][2];
     __shared__ int si[kBlock / 64][2];
-    const int len = (M + kFbSlices - 1) / kFbSlices;
-    const int j0 = blockIdx.y * len, j1 = min(M, j0 + len);
-    for (int f = blockIdx.x; f < nf; f += gridDim.x) {           // a small grid: usually there is nothing to do
-        const int qi = flag_list[f];
-        const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
-        float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
-        for (int j = j0 + threadIdx.x; j < j1; j += kBlock) {     // ascending j per thread: strict '<' keeps ties low
-            float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
-            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            if (d < d2) { if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; } }
+    __shared__ int s_last;
+    __shared__ float4 tile[kMTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (nf <= kFew) {
+        const int len = (M + kFbSlices - 1) / kFbSlices;
+        for (int w = blockIdx.x; w < nf * kFbSlices; w += gridDim.x) {
+            const int f = w / kFbSlices, sl = w % kFbSlices;
+            const int j0 = sl * len, j1 = min(M, j0 + len);
+            const int qi = flag_list[f];
+            const float qx = q[qi], qy = q[qi + (size_t)ldq], qz = q[qi + 2 * (size_t)ldq];
+            float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+            for (int j = j0 + threadIdx.x; j < j1; j += kBlock) {     // ascending j per thread: strict '<' keeps ties low
+                float dx = qx - m[j], dy = qy - m[j + (size_t)ldm], dz = qz - m[j + 2 * (size_t)ldm];
+                float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                if (d < d2) { if (d < d1) { d2 = d1; i2 = i1; d1 = d; i1 = j; } else { d2 = d; i2 = j; } }
+            }
+            top2_wave_merge(d1, d2, i1, i2);
+            __syncthreads();                                          // the previous trip's readers are done with sd / si
+            if (lane == 0) { sd[wave][0] = d1; sd[wave][1] = d2; si[wave][0] = i1; si[wave][1] = i2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                Top2T<float> t{INFINITY, INFINITY, -1, -1};
+                for (int k = 0; k < kBlock / 64; ++k) { top2_insert_lex_t(t, sd[k][0], si[k][0]); top2_insert_lex_t(t, sd[k][1], si[k][1]); }
+                const size_t o = ((size_t)f * kFbSlices + sl) * 2;
+                __hip_atomic_store(&part_idx[o], t.i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&part_idx[o + 1], t.i2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&part_dist[o], t.d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&part_dist[o + 1], t.d2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                const int old = __hip_atomic_fetch_add(&ctr->done[f], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == kFbSlices - 1) {                            // every slice of this query is in: merge
+                    Top2T<float> r{INFINITY, INFINITY, -1, -1};
+                    for (int s2 = 0; s2 < kFbSlices; ++s2) {
+                        const size_t p = ((size_t)f * kFbSlices + s2) * 2;
+                        const int a = __hip_atomic_load(&part_idx[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int b = __hip_atomic_load(&part_idx[p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float da = __hip_atomic_load(&part_dist[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float db = __hip_atomic_load(&part_dist[p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        top2_insert_lex_t(r, da, a); top2_insert_lex_t(r, db, b);
+                    }
+                    idx[(size_t)qi * 2] = r.i1 >= 0 ? r.i1 + idx_base : -1; idx[(size_t)qi * 2 + 1] = r.i2 >= 0 ? r.i2 + idx_base : -1;
+                    dist[(size_t)qi * 2] = r.d1; dist[(size_t)qi * 2 + 1] = r.d2;
+                }
+            }
+        }
+        return;
+    }
+    // many: tiles of kTailQ listed queries x S chunks of the model
+    const int n_qt = (nf + kTailQ - 1) / kTailQ;
+    const int max_S = (M + kMTile - 1) / kMTile;
+    int S = kTailGrid / n_qt; if (S < 1) S = 1; if (S > max_S) S = max_S; if (S < 1) S = 1;
+    const int chunk = ((M + S - 1) / S + kMTile - 1) / kMTile * kMTile;
+    S = M > 0 ? (M + chunk - 1) / chunk : 1;
+    const size_t slots_cap = (size_t)n_qt * kTailQ;
+    for (int w = blockIdx.x; w < n_qt * S; w += gridDim.x) {
+        const int qt = w / S, s = w % S;
+        const int m_begin = s * chunk, m_end = min(M, m_begin + chunk);
+        float qx[4], qy[4], qz[4]; Top2 best[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int slot = qt * kTailQ + r * kBlock + threadIdx.x;
+            const bool ok = slot < nf;
+            const int qi = ok ? flag_list[slot] : 0;
+            qx[r] = ok ? q[qi] : 0.0f; qy[r] = ok ? q[qi + (size_t)ldq] : 0.0f; qz[r] = ok ? q[qi + 2 * (size_t)ldq] : 0.0f;
+            best[r] = Top2{INFINITY, INFINITY, -1, -1};
+        }
+        for (int t0 = m_begin; t0 < m_end; t0 += kMTile) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kMTile / kBlock; ++k) {
+                const int j = t0 + k * kBlock + threadIdx.x;
+                float4 v;
+                if (j < m_end) { v.x = m[j]; v.y = m[j + (size_t)ldm]; v.z = m[j + 2 * (size_t)ldm]; v.w = 0.0f; }
+                else { v.x = v.y = v.z = INFINITY; v.w = 0.0f; }     // padding never beats anything
+                tile[k * kBlock + threadIdx.x] = v;
+            }
+            __syncthreads();
+            const int cnt = min(kMTile, m_end - t0);
+            const int nb = (cnt + 3) / 4 * 4;
+            for (int jb = 0; jb < nb; jb += 4) {
+                float4 mp[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) mp[u] = tile[jb + u];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float d[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float dx = qx[r] - mp[u].x, dy = qy[r] - mp[u].y, dz = qz[r] - mp[u].z;
+                        d[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    }
+                    const float mn = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                    if (mn < best[r].d2) {
+                        const int j0 = t0 + jb;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) top2_insert(best[r], d[u], j0 + u);
+                    }
+                }
+            }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            float e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
-            int j1s = __shfl_xor(i1, o), j2s = __shfl_xor(i2, o);
-            bool first_mine = lex_lt_f(d1, i1, e1, j1s);
-            float w1 = first_mine ? d1 : e1; int k1 = first_mine ? i1 : j1s;
-            float x2 = first_mine ? d2 : d1; int y2 = first_mine ? i2 : i1;
-            float x3 = first_mine ? e1 : e2; int y3 = first_mine ? j1s : j2s;
-            bool sec_mine = lex_lt_f(x2, y2, x3, y3);
-            d1 = w1; i1 = k1; d2 = sec_mine ? x2 : x3; i2 = sec_mine ? y2 : y3;
+        for (int r = 0; r < 4; ++r) {
+            const int slot = qt * kTailQ + r * kBlock + threadIdx.x;
+            if (slot < nf) {
+                const size_t o = ((size_t)s * slots_cap + slot) * 2;
+                __hip_atomic_store(&part_idx[o], best[r].i1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&part_idx[o + 1], best[r].i2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&part_dist[o], best[r].d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&part_dist[o + 1], best[r].d2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        const int w = threadIdx.x >> 6;
-        __syncthreads();                                          // the previous trip's readers are done with sd / si
-        if ((threadIdx.x & 63) == 0) { sd[w][0] = d1; sd[w][1] = d2; si[w][0] = i1; si[w][1] = i2; }
+        __threadfence();
         __syncthreads();
-        if (threadIdx.x == 0) {
-            Top2T<float> t{INFINITY, INFINITY, -1, -1};
-            for (int k = 0; k < kBlock / 64; ++k) { top2_insert_lex_t(t, sd[k][0], si[k][0]); top2_insert_lex_t(t, sd[k][1], si[k][1]); }
-            const size_t o = ((size_t)f * kFbSlices + blockIdx.y) * 2;
-            fb_idx[o] = t.i1; fb_idx[o + 1] = t.i2; fb_dist[o] = t.d1; fb_dist[o + 1] = t.d2;
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctr->done[qt], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+        __syncthreads();
+        if (s_last) {                         // every chunk of this tile is in: a wave per listed query merges its S partials
+            const int s_hi = min(nf, (qt + 1) * kTailQ);
+            for (int slot = qt * kTailQ + wave; slot < s_hi; slot += kBlock / 64) {
+                float d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+                for (int s2 = lane; s2 < S; s2 += 64) {           // chunks ascend in model index; (distance, index) order throughout
+                    const size_t p = ((size_t)s2 * slots_cap + slot) * 2;
+                    const int a = __hip_atomic_load(&part_idx[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int b = __hip_atomic_load(&part_idx[p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float da = __hip_atomic_load(&part_dist[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float db = __hip_atomic_load(&part_dist[p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (a >= 0 && lex_lt_f(da, a, d2, i2)) { if (lex_lt_f(da, a, d1, i1)) { d2 = d1; i2 = i1; d1 = da; i1 = a; } else { d2 = da; i2 = a; } }
+                    if (b >= 0 && lex_lt_f(db, b, d2, i2)) { if (lex_lt_f(db, b, d1, i1)) { d2 = d1; i2 = i1; d1 = db; i1 = b; } else { d2 = db; i2 = b; } }
+                }
+                top2_wave_merge(d1, d2, i1, i2);
+                if (lane == 0) {
+                    const int qi = flag_list[slot];
+                    idx[(size_t)qi * 2] = i1 >= 0 ? i1 + idx_base : -1; idx[(size_t)qi * 2 + 1] = i2 >= 0 ? i2 + idx_base : -1;
+                    dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2;
+                }
+            }
         }
     }
-}
-__global__ void knn_fallback_merge_kernel(const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag, int idx_base,
-                                          const int32_t* __restrict__ fb_idx, const float* __restrict__ fb_dist,
-                                          int32_t* __restrict__ idx, float* __restrict__ dist) {
-    const int nf = *n_flag, f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nf > kFew || f >= nf) return;
-    Top2T<float> t{INFINITY, INFINITY, -1, -1};
-    for (int sl = 0; sl < kFbSlices; ++sl) {
-        const size_t o = ((size_t)f * kFbSlices + sl) * 2;
-        top2_insert_lex_t(t, fb_dist[o], fb_idx[o]); top2_insert_lex_t(t, fb_dist[o + 1], fb_idx[o + 1]);
-    }
-    const int qi = flag_list[f];
-    idx[(size_t)qi * 2] = t.i1 >= 0 ? t.i1 + idx_base : -1; idx[(size_t)qi * 2 + 1] = t.i2 >= 0 ? t.i2 + idx_base : -1;
-    dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
 }
 
-int pick_splits_fast(int n_tiles, int M, int target) {
-    int S = (target + n_tiles - 1) / n_tiles;
-    int maxS = (M + kMTile - 1) / kMTile;
-    if (S > maxS) S = maxS;
-    return S < 1 ? 1 : S;
-}
+constexpr int kSeedMinM = 16 * 1024;             // below this the lists settle within the first tiles anyway
+// the grid is sized on the device (about M/2 cells plus the margin layer); this is the capacity it may use
+size_t seed_cell_cap(int M) { return std::min<size_t>((size_t)kSeedMaxCells, std::max<size_t>(4096, (size_t)M)); }
 
 }  // namespace
 
-// MFMA formulation of the candidate kernel (knn_mfma.hip, built with its own flags)
-int launch_knn_candidates_mfma(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
-                               unsigned* rm2, float* mtiles, int n_tiles, int tiles_per_chunk, int q_blocks, int S,
-                               unsigned* gthr, int32_t* part_idx, float* part_s, bool dry, hipStream_t st);
-
-// tiled exact kernel on a query list (implemented in knn_points.hip)
-int launch_knn2_points_exact_list(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
-                                  const int32_t* qlist, const int32_t* n_list, int min_active, int32_t* idx,
-                                  float* dist, void* ws, size_t ws_bytes, hipStream_t st);
-size_t knn2_points_exact_workspace_bytes(int Q, int M);
-
-// workspace layout: Prep | rm2 bits | n_flag | bbox partials | gthr [Q] | flag_list [Q]
-//                   | prepared model (16 B/point, padded to whole 16-point tiles)
-//                   | part_idx [S][Q][kc] | part_s | exact-kernel workspace (fallback)
-static constexpr int kPartCap = 40;           // upper bound of S * kc / 16 any variant may use (x16 entries per query)
-static constexpr int kSeedMinM = 16 * 1024;      // below this the lists settle within the first tiles anyway
-// the grid is sized on the device (about M/2 cells); this is the capacity it may use
-static size_t seed_cell_cap(int M) { return std::min<size_t>((size_t)kSeedMaxCells, std::max<size_t>(4096, (size_t)M)); }
-static size_t seed_bytes(int M) {
-    if (M < kSeedMinM) return 0;
-    const size_t cells = seed_cell_cap(M);
-    return align_up(cells * 4, 256) + align_up(cells * kSeedSlots * 16, 256);
+// ---- a prepared model in device memory ---------------------------------------------------------------------------
+// layout of the prepared block: Prep | R_m^2 bits | box partials | f16 tiles | seeding-grid counters | seeding-grid slots
+size_t model_prep_bytes(int M) {
+    size_t b = 256 + 256 + align_up(512 * 6 * sizeof(float), 256) + align_up(knn_f16_prep_bytes(M), 256);
+    if (M >= kSeedMinM) b += align_up(seed_cell_cap(M) * 4, 256) + align_up(seed_cell_cap(M) * kSeedSlots * 16, 256);
+    return b;
 }
-static size_t fast_fixed_bytes(int Q, int M) {
-    size_t q = (size_t)(Q > 0 ? Q : 1), mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
-    return 256 + 256 + 256 + align_up(512 * 12 * sizeof(float), 256) + align_up(q * 4, 256) + align_up(q * 4, 256) +
-           align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256) + 2 * align_up((size_t)kPartCap * 16 * q * 4, 256) +
-           seed_bytes(M) + 2 * align_up((size_t)1024 * 32 * 2 * 4, 256) + align_up(q * 4, 256);
+ModelView model_view(const float* m, int M, int ldm, void* block) {
+    ModelView v{};
+    char* w = (char*)block;
+    v.m = m; v.M = M; v.ldm = ldm;
+    v.prep = w; w += 256;
+    v.rm2 = (unsigned*)w; w += 256;
+    v.box_part = (float*)w; w += align_up(512 * 6 * sizeof(float), 256);
+    v.tiles = w; w += align_up(knn_f16_prep_bytes(M), 256);
+    v.seeded = M >= kSeedMinM && PCREG_EXP_ENV("PCREG_KNN_NOSEED", 0) == 0;
+    if (M >= kSeedMinM) {
+        v.seed_cnt = (int32_t*)w; w += align_up(seed_cell_cap(M) * 4, 256);
+        v.seed_slots = w;
+    }
+    return v;
+}
+// enqueue the two preparation passes (P1, P2) on `st`
+int launch_model_prepare(const ModelView& v, hipStream_t st) {
+    PCREG_ARG(v.M >= 0 && v.ldm >= v.M);
+    if (v.M == 0) return PCREG_OK;
+    int nb = (v.M + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(model_bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, v.m, v.M, v.ldm, v.box_part, v.seed_cnt,
+                       v.seeded ? (int)seed_cell_cap(v.M) : 0);
+    hipLaunchKernelGGL(model_bbox_final_kernel, dim3(1), dim3(64), 0, st, v.box_part, nb, v.M, (int)seed_cell_cap(v.M), (Prep*)v.prep, v.rm2);
+    PCREG_HIP(hipGetLastError());
+    return launch_prep_model_f16(v.m, v.M, v.ldm, v.prep, v.rm2, v.tiles, v.seeded ? v.seed_cnt : nullptr, v.seed_slots, st);
 }
 
-size_t knn2_points_fast_workspace_bytes(int Q, int M) {
-    return fast_fixed_bytes(Q, M) + knn2_points_exact_workspace_bytes(Q, M);
+// ---- the per-call workspace of a search (and of the match stage that follows it) ----------------------------------
+static constexpr int kTargetBlocks = 4096;
+SearchWs search_ws_layout(int Q, int M, void* base, size_t* bytes) {
+    SearchWs s{};
+    const size_t qq = (size_t)(Q > 0 ? Q : 1);
+    int q_blocks, S, tpc;
+    knn_f16_shape(Q > 0 ? Q : 1, M > 0 ? M : 1, kTargetBlocks, &q_blocks, &S, &tpc);
+    s.cap = S * KC;
+    char* w = (char*)base;
+    s.ctr = w; w += align_up(sizeof(SearchCounters), 256);
+    s.gthr = (unsigned*)w; w += align_up(qq * 4, 256);
+    s.flag_list = (int32_t*)w; w += align_up(qq * 4, 256);
+    s.cand_cnt = (int32_t*)w; w += align_up(qq * 4, 256);
+    s.cand_ent = w; w += align_up(qq * (size_t)(kF16MaxS * KC) * 8, 256);      // the call may see a smaller M than the sizing did
+    const size_t few = (size_t)kFew * kFbSlices * 2, many = (size_t)(kTailGrid + (qq + kTailQ - 1) / kTailQ) * kTailQ * 2;
+    s.tail_idx = (int32_t*)w; w += align_up(std::max(few, many) * 4, 256);
+    s.tail_dist = (float*)w; w += align_up(std::max(few, many) * 4, 256);
+    s.ug_cells = (int)ug_cells_cap(Q);
+    s.ug_nparts = (int)((qq * 8 + kBlock - 1) / kBlock);
+    s.ug_prep = w; w += 256;
+    s.ug_part = (float*)w; w += align_up((size_t)s.ug_nparts * 6 * 4, 256);
+    s.ug_cnt = (int32_t*)w; w += align_up((size_t)s.ug_cells * 4, 256);
+    s.ug_slots = w; w += align_up((size_t)s.ug_cells * kUgSlots * 16, 256);
+    *bytes = (size_t)(w - (char*)base);
+    return s;
 }
+size_t search_ws_bytes(int Q, int M) { size_t b; (void)search_ws_layout(Q, M, nullptr, &b); return b; }
 
-// PCREG_KNN_VARIANT: 40 (default) f16-split matrix-core candidates (knn_mfma16.hip), 41 its timing-only form;
-//                    0 VALU candidates QPT4/UB8 (the previous default); 11 QPT4/UB4; 12 QPT8/UB8; 13 QPT2/UB8; 19 VALU
-//                    timing-only (no insertions); 5 MFMA candidates; 9 MFMA timing-only.
-//                    The fp32 MFMA shares the SIMD's fp32 datapath with the VALU (measured: 32.5 -> 49 cycles per
-//                    MFMA once three VALU ops sit between issues, scripts/ubench/mfma_f32.hip), so the MFMA
-//                    formulation is slower than the 3-FMA VALU form here and is kept for reference only.
-//                    PCREG_KNN_BLOCKS: grid target.
-int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
-                                int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
-    PCREG_ARG(Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+// S1..S4 against a prepared model.  with_grid: also build the query grid (the match stage with Unique needs it).
+int launch_model_search(const ModelView& v, const float* q, int Q, int ldq, int32_t idx_base, int32_t* idx, float* dist,
+                        void* ws, size_t ws_bytes, bool with_grid, bool timed, hipStream_t st) {
+    PCREG_ARG(Q >= 0 && ldq >= Q && Q <= kMaxQTiles * 1024);
     if (Q == 0) return PCREG_OK;
-    size_t need = knn2_points_fast_workspace_bytes(Q, M);
-    if (ws_bytes < need) { set_error("knn (fast) workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
-    const int target_env = PCREG_EXP_ENV("PCREG_KNN_BLOCKS", 0);
-    const int variant = PCREG_EXP_ENV("PCREG_KNN_VARIANT", 40);
-    const bool use_mfma = variant >= 5 && variant < 10;
-    size_t qq = (size_t)Q, mm = (size_t)(M > 0 ? M : 1) + kMTile + 16;
-    char* w = (char*)ws;
-    Prep* prep = (Prep*)w;                 w += 256;
-    unsigned* rm2 = (unsigned*)w;          w += 256;
-    int32_t* n_flag = (int32_t*)w;         w += 256;
-    float* bpart = (float*)w;              w += align_up(512 * 12 * sizeof(float), 256);
-    unsigned* gthr = (unsigned*)w;         w += align_up(qq * 4, 256);
-    int32_t* flag_list = (int32_t*)w;      w += align_up(qq * 4, 256);
-    void* mprep = w;                       w += align_up(std::max(mm * 16, knn_f16_prep_bytes(M)), 256);
-    int32_t* part_idx = (int32_t*)w;       w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
-    float* part_s = (float*)w;             w += align_up((size_t)kPartCap * 16 * qq * 4, 256);
-    const size_t seed_cells = seed_cell_cap(M);
-    int32_t* seed_cnt = (int32_t*)w;       w += M >= kSeedMinM ? align_up(seed_cells * 4, 256) : 0;
-    float4* seed_slots = (float4*)w;       w += M >= kSeedMinM ? align_up(seed_cells * kSeedSlots * 16, 256) : 0;
-    int32_t* fb_idx = (int32_t*)w;         w += align_up((size_t)1024 * 32 * 2 * 4, 256);
-    float* fb_dist = (float*)w;            w += align_up((size_t)1024 * 32 * 2 * 4, 256);
-    int32_t* cand_cnt = (int32_t*)w;       w += align_up(qq * 4, 256);
-    void* ews = w;
-    size_t ews_bytes = ws_bytes - (size_t)(w - (char*)ws);
-
-    int nb = (M + Q + kBlock * 16 - 1) / (kBlock * 16); if (nb > 512) nb = 512; if (nb < 1) nb = 1;
-    const bool no_seed = PCREG_EXP_ENV("PCREG_KNN_NOSEED", 0) != 0;
-    const bool seeded = M >= kSeedMinM && !no_seed;
-    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nb), dim3(kBlock), 0, st, m, M, ldm, q, Q, ldq, bpart, seed_cnt, seeded ? (int)seed_cells : 0);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, st, bpart, nb, M, (int)seed_cell_cap(M), prep, rm2, n_flag);
-    int S = 1, kc = KC, e_mode = (variant == 40 || variant == 41) ? 1 : 0, group16 = 0;
-    bool sparse_lists = false;
-    if (seeded) {                               // first thresholds from the grid (stage 1c)
-        int fb = (M + kBlock - 1) / kBlock; if (fb > 16384) fb = 16384;     // one point per thread: the atomics want parallelism
-        hipLaunchKernelGGL(seed_fill_kernel, dim3(fb), dim3(kBlock), 0, st, m, M, ldm, prep, seed_cnt, seed_slots);
-        hipLaunchKernelGGL(seed_query_kernel, dim3((Q * 8 + kBlock - 1) / kBlock), dim3(kBlock), 0, st, q, Q, ldq, m, ldm, prep,
-                           seed_cnt, seed_slots, e_mode, gthr, PCREG_EXP_ENV("PCREG_KNN_SEED_RANK", 4));
-    } else {
-        PCREG_HIP(hipMemsetAsync(gthr, 0xFF, qq * 4, st));        // +inf in the ordered-uint image
-    }
-    if (variant == 40 || variant == 41) {        // f16-split matrix-core candidates (41: timing only)
-        kc = KC;
-        sparse_lists = true;             // entries of both 4-byte arrays' space: [Q][S * KC] (index, score) pairs
-        int rc = launch_knn_candidates_f16(q, Q, ldq, m, M, ldm, prep, rm2, mprep, gthr, part_idx, cand_cnt,
-                                           target_env > 0 ? target_env : 4096, kPartCap * 2, variant == 41, &S, &group16, st);
-        if (rc) return rc;
-    } else if (use_mfma) {
-        constexpr int NQ = 8;                    // must match knn_mfma.hip
-        const int n_tiles = (M + 15) / 16;
-        const int q_blocks = (Q + (kBlock / 64) * NQ * 16 - 1) / ((kBlock / 64) * NQ * 16);
-        // whole rounds of resident workgroups (4 per CU at <= 128 VGPRs): avoid a ragged last round
-        const int target = target_env > 0 ? target_env : 2048;
-        S = target / q_blocks; if (S < 1) S = 1;
-        if (S > kPartCap) S = kPartCap;
-        if (S > n_tiles) S = n_tiles > 0 ? n_tiles : 1;
-        int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
-        S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
-        kc = 16;
-        PCREG_HIP(hipMemsetAsync(part_idx, 0xFF, (size_t)S * qq * 16 * 4, st));     // -1: empty slots (M == 0, padding)
-        if (M > 0) {
-            int rc = launch_knn_candidates_mfma(q, Q, ldq, m, M, ldm, prep, rm2, (float*)mprep, n_tiles, tiles_per_chunk,
-                                                q_blocks, S, gthr, part_idx, part_s, variant == 9, st);
-            if (rc) return rc;
-        }
-    } else {
-        const int qpt = (variant == 12 || variant == 21) ? 8 : ((variant == 13 || variant == 22) ? 2 : ((variant == 15 || variant == 16 || variant == 32) ? 3 : 4));
-        int n_qt = (Q + kBlock * qpt - 1) / (kBlock * qpt);
-        S = pick_splits_fast(n_qt, M > 0 ? M : 1, target_env > 0 ? target_env : 4096);
-        if (S > kPartCap * 4) S = kPartCap * 4;
-        int chunk = (((M > 0 ? M : 1) + S - 1) / S + kMTile - 1) / kMTile * kMTile;
-        S = M > 0 ? (M + chunk - 1) / chunk : 1;
-        if (M > 0) {
-            int pb = (M + kMTile + kBlock * 4 - 1) / (kBlock * 4); if (pb > 2048) pb = 2048;
-            hipLaunchKernelGGL(prep_model_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, prep, (float4*)mprep, rm2);
-        }
-        dim3 grid(n_qt, S);
-#define PCREG_CAND_LAUNCH(QP, UBV) hipLaunchKernelGGL((knn_candidates_kernel<QP, UBV>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s)
-        switch (variant) {
-            case 20: hipLaunchKernelGGL((knn_candidates_sgpr_kernel<4>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
-            case 21: hipLaunchKernelGGL((knn_candidates_sgpr_kernel<8>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
-            case 22: hipLaunchKernelGGL((knn_candidates_sgpr_kernel<2>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, prep, gthr, part_idx, part_s); break;
-            case 30: hipLaunchKernelGGL((knn_candidates_dma_kernel<4, 8>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
-            case 31: hipLaunchKernelGGL((knn_candidates_dma_kernel<4, 4>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
-            case 32: hipLaunchKernelGGL((knn_candidates_dma_kernel<3, 4>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
-            case 15: PCREG_CAND_LAUNCH(3, 4); break;
-            case 16: PCREG_CAND_LAUNCH(3, 8); break;
-            case 11: PCREG_CAND_LAUNCH(4, 4); break;
-            case 12: PCREG_CAND_LAUNCH(8, 8); break;
-            case 13: PCREG_CAND_LAUNCH(2, 8); break;
-            case 19: hipLaunchKernelGGL((knn_candidates_kernel<4, 8, true>), grid, dim3(kBlock), 0, st, q, Q, ldq, (const float4*)mprep, M, chunk, chunk, prep, gthr, part_idx, part_s); break;
-            default: PCREG_CAND_LAUNCH(4, 8); break;
-        }
-#undef PCREG_CAND_LAUNCH
-    }
-    PCREG_HIP(hipGetLastError());
-    if (sparse_lists)
-        hipLaunchKernelGGL(knn_finalize_kernel<8>, dim3((Q + kBlock / 8 - 1) / (kBlock / 8)), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
-                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)cand_cnt, group16);
-    else
-        hipLaunchKernelGGL(knn_finalize_kernel<64>, dim3((Q + 3) / 4), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, prep, rm2, gthr,
-                           part_idx, part_s, S, kc, (int)idx_base, idx, dist, flag_list, n_flag, e_mode, (const int32_t*)nullptr, 0);
-    PCREG_HIP(hipGetLastError());
+    size_t need;
+    SearchWs s = search_ws_layout(Q, v.M, ws, &need);
+    if (ws_bytes < need) { set_error("search workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    SearchCounters* ctr = (SearchCounters*)s.ctr;
+    const bool grid = with_grid && v.M > 0;          // (an empty model matches nothing: the match stage never looks at the grid)
+    hipLaunchKernelGGL(seed_query_kernel, dim3(s.ug_nparts), dim3(kBlock), 0, st, q, Q, ldq, (const Prep*)v.prep, (const int32_t*)v.seed_cnt,
+                       (const float4*)v.seed_slots, (v.seeded && v.M > 0) ? 1 : 0, s.gthr, s.cand_cnt, ctr, grid ? s.ug_part : nullptr,
+                       grid ? s.ug_cnt : nullptr, s.ug_cells);
+    int S = 1;
+    const int variant = PCREG_EXP_ENV("PCREG_KNN_VARIANT", 40);      // 41: timing-only form of the candidate kernel (EXPERIMENTS builds)
+    const int target_env = PCREG_EXP_ENV("PCREG_KNN_BLOCKS", 0);      // (any shape fits: the lists are sized for kF16MaxS chunks)
+    int rc = launch_knn_candidates_f16(q, Q, ldq, v.M, v.prep, v.tiles, s.gthr, s.cand_ent, s.cand_cnt, target_env > 0 ? target_env : kTargetBlocks,
+                                       variant == 41, timed, grid ? s.ug_part : nullptr, s.ug_nparts, s.ug_cells, grid ? s.ug_prep : nullptr, &S, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(knn_finalize_kernel, dim3((Q + kBlock / LPQ - 1) / (kBlock / LPQ)), dim3(kBlock), 0, st, q, Q, ldq, v.m, v.M, v.ldm,
+                       (const Prep*)v.prep, (const unsigned*)v.rm2, (const unsigned*)s.gthr, (const uint2*)s.cand_ent, (const int32_t*)s.cand_cnt,
+                       S * KC, (int)idx_base, idx, dist, s.flag_list, &ctr->n_flag, grid ? (const UgPrep*)s.ug_prep : nullptr,
+                       s.ug_cnt, (float4*)s.ug_slots);
     if (PCREG_EXP_ENV("PCREG_KNN_DEBUG", 0)) {
         int32_t nf = 0;
-        PCREG_HIP(hipMemcpyAsync(&nf, n_flag, 4, hipMemcpyDeviceToHost, st)); PCREG_HIP(hipStreamSynchronize(st));
-        fprintf(stderr, "[pcreg] knn fast: Q=%d M=%d variant=%d S=%d kc=%d unproven=%d\n", Q, M, variant, S, kc, nf);
+        PCREG_HIP(hipMemcpyAsync(&nf, &ctr->n_flag, 4, hipMemcpyDeviceToHost, st)); PCREG_HIP(hipStreamSynchronize(st));
+        fprintf(stderr, "[pcreg] knn fast: Q=%d M=%d S=%d unproven=%d\n", Q, v.M, S, nf);
     }
-    // fallbacks (both launched; each decides from the device-side count which one works)
-    hipLaunchKernelGGL(knn_fallback_slice_kernel, dim3(64, kFbSlices), dim3(kBlock), 0, st, q, ldq, m, M, ldm, flag_list, n_flag, fb_idx, fb_dist);
-    hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3(kFew / 256), dim3(256), 0, st, flag_list, n_flag, (int)idx_base, fb_idx, fb_dist, idx, dist);
+    hipLaunchKernelGGL(knn_tail_kernel, dim3(kTailGrid), dim3(kBlock), 0, st, q, ldq, v.m, v.M, v.ldm, (int)idx_base, (const int32_t*)s.flag_list, ctr,
+                       s.tail_idx, s.tail_dist, idx, dist);
     PCREG_HIP(hipGetLastError());
-    return launch_knn2_points_exact_list(q, Q, ldq, m, M, ldm, idx_base, flag_list, n_flag, kFew, idx, dist, ews, ews_bytes, st);
+    return PCREG_OK;
+}
+
+// ---- the search without a handle: prepare into the caller's workspace, then search ---------------------------------
+size_t knn2_points_fast_workspace_bytes(int Q, int M) { return search_ws_bytes(Q, M) + model_prep_bytes(M); }
+
+int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
+                                int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st, bool timed) {
+    PCREG_ARG(Q >= 0 && M >= 0 && ldq >= Q && ldm >= M);
+    if (Q == 0) return PCREG_OK;
+    const size_t need = knn2_points_fast_workspace_bytes(Q, M);
+    if (ws_bytes < need) { set_error("knn (fast) workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    const size_t sb = search_ws_bytes(Q, M);
+    const ModelView v = model_view(m, M, ldm, (char*)ws + sb);
+    int rc = launch_model_prepare(v, st);
+    if (rc) return rc;
+    return launch_model_search(v, q, Q, ldq, idx_base, idx, dist, ws, sb, false, timed, st);
 }
 
 }  // namespace pcreg

@@ -51,18 +51,30 @@ __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x; l = (_Float16)opaque_f32(x - (float)h);
 }
 
-// model -> tiles of f16 operands; R_m^2 (unscaled) by atomicMax on the float bits
+// model -> tiles of f16 operands; R_m^2 (unscaled) by atomicMax on the float bits; and the model-wide seeding grid
+// (knn_fast.hip, stage 1c): up to kSeedSlots points per cell, whoever arrives first -- the thresholds it yields are
+// hints, results never depend on them.  One pass over the model, once per PREPARED model.
 __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __restrict__ m, int M, int ldm,
                                                                 const Prep* __restrict__ prep, uint4* __restrict__ out,
                                                                 int n_tiles, unsigned* __restrict__ rm2_bits,
-                                                                int32_t* __restrict__ cand_cnt, int Q) {
+                                                                int32_t* __restrict__ seed_cnt, float4* __restrict__ seed_slots) {
     const float cx = prep->cx, cy = prep->cy, cz = prep->cz, sg = prep->sigma;
+    const float gx0 = prep->gx0, gy0 = prep->gy0, gz0 = prep->gz0, ih = prep->inv_h;
+    const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
     float mx = 0.0f;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < Q; i += gridDim.x * kBlock) cand_cnt[i] = 0;     // the queries' candidate lists start empty
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n_tiles * kT16; i += gridDim.x * kBlock) {
         union { f16x8 v; uint4 u; } lo, hi;
         if (i < M) {
-            float x = m[i] - cx, y = m[i + (size_t)ldm] - cy, z = m[i + 2 * (size_t)ldm] - cz;     // the m~ of the fp32 path
+            const float px = m[i], py = m[i + (size_t)ldm], pz = m[i + 2 * (size_t)ldm];
+            if (seed_cnt) {
+                const float fx = floorf((px - gx0) * ih), fy = floorf((py - gy0) * ih), fz = floorf((pz - gz0) * ih);
+                if (fx >= 0.0f && fx < (float)nx && fy >= 0.0f && fy < (float)ny && fz >= 0.0f && fz < (float)nz) {
+                    const int cell = ((int)fz * ny + (int)fy) * nx + (int)fx;
+                    const int k = atomicAdd(&seed_cnt[cell], 1);
+                    if (k < kSeedSlots) seed_slots[(size_t)cell * kSeedSlots + k] = make_float4(px, py, pz, 0.0f);   // one 64-B line per cell
+                }
+            }
+            float x = px - cx, y = py - cy, z = pz - cz;     // the m~ of the fp32 path
             mx = fmaxf(mx, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
             x *= sg; y *= sg; z *= sg;                                                         // exact
             const float w = opaque_f32(__builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));    // <= 3 * 64^2; opaque: see split2
@@ -86,6 +98,37 @@ __global__ __launch_bounds__(kBlock) void prep_model_f16_kernel(const float* __r
     if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(rm2_bits, __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
+}
+
+// The search call builds the uniform grid over the QUERIES that the Unique back-check walks (knn_points.hip) as a
+// by-product: seed_query_kernel leaves per-workgroup boxes of the queries, ONE surplus workgroup of the candidate
+// kernel's grid folds them into the grid geometry (nothing waits for it: knn_finalize_kernel, the next launch, fills
+// the cells), so the match stage needs no box / fill launches of its own.
+__device__ void ug_reduce_boxes(const float* __restrict__ part /*[n][6]*/, int n, int Q, int cells_cap, UgPrep* __restrict__ prep) {
+    __shared__ float s_box[kBlock / 64][6];
+    float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int b = threadIdx.x; b < n; b += kBlock) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { v[c] = fminf(v[c], part[(size_t)b * 6 + c]); v[3 + c] = fmaxf(v[3 + c], part[(size_t)b * 6 + 3 + c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { v[c] = fminf(v[c], __shfl_xor(v[c], o)); v[3 + c] = fmaxf(v[3 + c], __shfl_xor(v[3 + c], o)); }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s_box[threadIdx.x >> 6][c] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lo[3], hi[3];
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = s_box[0][c]; hi[c] = s_box[0][3 + c];
+            for (int w = 1; w < kBlock / 64; ++w) { lo[c] = fminf(lo[c], s_box[w][c]); hi[c] = fmaxf(hi[c], s_box[w][3 + c]); }
+        }
+        ug_make_prep(lo, hi, Q, cells_cap, prep);
+    }
 }
 
 // ---- the candidate kernel: software-pipelined ------------------------------------------------------
@@ -112,8 +155,12 @@ template <int QG, bool DRY>   // DRY: timing only (no compare, no lists; PCREG_K
 __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_candidates_f16_pipe_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr, uint2* __restrict__ cand_ent, int32_t* __restrict__ cand_cnt,
-    int cap, int q_blocks, int xcd_map, int n_chunks) {
+    int cap, int q_blocks, int xcd_map, int n_chunks, const float* __restrict__ ug_part, int ug_nparts, int ug_cells, UgPrep* __restrict__ ug_prep) {
     static_assert(QG % 2 == 0, "two accumulator tiles alternate: an even number of steps per sub-tile");
+    if (blockIdx.x == gridDim.x - 1 && ug_prep != nullptr) {     // the surplus workgroup (the launcher adds it): query-grid geometry
+        ug_reduce_boxes(ug_part, ug_nparts, Q, ug_cells, ug_prep);
+        return;
+    }
     __shared__ __attribute__((aligned(16))) uint4 tile[2][2 * kT16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
@@ -133,8 +180,12 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
         const int qi = q_base + g * 32 + col;
         float X = 0.0f, Y = 0.0f, Z = 0.0f, one = 0.0f;
         if (qi < Q) {
-            X = -2.0f * (sg * (q[qi] - prep->cx)); Y = -2.0f * (sg * (q[qi + (size_t)ldq] - prep->cy));
-            Z = -2.0f * (sg * (q[qi + 2 * (size_t)ldq] - prep->cz)); one = 1.0f;
+            const float sx = sg * (q[qi] - prep->cx), sy = sg * (q[qi + (size_t)ldq] - prep->cy), sz = sg * (q[qi + 2 * (size_t)ldq] - prep->cz);
+            // a query far outside the prepared model's box (or not finite) is not scored here: all-zero operands, no list
+            // entries; knn_finalize_kernel applies the same test and sends it to the exact fallback
+            if (fabsf(sx) <= kQueryScaledMax && fabsf(sy) <= kQueryScaledMax && fabsf(sz) <= kQueryScaledMax) {
+                X = -2.0f * sx; Y = -2.0f * sy; Z = -2.0f * sz; one = 1.0f;
+            }
         }
         _Float16 Xh, Xl, Yh, Yl, Zh, Zl;
         split2(X, Xh, Xl); split2(Y, Yh, Yl); split2(Z, Zh, Zl);
@@ -297,8 +348,10 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
 }  // namespace
 
 // ---- live timing of the dominant kernel (bench.py's roofline line) --------------------------------
-// When enabled, the candidates kernel of every search is bracketed by two HIP events on the launch stream;
-// pcreg_dev_search_kernel_ms() returns the mean over the launches since the last call.
+// When enabled, the candidates kernel of every MAIN search (any size: a 125 k-row shard of an 8-GPU run as much as the
+// 1 M-row model) is bracketed by two HIP events on the launch stream; pcreg_dev_search_kernel_ms() returns the mean over
+// the launches since the last call.  A search the library runs for its own purposes (the Unique back-search of
+// PCREG_UNIQUE_MODE=1) passes timed = false.
 static bool g_time_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_time_ev;
 static size_t g_time_used = 0;
@@ -317,45 +370,62 @@ int knn_f16_timing_read(float* mean_ms, int* launches) {
 
 size_t knn_f16_prep_bytes(int M) { return (size_t)((M > 0 ? M : 1) + kT16 - 1) / kT16 * (2 * kT16) * sizeof(uint4); }
 
-// grid: q_blocks x S; KC = 4 list entries per (chunk, query).  Returns S and kc through the pointers.
-int launch_knn_candidates_f16(const float* q, int Q, int ldq, const float* m, int M, int ldm, const void* prep,
-                              unsigned* rm2, void* mtiles, unsigned* gthr, void* cand_ent, int32_t* cand_cnt,
-                              int target_blocks, int max_S, bool dry, int* S_out, int* group16_out, hipStream_t st) {
-    const int QGe = PCREG_EXP_ENV("PCREG_KNN_F16_QG", 4), QG = QGe == 8 ? 8 : (QGe == 2 ? 2 : 4);
-    *group16_out = 1;                       // list entries are groups of 16 model points (knn_finalize_kernel expands them)
+// the launch shape of the candidate kernel for Q queries against M model rows: q_blocks x S workgroups (+ surplus);
+// a (chunk, query) pair lists at most KC group entries, so a query's list holds at most S * KC
+void knn_f16_shape(int Q, int M, int target_blocks, int* q_blocks, int* S, int* tiles_per_chunk) {
+    constexpr int QG = 4;
     const int n_tiles = (M + kT16 - 1) / kT16;
-    const int q_blocks = (Q + (kBlock / 64) * QG * 32 - 1) / ((kBlock / 64) * QG * 32);
-    int S = (QG == 8 ? target_blocks / 2 : (QG == 2 ? target_blocks * 5 / 4 : target_blocks)) / q_blocks; if (S < 1) S = 1;
-    if (S > max_S) S = max_S;
-    if (S > n_tiles) S = n_tiles > 0 ? n_tiles : 1;
-    int tiles_per_chunk = n_tiles > 0 ? (n_tiles + S - 1) / S : 1;
-    S = n_tiles > 0 ? (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk : 1;
+    const int qb = (Q + (kBlock / 64) * QG * 32 - 1) / ((kBlock / 64) * QG * 32);
+    int s = target_blocks / (qb > 0 ? qb : 1); if (s < 1) s = 1;
+    if (s > kF16MaxS) s = kF16MaxS;
+    if (s > n_tiles) s = n_tiles > 0 ? n_tiles : 1;
+    const int tpc = n_tiles > 0 ? (n_tiles + s - 1) / s : 1;
+    s = n_tiles > 0 ? (n_tiles + tpc - 1) / tpc : 1;
+    *q_blocks = qb; *S = s; *tiles_per_chunk = tpc;
+}
+
+// model -> f16 tiles (+ the seeding grid when seed_cnt != nullptr); once per prepared model
+int launch_prep_model_f16(const float* m, int M, int ldm, const void* prep, unsigned* rm2, void* mtiles, int32_t* seed_cnt,
+                          void* seed_slots, hipStream_t st) {
+    if (M <= 0) return PCREG_OK;
+    const int n_tiles = (M + kT16 - 1) / kT16;
+    int pb = (n_tiles * kT16 + kBlock * 2 - 1) / (kBlock * 2); if (pb > 2048) pb = 2048;     // the fill's atomics want parallelism
+    hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2,
+                       seed_cnt, (float4*)seed_slots);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+
+// The candidate stage against a prepared model.  cand_cnt [Q] must be zero (seed_query_kernel clears it).
+// ug_*: the query-grid by-product (null: none).  Returns S (chunks) through S_out; list capacity per query = S * KC.
+int launch_knn_candidates_f16(const float* q, int Q, int ldq, int M, const void* prep, const void* mtiles, unsigned* gthr,
+                              void* cand_ent, int32_t* cand_cnt, int target_blocks, bool dry, bool timed, const float* ug_part,
+                              int ug_nparts, int ug_cells, void* ug_prep, int* S_out, hipStream_t st) {
+    int q_blocks, S, tiles_per_chunk;
+    knn_f16_shape(Q, M, target_blocks, &q_blocks, &S, &tiles_per_chunk);
+    *S_out = S;
+    if (M <= 0 || Q <= 0) return PCREG_OK;
+    const int n_tiles = (M + kT16 - 1) / kT16;
     // XCD-aware placement deals chunk c to the XCD that runs workgroups b = c (mod 8): the grid rounds the chunk count
     // up to a multiple of 8 and the surplus workgroups leave at once
     const int xcd_map = S >= 8 ? 1 : 0;
     const int grid_chunks = xcd_map ? (S + 7) / 8 * 8 : S;
-    *S_out = S;
-    // the prep kernel empties the per-query lists; an empty model has no prep
-    if (M <= 0) { PCREG_HIP(hipMemsetAsync(cand_cnt, 0, (size_t)Q * 4, st)); return PCREG_OK; }
-    int pb = (n_tiles * kT16 + kBlock * 4 - 1) / (kBlock * 4); if (pb > 512) pb = 512;
-    hipLaunchKernelGGL(prep_model_f16_kernel, dim3(pb), dim3(kBlock), 0, st, m, M, ldm, (const Prep*)prep, (uint4*)mtiles, n_tiles, rm2, cand_cnt, Q);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (g_time_on && Q * (long long)M >= (1LL << 33)) {          // the main search, not the small Unique back-check
+    if (g_time_on && timed) {
         if (g_time_used == g_time_ev.size()) { hipEvent_t a, b; PCREG_HIP(hipEventCreate(&a)); PCREG_HIP(hipEventCreate(&b)); g_time_ev.emplace_back(a, b); }
         ev0 = g_time_ev[g_time_used].first; ev1 = g_time_ev[g_time_used].second; ++g_time_used;
         PCREG_HIP(hipEventRecord(ev0, st));
     }
-#define PCREG_F16_LAUNCH(QGV, DRYV) hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<QGV, DRYV>), dim3(q_blocks * grid_chunks), dim3(kBlock), 0, st, q, Q, ldq, \
-                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map, S)
+    const int aux = ug_prep != nullptr ? 1 : 0;
+#define PCREG_F16_LAUNCH(QGV, DRYV) hipLaunchKernelGGL((knn_candidates_f16_pipe_kernel<QGV, DRYV>), dim3(q_blocks * grid_chunks + aux), dim3(kBlock), 0, st, q, Q, ldq, \
+                           (const uint4*)mtiles, n_tiles, tiles_per_chunk, (const Prep*)prep, gthr, (uint2*)cand_ent, cand_cnt, S * KC, q_blocks, xcd_map, S, \
+                           ug_part, ug_nparts, ug_cells, (UgPrep*)ug_prep)
 #ifdef PCREG_EXPERIMENTS
-    // measured and not kept: 8 query groups per wave at 2 waves per SIMD (timing-only form 1.37 ms, real 1.69 vs 1.61);
-    // 2 groups per wave at 5 waves per SIMD (88 VGPRs; 1.86-1.90 vs 1.58)
-    if (QG == 2) { if (dry) PCREG_F16_LAUNCH(2, true); else PCREG_F16_LAUNCH(2, false); }
-    else if (QG == 8) { if (dry) PCREG_F16_LAUNCH(8, true); else PCREG_F16_LAUNCH(8, false); }
-    else
+    if (dry) PCREG_F16_LAUNCH(4, true); else
 #endif
-    { if (dry) PCREG_F16_LAUNCH(4, true); else PCREG_F16_LAUNCH(4, false); }
+    PCREG_F16_LAUNCH(4, false);
 #undef PCREG_F16_LAUNCH
+    (void)dry;
     if (ev1) PCREG_HIP(hipEventRecord(ev1, st));
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;

@@ -19,6 +19,7 @@
 // Ties resolve to the lowest model index (MATLAB min / partial-sort behaviour).
 #include "common.hpp"
 #include "select.hpp"
+#include "knn_fast_common.hpp"               // kBlock, kMTile, the query grid (UgPrep ...), SearchCounters
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -26,11 +27,6 @@
 namespace pcreg {
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int QPT = 4;                       // queries per lane
-constexpr int kQTile = kBlock * QPT;         // queries per workgroup
-constexpr int kMTile = 1024;                 // model points per LDS tile (16 KiB)
-constexpr int UB = 4;                        // model points per batch
 
 struct Top2 { float d1, d2; int i1, i2; };
 
@@ -138,210 +134,42 @@ __global__ void merge_top2_list_kernel(const int32_t* __restrict__ part_idx, con
     }
 }
 
-// Unique back-check: for candidate k (model row j in this shard) find the first-best
-// query over all Q.  Same hot loop as the forward search with the roles swapped:
-// "queries" are the matched model points (gathered on the fly), the surface streams
-// through LDS.  Only the best index is needed.
-__global__ __launch_bounds__(kBlock) void unique_points_kernel(
-    const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm, int m_lo,
-    const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
-    int chunk, int32_t* __restrict__ part_idx, float* __restrict__ part_dist) {
-    __shared__ float4 tile[kMTile];
-    const int P = *n_cand;
-    const int tid = threadIdx.x;
-    const int k0 = blockIdx.x * kQTile;
-    if (k0 >= P) return;
-    const int s = blockIdx.y;
-    const int b_begin = s * chunk, b_end = min(Q, b_begin + chunk);
-    float px[QPT], py[QPT], pz[QPT], bd[QPT]; int bi[QPT];
-#pragma unroll
-    for (int r = 0; r < QPT; ++r) {
-        int k = k0 + r * kBlock + tid;
-        int j = k < P ? cand_m[k] - m_lo : -1;
-        bool ok = j >= 0 && j < M;
-        px[r] = ok ? m[j] : 0.0f; py[r] = ok ? m[j + (size_t)ldm] : 0.0f; pz[r] = ok ? m[j + 2 * (size_t)ldm] : 0.0f;
-        bd[r] = INFINITY; bi[r] = -1;
-    }
-    for (int t0 = b_begin; t0 < b_end; t0 += kMTile) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < kMTile / kBlock; ++k) {
-            int i = t0 + k * kBlock + tid;
-            float4 v;
-            if (i < b_end) { v.x = q[i]; v.y = q[i + (size_t)ldq]; v.z = q[i + 2 * (size_t)ldq]; v.w = 0.0f; }
-            else { v.x = v.y = v.z = INFINITY; v.w = 0.0f; }
-            tile[k * kBlock + tid] = v;
-        }
-        __syncthreads();
-        const int cnt = min(kMTile, b_end - t0);
-        const int nb = (cnt + UB - 1) / UB * UB;
-        for (int jb = 0; jb < nb; jb += UB) {
-            float4 mp[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) mp[u] = tile[jb + u];
-#pragma unroll
-            for (int r = 0; r < QPT; ++r) {
-                float d[UB];
-                // the score of (query i, model j) must be the bits the forward pass saw:
-                // dx = q - m, i.e. (surface - model)
-#pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    float dx = mp[u].x - px[r], dy = mp[u].y - py[r], dz = mp[u].z - pz[r];
-                    d[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                }
-                float mn = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
-                if (mn < bd[r]) {
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) if (d[u] < bd[r]) { bd[r] = d[u]; bi[r] = t0 + jb + u; }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < QPT; ++r) {
-        int k = k0 + r * kBlock + tid;
-        if (k < P) { size_t o = (size_t)s * Q + k; part_idx[o] = bi[r]; part_dist[o] = bd[r]; }
-    }
-}
-__global__ void unique_reduce_kernel(const int32_t* __restrict__ part_idx, const float* __restrict__ part_dist, int S,
-                                     int Q, int M, int m_lo, const int32_t* __restrict__ cand_q,
-                                     const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
-                                     int32_t* __restrict__ keep) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= *n_cand) return;
-    int j = cand_m[k] - m_lo;
-    if (j < 0 || j >= M) return;                 // another shard's row
-    float bd = INFINITY; int bi = -1;
-    for (int s = 0; s < S; ++s) {                // chunks ascend in query index: strict '<' keeps the first
-        float d = part_dist[(size_t)s * Q + k]; int i = part_idx[(size_t)s * Q + k];
-        if (i >= 0 && d < bd) { bd = d; bi = i; }
-    }
-    keep[k] = (bi == cand_q[k]);
-}
-
-// Unique through the certified search (default): the matched model points become the queries of one
-// more top-2 search over the surface; keep[k] = (nearest surface point of model row cand_m[k]) == cand_q[k].
-// d(p, s) uses dx = p - s here and dx = s - p in the forward pass: the same bits (squares of negated values).
-__global__ void unique_gather_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm, int m_lo,
-                                     const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand, float* __restrict__ pts /*[3][Q]*/) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Q) return;
-    const int j = k < *n_cand ? cand_m[k] - m_lo : -1;
-    const bool ok = j >= 0 && j < M;                 // rows of other shards / unused slots: any valid point (ignored later)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) pts[k + (size_t)c * Q] = ok ? m[j + (size_t)c * ldm] : q[(size_t)c * ldq];
-}
-__global__ void unique_keep_kernel(const int32_t* __restrict__ idx2, int M, int m_lo, const int32_t* __restrict__ cand_q,
-                                   const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand, int32_t* __restrict__ keep) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= *n_cand) return;
-    const int j = cand_m[k] - m_lo;
-    if (j < 0 || j >= M) return;                     // another shard's row
-    keep[k] = (idx2[(size_t)k * 2] == cand_q[k]);
-}
-
 // ---------------------------------------------------------------- Unique back-check on a grid of the queries
 // keep (i, j) iff no other query i' beats i for model point j in the (distance, index) order of the search.
 // That is a range-emptiness question with the candidate's OWN distance as radius (small: j is i's nearest
 // model point), so a uniform grid over the queries answers it exactly with a handful of distance evaluations
-// instead of a second all-pairs search.  Cells hold up to kUgSlots points; a candidate that meets a fuller
-// cell, or whose ball covers too many cells, is re-done by ug_brute_kernel against every query.
-constexpr int kUgSlots = 16;
-constexpr int kUgMaxCells = 4 << 20;
-constexpr int kUgMaxVisit = 343;
-struct UgPrep { float x0, y0, z0, inv_c; int nx, ny, nz, pad; };
-static size_t ug_cells_cap(int Q) { size_t c = 2 * (size_t)Q; if (c < 4096) c = 4096; if (c > (size_t)kUgMaxCells) c = kUgMaxCells; return c; }
+// instead of a second all-pairs search.  The grid is a by-product of the search call (knn_fast.hip: boxes in
+// seed_query_kernel, geometry by a surplus workgroup of the candidate kernel, cells in knn_finalize_kernel).  Cells
+// hold up to kUgSlots points; a candidate that meets a fuller cell, or whose ball covers too many cells, is
+// checked against every query by its wave (ug_walk's `undecided`).  The cell index is a monotone function of the
+// coordinate, so the cell range provably contains every query whose ROUNDED distance is <= d.
 
-__device__ __forceinline__ float ug_d2(float ax, float ay, float az, float bx, float by, float bz) {
-    const float dx = ax - bx, dy = ay - by, dz = az - bz;           // the search's exact formula (sign-symmetric)
-    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-}
-__device__ __forceinline__ int ug_cell1(float x, float x0, float inv_c, int n) {
-    const int c = (int)floorf((x - x0) * inv_c);                     // monotone in x: the range test relies on it
-    return min(max(c, 0), n - 1);
-}
+// ---------------------------------------------------------------- the match stage in ONE launch
+// threshold + ratio test (matchFeatures' removeWeakMatches / removeAmbiguousMatches), the Unique back-check on the
+// query grid the search call left in its workspace, and the ordered compaction into pairs + matched coordinates
+// (completeExperimentFast.m:205-206) -- round 2 ran eight launches for this.
+//   kMatchSingle     one rank: everything.
+//   kMatchTable      multi-GPU, before the exchange: this rank's contribution to the [4][Q] table of 4-byte words,
+//                    column = QUERY: rows 0-2 = coordinate bits of the query's nearest model point and row 3 = its
+//                    Unique verdict (1 if Unique is off) when that point's row lives in this shard and the query is
+//                    a candidate; zero otherwise -- an integer SUM over the ranks assembles the table exactly.
+//   kMatchFromTable  multi-GPU, after the exchange: candidates again (deterministic), verdicts and coordinates from
+//                    the table, ordered compaction.
+// Ordered compaction across workgroups without a second launch: workgroups take TICKETS (so workgroup b started
+// after every workgroup before it), publish their kept count with a ready bit and add up the counts of their
+// predecessors themselves -- a predecessor publishes before it waits, so nobody can wait for ever.
+enum { kMatchSingle = 0, kMatchTable = 1, kMatchFromTable = 2 };
+constexpr int kMatchCpbMax = 8;                 // chunks of 256 queries per workgroup: Q <= 2048 * 256 * 8
 
-__global__ __launch_bounds__(1024) void ug_bbox_kernel(const float* __restrict__ q, int Q, int ldq, int cells_cap,
-                                                       UgPrep* __restrict__ prep, int32_t* __restrict__ n_flag, int32_t* __restrict__ cnt) {
-    if (blockIdx.x > 0) {                     // workgroups 1.. clear the grid's counters (saves a memset launch); 0 finds the box
-        for (int i = (blockIdx.x - 1) * 1024 + threadIdx.x; i < cells_cap; i += (gridDim.x - 1) * 1024) cnt[i] = 0;
-        return;
-    }
-    __shared__ float s_lo[3][16], s_hi[3][16];
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i0 = threadIdx.x; i0 < Q; i0 += 4 * 1024) {
-        float v[4][3];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[u][c] = q[min(i0 + u * 1024, Q - 1) + (size_t)c * ldq];      // clamped repeats are harmless
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[u][c]); hi[c] = fmaxf(hi[c], v[u][c]); }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], o)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o)); }
-        if ((threadIdx.x & 63) == 0) { s_lo[c][threadIdx.x >> 6] = lo[c]; s_hi[c][threadIdx.x >> 6] = hi[c]; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float e[3];
-        for (int c = 0; c < 3; ++c) {
-            for (int w = 1; w < 16; ++w) { lo[c] = fminf(lo[c], s_lo[c][w]); hi[c] = fmaxf(hi[c], s_hi[c][w]); }
-            e[c] = fmaxf(hi[c] - lo[c], 0.0f);
-        }
-        // about two cells per query over the occupied extent; flat or degenerate axes get one layer
-        const float emax = fmaxf(e[0], fmaxf(e[1], e[2]));
-        float vol = 1.0f; int dims = 0;
-        for (int c = 0; c < 3; ++c) if (e[c] > 1e-6f * emax) { vol *= e[c]; ++dims; }
-        float cs = dims > 0 ? powf(vol / (2.0f * (float)Q), 1.0f / (float)dims) : 1.0f;
-        if (!(cs > 0.0f) || !isfinite(cs)) cs = 1.0f;
-        int nx, ny, nz;
-        for (;;) {
-            const float inv = 1.0f / cs;
-            const float fx = floorf(e[0] * inv) + 1.0f, fy = floorf(e[1] * inv) + 1.0f, fz = floorf(e[2] * inv) + 1.0f;
-            if (fx * fy * fz <= (float)cells_cap) { nx = (int)fx; ny = (int)fy; nz = (int)fz; break; }
-            cs *= 1.08f;
-        }
-        prep->x0 = lo[0]; prep->y0 = lo[1]; prep->z0 = lo[2]; prep->inv_c = 1.0f / cs;
-        prep->nx = nx; prep->ny = ny; prep->nz = nz; prep->pad = 0;
-        *n_flag = 0;
-    }
-}
-
-__global__ __launch_bounds__(256) void ug_fill_kernel(const float* __restrict__ q, int Q, int ldq, const UgPrep* __restrict__ prep,
-                                                      int32_t* __restrict__ cnt, float4* __restrict__ slots) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= Q) return;
-    const UgPrep P = *prep;
-    const float x = q[i], y = q[i + (size_t)ldq], z = q[i + 2 * (size_t)ldq];
-    const int cell = (ug_cell1(z, P.z0, P.inv_c, P.nz) * P.ny + ug_cell1(y, P.y0, P.inv_c, P.ny)) * P.nx + ug_cell1(x, P.x0, P.inv_c, P.nx);
-    const int s = atomicAdd(&cnt[cell], 1);
-    if (s < kUgSlots) slots[(size_t)cell * kUgSlots + s] = make_float4(x, y, z, __int_as_float(i));
-}
-
-__global__ __launch_bounds__(64) void ug_check_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm,
-                                                     int m_lo, const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
-                                                     const int32_t* __restrict__ n_cand, const UgPrep* __restrict__ prep,
-                                                     const int32_t* __restrict__ cnt, const float4* __restrict__ slots,
-                                                     int32_t* __restrict__ keep, int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag) {
-    const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= *n_cand) return;
-    const int j = cand_m[k] - m_lo;
-    if (j < 0 || j >= M) return;                                     // another shard's row
-    const int i = cand_q[k];
-    const UgPrep P = *prep;
-    const float px = m[j], py = m[j + (size_t)ldm], pz = m[j + 2 * (size_t)ldm];
-    const float di = ug_d2(q[i], q[i + (size_t)ldq], q[i + 2 * (size_t)ldq], px, py, pz);
+__device__ __forceinline__ void ug_walk(const float* __restrict__ q, int ldq, int i, float px, float py, float pz, float di,
+                                        const UgPrep& P, const int32_t* __restrict__ cnt, const float4* __restrict__ slots,
+                                        bool& kp, bool& undecided) {
     const float r = sqrtf(di) * 1.0001f + 1e-30f;                    // covers every point whose rounded distance is <= di
     const int x0 = ug_cell1(px - r, P.x0, P.inv_c, P.nx), x1 = ug_cell1(px + r, P.x0, P.inv_c, P.nx);
     const int y0 = ug_cell1(py - r, P.y0, P.inv_c, P.ny), y1 = ug_cell1(py + r, P.y0, P.inv_c, P.ny);
     const int z0 = ug_cell1(pz - r, P.z0, P.inv_c, P.nz), z1 = ug_cell1(pz + r, P.z0, P.inv_c, P.nz);
     bool brute = !(di == di) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > kUgMaxVisit;
-    bool kp = true;
+    kp = true;
     for (int cz = z0; cz <= z1 && !brute && kp; ++cz)
         for (int cy = y0; cy <= y1 && !brute && kp; ++cy)
             for (int cx = x0; cx <= x1 && kp; ++cx) {
@@ -355,129 +183,142 @@ __global__ __launch_bounds__(64) void ug_check_kernel(const float* __restrict__ 
                     if (d < di || (d == di && it < i)) { kp = false; break; }
                 }
             }
-    if (brute && kp) flag_list[atomicAdd(n_flag, 1)] = k;            // undecided: the exhaustive scan settles it
-    keep[k] = kp && !brute;
+    undecided = brute && kp;
 }
 
-// one workgroup per undecided candidate against every query (four loads in flight per thread: the scan is
-// latency-bound)
-__global__ __launch_bounds__(1024) void ug_brute_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm, int m_lo,
-                                                       const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
-                                                       const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag,
-                                                       int32_t* __restrict__ keep) {
-    const int nf = *n_flag;
-    for (int f = blockIdx.x; f < nf; f += gridDim.x) {
-        const int k = flag_list[f];
-        const int j = cand_m[k] - m_lo, i = cand_q[k];
-        const float px = m[j], py = m[j + (size_t)ldm], pz = m[j + 2 * (size_t)ldm];
-        const float di = ug_d2(q[i], q[i + (size_t)ldq], q[i + 2 * (size_t)ldq], px, py, pz);
-        bool b = false;
-        for (int t0 = threadIdx.x; t0 < Q && !b; t0 += 4 * 1024) {
-            float x[4], y[4], z[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = min(t0 + u * 1024, Q - 1);
-                x[u] = q[t]; y[u] = q[t + (size_t)ldq]; z[u] = q[t + 2 * (size_t)ldq];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + u * 1024;
-                const float d = ug_d2(x[u], y[u], z[u], px, py, pz);
-                b = b || (t < Q && (d < di || (d == di && t < i)));
-            }
-        }
-        const int beaten = __syncthreads_or(b);
-        if (threadIdx.x == 0) keep[k] = !beaten;
-    }
-}
-
-// Multi-GPU: this rank's contribution to the [4][Q] candidate table (4-byte words): rows 0-2 = coordinate bits of
-// the candidates whose model row lives in this shard, row 3 = their Unique verdict; zero everywhere else, so an
-// integer SUM over the ranks assembles the table exactly.
-__global__ void cand_table_kernel(const float* __restrict__ m, int M, int ldm, int m_lo, const int32_t* __restrict__ cand_m,
-                                  const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand, int Q,
-                                  int32_t* __restrict__ table) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Q) return;
-    int w[4] = {0, 0, 0, 0};
-    if (k < *n_cand) {
-        const int j = cand_m[k] - m_lo;
-        if (j >= 0 && j < M) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) w[c] = __float_as_int(m[j + (size_t)c * ldm]);
-            w[3] = keep ? (keep[k] != 0) : 1;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) table[k + (size_t)c * Q] = w[c];
-}
-
-// Ordered compaction of the kept candidates (three small launches: per-workgroup counts,
-// exclusive scan, scatter) into 1-based pairs and, optionally, the matched coordinates.
-__global__ void gather_count_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
-                                    int32_t* __restrict__ block_cnt) {
-    const int P = *n_cand;
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    bool kp = k < P && (keep == nullptr || keep[k] != 0);
-    __shared__ int s_cnt[4];
-    unsigned long long b = __ballot(kp);
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-}
-__global__ void gather_scatter_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
-                                      const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
-                                      const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
-                                      const int32_t* __restrict__ block_off, int self_prefix, int32_t* __restrict__ n_pairs,
-                                      uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2) {
-    const int P = *n_cand;
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    bool kp = k < P && (keep == nullptr || keep[k] != 0);
-    __shared__ int s_cnt[4];
-    __shared__ int s_pre[4];
-    const int pre = self_prefix ? block_self_prefix_256(block_off, blockIdx.x, gridDim.x, s_pre, n_pairs) : block_off[blockIdx.x];
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void match_finish_kernel(
+    const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm, int m_lo, int M_total,
+    const int32_t* __restrict__ idx, const float* __restrict__ dist, float thr, float ratio, int unique,
+    const UgPrep* __restrict__ ug_prep, const int32_t* __restrict__ ug_cnt, const float4* __restrict__ ug_slots,
+    int32_t* __restrict__ table, SearchCounters* __restrict__ ctr, int cpb,
+    uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2, int32_t* __restrict__ n_pairs) {
+    __shared__ int s_ticket;
+    __shared__ int s_cnt[kMatchCpbMax][kBlock / 64];
+    __shared__ int s_red[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long b = __ballot(kp);
-    if (lane == 0) s_cnt[wave] = __popcll(b);
+    int b = blockIdx.x;
+    if (MODE != kMatchTable) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(&ctr->ticket, 1);
+        __syncthreads();
+        b = s_ticket;
+    }
+    const int base_q = b * cpb * kBlock;
+    unsigned keep_bits = 0u;
+    for (int c = 0; c < cpb; ++c) {
+        const int qi = base_q + c * kBlock + threadIdx.x;
+        const bool cand = qi < Q && filter_keep<float>(idx, dist, qi, M_total, thr, ratio);
+        const int j = cand ? idx[(size_t)qi * 2] : -1;             // global model row
+        bool kp = cand;
+        if (MODE == kMatchFromTable) {
+            kp = cand && table[qi + 3 * (size_t)Q] != 0;
+        } else {
+            const int jl = j - m_lo;
+            const bool mine = cand && jl >= 0 && jl < M;
+            float px = 0.0f, py = 0.0f, pz = 0.0f, di = 0.0f;
+            bool und = false;
+            if (mine) { px = m[jl]; py = m[jl + (size_t)ldm]; pz = m[jl + 2 * (size_t)ldm]; }
+            if (mine && unique) {
+                const UgPrep P = *ug_prep;
+                di = ug_d2(q[qi], q[qi + (size_t)ldq], q[qi + 2 * (size_t)ldq], px, py, pz);
+                ug_walk(q, ldq, qi, px, py, pz, di, P, ug_cnt, ug_slots, kp, und);
+            }
+            // a candidate the grid could not decide (an overflowing cell, a ball over too many cells): the wave scans
+            // every query for it, together
+            unsigned long long um = __ballot(und);
+            while (um != 0ull) {
+                const int l = __builtin_ctzll(um); um &= um - 1ull;
+                const float bx = __shfl(px, l), by = __shfl(py, l), bz = __shfl(pz, l), bd = __shfl(di, l);
+                const int bi = __shfl(qi, l);
+                bool beaten = false;
+                for (int t0 = 0; t0 < Q && !beaten; t0 += 4 * 64) {
+                    bool bb = false;
+                    float x[4], y[4], z[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = min(t0 + u * 64 + lane, Q - 1);
+                        x[u] = q[t]; y[u] = q[t + (size_t)ldq]; z[u] = q[t + 2 * (size_t)ldq];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + u * 64 + lane;
+                        const float d = ug_d2(x[u], y[u], z[u], bx, by, bz);
+                        bb = bb || (t < Q && (d < bd || (d == bd && t < bi)));
+                    }
+                    beaten = __any(bb);
+                }
+                if (lane == l) kp = !beaten;
+            }
+            if (MODE == kMatchTable) {
+                if (qi < Q) {
+                    table[qi] = mine ? __float_as_int(px) : 0;
+                    table[qi + (size_t)Q] = mine ? __float_as_int(py) : 0;
+                    table[qi + 2 * (size_t)Q] = mine ? __float_as_int(pz) : 0;
+                    table[qi + 3 * (size_t)Q] = (mine && kp) ? 1 : 0;
+                }
+                continue;
+            }
+            kp = kp && mine;          // kMatchSingle holds the whole model: every candidate is `mine`
+        }
+        const unsigned long long bal = __ballot(kp);
+        if (lane == 0) s_cnt[c][wave] = __popcll(bal);
+        keep_bits |= kp ? (1u << c) : 0u;
+    }
+    if (MODE == kMatchTable) return;
     __syncthreads();
-    int base = pre;
-    for (int w = 0; w < wave; ++w) base += s_cnt[w];
-    if (kp) {
-        int o = base + __popcll(b & ((1ull << lane) - 1ull));
-        int qi = cand_q[k], mj = cand_m[k];
-        if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)mj + 1u; }
-        if (pts1) {
-            pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
-            pts2[o] = (double)m[mj]; pts2[o + (size_t)Q] = (double)m[mj + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[mj + 2 * (size_t)ldm];
-        }
+    int mine_total = 0;
+    for (int c = 0; c < cpb; ++c)
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) mine_total += s_cnt[c][w];
+    if (threadIdx.x == 0) __hip_atomic_store(&ctr->status[b], (int)(0x80000000u | (unsigned)mine_total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // the kept counts of the workgroups before this one
+    int v = 0;
+    for (int p = threadIdx.x; p < b; p += kBlock) {
+        int sv;
+        do { sv = __hip_atomic_load(&ctr->status[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (sv >= 0);
+        v += sv & 0x7FFFFFFF;
     }
-}
-
-// the same in ONE launch for capacities up to kCompactMax (select.hpp): one 1024-thread workgroup, contiguous runs
-__global__ __launch_bounds__(kCompactThreads) void gather_compact_kernel(const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int ldm,
-                                                                         const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
-                                                                         const int32_t* __restrict__ keep, const int32_t* __restrict__ n_cand,
-                                                                         uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2,
-                                                                         int32_t* __restrict__ n_pairs) {
-    __shared__ int s_wave[kCompactThreads / 64];
-    const int P = min(*n_cand, Q);
-    const int per = (P + kCompactThreads - 1) / kCompactThreads;
-    const int lo = min(P, (int)threadIdx.x * per), hi = min(P, lo + per);
-    int cnt = 0;
-    for (int k = lo; k < hi; ++k) cnt += (keep == nullptr || keep[k] != 0);
-    int total;
-    int o = block_exclusive_scan_1024(cnt, s_wave, &total);
-    for (int k = lo; k < hi; ++k) {
-        if (keep != nullptr && keep[k] == 0) continue;
-        const int qi = cand_q[k], mj = cand_m[k];
-        if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)mj + 1u; }
-        if (pts1) {
-            pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
-            pts2[o] = (double)m[mj]; pts2[o + (size_t)Q] = (double)m[mj + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[mj + 2 * (size_t)ldm];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) base += s_red[w];
+    if (b == (int)gridDim.x - 1 && threadIdx.x == 0) *n_pairs = base + mine_total;
+    for (int c = 0; c < cpb; ++c) {
+        const bool kp = (keep_bits >> c) & 1u;
+        const unsigned long long bal = __ballot(kp);
+        int o = base;
+        for (int w = 0; w < wave; ++w) o += s_cnt[c][w];
+        if (kp) {
+            o += __popcll(bal & ((1ull << lane) - 1ull));
+            const int qi = base_q + c * kBlock + threadIdx.x;
+            const int j = idx[(size_t)qi * 2];
+            if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)j + 1u; }
+            if (pts1) {
+                pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
+                if (MODE == kMatchFromTable) {
+                    pts2[o] = (double)__int_as_float(table[qi]); pts2[o + (size_t)Q] = (double)__int_as_float(table[qi + (size_t)Q]);
+                    pts2[o + 2 * (size_t)Q] = (double)__int_as_float(table[qi + 2 * (size_t)Q]);
+                } else {
+                    const int jl = j - m_lo;
+                    pts2[o] = (double)m[jl]; pts2[o + (size_t)Q] = (double)m[jl + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[jl + 2 * (size_t)ldm];
+                }
+            }
         }
-        ++o;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) base += s_cnt[c][w];
     }
-    if (threadIdx.x == 0) *n_pairs = total;
+    // the last workgroup through leaves the counters as it found them, so that the match stage may run again on the same
+    // search (every other workgroup has read the status words it needed before it counted itself in)
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctr->finished, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket == (int)gridDim.x - 1) {
+        for (int p = threadIdx.x; p < (int)gridDim.x; p += kBlock) ctr->status[p] = 0;
+        if (threadIdx.x == 0) { ctr->ticket = 0; ctr->finished = 0; }
+    }
 }
 
 // number of model chunks so that the grid has ~>= 8 workgroups per CU
@@ -505,7 +346,7 @@ size_t knn2_points_exact_workspace_bytes(int Q, int M) {
 size_t knn2_points_exact_workspace_bytes(int Q, int M);
 size_t knn2_points_fast_workspace_bytes(int Q, int M);
 int launch_knn2_points_fast_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
-                                int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st);
+                                int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st, bool timed);
 
 static int knn2_exact_impl(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
                            const int32_t* qlist, const int32_t* n_list, int min_active,
@@ -557,10 +398,10 @@ size_t knn2_points_workspace_bytes(int Q, int M) {
 }
 
 int launch_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
-                           int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st) {
+                           int32_t* idx, float* dist, void* ws, size_t ws_bytes, hipStream_t st, bool timed) {
     if (use_exact_only())
         return knn2_exact_impl(q, Q, ldq, m, M, ldm, idx_base, nullptr, nullptr, 0, idx, dist, ws, ws_bytes, st);
-    return launch_knn2_points_fast_f32(q, Q, ldq, m, M, ldm, idx_base, idx, dist, ws, ws_bytes, st);
+    return launch_knn2_points_fast_f32(q, Q, ldq, m, M, ldm, idx_base, idx, dist, ws, ws_bytes, st, timed);
 }
 
 int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, int Q, int32_t* idx, float* dist,
@@ -572,114 +413,53 @@ int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, in
     return PCREG_OK;
 }
 
-int launch_filter_top2_f32(const int32_t* idx, const float* dist, int Q, int M_total, float thr, float ratio,
-                           int32_t* cand_q, int32_t* cand_m, int32_t* n_cand, hipStream_t st) {
-    PCREG_ARG(Q >= 0);
-    void* tmp = nullptr;   // flags [Q] + per-workgroup counters
-    int rc = stream_scratch(st).get(20, ((size_t)Q + (Q + 255) / 256 + 1) * sizeof(int32_t), &tmp);
-    if (rc) return rc;
-    return run_filter_top2<float>(idx, dist, Q, M_total, thr, ratio, cand_q, cand_m, n_cand, (int32_t*)tmp, st);
+// ---- the match stage on a finished search: launchers ----------------------------------------------------------------
+static int match_shape(int Q, int* blocks, int* cpb) {
+    int c = 1;
+    while ((long long)kMatchMaxBlocks * kBlock * c < Q) ++c;
+    if (c > kMatchCpbMax) { set_error("match: %d queries exceed the %d a call handles", Q, kMatchMaxBlocks * kBlock * kMatchCpbMax); return PCREG_E_ARG; }
+    *cpb = c; *blocks = (Q + kBlock * c - 1) / (kBlock * c);
+    return PCREG_OK;
 }
-
-static size_t unique_direct_bytes(int Q) {
-    int n_tiles = (Q + kQTile - 1) / kQTile; if (n_tiles < 1) n_tiles = 1;
-    int S = pick_splits(n_tiles, Q > 0 ? Q : 1);
-    return 2 * align_up((size_t)S * (size_t)(Q > 0 ? Q : 1) * sizeof(float), 256);
-}
-// gathered points [3][Q] | idx2 [Q][2] | dist2 [Q][2] | search workspace
-static size_t unique_grid_bytes(int Q) {   // prep | n_flag | cell counts | cell slots | undecided list
-    return 256 + 256 + align_up(ug_cells_cap(Q) * 4, 256) + align_up(ug_cells_cap(Q) * kUgSlots * 16, 256) +
-           align_up((size_t)(Q > 0 ? Q : 1) * 4, 256);
-}
-size_t unique_points_workspace_bytes(int Q) {
-    size_t q = (size_t)(Q > 0 ? Q : 1);
-    size_t fast = align_up(q * 3 * 4, 256) + 2 * align_up(q * 2 * 4, 256) + knn2_points_workspace_bytes(Q, Q);
-    size_t direct = unique_direct_bytes(Q);
-    size_t grid = unique_grid_bytes(Q);
-    return std::max(std::max(fast, direct), grid);
-}
-
-int launch_unique_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t m_lo,
-                             const int32_t* cand_q, const int32_t* cand_m, const int32_t* n_cand, int32_t* keep,
-                             void* ws, size_t ws_bytes, hipStream_t st) {
-    PCREG_ARG(Q >= 0 && M >= 0);
-    if (Q == 0) return PCREG_OK;
-    size_t need = unique_points_workspace_bytes(Q);
-    if (ws_bytes < need) { set_error("unique workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
-    const int unique_mode = pcreg_env_int("PCREG_UNIQUE_MODE", 0);   // 1: second search
-    if (!use_exact_only() && Q >= 4096 && unique_mode == 0) {
-        // grid of the queries + exact range-emptiness test per candidate (see ug_* above)
-        char* w = (char*)ws;
-        UgPrep* prep = (UgPrep*)w;          w += 256;
-        int32_t* n_flag = (int32_t*)w;      w += 256;
-        const size_t cells = ug_cells_cap(Q);
-        int32_t* cnt = (int32_t*)w;         w += align_up(cells * 4, 256);
-        float4* slots = (float4*)w;         w += align_up(cells * kUgSlots * 16, 256);
-        int32_t* flag_list = (int32_t*)w;
-        hipLaunchKernelGGL(ug_bbox_kernel, dim3(1 + (unsigned)std::min<size_t>(64, (cells + 4095) / 4096)), dim3(1024), 0, st, q, Q, ldq, (int)cells, prep, n_flag, cnt);
-        hipLaunchKernelGGL(ug_fill_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, q, Q, ldq, prep, cnt, slots);
-        hipLaunchKernelGGL(ug_check_kernel, dim3((Q + 63) / 64), dim3(64), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo, cand_q, cand_m, n_cand,
-                           prep, cnt, slots, keep, flag_list, n_flag);
-        hipLaunchKernelGGL(ug_brute_kernel, dim3(512), dim3(1024), 0, st, q, Q, ldq, m, ldm, (int)m_lo, cand_q, cand_m, flag_list, n_flag, keep);
-        PCREG_HIP(hipGetLastError());
-        return PCREG_OK;
-    }
-    if (!use_exact_only() && Q >= 4096) {
-        size_t qq = (size_t)Q;
-        char* w = (char*)ws;
-        float* pts = (float*)w;             w += align_up(qq * 3 * 4, 256);
-        int32_t* idx2 = (int32_t*)w;        w += align_up(qq * 2 * 4, 256);
-        float* dist2 = (float*)w;           w += align_up(qq * 2 * 4, 256);
-        hipLaunchKernelGGL(unique_gather_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo, cand_m, n_cand, pts);
-        int rc = launch_knn2_points_f32(pts, Q, Q, q, Q, ldq, 0, idx2, dist2, w, ws_bytes - (size_t)(w - (char*)ws), st);
-        if (rc) return rc;
-        hipLaunchKernelGGL(unique_keep_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, idx2, M, (int)m_lo, cand_q, cand_m, n_cand, keep);
-        PCREG_HIP(hipGetLastError());
-        return PCREG_OK;
-    }
-    int n_tiles = (Q + kQTile - 1) / kQTile;         // capacity: every query matched
-    int S = pick_splits(n_tiles, Q);
-    int chunk = chunk_of(Q, S);
-    S = (Q + chunk - 1) / chunk;
-    int32_t* part_idx = (int32_t*)ws;
-    float* part_dist = (float*)((char*)ws + align_up((size_t)S * Q * sizeof(float), 256));
-    hipLaunchKernelGGL(unique_points_kernel, dim3(n_tiles, S), dim3(kBlock), 0, st, q, Q, ldq, m, M, ldm, (int)m_lo,
-                       cand_q, cand_m, n_cand, chunk, part_idx, part_dist);
-    hipLaunchKernelGGL(unique_reduce_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, part_idx, part_dist, S, Q, M,
-                       (int)m_lo, cand_q, cand_m, n_cand, keep);
+int launch_match_finish(const ModelView& v, const float* q, int Q, int ldq, const int32_t* idx, const float* dist, float thr,
+                        float ratio, int unique, void* ws, size_t ws_bytes, uint32_t* pairs, double* pts1, double* pts2,
+                        int32_t* n_pairs, hipStream_t st) {
+    PCREG_ARG(Q >= 0 && ldq >= Q && (pts1 == nullptr) == (pts2 == nullptr));
+    if (Q == 0 || v.M == 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
+    size_t need; SearchWs s = search_ws_layout(Q, v.M, ws, &need);
+    if (ws_bytes < need) { set_error("match workspace too small: %zu < %zu (pass the search call's workspace)", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    int blocks, cpb; { int rc = match_shape(Q, &blocks, &cpb); if (rc) return rc; }
+    hipLaunchKernelGGL(match_finish_kernel<kMatchSingle>, dim3(blocks), dim3(kBlock), 0, st, q, Q, ldq, v.m, v.M, v.ldm, 0, v.M, idx, dist, thr, ratio, unique,
+                       (const UgPrep*)s.ug_prep, (const int32_t*)s.ug_cnt, (const float4*)s.ug_slots, (int32_t*)nullptr, (SearchCounters*)s.ctr, cpb,
+                       pairs, pts1, pts2, n_pairs);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
-
-int launch_cand_table_f32(const float* m, int M, int ldm, int32_t m_lo, const int32_t* cand_m, const int32_t* keep,
-                          const int32_t* n_cand, int Q, int32_t* table, hipStream_t st) {
-    PCREG_ARG(Q >= 0 && M >= 0);
+int launch_match_table(const ModelView& v, int32_t m_lo, int M_total, const float* q, int Q, int ldq, const int32_t* idx,
+                       const float* dist, float thr, float ratio, int unique, void* ws, size_t ws_bytes, int32_t* table,
+                       hipStream_t st) {
+    PCREG_ARG(Q >= 0 && ldq >= Q && m_lo >= 0 && M_total >= 0);
     if (Q == 0) return PCREG_OK;
-    hipLaunchKernelGGL(cand_table_kernel, dim3((Q + 255) / 256), dim3(256), 0, st, m, M, ldm, (int)m_lo, cand_m, keep, n_cand, Q, table);
+    if (v.M == 0) { PCREG_HIP(hipMemsetAsync(table, 0, sizeof(int32_t) * 4 * (size_t)Q, st)); return PCREG_OK; }
+    size_t need; SearchWs s = search_ws_layout(Q, v.M, ws, &need);
+    if (ws_bytes < need) { set_error("match workspace too small: %zu < %zu (pass the search call's workspace)", ws_bytes, need); return PCREG_E_WORKSPACE; }
+    int blocks, cpb; { int rc = match_shape(Q, &blocks, &cpb); if (rc) return rc; }
+    hipLaunchKernelGGL(match_finish_kernel<kMatchTable>, dim3(blocks), dim3(kBlock), 0, st, q, Q, ldq, v.m, v.M, v.ldm, (int)m_lo, M_total, idx, dist, thr, ratio,
+                       unique, (const UgPrep*)s.ug_prep, (const int32_t*)s.ug_cnt, (const float4*)s.ug_slots, table, (SearchCounters*)s.ctr, cpb,
+                       (uint32_t*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
-
-int launch_gather_pairs_f32(const float* q, int Q, int ldq, const float* m, int ldm, const int32_t* cand_q,
-                            const int32_t* cand_m, const int32_t* keep, const int32_t* n_cand, uint32_t* pairs,
-                            double* pts1, double* pts2, int32_t* n_pairs, hipStream_t st) {
-    PCREG_ARG((pts1 == nullptr) == (pts2 == nullptr));
-    if (Q <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
-    if (Q <= kCompactMax) {
-        hipLaunchKernelGGL(gather_compact_kernel, dim3(1), dim3(kCompactThreads), 0, st, q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand, pairs, pts1, pts2, n_pairs);
-        PCREG_HIP(hipGetLastError());
-        return PCREG_OK;
-    }
-    const int nb = (Q + 255) / 256;                   // capacity launch: the kernels read the real count
-    void* tmp = nullptr;
-    int rc = stream_scratch(st).get(21, ((size_t)nb + 1) * sizeof(int32_t), &tmp);
-    if (rc) return rc;
-    int32_t* bc = (int32_t*)tmp;
-    hipLaunchKernelGGL(gather_count_kernel, dim3(nb), dim3(256), 0, st, keep, n_cand, bc);
-    const int self_prefix = nb <= kSelfPrefixMax;
-    if (!self_prefix) hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_pairs);
-    hipLaunchKernelGGL(gather_scatter_kernel, dim3(nb), dim3(256), 0, st, q, Q, ldq, m, ldm, cand_q, cand_m, keep, n_cand,
-                       bc, self_prefix, n_pairs, pairs, pts1, pts2);
+int launch_match_from_table(const float* q, int Q, int ldq, int M_total, const int32_t* idx, const float* dist, float thr,
+                            float ratio, const int32_t* table, void* ws, size_t ws_bytes, uint32_t* pairs, double* pts1,
+                            double* pts2, int32_t* n_pairs, hipStream_t st) {
+    PCREG_ARG(Q >= 0 && ldq >= Q && (pts1 == nullptr) == (pts2 == nullptr));
+    if (Q == 0 || M_total == 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
+    PCREG_ARG(ws != nullptr && ws_bytes >= align_up(sizeof(SearchCounters), 256));       // the counters at the head of the search workspace
+    int blocks, cpb; { int rc = match_shape(Q, &blocks, &cpb); if (rc) return rc; }
+    hipLaunchKernelGGL(match_finish_kernel<kMatchFromTable>, dim3(blocks), dim3(kBlock), 0, st, q, Q, ldq, (const float*)nullptr, 0, 0, 0, M_total, idx, dist, thr,
+                       ratio, 1, (const UgPrep*)nullptr, (const int32_t*)nullptr, (const float4*)nullptr, const_cast<int32_t*>(table), (SearchCounters*)ws, cpb,
+                       pairs, pts1, pts2, n_pairs);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -29,36 +29,74 @@ def soa(points: torch.Tensor) -> torch.Tensor:
     return points.t().contiguous()
 
 
+class PreparedModel:
+    """A model shard prepared ONCE for any number of searches (pcreg_dev_model_create: bounding box, matrix-core operand
+    tiles, model-wide seeding grid) -- one model, many surfaces is the reference's shape (completeExperimentFast.m:131-149).
+    Keeps the [3, M] float32 tensor alive; the handle is only valid while that tensor is unchanged."""
+
+    def __init__(self, model_soa: torch.Tensor):
+        if model_soa.dtype != torch.float32 or model_soa.dim() != 2 or model_soa.shape[0] != 3 or model_soa.stride(1) != 1:
+            raise TypeError("a model is a [3, M] float32 tensor with contiguous rows (column-major M x 3)")
+        self.tensor, self.version = model_soa, model_soa._version
+        self.M, self.ld = int(model_soa.shape[1]), int(model_soa.stride(0)) if model_soa.shape[1] > 0 else 1
+        self.handle = C.c_void_p()
+        with torch.cuda.device(model_soa.device):
+            check(lib().pcreg_dev_model_create(_p(model_soa), self.M, max(self.ld, 1), _stream(), C.byref(self.handle)))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            lib().pcreg_dev_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def as_prepared(model, cache: PreparedModel | None = None) -> PreparedModel:
+    """model: a PreparedModel (used as is) or a [3, M] tensor -- prepared now, unless `cache` was prepared from this very
+    tensor object and the tensor has not been written since."""
+    if isinstance(model, PreparedModel):
+        return model
+    if cache is not None and cache.tensor is model and cache.version == model._version and cache.handle.value:
+        return cache
+    return PreparedModel(model)
+
+
 class HipOps:
-    """The `ops` backend of ShardedMatcher on an MI355X (preallocated, no host syncs)."""
+    """The `ops` backend of ShardedMatcher on an MI355X (preallocated, no host syncs).  Five launches per match on one
+    rank: four for the search against the prepared model, one for filters + Unique + compaction."""
 
     def __init__(self, Q: int, M_local: int, device: torch.device):
         L = lib()
         self.device, self.Q, self.M_local = device, Q, M_local
         i32, f32, f64 = torch.int32, torch.float32, torch.float64
         kw = dict(device=device)
-        self.ws_knn = torch.empty(max(L.pcreg_dev_knn2_points_f32_workspace(Q, M_local), 256), dtype=torch.uint8, **kw)
-        self.ws_unq = torch.empty(max(L.pcreg_dev_unique_points_f32_workspace(Q), 256), dtype=torch.uint8, **kw)
+        self.ws = torch.empty(max(L.pcreg_dev_model_search_workspace(Q, M_local), 256), dtype=torch.uint8, **kw)
         self.top2_local = torch.empty((2, Q, 2), dtype=i32, **kw)        # one buffer: a single all_gather carries both
         self.idx_local = self.top2_local[0]
         self.dist_local = self.top2_local[1].view(f32)
         self.idx = torch.empty((Q, 2), dtype=i32, **kw)
         self.dist = torch.empty((Q, 2), dtype=f32, **kw)
-        self.cand_q = torch.empty(Q, dtype=i32, **kw)
-        self.cand_m = torch.empty(Q, dtype=i32, **kw)
-        self.keep = torch.zeros(Q, dtype=i32, **kw)
-        self.n_cand = torch.zeros(1, dtype=i32, **kw)
         self.n_pairs = torch.zeros(1, dtype=i32, **kw)
         self.pairs = torch.empty((Q, 2), dtype=i32, **kw)
         self.pts1 = torch.empty((3, Q), dtype=f64, **kw)
         self.pts2 = torch.empty((3, Q), dtype=f64, **kw)
-        self.ident = torch.arange(Q, dtype=i32, **kw)
-        self.table = torch.zeros((4, Q), dtype=i32, **kw)               # multi-GPU candidate table (sharded.py step 4)
+        self.table = torch.zeros((4, Q), dtype=i32, **kw)               # multi-GPU table, column = query (sharded.py step 3)
+        self._prepared = None
+
+    def prepared(self, model) -> PreparedModel:
+        self._prepared = as_prepared(model, self._prepared)
+        if self._prepared.M > self.M_local:
+            raise ValueError(f"model of {self._prepared.M} rows, the pipeline was sized for {self.M_local}")
+        return self._prepared
 
     def local_top2(self, q, model, m_lo):
-        check(lib().pcreg_dev_knn2_points_f32(_p(q), self.Q, q.shape[1], _p(model), model.shape[1], model.shape[1],
-                                              C.c_int32(m_lo), _p(self.idx_local), _p(self.dist_local),
-                                              _p(self.ws_knn), C.c_size_t(self.ws_knn.numel()), _stream()))
+        pm = self.prepared(model)
+        check(lib().pcreg_dev_model_search_f32(pm.handle, _p(q), self.Q, q.stride(0), C.c_int32(m_lo), _p(self.idx_local), _p(self.dist_local),
+                                               _p(self.ws), C.c_size_t(self.ws.numel()), _stream()))
         return self.idx_local, self.dist_local
 
     def merge_top2(self, idx_all, dist_all):
@@ -66,37 +104,24 @@ class HipOps:
                                                      C.c_size_t(idx_all.stride(0)), _p(self.idx), _p(self.dist), _stream()))
         return self.idx, self.dist
 
-    def filter_top2(self, idx, dist, M_total, thr, ratio):
-        check(lib().pcreg_dev_filter_top2_f32(_p(idx), _p(dist), self.Q, M_total, C.c_float(thr), C.c_float(ratio),
-                                              _p(self.cand_q), _p(self.cand_m), _p(self.n_cand), _stream()))
-        return self.cand_q, self.cand_m, self.n_cand
+    def match_single(self, q, model, idx, dist, thr, ratio, unique):
+        pm = self.prepared(model)
+        check(lib().pcreg_dev_model_match_f32(pm.handle, _p(q), self.Q, q.stride(0), _p(idx), _p(dist), C.c_float(thr), C.c_float(ratio),
+                                              int(bool(unique)), _p(self.ws), C.c_size_t(self.ws.numel()), _p(self.pairs), _p(self.pts1),
+                                              _p(self.pts2), _p(self.n_pairs), _stream()))
+        return self.pairs, self.pts1, self.pts2, self.n_pairs
 
-    def unique_local(self, q, model, m_lo, cand_q, cand_m, n_cand):
-        # keep[k] is written for every candidate of this shard and read for no other (include/pcreg.h): no clearing
-        check(lib().pcreg_dev_unique_points_f32(_p(q), self.Q, q.shape[1], _p(model), model.shape[1], model.shape[1],
-                                                C.c_int32(m_lo), _p(cand_q), _p(cand_m), _p(n_cand), _p(self.keep),
-                                                _p(self.ws_unq), C.c_size_t(self.ws_unq.numel()), _stream()))
-        return self.keep
-
-    def cand_table(self, model, m_lo, cand_m, keep, n_cand):
-        check(lib().pcreg_dev_cand_table_f32(_p(model), model.shape[1], model.shape[1], C.c_int32(m_lo), _p(cand_m),
-                                             _p(keep) if keep is not None else None, _p(n_cand), self.Q, _p(self.table), _stream()))
+    def match_table(self, q, model, m_lo, M_total, idx, dist, thr, ratio, unique):
+        pm = self.prepared(model)
+        check(lib().pcreg_dev_model_match_table_f32(pm.handle, C.c_int32(m_lo), M_total, _p(q), self.Q, q.stride(0), _p(idx), _p(dist),
+                                                    C.c_float(thr), C.c_float(ratio), int(bool(unique)), _p(self.ws),
+                                                    C.c_size_t(self.ws.numel()), _p(self.table), _stream()))
         return self.table
 
-    def gather_pairs(self, q, table, table_is_dense, cand_q, cand_m, keep, n_cand):
-        L = lib()
-        kp = _p(keep) if keep is not None else None
-        if not table_is_dense:
-            check(L.pcreg_dev_gather_pairs_f32(_p(q), self.Q, q.shape[1], _p(table), table.shape[1], _p(cand_q), _p(cand_m),
-                                               kp, _p(n_cand), _p(self.pairs), _p(self.pts1), _p(self.pts2),
-                                               _p(self.n_pairs), _stream()))
-        else:   # coordinates from the dense per-candidate table, pair indices from cand_m
-            check(L.pcreg_dev_gather_pairs_f32(_p(q), self.Q, q.shape[1], _p(table), table.shape[1], _p(cand_q),
-                                               _p(self.ident), kp, _p(n_cand), None, _p(self.pts1), _p(self.pts2),
-                                               _p(self.n_pairs), _stream()))
-            check(L.pcreg_dev_gather_pairs_f32(_p(q), self.Q, q.shape[1], _p(table), table.shape[1], _p(cand_q),
-                                               _p(cand_m), kp, _p(n_cand), _p(self.pairs), None, None,
-                                               _p(self.n_pairs), _stream()))
+    def match_from_table(self, q, M_total, idx, dist, thr, ratio, table):
+        check(lib().pcreg_dev_match_from_table_f32(_p(q), self.Q, q.stride(0), M_total, _p(idx), _p(dist), C.c_float(thr), C.c_float(ratio),
+                                                   _p(table), _p(self.ws), C.c_size_t(self.ws.numel()), _p(self.pairs), _p(self.pts1),
+                                                   _p(self.pts2), _p(self.n_pairs), _stream()))
         return self.pairs, self.pts1, self.pts2, self.n_pairs
 
 
@@ -119,7 +144,8 @@ class RegistrationPipeline:
         self._local = None
 
     def search_local(self, q_soa, model_soa):
-        """Top-2 of every query over THIS rank's model shard (the dominant kernel)."""
+        """Top-2 of every query over THIS rank's model shard (the dominant kernel).  model_soa: the [3, M] tensor (prepared
+        on first use and again whenever another tensor, or a modified one, is passed) or a PreparedModel."""
         self._local = self.ops.local_top2(q_soa, model_soa, self.m_lo)
 
     def match_after_search(self, q_soa, model_soa, thr_abs: float, max_ratio: float, unique: bool = True):

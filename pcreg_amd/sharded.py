@@ -6,12 +6,14 @@ Exchanges per match:
 
   1. ONE all_gather of every rank's per-query top-2 (idx i32 and dist f32 in a single [2,Q,2] buffer: Q*16
      bytes per rank) followed by a local merge ordered by (dist, idx)  -> identical global top-2 everywhere;
-  2. threshold / ratio filters run redundantly on every rank (deterministic);
-  3. the Unique back-check of a candidate is owned by the rank that holds its model row
-     (the queries are replicated, so the column minimum is shard-local);
-  4. ONE all_reduce(SUM) of a dense [4, Q] table of 4-byte words publishes the verdicts (row 3: the owner's
-     0/1 flag) and assembles the matched model coordinates (rows 0-2: float bit patterns); exactly one rank
-     contributes each column, so the integer sums are exact (x + 0).
+  2. threshold / ratio filters run redundantly on every rank (deterministic); the Unique back-check of a query's
+     nearest model point is owned by the rank that holds that point's row (the queries are replicated, so the
+     column minimum is shard-local);
+  3. ONE all_reduce(SUM) of a dense [4, Q] table of 4-byte words, column = QUERY: rows 0-2 = the coordinates of the
+     query's nearest model point (float bit patterns), row 3 = the owner's Unique verdict (1 when Unique is off);
+     a column is written by the owner and only for a query that passed the filters, zero elsewhere, so the integer
+     sums are exact (x + 0) and both publish the verdicts and assemble the matched coordinates;
+  4. filters again + ordered compaction from the summed table, on every rank.
   RANSAC with its hypotheses split over the ranks adds ONE all_gather of the 112-byte partial results
   (combine_gathered_parts / pcreg_dev_ransac_finish_parts).  Three collectives per registration in all.
 
@@ -19,13 +21,13 @@ The arithmetic is delegated to an `ops` object so that the protocol itself can b
 exercised on CPU (gloo, world_size 2) with the oracle standing in for the kernels --
 tests/test_sharded_cpu.py -- while production passes pcreg_amd.device.HipOps.
 
-`ops` interface (tensors live on ops.device):
+`ops` interface (tensors live on ops.device; `model` is whatever the ops object takes as this rank's shard):
     local_top2(q, model, m_lo)                     -> idx [Q,2] i32 (global rows), dist [Q,2] f32
     merge_top2(idx_all [R,Q,2], dist_all [R,Q,2])  -> idx [Q,2], dist [Q,2]
-    filter_top2(idx, dist, M_total, thr, ratio)    -> cand_q [Q] i32, cand_m [Q] i32, n_cand [1] i32
-    unique_local(q, model, m_lo, cand_q, cand_m, n_cand) -> keep [Q] i32 (1/0; 0 for rows of other shards)
-    gather_pairs(q, table, table_is_dense, cand_q, cand_m, keep|None, n_cand)
-                                                   -> pairs [Q,2] i32 (1-based), pts1 [3,Q] f64, pts2 [3,Q] f64, n_pairs [1] i32
+    match_single(q, model, idx, dist, thr, ratio, unique)                    (one rank: steps 2 and 4 in one)
+    match_table(q, model, m_lo, M_total, idx, dist, thr, ratio, unique)      -> table [4,Q] i32 (this rank's contribution)
+    match_from_table(q, M_total, idx, dist, thr, ratio, table)               (table after the SUM)
+        the last three -> pairs [Q,2] i32 (1-based), pts1 [3,Q] f64, pts2 [3,Q] f64, n_pairs [1] i32
 """
 from __future__ import annotations
 
@@ -103,27 +105,11 @@ class ShardedMatcher:
     # -- steps 2-4 ----------------------------------------------------------------------
     def finish(self, q, model, thr_abs: float, max_ratio: float, unique: bool = True):
         ops = self.ops
-        cand_q, cand_m, n_cand = ops.filter_top2(self.idx, self.dist, self.M_total, thr_abs, max_ratio)
-        keep = None
-        if unique:
-            keep = ops.unique_local(q, model, self.m_lo, cand_q, cand_m, n_cand)
         if not self.collective:
-            return ops.gather_pairs(q, model, False, cand_q, cand_m, keep, n_cand)
-        # dense [4,Q] table of 4-byte words: rows 0-2 = the candidates' model coordinates (float bits), row 3 = the
-        # Unique verdict; column k is written by the rank owning row cand_m[k], zero elsewhere, so ONE integer SUM
-        # both publishes the verdicts and assembles the coordinates, exactly
-        if hasattr(ops, "cand_table"):
-            table = ops.cand_table(model, self.m_lo, cand_m, keep, n_cand)
-        else:
-            Q = self.Q
-            ar = torch.arange(Q, device=cand_m.device, dtype=torch.int32)
-            local = (cand_m >= self.m_lo) & (cand_m < self.m_lo + self.M_local) & (ar < n_cand)
-            j = torch.where(local, cand_m - self.m_lo, torch.zeros_like(cand_m)).long()
-            table = torch.zeros((4, Q), dtype=torch.int32, device=model.device)
-            table[0:3] = torch.where(local.unsqueeze(0), model[:, j].contiguous().view(torch.int32), torch.zeros((), dtype=torch.int32, device=model.device))
-            table[3] = torch.where(local, (keep != 0).to(torch.int32) if unique else torch.ones_like(cand_m), torch.zeros_like(cand_m))
+            return ops.match_single(q, model, self.idx, self.dist, thr_abs, max_ratio, unique)
+        table = ops.match_table(q, model, self.m_lo, self.M_total, self.idx, self.dist, thr_abs, max_ratio, unique)
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=self.group)
-        return ops.gather_pairs(q, table[0:3].view(model.dtype), True, cand_q, cand_m, table[3] if unique else None, n_cand)
+        return ops.match_from_table(q, self.M_total, self.idx, self.dist, thr_abs, max_ratio, table)
 
     def match(self, q, model, thr_abs: float, max_ratio: float, unique: bool = True):
         self.search(q, model)

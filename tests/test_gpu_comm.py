@@ -59,3 +59,18 @@ def test_one_rank_communicator_equals_single_gpu(oracle_c):
     finally:
         check(L.pcreg_comm_destroy())
     assert L.pcreg_comm_rank(C.byref(r), C.byref(w)) != 0             # closed
+
+
+def test_two_ranks_through_the_c_abi_on_one_gpu():
+    """The N > 1 path of comm.hip with two PROCESSES on cuda:0 (host-staged communicator): rank strides of the gathered
+    top-2, one contributor per table column, empty shards, uneven / empty hypothesis shares, reuse of the scratch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = f"/pcreg_test_{os.getpid()}"
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "scripts", "cabi_two_ranks_one_gpu.py"), str(r), "2", name],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=root) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r}: cabi_world2_ok=True" in o, o[-3000:]

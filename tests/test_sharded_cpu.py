@@ -1,7 +1,7 @@
 """The N > 1 path on CPU: world_size-2 gloo run of pcreg_amd.sharded.ShardedMatcher with
 the ORACLE standing in for the kernels (tests may use the oracle; the product may not).
-Checks that the all_gather + merge, MAX-reduced Unique flags and SUM-assembled
-coordinates give exactly what one process gets on the unsharded model."""
+Checks that the all_gather + merge and the SUM-assembled [4, Q] table (Unique verdicts + matched
+coordinates, column = query) give exactly what one process gets on the unsharded model."""
 import os
 import socket
 
@@ -40,41 +40,53 @@ class OracleOps:
                 oi[qi, k], od[qi, k] = i, d
         return torch.from_numpy(oi), torch.from_numpy(od)
 
-    def filter_top2(self, idx, d, M_total, thr, ratio):
+    @staticmethod
+    def _filter(idx, d, M_total, thr, ratio):
+        """matchFeatures' threshold + ratio test on a merged top-2 (fp32 arithmetic, like the kernel)."""
         i, dd = idx.numpy(), d.numpy()
         keep = (i[:, 0] >= 0) & (dd[:, 0] <= np.float32(thr))
         if M_total > 1:
             z = dd[:, 1] < np.float32(1e-6)
             t1 = np.where(z, np.float32(1), dd[:, 0]); t2 = np.where(z, np.float32(1), dd[:, 1])
             keep &= (t1 / t2).astype(np.float32) <= np.float32(ratio)
-        qi = np.nonzero(keep)[0].astype(np.int32)
-        cq = np.zeros(self.Q, np.int32); cm = np.zeros(self.Q, np.int32)
-        cq[:len(qi)] = qi; cm[:len(qi)] = i[qi, 0]
-        return torch.from_numpy(cq), torch.from_numpy(cm), torch.tensor([len(qi)], dtype=torch.int32)
+        return keep
 
-    def unique_local(self, q, model, m_lo, cand_q, cand_m, n_cand):
-        from oracle import c_oracle
-        n = int(n_cand)
-        keep = np.zeros(self.Q, np.int32)
-        cm, cq = cand_m.numpy()[:n], cand_q.numpy()[:n]
-        M = model.shape[1]
-        loc = np.nonzero((cm >= m_lo) & (cm < m_lo + M))[0]
-        if len(loc):
-            back, _ = c_oracle.knn2_points_f32(model.numpy().T[cm[loc] - m_lo], q.numpy().T)
-            keep[loc] = (back[:, 0] == cq[loc]).astype(np.int32)
-        return torch.from_numpy(keep)
-
-    def gather_pairs(self, q, table, dense, cand_q, cand_m, keep, n_cand):
-        n = int(n_cand)
-        cq, cm = cand_q.numpy()[:n], cand_m.numpy()[:n]
-        k = np.ones(n, bool) if keep is None else keep.numpy()[:n].astype(bool)
-        sel = np.nonzero(k)[0]
+    def _compact(self, q, cq, cm, p2rows):
         pairs = np.zeros((self.Q, 2), np.int32); p1 = np.zeros((3, self.Q)); p2 = np.zeros((3, self.Q))
-        pairs[:len(sel), 0] = cq[sel] + 1; pairs[:len(sel), 1] = cm[sel] + 1
-        p1[:, :len(sel)] = q.numpy()[:, cq[sel]].astype(np.float64)
-        col = sel if dense else cm[sel]
-        p2[:, :len(sel)] = table.numpy()[:, col].astype(np.float64)
-        return torch.from_numpy(pairs), torch.from_numpy(p1), torch.from_numpy(p2), torch.tensor([len(sel)], dtype=torch.int32)
+        pairs[:len(cq), 0] = cq + 1; pairs[:len(cq), 1] = cm + 1
+        p1[:, :len(cq)] = q.numpy()[:, cq].astype(np.float64)
+        p2[:, :len(cq)] = p2rows.astype(np.float64)
+        return torch.from_numpy(pairs), torch.from_numpy(p1), torch.from_numpy(p2), torch.tensor([len(cq)], dtype=torch.int32)
+
+    def match_table(self, q, model, m_lo, M_total, idx, d, thr, ratio, unique):
+        """This rank's [4, Q] contribution, column = query: coordinate bits of the query's nearest model point + its
+        Unique verdict, only for candidates whose nearest point lives in this shard; zero elsewhere."""
+        from oracle import c_oracle
+        cand = self._filter(idx, d, M_total, thr, ratio)
+        j = idx.numpy()[:, 0]
+        M = model.shape[1]
+        mine = cand & (j >= m_lo) & (j < m_lo + M)
+        table = np.zeros((4, self.Q), np.int32)
+        loc = np.nonzero(mine)[0]
+        if len(loc):
+            rows = model.numpy().T[j[loc] - m_lo]
+            table[0:3, loc] = np.ascontiguousarray(rows.T).view(np.int32)
+            verdict = np.ones(len(loc), np.int32)
+            if unique:
+                back, _ = c_oracle.knn2_points_f32(rows, q.numpy().T)       # first-best query of each matched model point
+                verdict = (back[:, 0] == loc).astype(np.int32)
+            table[3, loc] = verdict
+        return torch.from_numpy(table)
+
+    def match_from_table(self, q, M_total, idx, d, thr, ratio, table):
+        cand = self._filter(idx, d, M_total, thr, ratio)
+        t = table.numpy()
+        cq = np.nonzero(cand & (t[3] != 0))[0]
+        return self._compact(q, cq, idx.numpy()[cq, 0], np.ascontiguousarray(t[0:3, cq]).view(np.float32))
+
+    def match_single(self, q, model, idx, d, thr, ratio, unique):
+        M = model.shape[1]
+        return self.match_from_table(q, M, idx, d, thr, ratio, self.match_table(q, model, 0, M, idx, d, thr, ratio, unique))
 
 
 def _data():
