@@ -336,7 +336,9 @@ __global__ __launch_bounds__(kBlock) void knn_finalize_kernel(
 // many: work item = (tile of kTailQ listed queries, chunk of the model); a lane owns four queries, the chunk streams
 // through LDS -- knn2_points_kernel's loop (6 VALU per pair, the oracle's bits).
 // Either way the workgroup that delivers the LAST partial of a query / tile (an arrival counter, cleared by S1) merges
-// the partials by (distance, index) and writes the result.
+// the partials by (distance, index) and writes the result.  Partials cross workgroups through device-coherent accesses
+// (relaxed agent-scope atomic stores / loads) and a relaxed counter: no agent-scope fence (it would write back / invalidate
+// the XCD's L2).
 constexpr int kFew = 1024, kFbSlices = 32;
 constexpr int kTailGrid = 2048, kTailQ = 4 * kBlock;              // tiled form: 1024 queries per tile
 struct Top2 { float d1, d2; int i1, i2; };
@@ -397,8 +399,8 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(
                 __hip_atomic_store(&part_idx[o + 1], t.i2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&part_dist[o], t.d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&part_dist[o + 1], t.d2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
-                const int old = __hip_atomic_fetch_add(&ctr->done[f], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the four stores above are complete (and device-coherent)
+                const int old = __hip_atomic_fetch_add(&ctr->done[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (old == kFbSlices - 1) {                            // every slice of this query is in: merge
                     Top2T<float> r{INFINITY, INFINITY, -1, -1};
                     for (int s2 = 0; s2 < kFbSlices; ++s2) {
@@ -480,9 +482,9 @@ __global__ __launch_bounds__(kBlock) void knn_tail_kernel(
                 __hip_atomic_store(&part_dist[o + 1], best[r].d2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctr->done[qt], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&ctr->done[qt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
         __syncthreads();
         if (s_last) {                         // every chunk of this tile is in: a wave per listed query merges its S partials
             const int s_hi = min(nf, (qt + 1) * kTailQ);

@@ -141,7 +141,7 @@ __global__ void merge_top2_list_kernel(const int32_t* __restrict__ part_idx, con
 // instead of a second all-pairs search.  The grid is a by-product of the search call (knn_fast.hip: boxes in
 // seed_query_kernel, geometry by a surplus workgroup of the candidate kernel, cells in knn_finalize_kernel).  Cells
 // hold up to kUgSlots points; a candidate that meets a fuller cell, or whose ball covers too many cells, is
-// checked against every query by its wave (ug_walk's `undecided`).  The cell index is a monotone function of the
+// checked against every query by its wave (`unsure` in match_finish_kernel).  The cell index is a monotone function of the
 // coordinate, so the cell range provably contains every query whose ROUNDED distance is <= d.
 
 // ---------------------------------------------------------------- the match stage in ONE launch
@@ -157,57 +157,38 @@ __global__ void merge_top2_list_kernel(const int32_t* __restrict__ part_idx, con
 //                    the table, ordered compaction.
 // Ordered compaction across workgroups without a second launch: workgroups take TICKETS (so workgroup b started
 // after every workgroup before it), publish their kept count with a ready bit and add up the counts of their
-// predecessors themselves -- a predecessor publishes before it waits, so nobody can wait for ever.
+// predecessors (decoupled look-back) -- a predecessor publishes before it waits, so nobody can wait for ever.
 enum { kMatchSingle = 0, kMatchTable = 1, kMatchFromTable = 2 };
-constexpr int kMatchCpbMax = 8;                 // chunks of 256 queries per workgroup: Q <= 2048 * 256 * 8
-
-__device__ __forceinline__ void ug_walk(const float* __restrict__ q, int ldq, int i, float px, float py, float pz, float di,
-                                        const UgPrep& P, const int32_t* __restrict__ cnt, const float4* __restrict__ slots,
-                                        bool& kp, bool& undecided) {
-    const float r = sqrtf(di) * 1.0001f + 1e-30f;                    // covers every point whose rounded distance is <= di
-    const int x0 = ug_cell1(px - r, P.x0, P.inv_c, P.nx), x1 = ug_cell1(px + r, P.x0, P.inv_c, P.nx);
-    const int y0 = ug_cell1(py - r, P.y0, P.inv_c, P.ny), y1 = ug_cell1(py + r, P.y0, P.inv_c, P.ny);
-    const int z0 = ug_cell1(pz - r, P.z0, P.inv_c, P.nz), z1 = ug_cell1(pz + r, P.z0, P.inv_c, P.nz);
-    bool brute = !(di == di) || (long long)(x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) > kUgMaxVisit;
-    kp = true;
-    for (int cz = z0; cz <= z1 && !brute && kp; ++cz)
-        for (int cy = y0; cy <= y1 && !brute && kp; ++cy)
-            for (int cx = x0; cx <= x1 && kp; ++cx) {
-                const int cell = (cz * P.ny + cy) * P.nx + cx;
-                const int c = cnt[cell];
-                if (c > kUgSlots) { brute = true; break; }
-                for (int s = 0; s < c; ++s) {
-                    const float4 t = slots[(size_t)cell * kUgSlots + s];
-                    const int it = __float_as_int(t.w);
-                    const float d = ug_d2(t.x, t.y, t.z, px, py, pz);
-                    if (d < di || (d == di && it < i)) { kp = false; break; }
-                }
-            }
-    undecided = brute && kp;
-}
+// EIGHT lanes per query (like seed_query_kernel): the cells a candidate's ball touches are dealt to the eight lanes, so
+// the walk is one dependent load chain deep instead of one per cell (a lane-per-candidate form of this kernel took 49 us
+// for the benchmark's 50 k queries).
+constexpr int kMB = 1024;                            // threads per workgroup: few workgroups = few tickets, few status words
+constexpr int kMLanes = 8, kMQ = kMB / kMLanes;      // 128 queries per chunk of a workgroup
+constexpr int kMatchCpbMax = 16;                     // chunks per workgroup: Q <= 2048 * 128 * 16 = 4 Mi
 
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void match_finish_kernel(
+__global__ __launch_bounds__(kMB) void match_finish_kernel(
     const float* __restrict__ q, int Q, int ldq, const float* __restrict__ m, int M, int ldm, int m_lo, int M_total,
     const int32_t* __restrict__ idx, const float* __restrict__ dist, float thr, float ratio, int unique,
     const UgPrep* __restrict__ ug_prep, const int32_t* __restrict__ ug_cnt, const float4* __restrict__ ug_slots,
     int32_t* __restrict__ table, SearchCounters* __restrict__ ctr, int cpb,
     uint32_t* __restrict__ pairs, double* __restrict__ pts1, double* __restrict__ pts2, int32_t* __restrict__ n_pairs) {
     __shared__ int s_ticket;
-    __shared__ int s_cnt[kMatchCpbMax][kBlock / 64];
-    __shared__ int s_red[kBlock / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_cnt[kMatchCpbMax][kMB / 64];
+    __shared__ int s_red[kMB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = threadIdx.x & (kMLanes - 1);
+    const unsigned long long heads = 0x0101010101010101ull;          // the lanes with sub == 0: one per query
     int b = blockIdx.x;
     if (MODE != kMatchTable) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(&ctr->ticket, 1);
         __syncthreads();
         b = s_ticket;
     }
-    const int base_q = b * cpb * kBlock;
-    unsigned keep_bits = 0u;
+    const int base_q = b * cpb * kMQ;
+    unsigned long long keep_bits = 0ull;
     for (int c = 0; c < cpb; ++c) {
-        const int qi = base_q + c * kBlock + threadIdx.x;
-        const bool cand = qi < Q && filter_keep<float>(idx, dist, qi, M_total, thr, ratio);
+        const int qi = base_q + c * kMQ + (threadIdx.x >> 3);
+        const bool cand = qi < Q && filter_keep<float>(idx, dist, qi, M_total, thr, ratio);     // the same in all eight lanes
         const int j = cand ? idx[(size_t)qi * 2] : -1;             // global model row
         bool kp = cand;
         if (MODE == kMatchFromTable) {
@@ -218,14 +199,46 @@ __global__ __launch_bounds__(kBlock) void match_finish_kernel(
             float px = 0.0f, py = 0.0f, pz = 0.0f, di = 0.0f;
             bool und = false;
             if (mine) { px = m[jl]; py = m[jl + (size_t)ldm]; pz = m[jl + 2 * (size_t)ldm]; }
-            if (mine && unique) {
-                const UgPrep P = *ug_prep;
-                di = ug_d2(q[qi], q[qi + (size_t)ldq], q[qi + 2 * (size_t)ldq], px, py, pz);
-                ug_walk(q, ldq, qi, px, py, pz, di, P, ug_cnt, ug_slots, kp, und);
+            if (unique) {                      // (the shuffles below want every lane here)
+                bool beaten = false, unsure = false;
+                if (mine) {
+                    const UgPrep P = *ug_prep;
+                    di = ug_d2(q[qi], q[qi + (size_t)ldq], q[qi + 2 * (size_t)ldq], px, py, pz);
+                    const float r = sqrtf(di) * 1.0001f + 1e-30f;                // covers every point whose rounded distance is <= di
+                    const int x0 = ug_cell1(px - r, P.x0, P.inv_c, P.nx), x1 = ug_cell1(px + r, P.x0, P.inv_c, P.nx);
+                    const int y0 = ug_cell1(py - r, P.y0, P.inv_c, P.ny), y1 = ug_cell1(py + r, P.y0, P.inv_c, P.ny);
+                    const int z0 = ug_cell1(pz - r, P.z0, P.inv_c, P.nz), z1 = ug_cell1(pz + r, P.z0, P.inv_c, P.nz);
+                    const int ex = x1 - x0 + 1, ey = y1 - y0 + 1;
+                    const long long ncl = (long long)ex * ey * (z1 - z0 + 1);
+                    unsure = !(di == di) || ncl > kUgMaxVisit;
+                    const int ncell = unsure ? 0 : (int)ncl;
+                    for (int k = sub; k < ncell && !beaten; k += kMLanes) {        // this lane's cells of the ball
+                        const int cx = x0 + k % ex, cy = y0 + (k / ex) % ey, cz = z0 + k / (ex * ey);
+                        const int cell = (cz * P.ny + cy) * P.nx + cx;
+                        const int cn = ug_cnt[cell];
+                        if (cn > kUgSlots) { unsure = true; continue; }             // an overflowing cell: the scan below decides
+                        for (int sl = 0; sl < cn; ++sl) {
+                            const float4 t = ug_slots[(size_t)cell * kUgSlots + sl];
+                            const int it = __float_as_int(t.w);
+                            const float d = ug_d2(t.x, t.y, t.z, px, py, pz);
+                            if (d < di || (d == di && it < qi)) { beaten = true; break; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 1; o < kMLanes; o <<= 1) {        // every lane takes part in every shuffle: no short-circuit `||` here
+                    const int ob = __shfl_xor((int)beaten, o), ou = __shfl_xor((int)unsure, o);
+                    beaten = beaten | (ob != 0);
+                    unsure = unsure | (ou != 0);
+                }
+                kp = mine && !beaten;
+                und = mine && !beaten && unsure;
+            } else {
+                kp = mine;
             }
             // a candidate the grid could not decide (an overflowing cell, a ball over too many cells): the wave scans
             // every query for it, together
-            unsigned long long um = __ballot(und);
+            unsigned long long um = __ballot(und) & heads;
             while (um != 0ull) {
                 const int l = __builtin_ctzll(um); um &= um - 1ull;
                 const float bx = __shfl(px, l), by = __shfl(py, l), bz = __shfl(pz, l), bd = __shfl(di, l);
@@ -247,10 +260,10 @@ __global__ __launch_bounds__(kBlock) void match_finish_kernel(
                     }
                     beaten = __any(bb);
                 }
-                if (lane == l) kp = !beaten;
+                if ((lane & ~(kMLanes - 1)) == l) kp = !beaten;             // the query's eight lanes
             }
             if (MODE == kMatchTable) {
-                if (qi < Q) {
+                if (qi < Q && sub == 0) {
                     table[qi] = mine ? __float_as_int(px) : 0;
                     table[qi + (size_t)Q] = mine ? __float_as_int(py) : 0;
                     table[qi + 2 * (size_t)Q] = mine ? __float_as_int(pz) : 0;
@@ -258,24 +271,28 @@ __global__ __launch_bounds__(kBlock) void match_finish_kernel(
                 }
                 continue;
             }
-            kp = kp && mine;          // kMatchSingle holds the whole model: every candidate is `mine`
         }
-        const unsigned long long bal = __ballot(kp);
+        const unsigned long long bal = __ballot(kp) & heads;
         if (lane == 0) s_cnt[c][wave] = __popcll(bal);
-        keep_bits |= kp ? (1u << c) : 0u;
+        keep_bits |= kp ? (1ull << c) : 0ull;
     }
     if (MODE == kMatchTable) return;
     __syncthreads();
     int mine_total = 0;
     for (int c = 0; c < cpb; ++c)
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) mine_total += s_cnt[c][w];
-    if (threadIdx.x == 0) __hip_atomic_store(&ctr->status[b], (int)(0x80000000u | (unsigned)mine_total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    // the kept counts of the workgroups before this one
+        for (int w = 0; w < kMB / 64; ++w) mine_total += s_cnt[c][w];
+    // The kept counts of the workgroups before this one (in ticket order): publish the own count with a ready bit, then
+    // all 1024 threads read the predecessors' words in ONE parallel round (every workgroup of this launch starts at about
+    // the same time, so a decoupled look-back finds only aggregates and degenerates into a serial walk: 24 windows of 64
+    // for the last workgroup, measured 20 us slower).  A status word is a self-contained flag, so every access is a RELAXED
+    // agent-scope atomic: an acquire or a release at agent scope invalidates / writes back the XCD's L2 on this chip (with
+    // acquire polls this loop took 670 us).
+    if (threadIdx.x == 0) __hip_atomic_store(&ctr->status[b], (int)(0x80000000u | (unsigned)mine_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int v = 0;
-    for (int p = threadIdx.x; p < b; p += kBlock) {
+    for (int p = threadIdx.x; p < b; p += kMB) {
         int sv;
-        do { sv = __hip_atomic_load(&ctr->status[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (sv >= 0);
+        do { sv = __hip_atomic_load(&ctr->status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (sv >= 0);
         v += sv & 0x7FFFFFFF;
     }
 #pragma unroll
@@ -284,39 +301,36 @@ __global__ __launch_bounds__(kBlock) void match_finish_kernel(
     __syncthreads();
     int base = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) base += s_red[w];
+    for (int w = 0; w < kMB / 64; ++w) base += s_red[w];
     if (b == (int)gridDim.x - 1 && threadIdx.x == 0) *n_pairs = base + mine_total;
     for (int c = 0; c < cpb; ++c) {
-        const bool kp = (keep_bits >> c) & 1u;
-        const unsigned long long bal = __ballot(kp);
+        const bool kp = (keep_bits >> c) & 1ull;
+        const unsigned long long bal = __ballot(kp) & heads;
         int o = base;
         for (int w = 0; w < wave; ++w) o += s_cnt[c][w];
-        if (kp) {
-            o += __popcll(bal & ((1ull << lane) - 1ull));
-            const int qi = base_q + c * kBlock + threadIdx.x;
+        if (kp) {                          // all eight lanes of a kept query: they share the writes
+            o += __popcll(bal & ((1ull << (lane & ~(kMLanes - 1))) - 1ull));
+            const int qi = base_q + c * kMQ + (threadIdx.x >> 3);
             const int j = idx[(size_t)qi * 2];
-            if (pairs) { pairs[(size_t)o * 2] = (uint32_t)qi + 1u; pairs[(size_t)o * 2 + 1] = (uint32_t)j + 1u; }
-            if (pts1) {
-                pts1[o] = (double)q[qi]; pts1[o + (size_t)Q] = (double)q[qi + (size_t)ldq]; pts1[o + 2 * (size_t)Q] = (double)q[qi + 2 * (size_t)ldq];
-                if (MODE == kMatchFromTable) {
-                    pts2[o] = (double)__int_as_float(table[qi]); pts2[o + (size_t)Q] = (double)__int_as_float(table[qi + (size_t)Q]);
-                    pts2[o + 2 * (size_t)Q] = (double)__int_as_float(table[qi + 2 * (size_t)Q]);
-                } else {
-                    const int jl = j - m_lo;
-                    pts2[o] = (double)m[jl]; pts2[o + (size_t)Q] = (double)m[jl + (size_t)ldm]; pts2[o + 2 * (size_t)Q] = (double)m[jl + 2 * (size_t)ldm];
-                }
+            if (pairs && sub == 6) pairs[(size_t)o * 2] = (uint32_t)qi + 1u;
+            if (pairs && sub == 7) pairs[(size_t)o * 2 + 1] = (uint32_t)j + 1u;
+            if (pts1 && sub < 3) pts1[o + (size_t)sub * Q] = (double)q[qi + (size_t)sub * ldq];
+            if (pts1 && sub >= 3 && sub < 6) {
+                const int cc = sub - 3;
+                if (MODE == kMatchFromTable) pts2[o + (size_t)cc * Q] = (double)__int_as_float(table[qi + (size_t)cc * Q]);
+                else pts2[o + (size_t)cc * Q] = (double)m[(j - m_lo) + (size_t)cc * ldm];
             }
         }
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) base += s_cnt[c][w];
+        for (int w = 0; w < kMB / 64; ++w) base += s_cnt[c][w];
     }
     // the last workgroup through leaves the counters as it found them, so that the match stage may run again on the same
     // search (every other workgroup has read the status words it needed before it counted itself in)
     __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctr->finished, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctr->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (s_ticket == (int)gridDim.x - 1) {
-        for (int p = threadIdx.x; p < (int)gridDim.x; p += kBlock) ctr->status[p] = 0;
+        for (int p = threadIdx.x; p < (int)gridDim.x; p += kMB) ctr->status[p] = 0;
         if (threadIdx.x == 0) { ctr->ticket = 0; ctr->finished = 0; }
     }
 }
@@ -416,9 +430,9 @@ int launch_merge_top2_f32(const int32_t* idx_in, const float* dist_in, int R, in
 // ---- the match stage on a finished search: launchers ----------------------------------------------------------------
 static int match_shape(int Q, int* blocks, int* cpb) {
     int c = 1;
-    while ((long long)kMatchMaxBlocks * kBlock * c < Q) ++c;
-    if (c > kMatchCpbMax) { set_error("match: %d queries exceed the %d a call handles", Q, kMatchMaxBlocks * kBlock * kMatchCpbMax); return PCREG_E_ARG; }
-    *cpb = c; *blocks = (Q + kBlock * c - 1) / (kBlock * c);
+    while ((long long)kMatchMaxBlocks * kMQ * c < Q) ++c;
+    if (c > kMatchCpbMax) { set_error("match: %d queries exceed the %d a call handles", Q, kMatchMaxBlocks * kMQ * kMatchCpbMax); return PCREG_E_ARG; }
+    *cpb = c; *blocks = (Q + kMQ * c - 1) / (kMQ * c);
     return PCREG_OK;
 }
 int launch_match_finish(const ModelView& v, const float* q, int Q, int ldq, const int32_t* idx, const float* dist, float thr,
@@ -429,7 +443,7 @@ int launch_match_finish(const ModelView& v, const float* q, int Q, int ldq, cons
     size_t need; SearchWs s = search_ws_layout(Q, v.M, ws, &need);
     if (ws_bytes < need) { set_error("match workspace too small: %zu < %zu (pass the search call's workspace)", ws_bytes, need); return PCREG_E_WORKSPACE; }
     int blocks, cpb; { int rc = match_shape(Q, &blocks, &cpb); if (rc) return rc; }
-    hipLaunchKernelGGL(match_finish_kernel<kMatchSingle>, dim3(blocks), dim3(kBlock), 0, st, q, Q, ldq, v.m, v.M, v.ldm, 0, v.M, idx, dist, thr, ratio, unique,
+    hipLaunchKernelGGL(match_finish_kernel<kMatchSingle>, dim3(blocks), dim3(kMB), 0, st, q, Q, ldq, v.m, v.M, v.ldm, 0, v.M, idx, dist, thr, ratio, unique,
                        (const UgPrep*)s.ug_prep, (const int32_t*)s.ug_cnt, (const float4*)s.ug_slots, (int32_t*)nullptr, (SearchCounters*)s.ctr, cpb,
                        pairs, pts1, pts2, n_pairs);
     PCREG_HIP(hipGetLastError());
@@ -444,7 +458,7 @@ int launch_match_table(const ModelView& v, int32_t m_lo, int M_total, const floa
     size_t need; SearchWs s = search_ws_layout(Q, v.M, ws, &need);
     if (ws_bytes < need) { set_error("match workspace too small: %zu < %zu (pass the search call's workspace)", ws_bytes, need); return PCREG_E_WORKSPACE; }
     int blocks, cpb; { int rc = match_shape(Q, &blocks, &cpb); if (rc) return rc; }
-    hipLaunchKernelGGL(match_finish_kernel<kMatchTable>, dim3(blocks), dim3(kBlock), 0, st, q, Q, ldq, v.m, v.M, v.ldm, (int)m_lo, M_total, idx, dist, thr, ratio,
+    hipLaunchKernelGGL(match_finish_kernel<kMatchTable>, dim3(blocks), dim3(kMB), 0, st, q, Q, ldq, v.m, v.M, v.ldm, (int)m_lo, M_total, idx, dist, thr, ratio,
                        unique, (const UgPrep*)s.ug_prep, (const int32_t*)s.ug_cnt, (const float4*)s.ug_slots, table, (SearchCounters*)s.ctr, cpb,
                        (uint32_t*)nullptr, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
     PCREG_HIP(hipGetLastError());
@@ -457,7 +471,7 @@ int launch_match_from_table(const float* q, int Q, int ldq, int M_total, const i
     if (Q == 0 || M_total == 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
     PCREG_ARG(ws != nullptr && ws_bytes >= align_up(sizeof(SearchCounters), 256));       // the counters at the head of the search workspace
     int blocks, cpb; { int rc = match_shape(Q, &blocks, &cpb); if (rc) return rc; }
-    hipLaunchKernelGGL(match_finish_kernel<kMatchFromTable>, dim3(blocks), dim3(kBlock), 0, st, q, Q, ldq, (const float*)nullptr, 0, 0, 0, M_total, idx, dist, thr,
+    hipLaunchKernelGGL(match_finish_kernel<kMatchFromTable>, dim3(blocks), dim3(kMB), 0, st, q, Q, ldq, (const float*)nullptr, 0, 0, 0, M_total, idx, dist, thr,
                        ratio, 1, (const UgPrep*)nullptr, (const int32_t*)nullptr, (const float4*)nullptr, const_cast<int32_t*>(table), (SearchCounters*)ws, cpb,
                        pairs, pts1, pts2, n_pairs);
     PCREG_HIP(hipGetLastError());

@@ -926,6 +926,9 @@ struct StagedArgs {
     unsigned char* cert;         // rank of the inlier set certified from the sample alone (rs_fit1 + rs_pass1)
     double* certq;               // [iters][2]: the sample's singular-value bounds / tolerance factor (0: no certificate)
     double* bounds;              // [4]: max |pts1 row|^2, max |pts2 row|^2, the same of the rows relative to correspondence 0
+    void* sel_ctr;               // SelCtr of ransac_select_multi_kernel (cleared by rs_stage1_kernel)
+    double* bpart;               // [record workgroups][4]: their maxima (rs_stage1_kernel -> rs_stage2_kernel; no atomics, no clearing)
+    int n_rec_blocks;
     double* mom;                 // [iters][27]
     int32_t* part;               // [kSMaxPB][iters]
     int pb;                      // point blocks in use
@@ -950,10 +953,10 @@ struct StagedArgs {
 __device__ __forceinline__ int staged_n(const RansacArgs& a) { return min(a.n_dev ? *a.n_dev : a.n_cap, a.n_cap); }
 
 // per-correspondence records of the moment sums (mom_core's fifteen terms), relative to correspondence 0
-__global__ __launch_bounds__(256) void rs_records_kernel(StagedArgs sa) {
+__device__ __forceinline__ void rs_records_body(const StagedArgs& sa, int block) {
     const RansacArgs& a = sa.a;
     const int n = staged_n(a);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = block * 256 + threadIdx.x;
     double m1 = 0.0, m2 = 0.0, c1m = 0.0, c2m = 0.0;
     if (i >= n && sa.use_lane && i < sa.nslots_cap * 64) {      // padding records must be finite: the sums multiply them by 0
         double* r = sa.rec + (size_t)i * kRec;
@@ -990,19 +993,17 @@ __global__ __launch_bounds__(256) void rs_records_kernel(StagedArgs sa) {
         m1 = fmax(m1, __shfl_xor(m1, o_)); m2 = fmax(m2, __shfl_xor(m2, o_));
         c1m = fmax(c1m, __shfl_xor(c1m, o_)); c2m = fmax(c2m, __shfl_xor(c2m, o_));
     }
-    if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (threadIdx.x & ~63) < n) {
-        if (c1m > ((volatile double*)sa.bounds)[2]) atomicMax((unsigned long long*)sa.bounds + 2, (unsigned long long)__double_as_longlong(c1m));
-        if (c2m > ((volatile double*)sa.bounds)[3]) atomicMax((unsigned long long*)sa.bounds + 3, (unsigned long long)__double_as_longlong(c2m));
-        // a plain read first: most waves find a maximum that already covers theirs and skip the atomic
-        if (m1 > ((volatile double*)sa.bounds)[0]) atomicMax((unsigned long long*)sa.bounds, (unsigned long long)__double_as_longlong(m1));
-        if (m2 > ((volatile double*)sa.bounds)[1]) atomicMax((unsigned long long*)sa.bounds + 1, (unsigned long long)__double_as_longlong(m2));
-    }
+    // this workgroup's four maxima (zero when it holds no correspondence): rs_stage2_kernel folds the workgroups'
+    __shared__ double s_mx[4][4];
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; s_mx[w][0] = m1; s_mx[w][1] = m2; s_mx[w][2] = c1m; s_mx[w][3] = c2m; }
+    __syncthreads();
+    if (threadIdx.x < 4) sa.bpart[(size_t)block * 4 + threadIdx.x] = fmax(fmax(s_mx[0][threadIdx.x], s_mx[1][threadIdx.x]), fmax(s_mx[2][threadIdx.x], s_mx[3][threadIdx.x]));
 }
 
-__global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
+__device__ __forceinline__ void rs_fit1_body(const StagedArgs& sa, int block) {
     const RansacArgs& a = sa.a;
     const int n = staged_n(a);
-    const int p = blockIdx.x * 64 + threadIdx.x;
+    const int p = block * 256 + threadIdx.x;
     if (p >= a.iters) return;
     double T1[12];
 #pragma unroll
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
                         const int r1 = (r0 + 1) % 3, c1 = (c0 + 1) % 3;
                         mm = fmax(mm, fabs(A2[r0][c0] * A2[r1][c1] - A2[r0][c1] * A2[r1][c0]));
                     }
-                // compared with tolf * max|row| in rs_pass1_kernel, once rs_records_kernel has the maxima
+                // compared with tolf * max|row| in rs_pass1_body, once the records' maxima are known
                 if (all_in && f1 > 0.0 && f2 > 0.0) { cq1 = 2.0 * fabs(det1) / (f1 * tolf); cq2 = mm / (sqrt(f2) * tolf); }
             }
         } else {
@@ -1074,7 +1075,76 @@ __global__ __launch_bounds__(64) void rs_fit1_kernel(StagedArgs sa) {
     for (int k = 0; k < 12; ++k) sa.T1[(size_t)p * 12 + k] = T1[k];
     sa.v1[p] = v1;
     sa.certq[2 * (size_t)p] = cq1; sa.certq[2 * (size_t)p + 1] = cq2;
-    if (p == 0) { *sa.n_pass = 0; sa.bounds[0] = 0.0; sa.bounds[1] = 0.0; sa.bounds[2] = 0.0; sa.bounds[3] = 0.0; }
+}
+
+// stage 1 of the staged chain in ONE launch: workgroups [0, n_fit) fit the samples (one hypothesis per lane), the rest
+// write the correspondence records; workgroup 0 also clears the refit list's counter (nothing reads it in this launch)
+__global__ __launch_bounds__(256) void rs_stage1_kernel(StagedArgs sa, int n_fit) {
+    if ((int)blockIdx.x < n_fit) {
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) *sa.n_pass = 0;
+            if (threadIdx.x < 64 + 2) ((int32_t*)sa.sel_ctr)[threadIdx.x] = 0;
+        }
+        rs_fit1_body(sa, blockIdx.x);
+    } else {
+        rs_records_body(sa, blockIdx.x - n_fit);
+    }
+}
+
+// ---- after each scoring pass: counts from the point blocks' rows of partial counts --------------------------------------
+// after the first pass the thInlr test, the rank certificate and the list of refits (rs_pass1), after the second the
+// refined counts and the `has` flags (rs_finish)
+__device__ __forceinline__ int rs_sum_parts(const StagedArgs& sa, int h) {
+    int c = 0;
+#pragma unroll 8
+    for (int pb = 0; pb < sa.pb; ++pb) c += sa.part[(size_t)pb * sa.a.iters + h];
+    return c;
+}
+__device__ __forceinline__ void rs_pass1_body(const StagedArgs& sa, int h) {
+    const RansacArgs& a = sa.a;
+    const int n = staged_n(a);
+    const int thInlr = matlab_round_i(a.ratio * (double)n);
+    int c = rs_sum_parts(sa, h);
+    const bool v = sa.v1[h] != 0;
+    if (!v) c = 0;
+    const bool pass = v && c >= thInlr;
+    a.cnt1[h] = c; a.cnt2[h] = 0;
+    sa.pass1[h] = pass;
+    // refit path: rank certified from the sample and more than three inliers -> masked record sums
+    const bool cert = a.refine && sa.certq[2 * (size_t)h] > sqrt(sa.bounds[0]) * (1.0 + 1e-12) &&
+                      sa.certq[2 * (size_t)h + 1] > sqrt(sa.bounds[1]) * (1.0 + 1e-12);
+    sa.cert[h] = cert;
+    const bool lane_path = sa.use_lane && a.refine && pass && cert && c >= 4;
+    sa.dense[h] = pass && !lane_path;
+    if (lane_path) sa.pass_list[atomicAdd(sa.n_pass, 1)] = h;
+    if (!a.refine) {
+        a.has[h] = pass;
+        if (pass) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) a.TF[(size_t)h * 12 + k] = sa.T1[(size_t)h * 12 + k];
+        }
+    }
+}
+__device__ __forceinline__ void rs_finish_body(const StagedArgs& sa, int h) {
+    const RansacArgs& a = sa.a;
+    const int n = staged_n(a);
+    const int thInlr = matlab_round_i(a.ratio * (double)n);
+    const int c = rs_sum_parts(sa, h);
+    const bool v = sa.v2[h] != 0;
+    a.cnt2[h] = v ? c : 0;
+    a.has[h] = v && c >= thInlr;
+}
+// Fusing these two into the scoring launches (the last point block of a chunk running them as an epilogue) was built and
+// measured: the arrival counter needs the block's rows of partial counts to be complete first, i.e. a wait for ALL of
+// its stores, the 40 MB of inlier masks included, which costs the first pass 25 us where the launch costs 6; and an
+// agent-scope fence (__threadfence) writes back / invalidates the XCD's whole L2 on this chip: 5 x slower passes.
+__global__ void rs_pass1_kernel(StagedArgs sa) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < sa.a.iters) rs_pass1_body(sa, h);
+}
+__global__ void rs_finish_kernel(StagedArgs sa) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < sa.a.iters) rs_finish_body(sa, h);
 }
 
 // grid (point blocks, hypothesis chunks).  part[pb][h] = inliers of hypothesis h among this block's points.
@@ -1173,10 +1243,31 @@ __device__ __forceinline__ void make_t32(const double (&T)[12], const double (&o
     out[12] = lo; out[13] = hi; out[14] = 0.0f; out[15] = 0.0f;
 }
 
-__global__ void rs_t32_kernel(StagedArgs sa, const double* __restrict__ TT, float* __restrict__ out) {
+// stage 2: every workgroup folds the record workgroups' maxima (a few hundred doubles: cheaper than a launch of its own),
+// workgroup 0 leaves them in sa.bounds for the later stages, and each thread writes the fp32 row of its sample fit
+__global__ __launch_bounds__(256) void rs_stage2_kernel(StagedArgs sa, const double* __restrict__ TT, float* __restrict__ out) {
     const RansacArgs& a = sa.a;
+    __shared__ double s_mx[4][4];
+    double mx[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < sa.n_rec_blocks; b += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = fmax(mx[k], sa.bpart[(size_t)b * 4 + k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) mx[k] = fmax(mx[k], __shfl_xor(mx[k], o_));
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_mx[threadIdx.x >> 6][k] = mx[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mx[k] = fmax(fmax(s_mx[0][k], s_mx[1][k]), fmax(s_mx[2][k], s_mx[3][k]));
+    if (blockIdx.x == 0 && threadIdx.x < 4) sa.bounds[threadIdx.x] = mx[threadIdx.x];
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= a.iters) return;
+    if (h >= a.iters || !sa.use_f32) return;
     const int n = staged_n(a);
     if (n < 1) return;
     Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
@@ -1184,7 +1275,7 @@ __global__ void rs_t32_kernel(StagedArgs sa, const double* __restrict__ TT, floa
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = TT[(size_t)h * 12 + k];
-    make_t32(T, o, sqrt(sa.bounds[2]) * (1.0 + 1e-12), sqrt(sa.bounds[3]) * (1.0 + 1e-12), a.thDist, out + (size_t)h * 16);
+    make_t32(T, o, sqrt(mx[2]) * (1.0 + 1e-12), sqrt(mx[3]) * (1.0 + 1e-12), a.thDist, out + (size_t)h * 16);
 }
 
 __device__ __forceinline__ float sqdist32(const float (&p)[6], const float (&T)[12]) {      // T: R rows (9), t' (3)
@@ -1275,14 +1366,19 @@ __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, con
                 sa.masks[(size_t)(H) * sa.nslots_cap + (size_t)pb * (kSPts / 64) + wave * kSS + lane] =            \
                     ((unsigned long long)(unsigned)mine_hi << 32) | (unsigned)mine_lo;                             \
         }
+        // Rule for the inline-asm row loads (the compiler believes an asm output is ready at once): a load's destination is
+        // never in flight across the loop's back edge -- RA is waited for at the END of the iteration that issued it, so
+        // only waited values are loop-carried (tests/test_isa_lint.py walks the emitted ISA from every such load to its
+        // wait, along every path, for an instruction that touches the destination SGPRs).
         PCREG_ROW_LOAD(RA, h0)
+        PCREG_ROW_WAIT(RA);
         for (int h = h0; h < h1; h += 2) {
-            PCREG_ROW_WAIT(RA); PCREG_ROW_LOAD(RB, h + 1)
+            PCREG_ROW_LOAD(RB, h + 1)
             PCREG_SCORE_HYP(h, RA)
             PCREG_ROW_WAIT(RB); PCREG_ROW_LOAD(RA, h + 2)
             if (h + 1 < h1) { PCREG_SCORE_HYP(h + 1, RB) }
+            PCREG_ROW_WAIT(RA);
         }
-        PCREG_ROW_WAIT(RA);                               // drain the last prefetch
 #undef PCREG_SCORE_HYP
 #undef PCREG_ROW_WAIT
 #undef PCREG_ROW_LOAD
@@ -1293,37 +1389,6 @@ __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, con
 #pragma unroll
         for (int w = 0; w < kSW; ++w) c += s_cnt[w][hl];
         sa.part[(size_t)blockIdx.x * a.iters + h0 + hl] = c;
-    }
-}
-
-// cnt1 / pass1 from the partial counts (one thread per hypothesis)
-__global__ void rs_pass1_kernel(StagedArgs sa) {
-    const RansacArgs& a = sa.a;
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= a.iters) return;
-    const int n = staged_n(a);
-    const int thInlr = matlab_round_i(a.ratio * (double)n);
-    int c = 0;
-#pragma unroll 8
-    for (int pb = 0; pb < sa.pb; ++pb) c += sa.part[(size_t)pb * a.iters + h];
-    const bool v = sa.v1[h] != 0;
-    if (!v) c = 0;
-    const bool pass = v && c >= thInlr;
-    a.cnt1[h] = c; a.cnt2[h] = 0;
-    sa.pass1[h] = pass;
-    // refit path: rank certified from the sample and more than three inliers -> masked record sums
-    const bool cert = a.refine && sa.certq[2 * (size_t)h] > sqrt(sa.bounds[0]) * (1.0 + 1e-12) &&
-                      sa.certq[2 * (size_t)h + 1] > sqrt(sa.bounds[1]) * (1.0 + 1e-12);
-    sa.cert[h] = cert;
-    const bool lane_path = sa.use_lane && a.refine && pass && cert && c >= 4;
-    sa.dense[h] = pass && !lane_path;
-    if (lane_path) sa.pass_list[atomicAdd(sa.n_pass, 1)] = h;
-    if (!a.refine) {
-        a.has[h] = pass;
-        if (pass) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) a.TF[(size_t)h * 12 + k] = sa.T1[(size_t)h * 12 + k];
-        }
     }
 }
 
@@ -1553,20 +1618,6 @@ __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
     }
 }
 
-__global__ void rs_finish_kernel(StagedArgs sa) {
-    const RansacArgs& a = sa.a;
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= a.iters) return;
-    const int n = staged_n(a);
-    const int thInlr = matlab_round_i(a.ratio * (double)n);
-    int c = 0;
-#pragma unroll 8
-    for (int pb = 0; pb < sa.pb; ++pb) c += sa.part[(size_t)pb * a.iters + h];
-    const bool v = sa.v2[h] != 0;
-    a.cnt2[h] = v ? c : 0;
-    a.has[h] = v && c >= thInlr;
-}
-
 // ---------------------------------------------------------------- winner + outputs
 // ransac.m:69-98.  One workgroup per registration.
 // result struct + inlierIdx = find(dist < thDist), ascending, 1-based (ransac.m:75-98), by one workgroup
@@ -1691,6 +1742,125 @@ __global__ __launch_bounds__(NTHR) void ransac_select_kernel(RansacArgs a, pcreg
     }
     if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : a.TF[(hyp0 + winner) * 12 + threadIdx.x];
     ransac_emit_result<NTHR>(a, n, off, out + b, inlier_idx, failed, s_T, ns, maxInl, winner_g, &s_base, s_wcnt);
+}
+
+// ---- the same over SEVERAL workgroups (one large registration: the staged chain) --------------------------------------
+// One workgroup spends most of ransac_select_kernel's 33 us reading the correspondences (1.5 MB through one CU) for the
+// ordered inlier list.  Here every workgroup finds the winner itself (10 k counts: nothing), tests ITS slice of the
+// correspondences, publishes its kept count with a ready bit, adds up the counts of the workgroups before it (ticket order,
+// relaxed agent-scope accesses: see match_finish_kernel) and writes its piece of the list; the last ticket also writes the
+// result struct.  The counters must be zero at entry (rs_stage1_kernel clears them); the last workgroup through leaves
+// them zero again.
+constexpr int kSelBlocks = 64, kSelThreads = 1024, kSelPerThread = 32;
+struct SelCtr { int32_t ticket, finished; int32_t status[kSelBlocks]; };
+__global__ __launch_bounds__(kSelThreads) void ransac_select_multi_kernel(RansacArgs a, pcreg_dev_ransac_result* out, int32_t* inlier_idx,
+                                                                           SelCtr* __restrict__ ctr, int per_block) {
+    constexpr int NW = kSelThreads / 64;
+    __shared__ unsigned long long s_key[NW];
+    __shared__ int s_cnt[NW];
+    __shared__ double s_T[12];
+    __shared__ int s_ticket;
+    __shared__ int s_wcnt[kSelPerThread][NW];
+    __shared__ int s_red[NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = min(a.n_dev ? *a.n_dev : a.n_cap, a.n_cap);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ctr->ticket, 1);
+    // the winner (ransac.m:69-73): first index of the maximum = max over (count << 32 | ~global index)
+    const int32_t* cc = a.refine ? a.cnt2 : a.cnt1;
+    const int thInlr = matlab_round_i(a.ratio * (double)n);
+    unsigned long long key = 0; int ns = 0;
+    for (int p = threadIdx.x; p < a.iters; p += kSelThreads) {
+        unsigned long long k = ((unsigned long long)(unsigned)cc[p] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(p + a.hyp0g));
+        key = k > key ? k : key;
+        ns += cc[p] >= thInlr;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+        ns += __shfl_xor(ns, o);
+    }
+    if (lane == 0) { s_key[wave] = key; s_cnt[wave] = ns; }
+    __syncthreads();
+    key = s_key[0]; ns = s_cnt[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { key = s_key[w] > key ? s_key[w] : key; ns += s_cnt[w]; }
+    const int winner_g = a.iters > 0 ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
+    const int winner = winner_g - a.hyp0g;
+    const int maxInl = (int)(key >> 32);
+    const bool failed = !(a.iters > 0 && a.has[winner]);                 // ransac.m:75-89
+    if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : a.TF[(size_t)winner * 12 + threadIdx.x];
+    __syncthreads();
+    const int b = s_ticket;
+    // this workgroup's slice: points [b * per_block, ...), thread t tests i0 + it * 1024 + t (coalesced), it < per_block / 1024
+    const int i0 = b * per_block, i1 = min(n, i0 + per_block);
+    unsigned mine = 0u; int my_total = 0;
+    if (!failed) {
+        double T[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = s_T[k];
+        Pts<false> P{a.p1, a.p2, a.ld, nullptr, n};
+        const int rounds = per_block / kSelThreads;
+        for (int it = 0; it < rounds; ++it) {
+            const int i = i0 + it * kSelThreads + threadIdx.x;
+            const bool act = i < i1;
+            double q[6]; P.load(act ? i : max(n - 1, 0), q);
+            const bool in = act && n > 0 && sqdist(q, T) < a.thDist;
+            const unsigned long long bal = __ballot(in);
+            if (lane == 0) s_wcnt[it][wave] = __popcll(bal);
+            mine |= in ? (1u << it) : 0u;
+        }
+        __syncthreads();
+        for (int it = 0; it < rounds; ++it)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) my_total += s_wcnt[it][w];
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&ctr->status[b], (int)(0x80000000u | (unsigned)my_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int v = 0;
+    if ((int)threadIdx.x < b) {
+        int sv;
+        do { sv = __hip_atomic_load(&ctr->status[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (sv >= 0);
+        v = sv & 0x7FFFFFFF;
+    }
+    if (wave == 0) {                                       // b <= 64 predecessors: one wave holds them all
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_red[0] = v;
+    }
+    __syncthreads();
+    int base = s_red[0];
+    if (b == (int)gridDim.x - 1) {                         // the last slice knows the total: the result struct (ransac.m:75-98)
+        pcreg_dev_ransac_result* r = out;
+        if (threadIdx.x < 16) {   // column-major 4x4: T(k,j) = R(j,k), T(4,j) = t(j)
+            const int k = threadIdx.x & 3, j = threadIdx.x >> 2;
+            double tv = 0.0;
+            if (!failed) tv = (j < 3) ? s_T[j * 4 + k] : (k == 3 ? 1.0 : 0.0);
+            r->T[k + 4 * j] = tv;
+        }
+        if (threadIdx.x == 0) {
+            r->failed = failed; r->num_success = failed ? 0 : ns; r->max_inliers = failed ? 0 : maxInl;
+            r->n = n; r->winner = winner_g; r->n_inliers = failed ? 0 : base + my_total;
+        }
+    }
+    if (!failed) {
+        const int rounds = per_block / kSelThreads;
+        for (int it = 0; it < rounds; ++it) {
+            const bool in = (mine >> it) & 1u;
+            const unsigned long long bal = __ballot(in);
+            int o = base;
+            for (int w = 0; w < wave; ++w) o += s_wcnt[it][w];
+            if (in) inlier_idx[o + __popcll(bal & ((1ull << lane) - 1ull))] = i0 + it * kSelThreads + threadIdx.x + 1;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) base += s_wcnt[it][w];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctr->finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket == (int)gridDim.x - 1) {
+        if ((int)threadIdx.x < kSelBlocks) ctr->status[threadIdx.x] = 0;
+        if (threadIdx.x == 0) { ctr->ticket = 0; ctr->finished = 0; }
+    }
 }
 
 // the shares' parts (key by MAX, num_success by SUM, has/T from the share whose key won; n_parts == 1: already
@@ -1867,7 +2037,8 @@ static size_t staged_slots_cap(int n_cap) { return (size_t)((n_cap + kSPts - 1) 
 static size_t staged_chunks_cap(int n_cap) { return (staged_slots_cap(n_cap) + kMomSlots - 1) / kMomSlots; }
 static size_t staged_extra_bytes(size_t h, int n_cap) {    // T1 | mom | part | v1 | pass1 | v2 | cert | dense | lane-path buffers
     size_t b = align_up(h * 12 * sizeof(double), 256) + align_up(h * 27 * sizeof(double), 256) +
-               align_up(h * kSMaxPB * sizeof(int32_t), 256) + 5 * align_up(h, 256) + 256 + align_up(h * 2 * sizeof(double), 256);
+               align_up(h * kSMaxPB * sizeof(int32_t), 256) + 5 * align_up(h, 256) + 256 + align_up(h * 2 * sizeof(double), 256) +
+               align_up((staged_slots_cap(n_cap) * 64 + 255) / 256 * 4 * sizeof(double), 256) + 512;
     if (n_cap >= kStagedMinN)
         b += align_up(staged_slots_cap(n_cap) * 64 * 6 * sizeof(float), 256) + 2 * align_up(h * 16 * sizeof(float), 256) +
              align_up(h * staged_slots_cap(n_cap) * 8, 256) + align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256) +
@@ -1899,6 +2070,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
     a.cnt2 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.has = (unsigned char*)w; w += align_up(h, 256);
     long long total = (long long)o.iterNum * B;
+    void* sel_ctr = nullptr;              // set by the staged chain: its selection runs on several workgroups
     size_t lds = (size_t)n_cap * 6 * sizeof(double);
     if (n_cap > 0 && lds <= 64 * 1024) {
         // small sets: correspondences resident in LDS; hypotheses per wave: fill the chip
@@ -1921,6 +2093,10 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.cert = (unsigned char*)w; w += align_up(h, 256);
         sa.dense = (unsigned char*)w; w += align_up(h, 256);
         sa.bounds = (double*)w; w += 256;
+        sa.n_rec_blocks = (int)((staged_slots_cap(n_cap) * 64 + 255) / 256);
+        sa.bpart = (double*)w; w += align_up((size_t)sa.n_rec_blocks * 4 * sizeof(double), 256);
+        sa.sel_ctr = w; w += 512;
+        sel_ctr = sa.sel_ctr;
         sa.certq = (double*)w; w += align_up(h * 2 * sizeof(double), 256);
         sa.nslots_cap = (int)staged_slots_cap(n_cap);
         sa.masks = (unsigned long long*)w; w += align_up(h * staged_slots_cap(n_cap) * 8, 256);
@@ -1943,10 +2119,12 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.a = a;
         const int it = o.iterNum;
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
-        hipLaunchKernelGGL(rs_fit1_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
-        if (a.refine || sa.use_f32) hipLaunchKernelGGL(rs_records_kernel, dim3((unsigned)((staged_slots_cap(n_cap) * 64 + 255) / 256)), dim3(256), 0, st, sa);
+        // 10 launches (round 2: 11 + select): stage1 (sample fits + records), stage2 (maxima + fp32 rows), scoring pass 1,
+        // pass1, lane refit sums, dense refit sums (normally idle), refits, scoring pass 2, finish; then select
+        const int n_fit = (it + 255) / 256;
+        hipLaunchKernelGGL(rs_stage1_kernel, dim3((unsigned)(n_fit + sa.n_rec_blocks)), dim3(256), 0, st, sa, n_fit);
+        hipLaunchKernelGGL(rs_stage2_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a);
         if (sa.use_f32) {
-            hipLaunchKernelGGL(rs_t32_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a);
             if (sa.use_lane)
                 hipLaunchKernelGGL(rs_score32_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1);
             else
@@ -1983,7 +2161,13 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         hipLaunchKernelGGL(ransac_hyp_tiled_kernel, grid, dim3(kTBlock), 0, st, a);
     }
     PCREG_HIP(hipGetLastError());
-    if (n_cap >= 8192) hipLaunchKernelGGL(ransac_select_kernel<1024>, dim3(B), dim3(1024), 0, st, a, out, inlier_idx, part);   // long inlier lists
+    if (sel_ctr && !part && n_cap <= kSelBlocks * kSelPerThread * kSelThreads) {
+        int per_block = 4 * kSelThreads;
+        if ((n_cap + per_block - 1) / per_block > kSelBlocks) per_block = ((n_cap + kSelBlocks - 1) / kSelBlocks + kSelThreads - 1) / kSelThreads * kSelThreads;
+        const int nb = std::max(1, (n_cap + per_block - 1) / per_block);
+        hipLaunchKernelGGL(ransac_select_multi_kernel, dim3(nb), dim3(kSelThreads), 0, st, a, out, inlier_idx, (SelCtr*)sel_ctr, per_block);
+    }
+    else if (n_cap >= 8192) hipLaunchKernelGGL(ransac_select_kernel<1024>, dim3(B), dim3(1024), 0, st, a, out, inlier_idx, part);   // long inlier lists
     else hipLaunchKernelGGL(ransac_select_kernel<kBlock>, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx, part);
     PCREG_HIP(hipGetLastError());
     if (iter_inl) PCREG_HIP(hipMemcpyAsync(iter_inl, a.cnt1, h * sizeof(int32_t), hipMemcpyDeviceToDevice, st));

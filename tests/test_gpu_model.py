@@ -105,3 +105,16 @@ def test_all_queries_unproven_take_the_tiled_tail(oracle_c):
     ridx, rdist = oracle_c.knn2_points_f32(q, m)
     np.testing.assert_array_equal(idx, ridx)
     np.testing.assert_array_equal(dist, rdist)
+
+
+def test_match_stage_with_several_chunks_per_workgroup(oracle_c):
+    """More than 2048 x 32 queries: a workgroup of the match launch owns several chunks of 32 queries (ordered compaction
+    across chunks, workgroups and the ticket order)."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(77)
+    model = (rng.random((20000, 3)) * [40, 30, 35]).astype(np.float32)
+    surf = (model[rng.integers(0, 20000, 70001)] + rng.normal(0, 0.05, (70001, 3))).astype(np.float32)
+    for unique in (True, False):
+        got = pc.match_points(surf, model, 0.25, 0.9, unique)
+        np.testing.assert_array_equal(got, oracle_c.match_points_f32(surf, model, 0.25, 0.9, unique))
+    assert len(got) > 20000

@@ -52,6 +52,9 @@ def test_bench_n2_control_flow_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["model_points_total"] == 200000
+    # the dominant kernel is timed on a SMALL shard too (100 k rows: round 2's Q * M >= 2^33 guard would have blanked it,
+    # exactly at the 125 k-row shards of the 8-GPU run), once per step, and the roofline is priced from that duration
+    assert two["knn_kernel"]["launches_timed"] == 2 and 0.0 < two["knn_kernel"]["ms"] < two["knn_kernel"]["search_call_ms"]
     assert "100000 rows per GPU" in two["config"]["workload"]
     for k in ("cfg3_model_2M", "weak_1M_per_gpu", "cfg5_batch"):
         assert k in two, k

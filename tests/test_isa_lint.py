@@ -137,3 +137,76 @@ def test_ubench_issues_eight_distinct_mfmas_per_iteration(tmp_path):
         assert len({s.split()[1].rstrip(",") for s in mf}) >= 2 or mode == 1      # distinct accumulators (mode 1 is the serial form)
         seen += 1
     assert seen == 5
+
+
+# ---- ransac.hip: inline-asm SCALAR loads (rs_score32_kernel's T32 rows, rs_moments_lane_kernel's records) ---------------
+def _sregs(text):
+    out = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(x) for x in re.findall(r"\bs(\d+)\b", text))
+    return out
+
+
+def _walk_to_wait(ins, labels, start, dst, name):
+    """Every path from instruction `start` to the first s_waitcnt that drains lgkmcnt: no instruction on the way may read or
+    write the SGPRs in `dst`.  Returns the number of instructions visited."""
+    seen, todo, visited = set(), [start], 0
+    while todo:
+        i = todo.pop()
+        while i < len(ins):
+            if i in seen:
+                break
+            seen.add(i)
+            t = ins[i]
+            if t.startswith(";;#") or t.startswith(".LBB"):
+                i += 1
+                continue
+            visited += 1
+            if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+                break
+            assert not t.startswith(("s_endpgm", "s_setpc", "s_swappc")), f"{name}: a scalar load into s{sorted(dst)[0]}.. is never waited for"
+            ops = t.split(None, 1)[1] if " " in t else ""
+            if not t.startswith("s_load_dword"):         # the other loads of the same asm statement name their own destinations
+                assert not (dst & _sregs(ops)), f"{name}: `{t}` touches the destination of an in-flight scalar load (s{sorted(dst)[0]}..)"
+            if t.startswith("s_branch"):
+                i = labels[ops.strip()]
+                continue
+            if t.startswith("s_cbranch"):
+                todo.append(labels[ops.strip()])
+            i += 1
+    return visited
+
+
+def test_no_sgpr_of_an_asm_scalar_load_is_touched_before_its_wait(tmp_path):
+    """rs_score32_kernel prefetches each hypothesis' row of T32 with inline-asm s_load_dwordx16 and waits in a separate asm
+    statement; rs_moments_lane_kernel does the same with its correspondence records.  The compiler believes an asm output
+    is ready at once, so a phi copy, an SGPR spill or a re-coalescing between load and wait would read stale registers
+    and give wrong inlier counts silently (ADVICE, round 2).  Walk the emitted ISA from every such load along EVERY path
+    (branches followed, back edges included) to the wait that drains it."""
+    flags = [f for f in FLAGS if f not in ("-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1")]
+    out = str(tmp_path / "ransac.s")
+    subprocess.check_call([HIPCC, *flags, "-I" + os.path.join(ROOT, "pcreg_amd", "csrc"), "-o", out,
+                           os.path.join(ROOT, "pcreg_amd", "csrc", "ransac.hip")], stderr=subprocess.DEVNULL)
+    funcs = _functions(open(out).read())
+    checked = {}
+    for name, ins in funcs.items():
+        if "rs_score32_kernel" not in name and "rs_moments_lane_kernel" not in name:
+            continue
+        labels = {s.rstrip(":").split(":")[0]: i for i, s in enumerate(ins) if s.startswith(".LBB")}
+        in_asm = False
+        for i, s in enumerate(ins):
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif s.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and s.startswith("s_load_dword"):
+                dst = _sregs(s.split(",")[0])
+                assert dst, s
+                # start after the END of this asm statement (its sibling loads are part of the same issue group)
+                j = next(k for k in range(i, len(ins)) if ins[k].startswith(";;#ASMEND")) + 1
+                assert _walk_to_wait(ins, labels, j, dst, name) > 0
+                checked[name] = checked.get(name, 0) + 1
+    kinds = {("score32" if "rs_score32" in n else "lane") for n in checked}
+    assert kinds == {"score32", "lane"}, checked
+    assert all(v >= 2 for v in checked.values()), checked
