@@ -341,18 +341,24 @@ def extra_descriptors(dev, with_cpu: bool) -> dict:
     opt = dict(min_pts=500, max_pts=6000, R=3.5, thVar=[3, 1.5], k=0.85, ALIGN_POINTS=True, VERBOSE=0)
     tp = torch.from_numpy(np.ascontiguousarray(pts.T)).to(dev); tk = torch.from_numpy(np.ascontiguousarray(kp.T)).to(dev)
     dp = DescriptorPipeline(dev)
-    dp.describe(tp[:, :50_000].contiguous(), tk[:, :1000].contiguous(), opt)
+    dp.describe(tp[:, :50_000].contiguous(), tk[:, :1000].contiguous(), opt, compact=True)
     V = [0]
     def run():
-        V[0] = dp.describe(tp, tk, opt)[2]
+        V[0] = dp.describe(tp, tk, opt, compact=True)[2]
     ms = _ev_ms(run, reps=2, warm=0)
-    alg_bytes = 24.0 * (P + S) + 8.0 * 983 * V[0]              # cloud + keypoints in, V x (3 + 980) doubles out
-    out = {"workload": f"getSpacialHistogramDescriptors, {S} keypoints on a {P}-point cloud, R 3.5, min/max 500/6000, k 0.85, ALIGN_POINTS",
+    # what a resident pipeline keeps: uint16 rows written once in keypoint order + the survivor list (device tier); the
+    # MATLAB-shaped double rows (8 x 980 B per keypoint) only exist at the host boundary
+    alg_bytes = 24.0 * (P + S) + (2.0 * 980 + 24 + 4) * V[0]
+    alg_bytes_f64 = 24.0 * (P + S) + 8.0 * 983 * V[0]
+    out = {"workload": f"getSpacialHistogramDescriptors, {S} keypoints on a {P}-point cloud, R 3.5, min/max 500/6000, k 0.85, ALIGN_POINTS; "
+                       f"uint16 rows written once + survivor list (pcreg_dev_spatial_histogram_descriptors_rows_u16)",
            "ms": round(ms, 2), "keypoints_per_s": round(S / ms * 1e3, 0), "descriptors": int(V[0]),
            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, 4), "traffic": None,
-                        "note": "algorithmic bytes = cloud + keypoints read once, V x 983 fp64 written (MATLAB-shaped output); the kernel is "
-                                "latency-bound on its dependent passes over each support (DESIGN 4.5), not on HBM"}}
+                        "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_matlab_double_rows": int(alg_bytes_f64),
+                        "note": "algorithmic bytes = cloud + keypoints read once, V x (980 uint16 + feat + index) written; SURVEY 8d's figure for "
+                                "MATLAB-shaped double rows is given beside it.  The kernel is bound by its dependent passes over each support "
+                                "(L2 gathers + fp64 moments, DESIGN 4.5), not by HBM"}}
     if with_cpu:
         from oracle import c_oracle
         cores = host_cores()

@@ -160,10 +160,9 @@ int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const i
                                    int B, int C1, int C2, double* aligned, double* coeff,
                                    double* c, int32_t* status);
 
-/* The same for `single` clouds (pcread gives single: upsampleMesh.m:21, GetPointcloudFromModel.m:269;
- * completeExperimentFast.m:291,309 feeds them on): inputs are widened to double exactly, the double kernels run,
- * outputs come back as float -- the class MATLAB would return.  MATLAB's own single arithmetic may decide a
- * borderline K-th-nearest / sign vote differently: documented in INTEGRATION.md, not reproduced. */
+/* The same for a `single` cloud: the outputs keep the class (AlignPoints_KNN.m:17,59: everything derives from pts).  Inputs
+ * are widened to double exactly, the double kernel runs, outputs are rounded once to float.  MATLAB's own single
+ * arithmetic may decide a borderline K-th-nearest / sign vote differently: documented in INTEGRATION.md, not reproduced. */
 int pcreg_align_points_knn_f32(const float* pts, int n, int ld, int C1, int C2,
                                float* aligned, float coeff[9], float c[3]);
 
@@ -188,11 +187,19 @@ typedef struct pcreg_desc_opts {
 int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
                                         const pcreg_desc_opts* options, double* feat, double* desc, int* V);
 
-/* `single` cloud and keypoints (completeExperimentFast.m:309): widened exactly, double kernels, feat / desc
- * returned as float (keypoint coordinates and integer counts: both exact).  Support membership `dists < R`
- * and the bin edges are evaluated in double where MATLAB would use single. */
+/* The same for `single` data (clouds from pcread are single: upsampleMesh.m:21, GetPointcloudFromModel.m:269, fed on by
+ * completeExperimentFast.m:291,309).  feat / desc are DOUBLE whatever the input classes: the reference preallocates them
+ * with nan(...) and assigns into them (getSpacialHistogramDescriptors.m:61-62).  When either input is single, MATLAB runs
+ * getLocalPoints.m:8-31 in single; what is element-wise there is reproduced in fp32 exactly as written -- the open box test,
+ * pts_cube - c, sqrt(x^2 + y^2 + z^2), dists < R -- i.e. WHICH keypoints survive and which points form a support, and the
+ * support's coordinates are MATLAB's single pts_rel values.  mean / pca / the histogram run in double on those values
+ * (INTEGRATION.md says what is not knowable).  _mixed takes each input in its own class: *_is_single != 0 -> const float*,
+ * else const double*. */
 int pcreg_spatial_histogram_descriptors_f32(const float* pts, int P, int ld, const float* sample_pts, int S, int lds,
-                                            const pcreg_desc_opts* options, float* feat, float* desc, int* V);
+                                            const pcreg_desc_opts* options, double* feat, double* desc, int* V);
+int pcreg_spatial_histogram_descriptors_mixed(const void* pts, int pts_is_single, int P, int ld, const void* sample_pts,
+                                              int sample_is_single, int S, int lds, const pcreg_desc_opts* options,
+                                              double* feat, double* desc, int* V);
 
 /* ---- device tier ------------------------------------------------------------------
  * All pointers are device memory on the current device; `stream` is a hipStream_t.
@@ -308,12 +315,16 @@ size_t pcreg_dev_spatial_histogram_descriptors_workspace(int P, int S);
 int pcreg_dev_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
                                             const pcreg_desc_opts* options, double* feat, double* desc,
                                             int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
-/* The same with the 980 counts of a row as uint16 (getSpacialHistogramDescriptors.m:166-171 produces integer counts
- * <= the support size): 1.96 KB per keypoint instead of 7.84 KB, what a resident pipeline wants to keep and hand to
- * pcreg_dev_get_matches_u16.  options->max_pts must be <= 65535 (else PCREG_E_ARG).  Same workspace. */
-int pcreg_dev_spatial_histogram_descriptors_u16(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
-                                                const pcreg_desc_opts* options, double* feat, uint16_t* desc,
-                                                int32_t* counters, void* workspace, size_t workspace_bytes, void* stream);
+/* What a resident pipeline keeps: the 980 counts of a row as uint16 (integer counts <= the support size <= 8191: 1.96 KB
+ * per keypoint instead of 7.84 KB), written ONCE, straight from the histogram in LDS: rows [S][980] in KEYPOINT order (row s is
+ * meaningful only for a surviving keypoint s), row_index [S] = the ascending list of the V survivors, feat [V][3] compact.
+ * pcreg_dev_get_matches_rows_u16 takes rows + index as they are.  single_mode: 0 double data; 1 `single` arithmetic for the
+ * support (see pcreg_spatial_histogram_descriptors_f32; data widened exactly to double by the caller), keypoints single;
+ * 2 the same with a single cloud and double keypoints.  Same workspace. */
+int pcreg_dev_spatial_histogram_descriptors_rows_u16(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                                     const pcreg_desc_opts* options, int single_mode, double* feat, uint16_t* rows,
+                                                     int32_t* row_index, int32_t* counters, void* workspace, size_t workspace_bytes,
+                                                     void* stream);
 
 /* getMatches.m:21-59 on device buffers.  layout: PCREG_LAYOUT_FEATURE_MAJOR = MATLAB's
  * column-major n x D (ld >= n); PCREG_LAYOUT_ROW_MAJOR = dense [n][D] (ld == D), what the
@@ -327,12 +338,12 @@ size_t pcreg_dev_get_matches_workspace(int Q, int M, int D);
 int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const double* descModel, int M, int ldM, int D,
                           int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric,
                           int32_t* n_pairs, void* workspace, size_t workspace_bytes, void* stream);
-/* The same on dense uint16 rows [n][D] (pcreg_dev_spatial_histogram_descriptors_u16's output): the counts are widened
- * to double, exactly, on the way into getMatches.m:24-37's private copies -- pairs and metric are those of the double
- * entry.  Same workspace. */
-int pcreg_dev_get_matches_u16(const uint16_t* descSurface, int Q, const uint16_t* descModel, int M, int D,
-                              const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
-                              void* workspace, size_t workspace_bytes, void* stream);
+/* The same on uint16 rows (pcreg_dev_spatial_histogram_descriptors_rows_u16's output): row i of a descriptor set is
+ * rows[index[i]] (index NULL: rows[i]); the counts are widened to double, exactly, on the way into getMatches.m:24-37's
+ * private copies -- pairs (numbered by i) and metric are those of the double entry.  Same workspace. */
+int pcreg_dev_get_matches_rows_u16(const uint16_t* rowsSurface, const int32_t* indexSurface, int Q, const uint16_t* rowsModel,
+                                   const int32_t* indexModel, int M, int D, const pcreg_match_opts* par, uint32_t* pairs,
+                                   double* metric, int32_t* n_pairs, void* workspace, size_t workspace_bytes, void* stream);
 
 /* completeExperimentFast.m:205-206: pts1 = featSurface(matches(:,1),:), pts2 =
  * featModel(matches(:,2),:) as n x 3 column-major with ld = cap -- the input of

@@ -7,6 +7,8 @@
 //   'getMatches', descSurface, descModel, par            -> matches (P x 2 uint32)
 //   'AlignPoints_KNN', pts, C1, C2                       -> pts_aligned, coeff_unambig, c
 //   'getSpacialHistogramDescriptors', pts, sample_pts, options -> feat (V x 3), desc (V x 980)
+//   'modelCreate', model (single M x 3) -> handle (uint64) | 'modelMatchPoints', handle, surface (single Q x 3), thrAbs, maxRatio, unique
+//                                          -> pairs (P x 2 uint32) | 'modelDestroy', handle      (one model, many surfaces)
 //   'setDevice', ordinal | 'commId' -> id | 'commInit', rank, world, id | 'commDestroy'     (one worker per GPU)
 //   'matchPointsSharded', surface, modelRows, m_lo, M_total, thrAbs, maxRatio, unique     -> pairs (P x 2 uint32, global model rows)
 //   'ransacSharded', pts1, pts2, coef, seed                -> T, inlierIdx, numSuccess, maxInliers, failed
@@ -19,6 +21,7 @@
 // This file is compile-gated on mex.h and is NOT part of libpcreg_hip.so.
 #if __has_include("mex.h")
 #include "mex.h"
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include "../include/pcreg.h"
@@ -138,29 +141,48 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             const mxArray* kk = mxGetField(p, 0, "k");
             o.k = (!kk || mxIsChar(kk)) ? 1.0 : mxGetScalar(kk);           // 'all' -> 1
             int P = (int)mxGetM(prhs[1]), S = (int)mxGetM(prhs[2]);
-            const bool sgl = mxIsSingle(prhs[1]) && mxIsSingle(prhs[2]);     // the wrapper casts a mixed pair to double
-            const mxClassID cls = sgl ? mxSINGLE_CLASS : mxDOUBLE_CLASS;
-            mxArray* f = mxCreateNumericMatrix(3, S > 0 ? S : 1, cls, mxREAL);     // row-major V x 3 == 3 x V column-major
-            mxArray* d = mxCreateNumericMatrix(PCREG_DESC_LEN, S > 0 ? S : 1, cls, mxREAL);
+            // each input in its own class (single or double); feat / desc are DOUBLE whatever the inputs: the reference
+            // preallocates them with nan(...) and assigns into them (getSpacialHistogramDescriptors.m:61-62)
+            const int ps = mxIsSingle(prhs[1]) ? 1 : 0, ss = mxIsSingle(prhs[2]) ? 1 : 0;
+            mxArray* f = mxCreateNumericMatrix(3, S > 0 ? S : 1, mxDOUBLE_CLASS, mxREAL);     // row-major V x 3 == 3 x V column-major
+            mxArray* d = mxCreateNumericMatrix(PCREG_DESC_LEN, S > 0 ? S : 1, mxDOUBLE_CLASS, mxREAL);
             int V = 0;
-            if (sgl) rc = pcreg_spatial_histogram_descriptors_f32((const float*)mxGetData(prhs[1]), P, P, (const float*)mxGetData(prhs[2]), S, S, &o,
-                                                                  (float*)mxGetData(f), (float*)mxGetData(d), &V);
-            else rc = pcreg_spatial_histogram_descriptors(mxGetPr(prhs[1]), P, P, mxGetPr(prhs[2]), S, S, &o, mxGetPr(f), mxGetPr(d), &V);
+            rc = pcreg_spatial_histogram_descriptors_mixed(mxGetData(prhs[1]), ps, P, P, mxGetData(prhs[2]), ss, S, S, &o, mxGetPr(f), mxGetPr(d), &V);
             if (rc == PCREG_OK) {      // transpose into MATLAB's V x 3 / V x 980
-                plhs[0] = mxCreateNumericMatrix(V, 3, cls, mxREAL);
-                if (nlhs > 1) plhs[1] = mxCreateNumericMatrix(V, PCREG_DESC_LEN, cls, mxREAL);
-                if (sgl) {
-                    const float* fs = (const float*)mxGetData(f); const float* ds = (const float*)mxGetData(d);
-                    float* fo = (float*)mxGetData(plhs[0]);
-                    for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) fo[v + (size_t)c * V] = fs[c + 3 * (size_t)v];
-                    if (nlhs > 1) { float* dd = (float*)mxGetData(plhs[1]); for (int v = 0; v < V; ++v) for (int c = 0; c < PCREG_DESC_LEN; ++c) dd[v + (size_t)c * V] = ds[c + PCREG_DESC_LEN * (size_t)v]; }
-                } else {
-                    for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) mxGetPr(plhs[0])[v + (size_t)c * V] = mxGetPr(f)[c + 3 * (size_t)v];
-                    if (nlhs > 1) for (int v = 0; v < V; ++v) for (int c = 0; c < PCREG_DESC_LEN; ++c) mxGetPr(plhs[1])[v + (size_t)c * V] = mxGetPr(d)[c + PCREG_DESC_LEN * (size_t)v];
-                }
+                plhs[0] = mxCreateNumericMatrix(V, 3, mxDOUBLE_CLASS, mxREAL);
+                if (nlhs > 1) plhs[1] = mxCreateNumericMatrix(V, PCREG_DESC_LEN, mxDOUBLE_CLASS, mxREAL);
+                for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) mxGetPr(plhs[0])[v + (size_t)c * V] = mxGetPr(f)[c + 3 * (size_t)v];
+                if (nlhs > 1) for (int v = 0; v < V; ++v) for (int c = 0; c < PCREG_DESC_LEN; ++c) mxGetPr(plhs[1])[v + (size_t)c * V] = mxGetPr(d)[c + PCREG_DESC_LEN * (size_t)v];
             }
             mxDestroyArray(f); mxDestroyArray(d);
         }
+    } else if (!strcmp(cmd, "modelCreate")) {                 // h = pcreg_mex('modelCreate', single(model)): uploaded and prepared ONCE
+        if (nrhs != 2 || !mxIsSingle(prhs[1]) || mxGetN(prhs[1]) != 3) usage = "modelCreate: model (single M x 3)";
+        else {
+            int M = (int)mxGetM(prhs[1]);
+            pcreg_model* h = nullptr;
+            rc = pcreg_model_create((const float*)mxGetData(prhs[1]), M, M > 0 ? M : 1, &h);
+            if (rc == PCREG_OK) { plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h; }
+        }
+    } else if (!strcmp(cmd, "modelMatchPoints")) {            // pairs = pcreg_mex('modelMatchPoints', h, single(surface), thrAbs, maxRatio, unique)
+        if (nrhs != 6 || !mxIsUint64(prhs[1]) || !mxIsSingle(prhs[2]) || mxGetN(prhs[2]) != 3) usage = "modelMatchPoints: handle (uint64), surface (single Q x 3), thrAbs, maxRatio, unique";
+        else {
+            pcreg_model* h = (pcreg_model*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]);
+            int Q = (int)mxGetM(prhs[2]);
+            mxArray* buf = mxCreateNumericMatrix(2, Q > 0 ? Q : 1, mxUINT32_CLASS, mxREAL);
+            int P = 0;
+            rc = pcreg_model_match_points_f32(h, (const float*)mxGetData(prhs[2]), Q, Q > 0 ? Q : 1, (float)mxGetScalar(prhs[3]), (float)mxGetScalar(prhs[4]),
+                                              (int)mxGetScalar(prhs[5]), (uint32_t*)mxGetData(buf), &P);
+            if (rc == PCREG_OK) {
+                plhs[0] = mxCreateNumericMatrix(P, 2, mxUINT32_CLASS, mxREAL);
+                const uint32_t* src = (const uint32_t*)mxGetData(buf); uint32_t* dst = (uint32_t*)mxGetData(plhs[0]);
+                for (int k = 0; k < P; ++k) { dst[k] = src[2 * k]; dst[k + P] = src[2 * k + 1]; }
+            }
+            mxDestroyArray(buf);
+        }
+    } else if (!strcmp(cmd, "modelDestroy")) {
+        if (nrhs != 2 || !mxIsUint64(prhs[1])) usage = "modelDestroy: handle (uint64)";
+        else rc = pcreg_model_destroy((pcreg_model*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]));
     } else if (!strcmp(cmd, "setDevice")) {                   // one GPU per parfor / spmd worker: pcreg_mex('setDevice', labindex - 1)
         if (nrhs != 2) usage = "setDevice: ordinal";
         else rc = pcreg_set_device((int)mxGetScalar(prhs[1]));

@@ -176,14 +176,16 @@ def desc_opts(options: dict) -> DescOpts:
                     kf, int(bool(options["ALIGN_POINTS"])))
 
 
-def getSpacialHistogramDescriptors(pts, sample_pts, options: dict, nthreads=0):
+def getSpacialHistogramDescriptors(pts, sample_pts, options: dict, nthreads=0, single_mode=0):
+    """single_mode: 0 double data; 1 = `single` arithmetic in getLocalPoints, keypoints single; 2 = cloud single, keypoints
+    double (oracle/pcreg_oracle.py::getLocalPoints).  The arrays are passed as doubles (single data widened exactly)."""
     p, k = _f(pts), _f(sample_pts)
     P, S = p.shape[0], k.shape[0]
     feat = np.zeros((max(S, 1), 3)); desc = np.zeros((max(S, 1), 980))
     o = desc_opts(options)
-    lib().orc_spatial_histogram_descriptors.restype = C.c_int
-    V = lib().orc_spatial_histogram_descriptors(_p(p), C.c_int(P), C.c_int(P), _p(k), C.c_int(S), C.c_int(S), C.byref(o),
-                                                _p(feat), _p(desc), C.c_int(nthreads))
+    lib().orc_spatial_histogram_descriptors_sm.restype = C.c_int
+    V = lib().orc_spatial_histogram_descriptors_sm(_p(p), C.c_int(P), C.c_int(P), _p(k), C.c_int(S), C.c_int(S), C.byref(o), C.c_int(single_mode),
+                                                   _p(feat), _p(desc), C.c_int(nthreads))
     return feat[:V].copy(), desc[:V].copy()
 
 

@@ -565,12 +565,34 @@ static int hist_loc(double x, const double* e, int ne) {   /* histcounts bin, 1-
     int k = 1; while (k < ne && x >= e[k]) ++k;            /* e[k-1] <= x < e[k] */
     return k;
 }
-static int desc_one(const double* pts, int P, int ld, const double c[3], const orc_desc_opts* o,
+static int desc_one(const double* pts, int P, int ld, const double c[3], const orc_desc_opts* o, int single_mode,
                     const double* rb, const double* tb, const double* pb, double* out /*980*/) {
     const double R = o->R;
     /* getLocalPoints.m:8-35: open box, then dists < R, min <= n <= max; points relative to c */
     int cap = 1024, n = 0;
     double* L = (double*)malloc(sizeof(double) * 3 * cap);
+    if (single_mode) {
+        /* MATLAB's arithmetic when either input is single: every binary operation on a single and a double operand runs in
+         * single, so :8-25 are element-wise float operations, each rounded once (this file is compiled with
+         * -ffp-contract=off: no fused multiply-add, no excess precision on x86-64 SSE).  1: c single -> xLim single (:8-10);
+         * 2: cloud single, c double -> xLim formed in double, converted in the comparison (:11-13). */
+        const float R32 = (float)R, c32[3] = { (float)c[0], (float)c[1], (float)c[2] };
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            if (single_mode == 1) { lo[a] = c32[a] + (-R32); hi[a] = c32[a] + R32; }
+            else { lo[a] = (float)(c[a] - R); hi[a] = (float)(c[a] + R); }
+        }
+        for (int i = 0; i < P; ++i) {
+            const float x = (float)pts[i], y = (float)pts[i + (size_t)ld], z = (float)pts[i + 2*(size_t)ld];
+            if (!(x > lo[0] && x < hi[0] && y > lo[1] && y < hi[1] && z > lo[2] && z < hi[2])) continue;      /* :11-13 */
+            const float dx = x - c32[0], dy = y - c32[1], dz = z - c32[2];                                     /* :23 */
+            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            const float s2 = xx + yy; const float s3 = s2 + zz;
+            if (!(sqrtf(s3) < R32)) continue;                                                                 /* :24-25 */
+            if (n == cap) { cap *= 2; L = (double*)realloc(L, sizeof(double) * 3 * cap); }
+            L[3*n] = (double)dx; L[3*n+1] = (double)dy; L[3*n+2] = (double)dz; ++n;
+        }
+    } else
     for (int i = 0; i < P; ++i) {
         double x = pts[i], y = pts[i + (size_t)ld], z = pts[i + 2*(size_t)ld];
         if (!(x > c[0] - R && x < c[0] + R && y > c[1] - R && y < c[1] + R && z > c[2] - R && z < c[2] + R)) continue;
@@ -642,6 +664,12 @@ static int desc_one(const double* pts, int P, int ld, const double c[3], const o
 
 int orc_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk,
                                       const orc_desc_opts* o, double* feat, double* desc, int nthreads) {
+    return orc_spatial_histogram_descriptors_sm(pts, P, ld, kp, S, ldk, o, 0, feat, desc, nthreads);
+}
+/* single_mode: 0 double data; 1 / 2 MATLAB's single arithmetic in getLocalPoints (see desc_one); feat / desc are double
+ * either way (getSpacialHistogramDescriptors.m:61-62) */
+int orc_spatial_histogram_descriptors_sm(const double* pts, int P, int ld, const double* kp, int S, int ldk,
+                                         const orc_desc_opts* o, int single_mode, double* feat, double* desc, int nthreads) {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #else
@@ -658,7 +686,7 @@ int orc_spatial_histogram_descriptors(const double* pts, int P, int ld, const do
     #pragma omp parallel for schedule(dynamic, 4)
     for (int s = 0; s < S; ++s) {
         double c[3] = { kp[s], kp[s + (size_t)ldk], kp[s + 2*(size_t)ldk] };
-        valid[s] = (char)desc_one(pts, P, ld, c, o, rb, tb, pb, tmp + (size_t)s * ND);
+        valid[s] = (char)desc_one(pts, P, ld, c, o, single_mode, rb, tb, pb, tmp + (size_t)s * ND);
     }
     int V = 0;
     for (int s = 0; s < S; ++s) if (valid[s]) {                               /* :177-179 */

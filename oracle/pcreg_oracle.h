@@ -79,6 +79,8 @@ typedef struct {
 /* getSpacialHistogramDescriptors: feat [V][3] and desc [V][980] ROW-major, returns V. */
 int  orc_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk,
                                        const orc_desc_opts* o, double* feat, double* desc, int nthreads);
+int  orc_spatial_histogram_descriptors_sm(const double* pts, int P, int ld, const double* kp, int S, int ldk,
+                                          const orc_desc_opts* o, int single_mode, double* feat, double* desc, int nthreads);
 
 int  orc_align_points_knn(const double* pts, int n, int ld, int C1, int C2,
                           double* aligned /* n x 3, ld n */, double coeff[9] /* col-major */,

@@ -442,8 +442,37 @@ def AlignPoints_KNN(pts, C1: bool = False, C2: bool = False):
     return pts @ coeff_unambig, coeff_unambig, c                # :59
 
 
-def getLocalPoints(pts, R, c, min_points, max_points):
-    """getLocalPoints.m:8-35 -> (pts_sphere relative to c, dists) or (None, None)."""
+def getLocalPoints(pts, R, c, min_points, max_points, single_mode: int = 0):
+    """getLocalPoints.m:8-35 -> (pts_sphere relative to c, dists) or (None, None).
+
+    single_mode != 0: MATLAB's arithmetic when either input is `single` (clouds from pcread are: upsampleMesh.m:21,
+    GetPointcloudFromModel.m:269; completeExperimentFast.m:291,309 feeds them on).  A binary operation on a single and a
+    double operand is carried out in single (the double is converted first), so every step below is element-wise float32,
+    each operation rounded once -- reproducible, unlike the summation order of mean / pca that follows:
+      1 = keypoint c single: xLim = c(1) + [-R, R] is single (:8-10, R converted to single first);
+      2 = cloud single, c double: xLim is formed in double and converted in the comparison with the single cloud (:11-13).
+    pts_rel = pts_cube - c (:23), vecnorm = sqrt(x^2 + y^2 + z^2) (:24) and dists < R (:25) are single either way; the
+    returned pts_sphere are those single values (widened)."""
+    if single_mode:
+        f32 = np.float32
+        p = np.asarray(pts).astype(f32)                              # a double cloud meets single limits: converted in the comparison
+        c64 = np.asarray(c, dtype=np.float64)
+        c32 = c64.astype(f32)
+        R32 = f32(R)
+        if single_mode == 1:
+            lo, hi = c32 + f32(-R32), c32 + R32                        # :8-10 in single
+        else:
+            lo, hi = (c64 - R).astype(f32), (c64 + R).astype(f32)      # :8-10 in double, converted at :11-13
+        m = np.all((p > lo) & (p < hi), axis=1)                        # :11-13 open box
+        cube = p[m]
+        if cube.shape[0] < min_points:                                 # :17
+            return None, None
+        rel = cube - c32                                               # :23 (single)
+        d = np.sqrt((rel[:, 0] * rel[:, 0] + rel[:, 1] * rel[:, 1]) + rel[:, 2] * rel[:, 2])   # :24, each step a float32 op
+        k = d < R32                                                    # :25
+        if k.sum() < min_points or k.sum() > max_points:               # :31
+            return None, None
+        return rel[k].astype(np.float64), d[k].astype(np.float64)
     pts = np.asarray(pts, dtype=np.float64)
     c = np.asarray(c, dtype=np.float64)
     m = np.all((pts > c - R) & (pts < c + R), axis=1)           # :8-13 open box
@@ -483,8 +512,13 @@ def histcounts_loc(x: np.ndarray, edges: np.ndarray) -> np.ndarray:
     return np.where(bad, 0, loc).astype(np.int64)
 
 
-def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
-    """getSpacialHistogramDescriptors.m:18-179 (+ histcn.m:94-131) -> (feat V x 3, desc V x 980).
+def getSpacialHistogramDescriptors(pts, sample_pts, options: dict, single_mode: int = 0):
+    """getSpacialHistogramDescriptors.m:18-179 (+ histcn.m:94-131) -> (feat V x 3, desc V x 980), both double whatever
+    the input classes (the reference preallocates them with nan(...), :61-62).
+
+    single_mode (see getLocalPoints): which keypoints survive and which points form a support follow MATLAB's single
+    arithmetic, and the support's coordinates are the single pts_rel values; everything after getLocalPoints is evaluated in
+    double on those values -- MATLAB would continue in single, with a summation order (mean, pca) that is not knowable.
 
     Restated quirks: the LRF sign vote uses k = K rows (:125,129-130); phi = atan2(y, y)
     (:152); NORMALIZE and LOCAL_PCA are hard-wired off (:31-32); points with r == 0 give
@@ -492,12 +526,16 @@ def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
     fewer than 2 is skipped (the reference would index an empty `variances`)."""
     pts = np.asarray(pts, dtype=np.float64)
     sample_pts = np.asarray(sample_pts, dtype=np.float64)
+    if single_mode:
+        pts = pts.astype(np.float32).astype(np.float64)                          # (already single values, or rounded in the comparison)
+        if single_mode == 1:
+            sample_pts = sample_pts.astype(np.float32).astype(np.float64)
     min_pts, max_pts = options["min_pts"], options["max_pts"]                   # :18-19
     R, thVar, K, ALIGN = float(options["R"]), options["thVar"], options["k"], bool(options["ALIGN_POINTS"])
     r_bins, theta_bins, phi_bins = histogram_edges(R)
     feat, desc = [], []
     for c in sample_pts:                                                        # :48-54 and :64-174 fused
-        pts_local, _ = getLocalPoints(pts, R, c, min_pts, max_pts)              # :50, :68
+        pts_local, _ = getLocalPoints(pts, R, c, min_pts, max_pts, single_mode) # :50, :68
         if pts_local is None or pts_local.shape[0] == 0:
             continue
         n = pts_local.shape[0]                                                  # :71

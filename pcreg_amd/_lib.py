@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcreg_hip.so")
+LIB_PATH = os.environ.get("PCREG_LIB") or os.path.join(_HERE, "libpcreg_hip.so")     # PCREG_LIB: another build of the same library (A/B runs)
 
 PCREG_OK, PCREG_E_ARG, PCREG_E_HIP, PCREG_E_NODEVICE, PCREG_E_WORKSPACE = 0, 1, 2, 3, 4
 METRIC_SAD, METRIC_SSD = 0, 1
@@ -57,13 +57,13 @@ SYMBOLS = [
     "pcreg_dev_model_create", "pcreg_dev_model_destroy", "pcreg_dev_model_search_workspace", "pcreg_dev_model_search_f32",
     "pcreg_dev_model_match_f32", "pcreg_dev_model_match_table_f32", "pcreg_dev_match_from_table_f32",
     "pcreg_align_points_knn", "pcreg_align_points_knn_f32", "pcreg_align_points_knn_batched", "pcreg_spatial_histogram_descriptors",
-    "pcreg_spatial_histogram_descriptors_f32",
+    "pcreg_spatial_histogram_descriptors_f32", "pcreg_spatial_histogram_descriptors_mixed",
     "pcreg_dev_knn2_points_f32_workspace", "pcreg_dev_knn2_points_f32", "pcreg_dev_merge_top2_f32", "pcreg_dev_merge_top2_strided_f32",
     "pcreg_dev_ransac_workspace", "pcreg_dev_ransac",
     "pcreg_dev_ransac_partial", "pcreg_dev_ransac_finish", "pcreg_dev_ransac_finish_parts",
     "pcreg_dev_search_kernel_timing", "pcreg_dev_search_kernel_ms",
     "pcreg_dev_spatial_histogram_descriptors_workspace", "pcreg_dev_spatial_histogram_descriptors",
-    "pcreg_dev_spatial_histogram_descriptors_u16", "pcreg_dev_get_matches_u16",
+    "pcreg_dev_spatial_histogram_descriptors_rows_u16", "pcreg_dev_get_matches_rows_u16",
     "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
     "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select",
     "pcreg_dev_gather_rows_f64", "pcreg_dev_sweep_plan", "pcreg_dev_sweep_gather", "pcreg_dev_ransac_batched_workspace",

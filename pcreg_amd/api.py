@@ -431,15 +431,20 @@ def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):
             raise KeyError(f"options.{k} is required (getSpacialHistogramDescriptors.m:18-23)")
     import time
     t0 = time.time()
-    if getattr(pts, "dtype", None) == np.float32 and getattr(sample_pts, "dtype", None) == np.float32:
-        # `single` clouds (pcread; completeExperimentFast.m:309): single feat / desc back, arithmetic in double
-        p = _fcol(np.asarray(pts).reshape(-1, 3), np.float32); s = _fcol(np.asarray(sample_pts).reshape(-1, 3), np.float32)
+    ps, ss = getattr(pts, "dtype", None) == np.float32, getattr(sample_pts, "dtype", None) == np.float32
+    if ps or ss:
+        # `single` data (pcread; completeExperimentFast.m:309).  feat / desc are DOUBLE (the reference preallocates them with
+        # nan(...), getSpacialHistogramDescriptors.m:61-62); getLocalPoints' element-wise single arithmetic -- which keypoints
+        # survive, which points form a support -- is reproduced (include/pcreg.h)
+        p = _fcol(np.asarray(pts).reshape(-1, 3), np.float32 if ps else np.float64)
+        s = _fcol(np.asarray(sample_pts).reshape(-1, 3), np.float32 if ss else np.float64)
         P, S = p.shape[0], s.shape[0]
         o = _desc_opts(options)
-        feat = np.zeros((max(S, 1), 3), np.float32); desc = np.zeros((max(S, 1), 980), np.float32)
+        feat = np.zeros((max(S, 1), 3)); desc = np.zeros((max(S, 1), 980))
         V = C.c_int(0)
-        check(lib().pcreg_spatial_histogram_descriptors_f32(_ptr(p, C.c_float), C.c_int(P), C.c_int(P), _ptr(s, C.c_float), C.c_int(S),
-                                                            C.c_int(S), C.byref(o), _ptr(feat, C.c_float), _ptr(desc, C.c_float), C.byref(V)))
+        check(lib().pcreg_spatial_histogram_descriptors_mixed(p.ctypes.data_as(C.c_void_p), C.c_int(int(ps)), C.c_int(P), C.c_int(P),
+                                                              s.ctypes.data_as(C.c_void_p), C.c_int(int(ss)), C.c_int(S), C.c_int(S), C.byref(o),
+                                                              _ptr(feat, C.c_double), _ptr(desc, C.c_double), C.byref(V)))
         if options.get("VERBOSE", 1):
             print("Calculated descriptors in %0.1f seconds..." % (time.time() - t0))
         return feat[:V.value].copy(), desc[:V.value].copy()

@@ -496,10 +496,9 @@ int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2, dou
     return PCREG_OK;
 }
 
-int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
-                                        const pcreg_desc_opts* options, double* feat, double* desc, int* V) {
-    PCREG_ARG(pts && sample_pts && options && feat && desc && V && P >= 0 && S >= 0 && ld >= P && lds >= S);
-    GUARD();
+// pts / sample_pts: double arrays (single data widened exactly by the caller); single_mode: see launch_descriptors
+static int descriptors_host(const double* pts, int P, int ld, const double* sample_pts, int S, int lds, const pcreg_desc_opts* options,
+                            int single_mode, double* feat, double* desc, int* V) {
     *V = 0;
     if (P == 0 || S == 0) return PCREG_OK;
     void *dp, *dk, *dfeat, *ddesc, *dcnt, *ws;
@@ -513,7 +512,8 @@ int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const 
     int32_t* dV = (int32_t*)dcnt; int32_t* dErr = dV + 1;
     TRY(upload_cols(pts, P, ld, 3, (double*)dp, g_stream));
     TRY(upload_cols(sample_pts, S, lds, 3, (double*)dk, g_stream));
-    TRY(launch_descriptors((double*)dp, P, P, (double*)dk, S, S, *options, (double*)dfeat, ddesc, false, dV, dErr, ws, wsb, g_stream));
+    TRY(launch_descriptors((double*)dp, P, P, (double*)dk, S, S, *options, single_mode, (double*)dfeat, (double*)ddesc, nullptr, nullptr, dV, dErr,
+                           ws, wsb, g_stream));
     int32_t hv[2] = {0, 0};
     PCREG_HIP(hipMemcpyAsync(hv, dcnt, sizeof hv, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipStreamSynchronize(g_stream));
@@ -526,12 +526,16 @@ int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const 
     return PCREG_OK;
 }
 
-// ------------------------------------------------------------------ device tier
+int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                        const pcreg_desc_opts* options, double* feat, double* desc, int* V) {
+    PCREG_ARG(pts && sample_pts && options && feat && desc && V && P >= 0 && S >= 0 && ld >= P && lds >= S);
+    GUARD();
+    return descriptors_host(pts, P, ld, sample_pts, S, lds, options, 0, feat, desc, V);
+}
+
 // ---- `single` inputs (clouds read by pcread are single: upsampleMesh.m:21, GetPointcloudFromModel.m:269) ----------------
-// The float -> double widening is exact; the arithmetic is the double kernels'; outputs are rounded once to float
-// (counts are integers: exact).  MATLAB itself would evaluate the support test, the LRF and the binning in single
-// arithmetic for single inputs: points within rounding of a sphere / bin boundary may land on the other side
-// ("Differences a user can observe").  Class-preserving drop-in, not bit parity with single MATLAB.
+// AlignPoints_KNN keeps its class (AlignPoints_KNN.m:17,59: everything derives from pts): the float -> double widening is
+// exact, the arithmetic is the double kernel's, the outputs are rounded once to float.
 int pcreg_align_points_knn_f32(const float* pts, int n, int ld, int C1, int C2, float* aligned, float coeff[9], float c[3]) {
     PCREG_ARG(pts && aligned && coeff && c && n >= 2 && ld >= n);
     std::vector<double> in((size_t)n * 3), out((size_t)n * 3);
@@ -544,20 +548,39 @@ int pcreg_align_points_knn_f32(const float* pts, int n, int ld, int C1, int C2, 
     return PCREG_OK;
 }
 
-int pcreg_spatial_histogram_descriptors_f32(const float* pts, int P, int ld, const float* sample_pts, int S, int lds,
-                                            const pcreg_desc_opts* options, float* feat, float* desc, int* V) {
+// getSpacialHistogramDescriptors with a `single` cloud and / or `single` keypoints.  The OUTPUTS are double whatever the
+// inputs (getSpacialHistogramDescriptors.m:61-62 preallocates desc / feat with nan(...) and assigns into them).  What runs in
+// single inside MATLAB and is element-wise -- hence reproducible -- is reproduced: getLocalPoints.m:8-31's open box test,
+// pts_cube - c, sqrt(x^2 + y^2 + z^2), dists < R and with them WHICH keypoints survive and which points form a support;
+// the support's coordinates are MATLAB's single pts_rel values.  mean / pca / the histogram then run in double on those
+// values (the summation order of MATLAB's single mean and pca is not knowable: INTEGRATION.md).
+int pcreg_spatial_histogram_descriptors_mixed(const void* pts, int pts_is_single, int P, int ld, const void* sample_pts,
+                                              int sample_is_single, int S, int lds, const pcreg_desc_opts* options,
+                                              double* feat, double* desc, int* V) {
     PCREG_ARG(pts && sample_pts && options && feat && desc && V && P >= 0 && S >= 0 && ld >= P && lds >= S);
-    std::vector<double> p((size_t)P * 3), k((size_t)S * 3), f((size_t)(S > 0 ? S : 1) * 3), d((size_t)(S > 0 ? S : 1) * PCREG_DESC_LEN);
-    for (int c = 0; c < 3; ++c) {
-        for (int i = 0; i < P; ++i) p[(size_t)c * P + i] = (double)pts[(size_t)c * ld + i];
-        for (int i = 0; i < S; ++i) k[(size_t)c * S + i] = (double)sample_pts[(size_t)c * lds + i];
+    GUARD();
+    std::vector<double> p, k;
+    const double* pp = (const double*)pts; const double* kk = (const double*)sample_pts;
+    int lp = ld, lk = lds;
+    if (pts_is_single) {
+        p.resize((size_t)P * 3);
+        for (int c = 0; c < 3; ++c) for (int i = 0; i < P; ++i) p[(size_t)c * P + i] = (double)((const float*)pts)[(size_t)c * ld + i];
+        pp = p.data(); lp = P;
     }
-    TRY(pcreg_spatial_histogram_descriptors(p.data(), P, P, k.data(), S, S, options, f.data(), d.data(), V));
-    for (size_t i = 0; i < (size_t)*V * 3; ++i) feat[i] = (float)f[i];                 // exact: they are the input keypoints
-    for (size_t i = 0; i < (size_t)*V * PCREG_DESC_LEN; ++i) desc[i] = (float)d[i];     // exact: integer counts <= max_pts
-    return PCREG_OK;
+    if (sample_is_single) {
+        k.resize((size_t)S * 3);
+        for (int c = 0; c < 3; ++c) for (int i = 0; i < S; ++i) k[(size_t)c * S + i] = (double)((const float*)sample_pts)[(size_t)c * lds + i];
+        kk = k.data(); lk = S;
+    }
+    const int mode = sample_is_single ? 1 : (pts_is_single ? 2 : 0);
+    return descriptors_host(pp, P, lp, kk, S, lk, options, mode, feat, desc, V);
+}
+int pcreg_spatial_histogram_descriptors_f32(const float* pts, int P, int ld, const float* sample_pts, int S, int lds,
+                                            const pcreg_desc_opts* options, double* feat, double* desc, int* V) {
+    return pcreg_spatial_histogram_descriptors_mixed(pts, 1, P, ld, sample_pts, 1, S, lds, options, feat, desc, V);
 }
 
+// ------------------------------------------------------------------ device tier
 size_t pcreg_dev_knn2_points_f32_workspace(int Q, int M) { return knn2_points_workspace_bytes(Q, M); }
 
 int pcreg_dev_knn2_points_f32(const float* q, int Q, int ldq, const float* m, int M, int ldm, int32_t idx_base,
@@ -633,17 +656,18 @@ int pcreg_dev_spatial_histogram_descriptors(const double* pts, int P, int ld, co
                                             void* workspace, size_t workspace_bytes, void* stream) {
     PCREG_ARG(pts && sample_pts && options && feat && desc && counters && workspace && P >= 1 && S >= 1 && ld >= P && lds >= S);
     GUARD();
-    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, feat, desc, false, counters, counters + 1, workspace,
+    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, 0, feat, desc, nullptr, nullptr, counters, counters + 1, workspace,
                               workspace_bytes, (hipStream_t)stream);
 }
 
-int pcreg_dev_spatial_histogram_descriptors_u16(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
-                                                const pcreg_desc_opts* options, double* feat, uint16_t* desc, int32_t* counters,
-                                                void* workspace, size_t workspace_bytes, void* stream) {
-    PCREG_ARG(pts && sample_pts && options && feat && desc && counters && workspace && P >= 1 && S >= 1 && ld >= P && lds >= S);
+int pcreg_dev_spatial_histogram_descriptors_rows_u16(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
+                                                     const pcreg_desc_opts* options, int single_mode, double* feat, uint16_t* rows,
+                                                     int32_t* row_index, int32_t* counters, void* workspace, size_t workspace_bytes,
+                                                     void* stream) {
+    PCREG_ARG(pts && sample_pts && options && feat && rows && row_index && counters && workspace && P >= 1 && S >= 1 && ld >= P && lds >= S);
     GUARD();
-    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, feat, desc, true, counters, counters + 1, workspace,
-                              workspace_bytes, (hipStream_t)stream);
+    return launch_descriptors(pts, P, ld, sample_pts, S, lds, *options, single_mode, feat, nullptr, rows, row_index, counters, counters + 1,
+                              workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 static constexpr int kLayoutRowMajorU16 = 1000;      // internal: dense uint16 rows (pcreg_dev_get_matches_u16)
@@ -664,7 +688,8 @@ size_t pcreg_dev_get_matches_workspace(int Q, int M, int D) {
 
 static int dev_get_matches_impl(const void* descSurface, int Q, int ldS, const void* descModel, int M, int ldM, int D,
                                 int layout, const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
-                                void* workspace, size_t workspace_bytes, hipStream_t st) {
+                                void* workspace, size_t workspace_bytes, hipStream_t st, const int32_t* idxS = nullptr,
+                                const int32_t* idxM = nullptr) {
     if (Q == 0 || M == 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, sizeof(int32_t), st)); return PCREG_OK; }
     const int Dp = D + (par->unnormalize ? 1 : 0);
     size_t off[6];
@@ -680,8 +705,8 @@ static int dev_get_matches_impl(const void* descSurface, int Q, int ldS, const v
         TRY(launch_transpose_rows((const double*)descModel, D, D, M, rawM, st));
         inS = rawS; inM = rawM; ls = Q; lm = M;
     } else if (layout == kLayoutRowMajorU16) {     // dense u16 rows (counts) -> feature-major doubles, exactly
-        TRY(launch_widen_rows_u16((const uint16_t*)descSurface, Q, D, rawS, st));
-        TRY(launch_widen_rows_u16((const uint16_t*)descModel, M, D, rawM, st));
+        TRY(launch_widen_rows_u16((const uint16_t*)descSurface, idxS, Q, D, rawS, st));
+        TRY(launch_widen_rows_u16((const uint16_t*)descModel, idxM, M, D, rawM, st));
         inS = rawS; inM = rawM; ls = Q; lm = M;
     }
     // getMatches.m:24-37 always works on private copies (the caller's descriptors stay untouched)
@@ -704,14 +729,14 @@ int pcreg_dev_get_matches(const double* descSurface, int Q, int ldS, const doubl
                                 workspace_bytes, (hipStream_t)stream);
 }
 
-int pcreg_dev_get_matches_u16(const uint16_t* descSurface, int Q, const uint16_t* descModel, int M, int D,
-                              const pcreg_match_opts* par, uint32_t* pairs, double* metric, int32_t* n_pairs,
-                              void* workspace, size_t workspace_bytes, void* stream) {
-    PCREG_ARG(descSurface && descModel && par && pairs && n_pairs && workspace && Q >= 0 && M >= 0 && D >= 1);
+int pcreg_dev_get_matches_rows_u16(const uint16_t* rowsSurface, const int32_t* indexSurface, int Q, const uint16_t* rowsModel,
+                                   const int32_t* indexModel, int M, int D, const pcreg_match_opts* par, uint32_t* pairs, double* metric,
+                                   int32_t* n_pairs, void* workspace, size_t workspace_bytes, void* stream) {
+    PCREG_ARG(rowsSurface && rowsModel && par && pairs && n_pairs && workspace && Q >= 0 && M >= 0 && D >= 1);
     PCREG_ARG(par->metric == PCREG_METRIC_SAD || par->metric == PCREG_METRIC_SSD);
     GUARD();
-    return dev_get_matches_impl(descSurface, Q, D, descModel, M, D, D, kLayoutRowMajorU16, par, pairs, metric, n_pairs, workspace,
-                                workspace_bytes, (hipStream_t)stream);
+    return dev_get_matches_impl(rowsSurface, Q, D, rowsModel, M, D, D, kLayoutRowMajorU16, par, pairs, metric, n_pairs, workspace,
+                                workspace_bytes, (hipStream_t)stream, indexSurface, indexModel);
 }
 
 int pcreg_dev_gather_matched_rows(const uint32_t* pairs, const int32_t* n_pairs, int cap, const double* featSurface,

@@ -146,7 +146,7 @@ int launch_refine_by_distance(const double* p1, const double* p2, const int32_t*
 void knn_f16_timing_enable(bool on);
 int knn_f16_timing_read(float* mean_ms, int* launches);
 int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st);
-int launch_widen_rows_u16(const uint16_t* rows, int n, int D, double* featmajor, hipStream_t st);   // [n][D] u16 -> feature-major f64
+int launch_widen_rows_u16(const uint16_t* rows, const int32_t* index, int n, int D, double* featmajor, hipStream_t st);   // rows[index[i]] (u16) -> feature-major f64
 int launch_sweep_plan(const int32_t* n_pairs, int S, int thresh, int32_t* trial_idx, int32_t* offsets, int32_t* n_trials, hipStream_t st);
 int launch_sweep_gather(const uint32_t* pairs_all, int VS, const int32_t* n_pairs, const int32_t* trial_idx, const int32_t* offsets,
                         const int32_t* n_trials, int S, const double* featS, const double* featCur_all, const int64_t* row_off,
@@ -161,8 +161,8 @@ int launch_align_points_knn(const double* pts, int ld, const int32_t* offsets_de
 
 // spatial-histogram descriptors (cfg 4)
 size_t descriptors_workspace_bytes(int P, int S);
-int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o,
-                       double* feat, void* desc, bool desc_u16, int32_t* V_dev, int32_t* err_dev, void* ws, size_t ws_bytes,
-                       hipStream_t st);
+int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o, int single_mode,
+                       double* feat, double* desc_f64, uint16_t* rows_u16, int32_t* row_index, int32_t* V_dev, int32_t* err_dev,
+                       void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace pcreg

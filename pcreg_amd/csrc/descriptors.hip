@@ -31,10 +31,20 @@
 namespace pcreg {
 namespace {
 
+#ifndef PCREG_DESC_DC
+#define PCREG_DESC_DC 8
+#endif
+#ifndef PCREG_DESC_D64
+#define PCREG_DESC_D64 4
+#endif
+#ifndef PCREG_DESC_D32
+#define PCREG_DESC_D32 8
+#endif
 constexpr int kBlock = 256;
 constexpr int kSortTile = 2048;            // points per counting-sort tile
 constexpr int kMaxCells = 1 << 16;
 constexpr int NR = 10, NT = 7, NP = 14, ND = NR * NT * NP;
+static_assert(NT == 7, "bin_fast32 folds the seven theta bins about pi / 2");
 
 struct Grid {
     double ox, oy, oz;                     // origin
@@ -42,6 +52,7 @@ struct Grid {
     double hy, hz;                         // cell edges along y and z
     int nx, ny, nz, ncells;
     int fx, fy, fz;                        // h / edge per axis: a sphere of radius R <= h reaches at most f cells to either side
+    double L;                              // the cloud's largest extent: bounds |p - origin| (error bound of the fp32 copies)
 };
 // ct = cos(t); r2ge[k] = the smallest d2 with sqrt(d2) >= r[k], r2gt = the smallest d2 with sqrt(d2) > r[NR] (the radial
 // bin of a point follows from its SQUARED distance, exactly); cts[k] = ct[k] |ct[k]| (theta's bin from z |z| vs cts d2)
@@ -107,6 +118,7 @@ __global__ void grid_setup_kernel(const double* __restrict__ part, int nparts, d
     g->hy = cell / g->fy; g->hz = cell / g->fz;
     g->nx = (int)(floor((hi[0] - lo[0]) * g->invx) + 1); g->ny = (int)(floor((hi[1] - lo[1]) * g->invy) + 1); g->nz = (int)(floor((hi[2] - lo[2]) * g->invz) + 1);
     g->ncells = g->nx * g->ny * g->nz;
+    g->L = fmax(hi[0] - lo[0], fmax(hi[1] - lo[1], hi[2] - lo[2]));
 }
 
 // ---- grid: deterministic counting sort ------------------------------------------------------
@@ -159,7 +171,8 @@ __global__ __launch_bounds__(kBlock) void grid_scatter_kernel(const double* __re
                                                               const int32_t* __restrict__ counts /*prefix over tiles*/,
                                                               const int32_t* __restrict__ cell_start,
                                                               int32_t* __restrict__ sorted_idx, double* __restrict__ sx,
-                                                              double* __restrict__ sy, double* __restrict__ sz) {
+                                                              double* __restrict__ sy, double* __restrict__ sz,
+                                                              const Grid* __restrict__ gp, int single_mode, float4* __restrict__ f4) {
     __shared__ unsigned long long key[kSortTile];
     __shared__ int run_start[kSortTile];
     const int t0 = blockIdx.x * kSortTile;
@@ -198,7 +211,14 @@ __global__ __launch_bounds__(kBlock) void grid_scatter_kernel(const double* __re
         int c = (int)(kk >> 32), idx = (int)(kk & 0xFFFFFFFFull);
         int dst = cell_start[c] + row[c] + (i - run_start[i]);
         sorted_idx[dst] = idx;
-        sx[dst] = p[idx]; sy[dst] = p[idx + (size_t)ld]; sz[dst] = p[idx + 2 * (size_t)ld];
+        const double X = p[idx], Y = p[idx + (size_t)ld], Z = p[idx + 2 * (size_t)ld];
+        sx[dst] = X; sy[dst] = Y; sz[dst] = Z;
+        // the fp32 copies desc_kernel streams: single data -> the single values themselves (MATLAB's arithmetic runs on them),
+        // double data -> relative to the grid's origin (screening only: small magnitudes, whatever the georeference)
+        // (one 16-byte element per point: a single load instruction and address per gather -- the kernel is bound by
+        // instruction issue, not by bytes)
+        if (single_mode) f4[dst] = make_float4((float)X, (float)Y, (float)Z, 0.0f);
+        else f4[dst] = make_float4((float)(X - gp->ox), (float)(Y - gp->oy), (float)(Z - gp->oz), 0.0f);
     }
 }
 
@@ -259,13 +279,34 @@ __device__ __forceinline__ int hist_loc(double x, const double (&e)[NE]) {
     return k;
 }
 
+// fp32 images of the bin edges (screening): the squared radial edges and cos |cos| of the theta edges
+struct Edges32 { float r2ge[NR + 1], r2gt, cts[NT + 1]; };
+
+// the smallest double t with sqrt(t) >= r under IEEE round-to-nearest (r > 0 finite): sqrt(d2) < r <=> d2 < t
+__host__ __device__ inline double sqrt_threshold(double r) {
+    if (!(r > 0.0) || !(r < INFINITY)) return r > 0.0 ? r : 0.0;       // r <= 0 or NaN: nothing is inside; +inf: everything finite
+    double t = r * r;
+    for (int it = 0; it < 64 && t > 0.0 && sqrt(t) >= r; ++it) t = nextafter(t, 0.0);
+    for (int it = 0; it < 64 && sqrt(t) < r; ++it) t = nextafter(t, INFINITY);
+    return t;
+}
+
+// SM = 0: double inputs, double arithmetic (fp32 only SCREENS decisions that fp64 re-takes when they are close).
+// SM = 1: MATLAB's arithmetic for `single` data (either input single: getLocalPoints.m:8-31 then runs in single): the open
+//         box test, pts_cube - c, sqrt(x^2 + y^2 + z^2) and dists < R are evaluated in fp32 exactly as written, which decides
+//         WHICH keypoints survive and which points form a support; the support's coordinates are MATLAB's single pts_rel
+//         values.  Everything after that (mean, pca, the histogram) stays in double on those values: the summation order of
+//         MATLAB's single mean / pca is not knowable.
+template <int SM>
 __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ sz,
+    const float4* __restrict__ f4,
     const int32_t* __restrict__ sorted_idx, const int32_t* __restrict__ cell_start, const Grid* __restrict__ gp,
-    const double* __restrict__ kp, const int32_t* __restrict__ perm, int S, int ldk, pcreg_desc_opts o, Edges ed, double R2T, int cap, int dbg_stop, int xcd_chunk,
-    uint32_t* __restrict__ rows /*[S][ND]*/, int32_t* __restrict__ valid, int32_t* __restrict__ err) {
+    const double* __restrict__ kp, const int32_t* __restrict__ perm, int S, int ldk, pcreg_desc_opts o, const Edges* __restrict__ edp, Edges32 e32, double R2T,
+    int kp_single, int cap, int dbg_stop, int xcd_chunk, void* __restrict__ rows_out /*[S][ND] u32 or u16*/, int rows_u16,
+    int32_t* __restrict__ valid, int32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int* lpos = reinterpret_cast<int*>(smem);                           // [cap] position in the sorted arrays (+ a "kept" flag bit)
+    int* lpos = reinterpret_cast<int*>(smem);                           // [cap] position in the sorted arrays
     __shared__ double s_redn[4 * 9];
     __shared__ int s_redi[4];
     __shared__ unsigned s_cnt[ND];
@@ -273,16 +314,19 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     constexpr int kSmall = 256;
     __shared__ unsigned long long s_small[kSmall];
     __shared__ int s_hist[256];
-    __shared__ unsigned long long s_vk;
-    __shared__ int s_nsmall, s_bin, s_below, s_nless, s_neq;
+    __shared__ unsigned long long s_vk, s_tlo, s_thi;
+    __shared__ int s_nsmall, s_bin, s_below;
     __shared__ int s_ok;
     __shared__ double s_m[9];
     __shared__ double s_V[9];
     constexpr int kDef = 128;
-    __shared__ int s_def[kDef];
-    __shared__ int s_ndef;
+    __shared__ int s_def[kDef], s_vdef[kDef];
+    __shared__ int s_ndef, s_nvdef;
 
     const Grid g = *gp;
+    // the fp64 bin edges stay in device memory: the literal path indexes them dynamically (hist_loc), and a by-value struct
+    // would be copied to scratch by every workgroup for it (496 B per lane at kernel entry: measured 1 ms per 100 k keypoints)
+    const Edges& ed = *edp;
     // workgroups are dealt round-robin over the 8 XCDs: XCD x walks its own eighth of the cell-ordered keypoints, so its
     // L2 holds the few cells its ~128 concurrent keypoints share instead of a slice of everybody's (PCREG_DESC_XCD=0: off)
     int slot = blockIdx.x;
@@ -291,9 +335,19 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double cx = kp[s], cy = kp[s + (size_t)ldk], cz = kp[s + 2 * (size_t)ldk];
     const double R = o.R;
-    // sqrt(d2) < R (getLocalPoints.m:23-25) <=> d2 < R2T, R2T = the smallest double whose correctly rounded square root
-    // is >= R (found by the launcher): the same decision for every d2, without ~25 fp64 instructions per candidate
-    if (tid == 0) { valid[s] = 0; s_ndef = 0; }
+    // the keypoint in the frame of the fp32 copies: SM 0: relative to the grid's origin (screening), SM 1: the single value itself
+    const float cxf = SM ? (float)cx : (float)(cx - g.ox), cyf = SM ? (float)cy : (float)(cy - g.oy), czf = SM ? (float)cz : (float)(cz - g.oz);
+    const float R32 = (float)R;
+    // SM 1, getLocalPoints.m:8-13: xLim = c(1) + [-R, R] is single when c is single (R rounds to single first), double otherwise
+    // -- and then rounds to single in the comparison with the single cloud
+    const float xlo = kp_single ? cxf + (-R32) : (float)(cx - R), xhi = kp_single ? cxf + R32 : (float)(cx + R);
+    const float ylo32 = kp_single ? cyf + (-R32) : (float)(cy - R), yhi32 = kp_single ? cyf + R32 : (float)(cy + R);
+    const float zlo32 = kp_single ? czf + (-R32) : (float)(cz - R), zhi32 = kp_single ? czf + R32 : (float)(cz + R);
+    // the fp32 copies' error per coordinate of (p - c), u = 2^-24: SM 0: copy and keypoint are rounded relative to the grid's
+    // origin (u L each, L = the cloud's extent + R) and subtracted (one more rounding); SM 1: the copies ARE the data
+    const float u32 = 5.9604644775390625e-08f;
+    const float dlt = SM ? 0.0f : 2.0f * u32 * (float)(g.L + R) + 2.0f * u32 * (2.0f * R32);
+    if (tid == 0) { valid[s] = 0; s_ndef = 0; s_nvdef = 0; }
     for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
     __syncthreads();
 
@@ -304,6 +358,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     // 64 consecutive points; wave w takes the chunks w, w + 4, ... of the whole sequence (balanced whatever the row
     // lengths), the list is wave-major (all of wave 0's points, then wave 1's, ...): deterministic, and the later
     // passes do not care -- ties go by ORIGINAL index.
+    constexpr int kDC = PCREG_DESC_DC, kD64 = PCREG_DESC_D64, kD32 = PCREG_DESC_D32;     // gathers in flight per lane and pass
     constexpr int kRowsMax = 25;
     __shared__ int s_rowb[kRowsMax], s_rowe[kRowsMax], s_cp[kRowsMax + 1], s_wtot[4];
     const int nyo = g.fy, nzo = g.fz, wy = 2 * nyo + 1, nrows = wy * (2 * nzo + 1);
@@ -314,12 +369,17 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         // a keypoint outside the cloud's box by more than R has no neighbours: all its rows are then farther than R
         if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
             // the row's slab in y and z keeps every point at least (gy, gz) away from the keypoint: what is left of R^2
-            // bounds |x - cx|.  Margins of 1e-9 (cell edges are products rounded once, cell_coord is monotone in x).
+            // bounds |x - cx|.  The margins cover the rounding of the slab edges (oy + yy hy: about an ulp of the largest
+            // term, which for georeferenced clouds is the coordinate itself, not the cell) and of w; cell_coord is
+            // monotone in x.  SM 1 widens R by the single-precision slack of its own test.
+            const double Rr = SM ? R * (1.0 + 1e-6) : R;
             const double ylo = g.oy + yy * g.hy, zlo = g.oz + zz * g.hz;
-            const double gy = fmax(0.0, fmax(ylo - cy, cy - (ylo + g.hy)) - 1e-9 * g.hy), gz = fmax(0.0, fmax(zlo - cz, cz - (zlo + g.hz)) - 1e-9 * g.hz);
-            const double w2 = R * R - gy * gy - gz * gz;
+            const double my_ = 1e-9 * g.hy + 8.0 * DBL_EPSILON * (fabs(g.oy) + fabs(cy) + fabs(yy * g.hy)) + (SM ? 2e-7 * (fabs(cy) + R) : 0.0);
+            const double mz_ = 1e-9 * g.hz + 8.0 * DBL_EPSILON * (fabs(g.oz) + fabs(cz) + fabs(zz * g.hz)) + (SM ? 2e-7 * (fabs(cz) + R) : 0.0);
+            const double gy = fmax(0.0, fmax(ylo - cy, cy - (ylo + g.hy)) - my_), gz = fmax(0.0, fmax(zlo - cz, cz - (zlo + g.hz)) - mz_);
+            const double w2 = Rr * Rr - gy * gy - gz * gz;
             if (w2 >= 0.0) {
-                const double w = sqrt(w2) + 1e-9 * R;
+                const double w = sqrt(w2) + 1e-9 * R + 8.0 * DBL_EPSILON * (fabs(g.ox) + fabs(cx) + R) + (SM ? 2e-7 * (fabs(cx) + R) : 0.0);
                 const int x0 = cell_coord(cx - w, g.ox, g.invx, g.nx), x1 = cell_coord(cx + w, g.ox, g.invx, g.nx);
                 b = cell_start[(zz * g.ny + yy) * g.nx + x0]; e = cell_start[(zz * g.ny + yy) * g.nx + x1 + 1];   // x-adjacent cells are contiguous
             }
@@ -334,43 +394,95 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     }
     __syncthreads();
     const int n_chunks = s_cp[nrows];
-    // pass 1 streams the candidates ONCE (four 64-point chunks = twelve loads in flight per wave) and keeps
+    // pass 1 streams the candidates ONCE (four 64-point chunks = twelve 4-byte loads in flight per wave) and keeps
     // every chunk's ballot; pass 2 replays the ballots, so it touches no global memory
     constexpr int kMaskCap = 160;                   // chunks per wave whose ballot is kept (beyond: re-tested)
     __shared__ unsigned long long s_mask[4][kMaskCap];
-    // chunk c -> (first position, end of its row); the row pointer only moves forward (chunks are visited in order)
-    auto chunk_range = [&](int c, int& rp, int& j0, int& end) {
+    // chunk c -> (first position, end of its row).  The lookup walks two LDS tables, and doing it inside the streaming loop
+    // put ~4 dependent LDS round trips in front of every chunk's loads (the collection took 1.7 ms per 100 k keypoints for
+    // 0.3 ms worth of loads and tests).  Every lane therefore resolves ONE chunk of its wave up front -- lane l owns the
+    // wave's l-th chunk, chunks wave + 4 l -- and the loop reads the pair with v_readlane (a wave meets at most
+    // kMaskCap + ... chunks; beyond 64 per wave a second, third ... round of lookups follows).
+    auto chunk_lookup = [&](int c, int& j0, int& end) {
+        int rp = 0;
         while (c >= s_cp[rp + 1]) ++rp;
         j0 = s_rowb[rp] + ((c - s_cp[rp]) << 6); end = s_rowe[rp];
     };
-    auto in_sphere = [&](int j, int end) -> bool {
-        if (j >= end) return false;
-        const double x = sx[j] - cx, y = sy[j] - cy, z = sz[j] - cz;
-        return x * x + y * y + z * z < R2T;                                 // getLocalPoints.m:23-25 (see R2T)
+    int my_j0 = 0, my_end = 0, my_round = -1;
+    auto chunk_range = [&](int ord /* the wave's ord-th chunk: wave-uniform */, int& j0, int& end) {
+        const int round = ord >> 6;
+        if (round != my_round) {                       // wave-uniform
+            my_round = round;
+            const int c = wave + 4 * (round * 64 + lane);
+            my_j0 = 0; my_end = 0;
+            if (c < n_chunks) chunk_lookup(c, my_j0, my_end);
+        }
+        j0 = __builtin_amdgcn_readlane(my_j0, ord & 63); end = __builtin_amdgcn_readlane(my_end, ord & 63);
+    };
+    // is candidate j inside?  SM 1: (X, Y, Z) the single point, (x, y, z) = pts_cube - c in single (getLocalPoints.m:8-25 as
+    // MATLAB runs it for single data); SM 0: the fp64 test on the double coordinates
+    auto inside = [&](int j, float X, float Y, float Z, float x, float y, float z) -> bool {
+        if (SM) {
+            const bool box = X > xlo && X < xhi && Y > ylo32 && Y < yhi32 && Z > zlo32 && Z < zhi32;
+            return box && sqrtf((x * x + y * y) + z * z) < R32;
+        }
+        const double ex = sx[j] - cx, ey = sy[j] - cy, ez = sz[j] - cz;
+        return ex * ex + ey * ey + ez * ez < R2T;                          // getLocalPoints.m:23-25 (see R2T)
     };
     double a3[3] = {0, 0, 0};
     {
-        int rp = 0, cnt = 0, ch = 0;                 // ch: running chunk number of this wave
-        for (int c0 = wave; c0 < n_chunks; c0 += 16) {
-            double X[4], Y[4], Z[4]; int J0[4], E[4];
+        int cnt = 0, ch = 0;                         // ch: running chunk number of this wave
+        // SM 0 streams the DOUBLE coordinates once (test + centroid sums from the same registers).  A form that screened
+        // the test on the fp32 copy and fetched the doubles of the inside lanes only was 1.6 ms per 100 k keypoints slower:
+        // with 40 % of the candidates inside, every sector of the double arrays is touched anyway, on top of the copy.
+        if constexpr (SM == 0) {
+            constexpr int kD = 4;                    // chunks in flight per wave: 12 eight-byte loads per lane
+            for (int c0 = wave; c0 < n_chunks; c0 += 4 * kD) {
+                double X[kD], Y[kD], Z[kD]; int J0[kD], E[kD];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + 4 * u;
-                J0[u] = 0; E[u] = 0;
-                if (c < n_chunks) chunk_range(c, rp, J0[u], E[u]);           // wave-uniform
-                const int j = max(min(J0[u] + lane, E[u] - 1), 0);
-                X[u] = sx[j]; Y[u] = sy[j]; Z[u] = sz[j];
+                for (int u = 0; u < kD; ++u) {
+                    const int c = c0 + 4 * u;
+                    J0[u] = 0; E[u] = 0;
+                    if (c < n_chunks) chunk_range((c - wave) >> 2, J0[u], E[u]);  // wave-uniform
+                    const int j = max(min(J0[u] + lane, E[u] - 1), 0);
+                    X[u] = sx[j]; Y[u] = sy[j]; Z[u] = sz[j];
+                }
+#pragma unroll
+                for (int u = 0; u < kD; ++u) {
+                    if (c0 + 4 * u < n_chunks) {         // wave-uniform
+                        const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
+                        const bool in = (J0[u] + lane < E[u]) && x * x + y * y + z * z < R2T;   // getLocalPoints.m:23-25 (see R2T)
+                        if (in) { a3[0] += x; a3[1] += y; a3[2] += z; }        // the local centroid's sums ride along (:80)
+                        const unsigned long long bal = __ballot(in);
+                        if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
+                        ++ch;
+                        cnt += __popcll(bal);
+                    }
+                }
             }
+        } else {
+            for (int c0 = wave; c0 < n_chunks; c0 += 4 * kDC) {
+                float X[kDC], Y[kDC], Z[kDC]; int J0[kDC], E[kDC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (c0 + 4 * u < n_chunks) {         // wave-uniform
-                    const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
-                    const bool in = (J0[u] + lane < E[u]) && x * x + y * y + z * z < R2T;
-                    if (in) { a3[0] += x; a3[1] += y; a3[2] += z; }        // the local centroid's sums ride along (:80)
-                    const unsigned long long bal = __ballot(in);
-                    if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
-                    ++ch;
-                    cnt += __popcll(bal);
+                for (int u = 0; u < kDC; ++u) {
+                    const int c = c0 + 4 * u;
+                    J0[u] = 0; E[u] = 0;
+                    if (c < n_chunks) chunk_range((c - wave) >> 2, J0[u], E[u]);  // wave-uniform
+                    const int j = max(min(J0[u] + lane, E[u] - 1), 0);
+                    const float4 t4 = f4[j]; X[u] = t4.x; Y[u] = t4.y; Z[u] = t4.z;
+                }
+#pragma unroll
+                for (int u = 0; u < kDC; ++u) {
+                    if (c0 + 4 * u < n_chunks) {         // wave-uniform
+                        const int j = J0[u] + lane;
+                        const float x = X[u] - cxf, y = Y[u] - cyf, z = Z[u] - czf;
+                        const bool in = j < E[u] && inside(j, X[u], Y[u], Z[u], x, y, z);
+                        if (in) { a3[0] += (double)x; a3[1] += (double)y; a3[2] += (double)z; }   // MATLAB's single pts_rel values (:80 sums them)
+                        const unsigned long long bal = __ballot(in);
+                        if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
+                        ++ch;
+                        cnt += __popcll(bal);
+                    }
                 }
             }
         }
@@ -384,11 +496,18 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     if (n < 1 || n < o.min_pts || n > o.max_pts) return;                   // getLocalPoints.m:17,31
     if (n > cap) { if (tid == 0) atomicMax(err, n); return; }              // support larger than the LDS list
     {
-        int rp = 0, ch = 0, pos = my_base;
+        int ch = 0, pos = my_base;
         for (int c = wave; c < n_chunks; c += 4, ++ch) {
             int j0, end;
-            chunk_range(c, rp, j0, end);
-            const unsigned long long bal = ch < kMaskCap ? s_mask[wave][ch] : __ballot(in_sphere(j0 + lane, end));
+            chunk_range(ch, j0, end);
+            unsigned long long bal;
+            if (ch < kMaskCap) bal = s_mask[wave][ch];
+            else {
+                const int j = j0 + lane, jc = max(min(j, end - 1), 0);
+                float X = 0.0f, Y = 0.0f, Z = 0.0f;
+                if (SM) { const float4 t4 = f4[jc]; X = t4.x; Y = t4.y; Z = t4.z; }
+                bal = __ballot(j < end && inside(jc, X, Y, Z, X - cxf, Y - cyf, Z - czf));
+            }
             if ((bal >> lane) & 1ull) lpos[pos + __popcll(bal & ((1ull << lane) - 1ull))] = j0 + lane;
             pos += __popcll(bal);
         }
@@ -397,21 +516,24 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
 
     if (dbg_stop == 1) return;            // timing experiments only (PCREG_DESC_STOP)
     // A pass over the support: thread t visits its entries i = t + 256 r in ascending order; px/py/pz = the
-    // point relative to the keypoint, psel = kept by the K-nearest selection (bit r of selmask).  Four
-    // entries' gathers are issued before the first is used: the sorted cloud sits in the Infinity Cache
-    // (~1-2 us away), so the passes are latency-bound and memory-level parallelism is what they need.
+    // point relative to the keypoint (SM 1: MATLAB's single pts_rel value, widened), psel = kept by the K-nearest selection
+    // (bit r of selmask).  Four entries' gathers are issued before the first is used: the sorted cloud sits in the L2 /
+    // Infinity Cache, so the passes are latency-bound and memory-level parallelism is what they need.
     unsigned selmask = 0xFFFFFFFFu;                  // cap <= 8191 -> r < 32
+#define PCREG_LOAD_REL(j_, X_, Y_, Z_)                                                               \
+    if (SM) { const float4 t4_ = f4[j_]; X_ = (double)(t4_.x - cxf); Y_ = (double)(t4_.y - cyf); Z_ = (double)(t4_.z - czf); } \
+    else { X_ = sx[j_] - cx; Y_ = sy[j_] - cy; Z_ = sz[j_] - cz; }
 #define PCREG_MY_PTS(...)                                                                            \
-    for (int i0_ = tid, r0_ = 0; i0_ < n; i0_ += 4 * kBlock, r0_ += 4) {                             \
-        double X_[4], Y_[4], Z_[4];                                                                  \
-        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                           \
+    for (int i0_ = tid, r0_ = 0; i0_ < n; i0_ += kD64 * kBlock, r0_ += kD64) {                       \
+        double X_[kD64], Y_[kD64], Z_[kD64];                                                         \
+        _Pragma("unroll") for (int u_ = 0; u_ < kD64; ++u_) {                                        \
             const int j_ = lpos[min(i0_ + u_ * kBlock, n - 1)];                                      \
-            X_[u_] = sx[j_]; Y_[u_] = sy[j_]; Z_[u_] = sz[j_];                                       \
+            PCREG_LOAD_REL(j_, X_[u_], Y_[u_], Z_[u_])                                               \
         }                                                                                            \
-        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                           \
+        _Pragma("unroll") for (int u_ = 0; u_ < kD64; ++u_) {                                        \
             const int i = i0_ + u_ * kBlock, pr = r0_ + u_;                                          \
             if (i < n) {                                                                             \
-                const double px = X_[u_] - cx, py = Y_[u_] - cy, pz = Z_[u_] - cz;                   \
+                const double px = X_[u_], py = Y_[u_], pz = Z_[u_];                                  \
                 const bool psel = (selmask >> pr) & 1u; (void)psel; (void)i;                         \
                 __VA_ARGS__                                                                          \
             }                                                                                        \
@@ -425,24 +547,35 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     bsum_n<3>(a3, s_redn);                          // summed while the candidates streamed by (collection pass 1)
     const double gx = a3[0] / n, gy = a3[1] / n, gz = a3[2] / n;
     if (!all) {
-#define PCREG_KEY(px, py, pz) kth_key(sqrt(((px) - gx) * ((px) - gx) + ((py) - gy) * ((py) - gy) + ((pz) - gz) * ((pz) - gz)))
+        // The reference sorts dists = vecnorm(pts_local - centroid) (stable: ties keep their original order).  The sort key
+        // here is the SQUARED distance d2 (the argument of that square root; no fp64 sqrt per point): sqrt is monotone, so
+        // the K-th smallest distance is sK = sqrt(K-th smallest d2), and the points tied WITH it in the reference's order are
+        // exactly those whose d2 lies in sqrt's preimage of sK, [t_lo, t_hi) -- found with a handful of square roots by one
+        // thread.  Selection: d2 < t_lo, plus the lowest original indices of the tie group.
+#define PCREG_KEY(px, py, pz) kth_key(((px) - gx) * ((px) - gx) + ((py) - gy) * ((py) - gy) + ((pz) - gz) * ((pz) - gz))
         // every thread keeps the keys of ITS entries in registers (one more gather pass, fully unrolled so
         // that the register index is a constant); the selection itself then never touches memory
         unsigned long long kreg[32];
 #pragma unroll
-        for (int t_ = 0; t_ < 8; ++t_) {
-            double X_[4], Y_[4], Z_[4];
+        for (int t_ = 0; t_ < 32 / kD64; ++t_) {
+            if (t_ * kD64 * kBlock >= n) {             // block-uniform: the unrolled loop is sized for 8191 entries, a typical support holds half
 #pragma unroll
-            for (int u_ = 0; u_ < 4; ++u_) {
-                const int j_ = lpos[min(tid + (t_ * 4 + u_) * kBlock, n - 1)];
-                X_[u_] = sx[j_]; Y_[u_] = sy[j_]; Z_[u_] = sz[j_];
+                for (int u_ = 0; u_ < kD64; ++u_) kreg[t_ * kD64 + u_] = 0ull;
+                continue;
+            }
+            double X_[kD64], Y_[kD64], Z_[kD64];
+#pragma unroll
+            for (int u_ = 0; u_ < kD64; ++u_) {
+                const int j_ = lpos[min(tid + (t_ * kD64 + u_) * kBlock, n - 1)];
+                PCREG_LOAD_REL(j_, X_[u_], Y_[u_], Z_[u_])
             }
 #pragma unroll
-            for (int u_ = 0; u_ < 4; ++u_) kreg[t_ * 4 + u_] = PCREG_KEY(X_[u_] - cx, Y_[u_] - cy, Z_[u_] - cz);
+            for (int u_ = 0; u_ < kD64; ++u_) kreg[t_ * kD64 + u_] = PCREG_KEY(X_[u_], Y_[u_], Z_[u_]);
         }
-#define PCREG_MY_KEYS(...) _Pragma("unroll") for (int pr = 0; pr < 32; ++pr) { const int i = tid + pr * kBlock; if (i < n) { const unsigned long long k = kreg[pr]; (void)i; __VA_ARGS__ } }
+#define PCREG_MY_KEYS(...) _Pragma("unroll") for (int pg_ = 0; pg_ < 8; ++pg_) { if (pg_ * 4 * kBlock < n) { /* block-uniform */ \
+        _Pragma("unroll") for (int pq_ = 0; pq_ < 4; ++pq_) { const int pr = pg_ * 4 + pq_; const int i = tid + pr * kBlock; if (i < n) { const unsigned long long k = kreg[pr]; (void)i; __VA_ARGS__ } } } }
         // K-th smallest by ONE 256-bin histogram over [min, max] (the bin index is monotone in the
-        // distance), then an exact rank inside the bin that holds it; bisection only if that bin is crowded
+        // key), then an exact rank inside the bin that holds it; bisection only if that bin is crowded
         unsigned long long lo = ~0ull, hi = 0ull;
         PCREG_MY_KEYS(lo = k < lo ? k : lo; hi = k > hi ? k : hi;)
         // the keys are bit patterns of non-negative doubles: reduce them as doubles (DPP, wave_math.hpp)
@@ -450,7 +583,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         hi = kth_key(wave_max_dpp(__longlong_as_double((long long)hi)));
         if (lane == 0) { s_u64[wave] = lo; s_u64[4 + wave] = hi; }
         for (int i = tid; i < 256; i += kBlock) s_hist[i] = 0;
-        if (tid == 0) { s_nsmall = 0; s_vk = 0ull; s_nless = 0; s_neq = 0; }
+        if (tid == 0) { s_nsmall = 0; s_vk = 0ull; }
         __syncthreads();
         lo = s_u64[0]; hi = s_u64[4];
 #pragma unroll
@@ -484,16 +617,16 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         PCREG_MY_KEYS(if (bin_of(k) == bstar) { const int q = atomicAdd(&s_nsmall, 1); if (q < kSmall) s_small[q] = k; })
         __syncthreads();
         const int m = s_nsmall, Kp = K - below;
-        unsigned long long vK; int n_less, n_eq;
+        unsigned long long vK;
         if (m <= kSmall) {
             for (int t = tid; t < m; t += kBlock) {
                 const unsigned long long x = s_small[t];
                 int less = 0, eq = 0;
                 for (int u = 0; u < m; ++u) { const unsigned long long yv = s_small[u]; less += yv < x; eq += yv == x; }
-                if (less < Kp && Kp <= less + eq) { s_vk = x; s_nless = below + less; s_neq = eq; }   // every writer writes the same
+                if (less < Kp && Kp <= less + eq) s_vk = x;     // every writer writes the same
             }
             __syncthreads();
-            vK = s_vk; n_less = s_nless; n_eq = s_neq;
+            vK = s_vk;
         } else {                                     // crowded bin (many equal distances): plain bisection on the keys
             unsigned long long blo = lo, bhi = hi;
             while (blo < bhi) {
@@ -504,26 +637,36 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
                 if (c >= K) bhi = mid; else blo = mid + 1;
             }
             vK = blo;
-            int c1 = 0, c2 = 0;
-            PCREG_MY_KEYS(c1 += k < vK; c2 += k == vK;)
-            n_less = bsum_i(c1, s_redi); n_eq = bsum_i(c2, s_redi);
         }
+        // sqrt's preimage of the K-th distance: every d2 in [t_lo, t_hi) has the reference's sort key sK
+        if (tid == 0) {
+            const double sK = sqrt(__longlong_as_double((long long)vK));
+            s_tlo = kth_key(sqrt_threshold(sK));
+            s_thi = kth_key(sqrt_threshold(nextafter(sK, INFINITY)));
+        }
+        __syncthreads();
+        const unsigned long long t_lo = s_tlo, t_hi = s_thi;
+        int c1 = 0, c2 = 0;
+        PCREG_MY_KEYS(c1 += k < t_lo; c2 += (k >= t_lo && k < t_hi);)
+        const int n_less = bsum_i(c1, s_redi), n_eq = bsum_i(c2, s_redi);
         if (dbg_stop == 6) return;
         const int take_eq = K - n_less;
         // ties at the K-th distance: the stable sort keeps the lowest ORIGINAL indices
         unsigned sm = 0u;
         PCREG_MY_KEYS(
             const unsigned long long key = k;
-            bool sel = key < vK;
-            if (key == vK) {
+            bool sel = key < t_lo;
+            if (key >= t_lo && key < t_hi) {
                 if (n_eq == take_eq) sel = true;
                 else {
                     const int me = sorted_idx[lpos[i]];
                     int rank = 0;
                     for (int t = 0; t < n; ++t) {
                         const int jt = lpos[t];
-                        const double tx = sx[jt] - cx, ty = sy[jt] - cy, tz = sz[jt] - cz;
-                        if (PCREG_KEY(tx, ty, tz) == vK && sorted_idx[jt] < me) ++rank;
+                        double tx, ty, tz;
+                        PCREG_LOAD_REL(jt, tx, ty, tz)
+                        const unsigned long long kt = PCREG_KEY(tx, ty, tz);
+                        if (kt >= t_lo && kt < t_hi && sorted_idx[jt] < me) ++rank;
                     }
                     sel = rank < take_eq;
                 }
@@ -547,6 +690,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
             mo[3] += x * x; mo[4] += x * y; mo[5] += x * z; mo[6] += y * y; mo[7] += y * z; mo[8] += z * z;
         })
     bsum_n<9>(mo, s_redn);
+    if (dbg_stop == 7) return;
     const double dx = mo[0] / K, dy = mo[1] / K, dz = mo[2] / K;
     const double mx = gx + dx, my = gy + dy, mz = gz + dz;
     double cv[6] = {mo[3] - K * dx * dx, mo[4] - K * dx * dy, mo[5] - K * dx * dz, mo[6] - K * dy * dy, mo[7] - K * dy * dz, mo[8] - K * dz * dz};
@@ -572,7 +716,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         }
     }
     __syncthreads();
-    if (!s_ok) return;
+    if (!s_ok || dbg_stop == 8) return;
     double cu[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) cu[k] = s_m[k];
@@ -581,20 +725,49 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     // needs its transcendental -- or even the square root and the division -- for the bin:
     //  * r's bin from d2 = x^2 + y^2 + z^2 against the exact squared images of the edges (Edges::r2ge);
     //  * phi only depends on the sign of y (two constants, binned once);
-    //  * theta's bin from z |z| against cos(edge) |cos(edge)| d2, both monotone images of z / r and cos(edge), unless the
-    //    two are within 1e-12 d2 of each other (then |z / r - cos(edge)| could be below the 1e-13 that keeps the computed
-    //    acos on its side of the edge, |acos'| >= 1) or the point is within 1e-6 rad of the z axis: those points, and
-    //    any with y == 0, take the literal path (sqrt, division, fp64 acos / atan2).
+    //  * theta's bin from z |z| against cos(edge) |cos(edge)| d2, both monotone images of z / r and cos(edge).
     // With ALIGN_POINTS the vote and the histogram share ONE pass.  The vote only flips signs: column 0 by xs, column 2
     // by zs, and column 1 is scaled by ys = det(the flipped matrix) (:53) = xs zs det(the unflipped one) -- every term of
     // the determinant holds one entry of each column, so the flips factor out of the rounded expression exactly.  The
     // pass therefore bins every point in the frame (c0, c1 det0, c2), whose coordinates are the final ones up to the
     // signs (xs, xs zs, zs), bit for bit, and the row is written through the permutation the signs induce: theta's bins
-    // mirror (the edges are symmetric to rounding, which the 1e-12 band covers), phi's two populated bins swap.  Points
-    // that are not safe are deferred and binned literally in the final frame.
+    // mirror, phi's two populated bins swap.
+    // Round 3: that pass runs in fp32 -- the point relative to the keypoint from the fp32 copies (4-byte gathers instead of
+    // 8), rotation and bin tests at the full vector rate -- as a SCREEN: every comparison carries the bound of its fp32
+    // error (e_rot per rotated coordinate: input error dlt per coordinate, 3 products and 2 sums at one ulp each on
+    // |p| <= R, the matrix entries rounded to fp32), and a point whose comparisons do not all clear their bound is deferred
+    // and binned literally in fp64 (sqrt, division, acos / atan2) in the final frame, as is any vote whose sign fp32 cannot
+    // certify.  A cleared comparison has the sign of the exact one, so the counts are those of the all-fp64 form.
     const double ph_pos = atan2(1.0, 1.0), ph_neg = atan2(-1.0, -1.0);
     const int lp_pos = hist_loc<NP + 1>(ph_pos, ed.p), lp_neg = hist_loc<NP + 1>(ph_neg, ed.p);
-    auto bin_fast = [&](double x, double y, double z, bool& safe) -> int {
+    const float e_rot = 3.0f * dlt + 10.0f * u32 * R32;
+    // Few instructions per point matter here (the kernel is bound by VALU issue: 87 % busy, profiles/r03_pmc_desc_kernel.json):
+    //  * the radial bins are equal-volume, edge k = cbrt(k R^3 / NR): the bin is floor(t) + 1 with t = NR (r / R)^3, safe
+    //    when t keeps its integer part under the error of d2 (the rounded edges sit 1e-16 off this formula: inside the margin);
+    //  * the theta edges are symmetric about pi / 2 (cos(pi - x) = -cos x): three comparisons of z^2 with cos^2(edge) d2
+    //    count the edges between the point and its pole, the sign of z picks the side (near z = 0 both sides give bin 4).
+    const float k3 = (float)((double)NR / (R * R * R));
+    auto bin_fast32 = [&](float x, float y, float z, bool& safe) -> int {
+        const float xy2 = x * x + y * y; const float d2 = xy2 + z * z;
+        const float r = sqrtf(d2);
+        const float e_d2 = 3.5f * r * e_rot + 3.0f * e_rot * e_rot + 6.0f * u32 * d2;     // |d2 - exact|
+        const float t = d2 * r * k3;                                                        // NR (r / R)^3
+        const float e_t = t * (1.5f * e_d2 / d2 + 12.0f * u32) + 2e-6f;                    // d(r^3) / r^3 = 1.5 d(d2) / d2
+        const float fr = t - floorf(t);
+        safe = fabsf(y) > e_rot && fr > e_t && fr < 1.0f - e_t && t < (float)NR - e_t && d2 > e_d2;
+        const int lr = (int)t + 1;
+        const float a = z * z;
+        const float e_a = 2.0f * r * e_rot + e_rot * e_rot + e_d2 + 4.0f * u32 * d2;        // |(z^2 - c^2 d2) - exact|, c^2 <= 1
+        int m = 0;
+#pragma unroll
+        for (int jj = 1; jj <= 3; ++jj) { const float dl = a - e32.cts[jj] * d2; safe = safe && fabsf(dl) > e_a; m += dl < 0.0f; }
+        const int lt = z >= 0.0f ? 1 + m : 7 - m;
+        const int lp = y > 0.0f ? lp_pos : lp_neg;
+        return (lr >= 1 && lr <= NR && lp > 0) ? (lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1) : -1;
+    };
+    // a deferred point is first binned with the fp64 images (no transcendental); only inside THEIR 1e-12 band -- where the
+    // computed acos could land on the other side of an edge -- it takes the literal path
+    auto bin_fast64 = [&](double x, double y, double z, bool& safe) -> int {
         const double xy2 = x * x + y * y; const double d2 = xy2 + z * z;
         const double zq = z * fabs(z);
         safe = xy2 > 1e-12 * d2 && y != 0.0;
@@ -617,24 +790,67 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         const int lt = hist_loc<NT + 1>(acos(u), ed.t), lr = hist_loc<NR + 1>(r, ed.r), lp = hist_loc<NP + 1>(atan2(y, y), ed.p);
         return (lr > 0 && lt > 0 && lp > 0) ? (lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1) : -1;
     };
-    uint32_t* row = rows + (size_t)s * ND;
+    // the fp32 pass over the support: ax/ay/az = the point relative to the keypoint in fp32 (SM 1: exactly pts_rel)
+#define PCREG_MY_PTS32(...)                                                                          \
+    for (int i0_ = tid, r0_ = 0; i0_ < n; i0_ += kD32 * kBlock, r0_ += kD32) {                       \
+        float X_[kD32], Y_[kD32], Z_[kD32];                                                          \
+        _Pragma("unroll") for (int u_ = 0; u_ < kD32; ++u_) {                                        \
+            const int j_ = lpos[min(i0_ + u_ * kBlock, n - 1)];                                      \
+            { const float4 t4_ = f4[j_]; X_[u_] = t4_.x; Y_[u_] = t4_.y; Z_[u_] = t4_.z; }                  \
+        }                                                                                            \
+        _Pragma("unroll") for (int u_ = 0; u_ < kD32; ++u_) {                                        \
+            const int i = i0_ + u_ * kBlock, pr = r0_ + u_;                                          \
+            if (i < n) {                                                                             \
+                const float ax = X_[u_] - cxf, ay = Y_[u_] - cyf, az = Z_[u_] - czf;                 \
+                const bool psel = (selmask >> pr) & 1u; (void)psel; (void)i;                         \
+                __VA_ARGS__                                                                          \
+            }                                                                                        \
+        }                                                                                            \
+    }
     bool permuted = false;
+    double xs = 1.0, zs = 1.0;
     if (o.ALIGN_POINTS) {
         const double det0 = cu[0] * (cu[4] * cu[8] - cu[5] * cu[7]) - cu[1] * (cu[3] * cu[8] - cu[5] * cu[6]) + cu[2] * (cu[3] * cu[7] - cu[4] * cu[6]);
         const double c1x = cu[1] * det0, c1y = cu[4] * det0, c1z = cu[7] * det0;
+        const float f0 = (float)cu[0], f3 = (float)cu[3], f6 = (float)cu[6], f2 = (float)cu[2], f5 = (float)cu[5], f8 = (float)cu[8];
+        const float g1x = (float)c1x, g1y = (float)c1y, g1z = (float)c1z;
+        const float mxf = (float)mx, myf = (float)my, mzf = (float)mz;
+        // a vote's dot product runs on (p - mean): one more fp32 rounding per coordinate on values up to 2 R
+        const float e_vote = 3.0f * (dlt + 4.0f * u32 * R32) + 12.0f * u32 * (2.0f * R32);
         int votes = 0;                              // vx | vz << 16 (K <= n <= 8191)
-        PCREG_MY_PTS(
+        PCREG_MY_PTS32(
+            bool need = false;
             if (psel) {
+                const float x = ax - mxf, y = ay - myf, z = az - mzf;
+                const float vx = x * f0 + y * f3 + z * f6, vz = x * f2 + y * f5 + z * f8;
+                if (fabsf(vx) > e_vote && fabsf(vz) > e_vote) votes += (vx > 0.0f ? 1 : 0) + (vz > 0.0f ? 1 << 16 : 0);
+                else need = true;
+            }
+            if (need) { const int qv = atomicAdd(&s_nvdef, 1); if (qv < kDef) s_vdef[qv] = i; }
+            const float x0 = ax * f0 + ay * f3 + az * f6, y0 = ax * g1x + ay * g1y + az * g1z, z0 = ax * f2 + ay * f5 + az * f8;
+            bool safe; const int bb = bin_fast32(x0, y0, z0, safe);
+            if (safe) { if (bb >= 0) atomicAdd(&s_cnt[bb], 1u); }
+            else { const int q = atomicAdd(&s_ndef, 1); if (q < kDef) s_def[q] = i; })
+        __syncthreads();                            // completes s_cnt, s_ndef, s_nvdef
+        const int nvdef = s_nvdef;
+        if (nvdef <= kDef) {                        // the votes fp32 could not certify: the fp64 expressions
+            for (int qv = tid; qv < nvdef; qv += kBlock) {
+                double px, py, pz;
+                PCREG_LOAD_REL(lpos[s_vdef[qv]], px, py, pz)
                 const double x = px - mx, y = py - my, z = pz - mz;
                 votes += ((x * cu[0] + y * cu[3] + z * cu[6]) > 0 ? 1 : 0) + ((x * cu[2] + y * cu[5] + z * cu[8]) > 0 ? 1 << 16 : 0);
             }
-            const double x0 = px * cu[0] + py * cu[3] + pz * cu[6], y0 = px * c1x + py * c1y + pz * c1z, z0 = px * cu[2] + py * cu[5] + pz * cu[8];
-            bool safe; const int bb = bin_fast(x0, y0, z0, safe);
-            if (safe) { if (bb >= 0) atomicAdd(&s_cnt[bb], 1u); }
-            else { const int q = atomicAdd(&s_ndef, 1); if (q < kDef) s_def[q] = i; })
-        votes = bsum_i(votes, s_redi);              // its barriers also complete s_cnt and s_ndef
+        } else {                                    // (never seen: a support whose kept points all sit on the frame's planes) all votes in fp64
+            votes = 0;
+            PCREG_MY_PTS(
+                if (psel) {
+                    const double x = px - mx, y = py - my, z = pz - mz;
+                    votes += ((x * cu[0] + y * cu[3] + z * cu[6]) > 0 ? 1 : 0) + ((x * cu[2] + y * cu[5] + z * cu[8]) > 0 ? 1 << 16 : 0);
+                })
+        }
+        votes = bsum_i(votes, s_redi);
         const int vx = votes & 0xFFFF, vz = votes >> 16;
-        double xs = (2.0 * vx >= (double)K) ? 1.0 : -1.0, zs = (2.0 * vz >= (double)K) ? 1.0 : -1.0;
+        xs = (2.0 * vx >= (double)K) ? 1.0 : -1.0; zs = (2.0 * vz >= (double)K) ? 1.0 : -1.0;
         double M[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r) { M[r * 3] = cu[r * 3] * xs; M[r * 3 + 1] = cu[r * 3 + 1]; M[r * 3 + 2] = cu[r * 3 + 2] * zs; }
@@ -642,50 +858,70 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
 #pragma unroll
         for (int r = 0; r < 3; ++r) { cu[r * 3] = cu[r * 3] * xs; cu[r * 3 + 1] = cu[r * 3 + 1] * ys; cu[r * 3 + 2] = cu[r * 3 + 2] * zs; }
         if (dbg_stop == 3) return;
-        const int ndef = s_ndef;
-        if (ndef <= kDef) {
-            permuted = true;
-            for (int i = tid; i < ND; i += kBlock) {
-                const int lr1 = i % NR, lt1 = (i / NR) % NT, lp1 = i / (NR * NT);
-                const int st = zs < 0.0 ? NT - 1 - lt1 : lt1;
-                int sp = lp1;
-                if (xs * zs < 0.0) sp = lp1 == lp_pos - 1 ? lp_neg - 1 : (lp1 == lp_neg - 1 ? lp_pos - 1 : lp1);
-                row[i] = s_cnt[lr1 + NR * st + NR * NT * sp];
-            }
+        permuted = s_ndef <= kDef;
+        if (!permuted) {                            // too many deferred points: bin everything again, literally, in the final frame
             __syncthreads();
-            for (int q = tid; q < ndef; q += kBlock) {
-                const int j = lpos[s_def[q]];
-                const double px = sx[j] - cx, py = sy[j] - cy, pz = sz[j] - cz;
-                const int bb = bin_literal(px * cu[0] + py * cu[3] + pz * cu[6], px * cu[1] + py * cu[4] + pz * cu[7], px * cu[2] + py * cu[5] + pz * cu[8]);
-                if (bb >= 0) atomicAdd(&row[bb], 1u);
-            }
-        } else {                                    // too many deferred points: bin everything again in the final frame
+            for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
+            __syncthreads();
+        }
+    } else {
+        // no alignment: the points are binned as they are (identity frame); same screen, deferred points literally
+        PCREG_MY_PTS32(
+            bool safe; const int bb = bin_fast32(ax, ay, az, safe);
+            if (safe) { if (bb >= 0) atomicAdd(&s_cnt[bb], 1u); }
+            else { const int q = atomicAdd(&s_ndef, 1); if (q < kDef) s_def[q] = i; })
+        __syncthreads();
+        permuted = s_ndef <= kDef;                  // (identity permutation: xs = zs = 1)
+        if (!permuted) {
             for (int i = tid; i < ND; i += kBlock) s_cnt[i] = 0u;
             __syncthreads();
         }
     }
-    if (!permuted) {
+    if (permuted) {
+        // the deferred points: literally, in the final frame, into the bins of the UNPERMUTED histogram's image
+        const int ndef = s_ndef;
+        unsigned* s_fin = reinterpret_cast<unsigned*>(&s_mask[0][0]);     // the collection's ballots are dead: 5 KiB >= 980 words
+        static_assert(sizeof(unsigned long long) * 4 * kMaskCap >= sizeof(unsigned) * ND, "s_fin aliases s_mask");
+        for (int i = tid; i < ND; i += kBlock) {
+            const int lr1 = i % NR, lt1 = (i / NR) % NT, lp1 = i / (NR * NT);
+            const int st = zs < 0.0 ? NT - 1 - lt1 : lt1;
+            int sp = lp1;
+            if (xs * zs < 0.0) sp = lp1 == lp_pos - 1 ? lp_neg - 1 : (lp1 == lp_neg - 1 ? lp_pos - 1 : lp1);
+            s_fin[i] = s_cnt[lr1 + NR * st + NR * NT * sp];
+        }
+        __syncthreads();
+        for (int q = tid; q < ndef; q += kBlock) {
+            double px, py, pz;
+            PCREG_LOAD_REL(lpos[s_def[q]], px, py, pz)
+            double x = px, y = py, z = pz;
+            if (o.ALIGN_POINTS) { x = px * cu[0] + py * cu[3] + pz * cu[6]; y = px * cu[1] + py * cu[4] + pz * cu[7]; z = px * cu[2] + py * cu[5] + pz * cu[8]; }
+            bool safe64; int bb = bin_fast64(x, y, z, safe64);
+            if (!safe64) bb = bin_literal(x, y, z);
+            if (bb >= 0) atomicAdd(&s_fin[bb], 1u);
+        }
+        __syncthreads();
+        // ONE write of the finished row, in its final type (u16 rows: counts <= max_pts <= 65535)
+        if (rows_u16) { uint16_t* row = (uint16_t*)rows_out + (size_t)s * ND; for (int i = tid; i < ND; i += kBlock) row[i] = (uint16_t)s_fin[i]; }
+        else { uint32_t* row = (uint32_t*)rows_out + (size_t)s * ND; for (int i = tid; i < ND; i += kBlock) row[i] = s_fin[i]; }
+    } else {
         PCREG_MY_PTS(
             double x = px; double y = py; double z = pz;
             if (o.ALIGN_POINTS) { x = px * cu[0] + py * cu[3] + pz * cu[6]; y = px * cu[1] + py * cu[4] + pz * cu[7]; z = px * cu[2] + py * cu[5] + pz * cu[8]; }
-            bool safe; int bb = bin_fast(x, y, z, safe);
-            if (!safe) bb = bin_literal(x, y, z);
+            bool safe64; int bb = bin_fast64(x, y, z, safe64);
+            if (!safe64) bb = bin_literal(x, y, z);
             if (bb >= 0) atomicAdd(&s_cnt[bb], 1u);)
         __syncthreads();
-        for (int i = tid; i < ND; i += kBlock) row[i] = s_cnt[i];
+        if (rows_u16) { uint16_t* row = (uint16_t*)rows_out + (size_t)s * ND; for (int i = tid; i < ND; i += kBlock) row[i] = (uint16_t)s_cnt[i]; }
+        else { uint32_t* row = (uint32_t*)rows_out + (size_t)s * ND; for (int i = tid; i < ND; i += kBlock) row[i] = s_cnt[i]; }
     }
     if (tid == 0) valid[s] = 1;
 #undef PCREG_MY_PTS
+#undef PCREG_MY_PTS32
+#undef PCREG_LOAD_REL
 }
 
-// the smallest double t with sqrt(t) >= r under IEEE round-to-nearest (host; r > 0 finite): sqrt(d2) < r <=> d2 < t
-static double sqrt_threshold(double r) {
-    if (!(r > 0.0) || !std::isfinite(r)) return r > 0.0 ? r : 0.0;       // r <= 0 or NaN: nothing is inside; +inf: everything finite
-    double t = r * r;
-    while (t > 0.0 && std::sqrt(t) >= r) t = std::nextafter(t, 0.0);
-    while (std::sqrt(t) < r) t = std::nextafter(t, INFINITY);
-    return t;
-}
+// the bin edges are computed on the HOST (the oracle's libm values) and parked in the workspace by one thread
+__global__ void edges_store_kernel(Edges ed, Edges* __restrict__ out) { *out = ed; }
 
 // ---- compaction of the surviving rows (:177-179) ----------------------------------------------
 __global__ void desc_count_kernel(const int32_t* __restrict__ valid, int S, int32_t* __restrict__ block_cnt) {
@@ -710,38 +946,58 @@ __global__ void desc_slot_kernel(const int32_t* __restrict__ valid, int S, const
     for (int w = 0; w < wave; ++w) base += s_c[w];
     if (s < S) slot[s] = kp ? base + __popcll(b & ((1ull << lane) - 1ull)) : -1;
 }
-template <typename OutT>
-__global__ __launch_bounds__(kBlock) void desc_emit_kernel(const uint32_t* __restrict__ rows, const int32_t* __restrict__ slot,
+// desc != nullptr: the MATLAB-shaped output -- row v of desc = the v-th surviving keypoint's counts as doubles (from the
+// u16 staging rows; counts <= the support size <= 8191).  desc == nullptr: the rows stay where desc_kernel wrote them (row s =
+// keypoint s) and row_index[v] = s lists the survivors.  feat rows are compact either way.
+__global__ __launch_bounds__(kBlock) void desc_emit_kernel(const uint16_t* __restrict__ rows, const int32_t* __restrict__ slot,
                                                            const double* __restrict__ kp, int S, int ldk,
-                                                           double* __restrict__ feat, OutT* __restrict__ desc) {
+                                                           double* __restrict__ feat, double* __restrict__ desc,
+                                                           int32_t* __restrict__ row_index) {
     const int s = blockIdx.x;
     const int v = slot[s];
     if (v < 0) return;
-    const uint32_t* row = rows + (size_t)s * ND;
-    OutT* out = desc + (size_t)v * ND;
-    for (int i = threadIdx.x; i < ND; i += kBlock) out[i] = (OutT)row[i];     // counts <= max_pts: exact in either type
+    if (desc) {
+        const uint16_t* row = rows + (size_t)s * ND;
+        double* out = desc + (size_t)v * ND;
+        for (int i = threadIdx.x; i < ND; i += kBlock) out[i] = (double)row[i];
+    }
     if (threadIdx.x < 3) feat[(size_t)v * 3 + threadIdx.x] = kp[s + (size_t)threadIdx.x * ldk];
+    if (row_index && threadIdx.x == 0) row_index[v] = s;
+}
+// the index form needs no pass over the rows: one thread per keypoint
+__global__ void desc_index_kernel(const int32_t* __restrict__ slot, const double* __restrict__ kp, int S, int ldk,
+                                  double* __restrict__ feat, int32_t* __restrict__ row_index) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int v = slot[s];
+    if (v < 0) return;
+    for (int c = 0; c < 3; ++c) feat[(size_t)v * 3 + c] = kp[s + (size_t)c * ldk];
+    row_index[v] = s;
 }
 
 }  // namespace
 
-// workspace: Grid | bbox partials | cell_total | cell_start | cell_id [P] | counts [tiles][kMaxCells]
-//            | sorted_idx [P] | sx sy sz [P] | rows u32 [S][980] | valid [S] | slot [S] | block counters
-//            | keypoint cell counts / starts / fill | keypoint cell [S] | perm [S]
+// workspace: Grid | Edges | bbox partials | cell_total | cell_start | cell_id [P] | counts [tiles][kMaxCells]
+//            | sorted_idx [P] | sx sy sz [P] (f64) | f4 [P] (float4) | staging rows u16 [S][980] | valid [S] | slot [S]
+//            | block counters | keypoint cell counts / starts / fill | keypoint cell [S] | perm [S]
 size_t descriptors_workspace_bytes(int P, int S) {
     size_t p = (size_t)(P > 0 ? P : 1), s = (size_t)(S > 0 ? S : 1);
     size_t tiles = (p + kSortTile - 1) / kSortTile;
-    return 256 + align_up(512 * 6 * 8, 256) + 2 * align_up(((size_t)kMaxCells + 1) * 4, 256) + align_up(p * 4, 256) +
-           align_up(tiles * kMaxCells * 4, 256) + align_up(p * 4, 256) + 3 * align_up(p * 8, 256) +
-           align_up(s * ND * 4, 256) + 2 * align_up(s * 4, 256) + align_up((s / 256 + 2) * 4, 256) +
+    return 256 + 1024 + align_up(512 * 6 * 8, 256) + 2 * align_up(((size_t)kMaxCells + 1) * 4, 256) + align_up(p * 4, 256) +
+           align_up(tiles * kMaxCells * 4, 256) + align_up(p * 4, 256) + 3 * align_up(p * 8, 256) + align_up(p * 16, 256) +
+           align_up(s * ND * 2, 256) + 2 * align_up(s * 4, 256) + align_up((s / 256 + 2) * 4, 256) +
            3 * align_up(((size_t)kMaxCells + 1) * 4, 256) + 2 * align_up(s * 4, 256);
 }
 
-int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o,
-                       double* feat, void* desc, bool desc_u16, int32_t* V_dev, int32_t* err_dev, void* ws, size_t ws_bytes,
-                       hipStream_t st) {
-    PCREG_ARG(P >= 0 && S >= 0 && o.R > 0 && o.k > 0 && o.min_pts >= 0);
-    if (desc_u16 && o.max_pts > 65535) { set_error("u16 descriptor rows need max_pts <= 65535 (a count can reach max_pts)"); return PCREG_E_ARG; }
+// single_mode: 0 = double data; 1 = single data, keypoints single; 2 = single cloud, double keypoints (MATLAB: "single wins",
+// but getLocalPoints.m:8-10's xLim = c + [-R, R] is then formed in double).  The inputs are double arrays either way
+// (single data widened exactly).  Output forms: desc_f64 (compact doubles, MATLAB's shape) or rows_u16 + row_index (rows in
+// keypoint order, written ONCE by desc_kernel, + the ascending list of the survivors).
+int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S, int ldk, const pcreg_desc_opts& o, int single_mode,
+                       double* feat, double* desc_f64, uint16_t* rows_u16, int32_t* row_index, int32_t* V_dev, int32_t* err_dev,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+    PCREG_ARG(P >= 0 && S >= 0 && o.R > 0 && o.k > 0 && o.min_pts >= 0 && single_mode >= 0 && single_mode <= 2);
+    PCREG_ARG((desc_f64 != nullptr) != (rows_u16 != nullptr) && (rows_u16 == nullptr || row_index != nullptr));
     PCREG_HIP(hipMemsetAsync(V_dev, 0, sizeof(int32_t), st));
     PCREG_HIP(hipMemsetAsync(err_dev, 0, sizeof(int32_t), st));
     if (S == 0 || P == 0) return PCREG_OK;
@@ -751,6 +1007,8 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     const int tiles = (P + kSortTile - 1) / kSortTile;
     char* w = (char*)ws;
     Grid* grid = (Grid*)w;                  w += 256;
+    Edges* edges_dev = (Edges*)w;           w += 1024;
+    static_assert(sizeof(Edges) <= 1024, "Edges fits its slot");
     double* bpart = (double*)w;             w += align_up(512 * 6 * 8, 256);
     int32_t* cell_total = (int32_t*)w;      w += align_up(((size_t)kMaxCells + 1) * 4, 256);
     int32_t* cell_start = (int32_t*)w;      w += align_up(((size_t)kMaxCells + 1) * 4, 256);
@@ -760,7 +1018,8 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     double* sx = (double*)w;                w += align_up(p * 8, 256);
     double* sy = (double*)w;                w += align_up(p * 8, 256);
     double* sz = (double*)w;                w += align_up(p * 8, 256);
-    uint32_t* rows = (uint32_t*)w;          w += align_up(s * ND * 4, 256);
+    float4* f4 = (float4*)w;                w += align_up(p * 16, 256);
+    uint16_t* stage = (uint16_t*)w;         w += align_up(s * ND * 2, 256);
     int32_t* valid = (int32_t*)w;           w += align_up(s * 4, 256);
     int32_t* slot = (int32_t*)w;            w += align_up(s * 4, 256);
     int32_t* bcnt = (int32_t*)w;            w += align_up((s / 256 + 2) * 4, 256);
@@ -778,7 +1037,7 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     hipLaunchKernelGGL(grid_cell_prefix_kernel, dim3((kMaxCells + 1 + 255) / 256), dim3(256), 0, st, counts, tiles, grid, cell_total);
     hipLaunchKernelGGL(grid_cell_scan_kernel, dim3(1), dim3(256), 0, st, cell_total, cell_start);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(tiles), dim3(kBlock), 0, st, pts, P, ld, cell_id, counts, cell_start,
-                       sorted_idx, sx, sy, sz);
+                       sorted_idx, sx, sy, sz, (const Grid*)grid, single_mode != 0 ? 1 : 0, f4);
     // keypoints in cell order (kc_total | kc_start | kc_fill are contiguous: one memset)
     PCREG_HIP(hipMemsetAsync(kc_total, 0, 3 * align_up(((size_t)kMaxCells + 1) * 4, 256), st));
     hipLaunchKernelGGL(kp_count_kernel, dim3((S + 255) / 256), dim3(256), 0, st, kp, S, ldk, grid, kcell, kc_total);
@@ -786,28 +1045,40 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     hipLaunchKernelGGL(kp_scatter_kernel, dim3((S + 255) / 256), dim3(256), 0, st, kcell, S, kc_start, kc_fill, perm);
     PCREG_HIP(hipGetLastError());
 
-    Edges ed;
+    Edges ed; Edges32 e32;
     const double r3 = o.R * o.R * o.R, pi = 3.14159265358979323846;
     for (int k = 0; k <= NR; ++k) ed.r[k] = cbrt(k * (r3 / NR));                 // nthroot(0:R^3/10:R^3, 3)
     for (int k = 0; k <= NT; ++k) { ed.t[k] = k * (pi / NT); ed.ct[k] = cos(ed.t[k]); ed.cts[k] = ed.ct[k] * fabs(ed.ct[k]); }   // 0:pi/7:pi
     for (int k = 0; k <= NR; ++k) ed.r2ge[k] = sqrt_threshold(ed.r[k]);
     ed.r2gt = sqrt_threshold(std::nextafter(ed.r[NR], INFINITY));
     for (int k = 0; k <= NP; ++k) ed.p[k] = -pi + k * (2 * pi / NP);             // -pi:2*pi/14:pi
+    for (int k = 0; k <= NR; ++k) e32.r2ge[k] = (float)ed.r2ge[k];
+    e32.r2gt = (float)ed.r2gt;
+    for (int k = 0; k <= NT; ++k) e32.cts[k] = (float)ed.cts[k];
     int cap = o.max_pts < 8190 ? o.max_pts + 1 : 8191;
     if (cap < 64) cap = 64;
     size_t lds = (size_t)cap * sizeof(int);
-    PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int xcd_chunk = PCREG_EXP_ENV("PCREG_DESC_XCD", 1) ? (S + 7) / 8 : 0;
     const double R2T = sqrt_threshold(o.R);
-    hipLaunchKernelGGL(desc_kernel, dim3(xcd_chunk ? 8 * xcd_chunk : S), dim3(kBlock), lds, st, sx, sy, sz, sorted_idx, cell_start, grid, kp, perm, S, ldk, o,
-                       ed, R2T, cap, PCREG_EXP_ENV("PCREG_DESC_STOP", 0), xcd_chunk, rows, valid, err_dev);
+    hipLaunchKernelGGL(edges_store_kernel, dim3(1), dim3(1), 0, st, ed, edges_dev);
+    void* rows_out = rows_u16 ? (void*)rows_u16 : (void*)stage;
+    const int dbg = PCREG_EXP_ENV("PCREG_DESC_STOP", 0);
+    if (single_mode) {
+        PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(desc_kernel<1>, dim3(xcd_chunk ? 8 * xcd_chunk : S), dim3(kBlock), lds, st, sx, sy, sz, (const float4*)f4, sorted_idx, cell_start, grid, kp, perm,
+                           S, ldk, o, (const Edges*)edges_dev, e32, R2T, single_mode == 1 ? 1 : 0, cap, dbg, xcd_chunk, rows_out, 1, valid, err_dev);
+    } else {
+        PCREG_HIP(hipFuncSetAttribute((const void*)desc_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(desc_kernel<0>, dim3(xcd_chunk ? 8 * xcd_chunk : S), dim3(kBlock), lds, st, sx, sy, sz, (const float4*)f4, sorted_idx, cell_start, grid, kp, perm,
+                           S, ldk, o, (const Edges*)edges_dev, e32, R2T, 0, cap, dbg, xcd_chunk, rows_out, 1, valid, err_dev);
+    }
     PCREG_HIP(hipGetLastError());
     const int nbs = (S + 255) / 256;
     hipLaunchKernelGGL(desc_count_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bcnt, nbs, V_dev);
     hipLaunchKernelGGL(desc_slot_kernel, dim3(nbs), dim3(256), 0, st, valid, S, bcnt, slot);
-    if (desc_u16) hipLaunchKernelGGL(desc_emit_kernel<uint16_t>, dim3(S), dim3(kBlock), 0, st, rows, slot, kp, S, ldk, feat, (uint16_t*)desc);
-    else hipLaunchKernelGGL(desc_emit_kernel<double>, dim3(S), dim3(kBlock), 0, st, rows, slot, kp, S, ldk, feat, (double*)desc);
+    if (desc_f64) hipLaunchKernelGGL(desc_emit_kernel, dim3(S), dim3(kBlock), 0, st, (const uint16_t*)stage, slot, kp, S, ldk, feat, desc_f64, row_index);
+    else hipLaunchKernelGGL(desc_index_kernel, dim3(nbs), dim3(256), 0, st, slot, kp, S, ldk, feat, row_index);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -489,15 +489,17 @@ int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hi
     return PCREG_OK;
 }
 
-// dense u16 rows [n][D] (the descriptor entry's compact output) -> feature-major doubles [D][n]: counts are exact in both
-__global__ __launch_bounds__(kBlock) void widen_rows_u16_kernel(const uint16_t* __restrict__ rows, int n, int D, double* __restrict__ out) {
+// u16 rows [.][D] (the descriptor entry's rows, written once in keypoint order) -> feature-major doubles [D][n]: counts are
+// exact in both.  index (or null = identity): row i of the output is rows[index[i]] -- the list of surviving keypoints.
+__global__ __launch_bounds__(kBlock) void widen_rows_u16_kernel(const uint16_t* __restrict__ rows, const int32_t* __restrict__ index, int n, int D,
+                                                                double* __restrict__ out) {
     __shared__ uint16_t tile[64][66];
     const int i0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int i = i0 + ty + 4 * k, d = d0 + tx;
-        tile[ty + 4 * k][tx] = (i < n && d < D) ? rows[(size_t)i * D + d] : (uint16_t)0;
+        tile[ty + 4 * k][tx] = (i < n && d < D) ? rows[(size_t)(index ? index[i] : i) * D + d] : (uint16_t)0;
     }
     __syncthreads();
 #pragma unroll
@@ -506,9 +508,9 @@ __global__ __launch_bounds__(kBlock) void widen_rows_u16_kernel(const uint16_t* 
         if (i < n && d < D) out[i + (size_t)d * n] = (double)tile[tx][ty + 4 * k];
     }
 }
-int launch_widen_rows_u16(const uint16_t* rows, int n, int D, double* featmajor, hipStream_t st) {
+int launch_widen_rows_u16(const uint16_t* rows, const int32_t* index, int n, int D, double* featmajor, hipStream_t st) {
     if (n <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(widen_rows_u16_kernel, dim3((n + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, rows, n, D, featmajor);
+    hipLaunchKernelGGL(widen_rows_u16_kernel, dim3((n + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, rows, index, n, D, featmajor);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -207,6 +207,18 @@ class RegistrationPipeline:
                     failed=bool(r.failed), n=r.n, winner=r.winner, inlierIdx=self.inliers[:r.n_inliers].cpu().numpy())
 
 
+class U16Rows:
+    """Descriptor rows as the kernel leaves them: uint16 counts [S, 980] in keypoint order + the ascending list of the
+    surviving keypoints (pcreg_dev_spatial_histogram_descriptors_rows_u16)."""
+
+    def __init__(self, rows: torch.Tensor, index: torch.Tensor):
+        self.rows, self.index = rows, index
+
+    def compact(self, V: int) -> torch.Tensor:
+        """[V, 980] uint16: the survivors' rows in order (a copy; for inspection and tests)."""
+        return self.rows.view(torch.int16)[self.index[:V].long()].view(torch.uint16)      # (torch cannot index uint16 tensors)
+
+
 class DescriptorPipeline:
     """One sphere position of completeExperimentFast.m:131-213, resident in HBM:
     getSpacialHistogramDescriptors (surface + model) -> getMatches -> matched keypoints -> ransac.
@@ -228,26 +240,38 @@ class DescriptorPipeline:
             t = self._ws[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.dev)
         return t
 
-    def describe(self, pts: torch.Tensor, sample_pts: torch.Tensor, options: dict, compact: bool = False):
-        """-> (feat [S,3], desc [S,980], V): rows < V are the surviving keypoints in sample order.
-        compact: the counts as uint16 (a quarter of the bytes; `match` takes either)."""
+    def describe(self, pts: torch.Tensor, sample_pts: torch.Tensor, options: dict, compact: bool = False, single_mode: int = 0):
+        """-> (feat [S,3], desc, V): rows < V of feat are the surviving keypoints in sample order.
+        compact=False: desc [S,980] float64, rows < V compact (MATLAB's shape).
+        compact=True: desc is a U16Rows -- the counts as uint16 rows in KEYPOINT order, written once by the kernel, plus the
+        list of the V survivors (a quarter of the bytes and no staging copy; `match` takes it as it is).
+        single_mode: 0 double data; 1 / 2 `single` arithmetic for the support (include/pcreg.h), compact form only."""
         from .api import _desc_opts
         L = lib()
         o = _desc_opts(options)
         P, S = pts.shape[1], sample_pts.shape[1]
         feat = torch.empty((S, 3), dtype=torch.float64, device=self.dev)
-        desc = torch.empty((S, self.ND), dtype=torch.uint16 if compact else torch.float64, device=self.dev)
         counters = torch.zeros(2, dtype=torch.int32, device=self.dev)
         ws = self._workspace("desc", L.pcreg_dev_spatial_histogram_descriptors_workspace(P, S))
-        entry = L.pcreg_dev_spatial_histogram_descriptors_u16 if compact else L.pcreg_dev_spatial_histogram_descriptors
-        check(entry(_p(pts), P, pts.stride(0), _p(sample_pts), S, sample_pts.stride(0), C.byref(o), _p(feat), _p(desc), _p(counters), _p(ws),
-                    C.c_size_t(ws.numel()), _stream()))
+        if compact:
+            rows = torch.empty((S, self.ND), dtype=torch.uint16, device=self.dev)
+            index = torch.empty(S, dtype=torch.int32, device=self.dev)
+            check(L.pcreg_dev_spatial_histogram_descriptors_rows_u16(_p(pts), P, pts.stride(0), _p(sample_pts), S, sample_pts.stride(0), C.byref(o),
+                                                                     int(single_mode), _p(feat), _p(rows), _p(index), _p(counters), _p(ws),
+                                                                     C.c_size_t(ws.numel()), _stream()))
+            desc = U16Rows(rows, index)
+        else:
+            if single_mode:
+                raise ValueError("single_mode is implemented for the compact (uint16 rows) form and for the host tier")
+            desc = torch.empty((S, self.ND), dtype=torch.float64, device=self.dev)
+            check(L.pcreg_dev_spatial_histogram_descriptors(_p(pts), P, pts.stride(0), _p(sample_pts), S, sample_pts.stride(0), C.byref(o), _p(feat),
+                                                            _p(desc), _p(counters), _p(ws), C.c_size_t(ws.numel()), _stream()))
         V, overflow = (int(v) for v in counters.cpu())
         if overflow:
             raise ValueError(f"a support holds {overflow} points: more than an LDS-resident support may have (lower max_pts)")
         return feat, desc, V
 
-    def match(self, descS: torch.Tensor, VS: int, descM: torch.Tensor, VM: int, par: dict, pairs_out: torch.Tensor | None = None,
+    def match(self, descS, VS: int, descM, VM: int, par: dict, pairs_out: torch.Tensor | None = None,
               n_pairs_out: torch.Tensor | None = None, ws_cap: tuple | None = None):
         """-> (pairs [VS,2] int32 1-based, n_pairs device int32).  pairs_out / n_pairs_out: write into the caller's
         buffers (the batched sweep); ws_cap = (VS, VM) sizes the workspace once for a series of calls."""
@@ -256,15 +280,17 @@ class DescriptorPipeline:
         o = _match_opts(par)
         pairs = pairs_out if pairs_out is not None else torch.empty((max(VS, 1), 2), dtype=torch.int32, device=self.dev)
         n_pairs = n_pairs_out if n_pairs_out is not None else self.n_pairs
-        D = descS.shape[1]
         cap = ws_cap or (VS, VM)
-        ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(cap[0], cap[1], D))
-        if descS.dtype == torch.uint16:                 # compact descriptors (describe(..., compact=True)) on both sides
-            if descM.dtype != torch.uint16:
-                raise TypeError("compact (uint16) descriptors on one side only")
-            check(L.pcreg_dev_get_matches_u16(_p(descS), VS, _p(descM), VM, D, C.byref(o), _p(pairs), None, _p(n_pairs), _p(ws),
-                                              C.c_size_t(ws.numel()), _stream()))
+        if isinstance(descS, U16Rows) or isinstance(descM, U16Rows):        # uint16 rows + survivor lists on both sides
+            if not (isinstance(descS, U16Rows) and isinstance(descM, U16Rows)):
+                raise TypeError("uint16 rows on one side only")
+            D = descS.rows.shape[1]
+            ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(cap[0], cap[1], D))
+            check(L.pcreg_dev_get_matches_rows_u16(_p(descS.rows), _p(descS.index), VS, _p(descM.rows), _p(descM.index), VM, D, C.byref(o),
+                                                   _p(pairs), None, _p(n_pairs), _p(ws), C.c_size_t(ws.numel()), _stream()))
         else:
+            D = descS.shape[1]
+            ws = self._workspace("match", L.pcreg_dev_get_matches_workspace(cap[0], cap[1], D))
             check(L.pcreg_dev_get_matches(_p(descS), VS, D, _p(descM), VM, D, D, _l.LAYOUT_ROW_MAJOR,
                                           C.byref(o), _p(pairs), None, _p(n_pairs), _p(ws), C.c_size_t(ws.numel()),
                                           _stream()))

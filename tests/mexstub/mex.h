@@ -1,8 +1,8 @@
 /* tests/mexstub/mex.h -- TEST INFRASTRUCTURE, not a MATLAB compatibility claim.
  * A minimal stand-in for MATLAB's mex.h / matrix.h, just large enough to put
  * mex/pcreg_mex.cpp through a compiler (-Wall -Wextra) and to drive its mexFunction
- * from tests/mexstub/mex_driver.cpp: column-major numeric matrices (double, int32,
- * uint32), char row vectors, 1x1 structs with named fields.  mexErrMsgIdAndTxt does
+ * from tests/mexstub/mex_driver.cpp: column-major numeric matrices (double, single, int32,
+ * uint32, uint64, uint8), char row vectors, 1x1 structs with named fields.  mexErrMsgIdAndTxt does
  * not return (MATLAB longjmps; here it throws MexError), so the shim's "no C++ object
  * alive at the raise" rule is exercised too. */
 #ifndef PCREG_TEST_MEX_H
@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-typedef enum { mxDOUBLE_CLASS, mxSINGLE_CLASS, mxINT32_CLASS, mxUINT32_CLASS, mxUINT8_CLASS, mxCHAR_CLASS, mxSTRUCT_CLASS } mxClassID;
+typedef enum { mxDOUBLE_CLASS, mxSINGLE_CLASS, mxINT32_CLASS, mxUINT32_CLASS, mxUINT8_CLASS, mxUINT64_CLASS, mxCHAR_CLASS, mxSTRUCT_CLASS } mxClassID;
 typedef enum { mxREAL, mxCOMPLEX } mxComplexity;
 typedef size_t mwSize;
 
@@ -35,7 +35,7 @@ struct MexError {
 
 extern int g_mex_live_arrays;                        /* leak check: arrays created minus destroyed */
 
-inline size_t mx_elem_size(mxClassID c) { return c == mxDOUBLE_CLASS ? 8 : (c == mxINT32_CLASS || c == mxUINT32_CLASS || c == mxSINGLE_CLASS) ? 4 : 1; }
+inline size_t mx_elem_size(mxClassID c) { return (c == mxDOUBLE_CLASS || c == mxUINT64_CLASS) ? 8 : (c == mxINT32_CLASS || c == mxUINT32_CLASS || c == mxSINGLE_CLASS) ? 4 : 1; }
 inline mxArray* mxCreateNumericMatrix(size_t m, size_t n, mxClassID c, mxComplexity) {
     mxArray* a = new mxArray; a->cls = c; a->m = m; a->n = n; a->data.assign(m * n * mx_elem_size(c), 0); ++g_mex_live_arrays; return a;
 }
@@ -51,6 +51,9 @@ inline bool mxIsChar(const mxArray* a) { return a && a->cls == mxCHAR_CLASS; }
 inline bool mxIsInt32(const mxArray* a) { return a && a->cls == mxINT32_CLASS; }
 inline bool mxIsSingle(const mxArray* a) { return a && a->cls == mxSINGLE_CLASS; }
 inline bool mxIsUint8(const mxArray* a) { return a && a->cls == mxUINT8_CLASS; }
+inline bool mxIsUint64(const mxArray* a) { return a && a->cls == mxUINT64_CLASS; }
+inline bool mxIsDouble(const mxArray* a) { return a && a->cls == mxDOUBLE_CLASS; }
+inline mxArray* mxDuplicateArray(const mxArray* a) { mxArray* b = mxCreateNumericMatrix(a->m, a->n, a->cls, mxREAL); b->data = a->data; return b; }
 inline bool mxIsEmpty(const mxArray* a) { return !a || a->m * a->n == 0; }
 inline size_t mxGetM(const mxArray* a) { return a->m; }
 inline size_t mxGetN(const mxArray* a) { return a->n; }

@@ -118,20 +118,46 @@ int drv_align_points_knn_f32(const float* pts, int n, float* aligned, float* coe
     return 0;
 }
 
-int drv_descriptors_f32(const float* pts, int Pn, const float* kp, int S, const double* opts6, float* feat, float* desc, int* V, char* err, int errlen) {
+// each input in its own class (single or double); the outputs must be DOUBLE whatever the inputs (getSpacialHistogramDescriptors.m:61-62)
+int drv_descriptors_classes(const void* pts, int pts_single, int Pn, const void* kp, int kp_single, int S, const double* opts6, double* feat,
+                            double* desc, int* V, char* err, int errlen) {
     mxArray* o = mxCreateStructMatrix(1, 1, 0, nullptr);
     put(o, "min_pts", opts6[0]); put(o, "max_pts", opts6[1]); put(o, "R", opts6[2]);
     const double tv[2] = {opts6[3], opts6[4]};
     mxSetField(o, 0, "thVar", dmat(tv, 1, 2)); put(o, "ALIGN_POINTS", opts6[5]); mxSetField(o, 0, "k", mxCreateString("all")); put(o, "VERBOSE", 0);
-    std::vector<mxArray*> rhs{mxCreateString("getSpacialHistogramDescriptors"), fmat(pts, Pn, 3), fmat(kp, S, 3), o};
+    std::vector<mxArray*> rhs{mxCreateString("getSpacialHistogramDescriptors"),
+                              pts_single ? fmat((const float*)pts, Pn, 3) : dmat((const double*)pts, Pn, 3),
+                              kp_single ? fmat((const float*)kp, S, 3) : dmat((const double*)kp, S, 3), o};
     mxArray* lhs[2] = {nullptr, nullptr};
     if (call(2, lhs, rhs, err, errlen)) return 1;
-    if (!mxIsSingle(lhs[0]) || !mxIsSingle(lhs[1])) { snprintf(err, errlen, "outputs are not single"); return 1; }
+    if (!mxIsDouble(lhs[0]) || !mxIsDouble(lhs[1])) { snprintf(err, errlen, "feat / desc must be double whatever the input classes"); return 1; }
     *V = (int)mxGetM(lhs[0]);
-    memcpy(feat, mxGetData(lhs[0]), (size_t)*V * 3 * 4);
-    memcpy(desc, mxGetData(lhs[1]), (size_t)*V * mxGetN(lhs[1]) * 4);
+    memcpy(feat, mxGetPr(lhs[0]), (size_t)*V * 3 * 8);
+    memcpy(desc, mxGetPr(lhs[1]), (size_t)*V * mxGetN(lhs[1]) * 8);
     for (mxArray* a : lhs) mxDestroyArray(a);
     return 0;
+}
+
+// the prepared-model commands: modelCreate -> handle, modelMatchPoints x n_surfaces, modelDestroy
+int drv_model_round_trip(const float* model, int M, const float* surfaces /* n_surf x (Q x 3 col-major) */, int Q, int n_surf, float thr, float ratio,
+                         int unique, uint32_t* pairs_colmajor /* n_surf x (Q x 2) */, int* P /* n_surf */, char* err, int errlen) {
+    mxArray* lhs[1] = {nullptr};
+    { std::vector<mxArray*> rhs{mxCreateString("modelCreate"), fmat(model, M, 3)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* h = lhs[0]; lhs[0] = nullptr;
+    if (!mxIsUint64(h)) { snprintf(err, errlen, "the handle is not uint64"); return 1; }
+    int rc = 0;
+    for (int k = 0; k < n_surf && !rc; ++k) {
+        std::vector<mxArray*> rhs{mxCreateString("modelMatchPoints"), mxDuplicateArray(h), fmat(surfaces + (size_t)k * Q * 3, Q, 3), mxCreateDoubleScalar(thr),
+                                  mxCreateDoubleScalar(ratio), mxCreateDoubleScalar(unique)};
+        rc = call(1, lhs, rhs, err, errlen);
+        if (!rc) {
+            P[k] = (int)mxGetM(lhs[0]);
+            memcpy(pairs_colmajor + (size_t)k * Q * 2, mxGetData(lhs[0]), (size_t)P[k] * 2 * 4);
+            mxDestroyArray(lhs[0]); lhs[0] = nullptr;
+        }
+    }
+    { std::vector<mxArray*> rhs{mxCreateString("modelDestroy"), h}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    return rc;
 }
 
 // one-worker rehearsal of the spmd block of INTEGRATION.md section 3: setDevice, commId, commInit, matchPointsSharded,

@@ -101,8 +101,9 @@ def test_dev_get_matches_feature_major_layout_and_empty(oracle_c):
 
 
 def test_compact_u16_descriptors_give_the_same_chain(oracle_c):
-    """pcreg_dev_spatial_histogram_descriptors_u16 -> pcreg_dev_get_matches_u16: the counts as uint16 rows (a quarter
-    of the bytes) equal the double rows value for value, and the pairs are those of the double chain and the oracle."""
+    """pcreg_dev_spatial_histogram_descriptors_rows_u16 -> pcreg_dev_get_matches_rows_u16: the counts as uint16 rows in
+    keypoint order + the survivor list (a quarter of the bytes, written once) equal the double rows value for value, and the
+    pairs are those of the double chain and the oracle."""
     import torch
     from pcreg_amd.device import DescriptorPipeline, soa
     from pcreg_amd._lib import PcregError
@@ -115,14 +116,15 @@ def test_compact_u16_descriptors_give_the_same_chain(oracle_c):
     t = lambda a: soa(torch.from_numpy(np.ascontiguousarray(a)).to(dev))
     featM, descM, VM = pipe.describe(t(model), t(kpM), OPT, compact=True)
     featS, descS, VS = pipe.describe(t(surface), t(kpS), OPT, compact=True)
-    assert descM.dtype == torch.uint16 and (VM, VS) == (len(fM), len(fS))
-    np.testing.assert_array_equal(descM[:VM].cpu().numpy().astype(np.float64), dM)
-    np.testing.assert_array_equal(descS[:VS].cpu().numpy().astype(np.float64), dS)
+    assert descM.rows.dtype == torch.uint16 and (VM, VS) == (len(fM), len(fS))
+    assert (np.diff(descM.index[:VM].cpu().numpy()) > 0).all()                   # ascending keypoint numbers
+    np.testing.assert_array_equal(descM.compact(VM).cpu().numpy().astype(np.float64), dM)
+    np.testing.assert_array_equal(descS.compact(VS).cpu().numpy().astype(np.float64), dS)
     np.testing.assert_array_equal(featS[:VS].cpu().numpy(), fS)
     pairs, n_pairs = pipe.match(descS, VS, descM, VM, PAR)
     n = int(n_pairs.item())
     assert n == len(ref_pairs) >= 3
     np.testing.assert_array_equal(pairs[:n].cpu().numpy().astype(np.uint32), ref_pairs)
-    # a count can reach max_pts: a u16 row cannot promise more than 65535
-    with pytest.raises(PcregError):
-        pipe.describe(t(model), t(kpM), dict(OPT, max_pts=70000), compact=True)
+    # max_pts beyond 65535 is fine: a count cannot exceed the support an LDS-resident list can hold (8191)
+    f2, d2, V2 = pipe.describe(t(model), t(kpM), dict(OPT, max_pts=70000), compact=True)
+    assert V2 >= VM

@@ -69,3 +69,80 @@ def test_descriptors_duplicate_points_and_far_keypoints(oracle_c):
     assert len(rfeat) > 20
     np.testing.assert_array_equal(feat, rfeat)
     np.testing.assert_array_equal(desc, rdesc)
+
+
+# ---- `single` data: MATLAB's single arithmetic in getLocalPoints (which keypoints survive, which points form a support) ----
+@pytest.mark.parametrize("mode", ["both single", "single cloud, double keypoints", "double cloud, single keypoints"])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_single_inputs_follow_matlabs_single_arithmetic(mode, seed, oracle_c):
+    """Points planted within an ulp(single) of the sphere and of the box faces: the HIP path must take the decisions of the
+    single-arithmetic oracle (tests/test_oracle_single.py shows they differ from the double ones), return DOUBLE feat / desc
+    (getSpacialHistogramDescriptors.m:61-62) and exactly the oracle's counts."""
+    import pcreg_amd as pc
+    from test_oracle_single import OPT as SOPT, planted_scene
+    pts32, kp32 = planted_scene(10 + seed)
+    if mode == "both single":
+        pts, kp, sm = pts32, kp32, 1
+    elif mode == "single cloud, double keypoints":
+        pts, kp, sm = pts32, kp32.astype(np.float64) + 1e-9, 2
+    else:
+        pts, kp, sm = pts32.astype(np.float64) + 1e-9, kp32, 1
+    feat, desc = pc.getSpacialHistogramDescriptors(pts, kp, SOPT)
+    assert feat.dtype == np.float64 and desc.dtype == np.float64
+    rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(np.asarray(pts, np.float64), np.asarray(kp, np.float64), SOPT, single_mode=sm)
+    assert len(rfeat) >= 3
+    np.testing.assert_array_equal(feat, rfeat)
+    np.testing.assert_array_equal(desc, rdesc)
+    # and they are NOT the double-arithmetic supports: the row sums (support sizes) differ for some keypoint
+    dfeat, ddesc = oracle_c.getSpacialHistogramDescriptors(np.asarray(pts, np.float64), np.asarray(kp, np.float64), SOPT)
+    if len(dfeat) == len(rfeat):
+        assert (ddesc.sum(axis=1) != rdesc.sum(axis=1)).any()
+
+
+def test_device_tier_single_mode_rows(oracle_c):
+    """pcreg_dev_spatial_histogram_descriptors_rows_u16 with single_mode: uint16 rows in keypoint order + survivor list."""
+    import torch
+    from pcreg_amd.device import DescriptorPipeline, soa
+    from test_oracle_single import OPT as SOPT, planted_scene
+    pts32, kp32 = planted_scene(21)
+    dev = torch.device("cuda", 0)
+    t = lambda a: soa(torch.from_numpy(np.ascontiguousarray(a.astype(np.float64))).to(dev))
+    feat, rows, V = DescriptorPipeline(dev).describe(t(pts32), t(kp32), SOPT, compact=True, single_mode=1)
+    rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(pts32.astype(np.float64), kp32.astype(np.float64), SOPT, single_mode=1)
+    assert V == len(rfeat) > 0
+    np.testing.assert_array_equal(feat[:V].cpu().numpy(), rfeat)
+    np.testing.assert_array_equal(rows.compact(V).cpu().numpy().astype(np.float64), rdesc)
+
+
+def test_descriptors_on_a_georeferenced_cloud(oracle_c):
+    """Coordinates around 4e6 (ADVICE, round 2): the slab-edge margins of the candidate rows must scale with the coordinate
+    magnitude, and the fp32 screens work relative to the grid's origin -- counts still equal the oracle's."""
+    import pcreg_amd as pc
+    off = np.array([4.2e6, -3.9e6, 5.1e5])
+    pts, kp = strips(30000, 7) + off, keypoints(150, 8) + off
+    feat, desc = pc.getSpacialHistogramDescriptors(pts, kp, OPT)
+    rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(pts, kp, OPT)
+    assert len(rfeat) > 30
+    np.testing.assert_array_equal(feat, rfeat)
+    np.testing.assert_array_equal(desc, rdesc)
+
+
+def test_k_nearest_boundary_where_square_roots_collide(oracle_c):
+    """The selection sorts SQUARED distances; the reference sorts their square roots, which collide for neighbouring doubles
+    (sqrt halves the relative spacing): points whose squared distances differ by one ulp can be TIED in the reference's order
+    and then go by original index.  A lattice cloud (massively equal and near-equal distances) exercises exactly that."""
+    import pcreg_amd as pc
+    g = np.arange(-8, 9) * 0.4
+    X, Y, Z = np.meshgrid(g, g * 0.6, g * 0.2, indexing="ij")
+    lattice = np.column_stack([X.ravel(), Y.ravel(), Z.ravel()])
+    rng = np.random.default_rng(12)
+    pts = np.vstack([lattice + [20.0, 10.0, 5.0], lattice[rng.permutation(len(lattice))[:1500]] + [20.0, 10.0, 5.0]])
+    pts = pts[rng.permutation(len(pts))]
+    kp = np.array([[20.0, 10.0, 5.0], [20.2, 10.0, 5.0], [20.3, 10.1, 5.05], [19.9, 9.95, 5.0]])
+    for k in (0.85, 0.5, 0.31):
+        opt = dict(OPT, min_pts=100, max_pts=8000, thVar=[1.0, 1.0], k=k)
+        feat, desc = pc.getSpacialHistogramDescriptors(pts, kp, opt)
+        rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(pts, kp, opt)
+        assert len(rfeat) == 4
+        np.testing.assert_array_equal(feat, rfeat)
+        np.testing.assert_array_equal(desc, rdesc)

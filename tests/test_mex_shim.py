@@ -132,17 +132,30 @@ def test_shim_round_trips_equal_the_ctypes_path(drv):
     assert np.array_equal(al32, wal.astype(np.float32)) and np.array_equal(co32.reshape(3, 3, order="F"), wco.astype(np.float32))
     pal, pco, pcc = pc.AlignPoints_KNN(Xs)                                      # the Python mirror dispatches on the class too
     assert pal.dtype == np.float32 and np.array_equal(pal, al32) and np.array_equal(pcc.ravel(), c32)
+    # getSpacialHistogramDescriptors with single inputs: feat / desc come back DOUBLE whatever the input classes (the reference
+    # preallocates them with nan(...): getSpacialHistogramDescriptors.m:61-62), every class combination goes through in its own class
     cl32, kp32 = cloud.astype(np.float32), kp.astype(np.float32)
-    f32 = np.zeros((12, 3), np.float32, order="F"); d32 = np.zeros((12, 980), np.float32, order="F")
-    assert drv.drv_descriptors_f32(_p(np.asfortranarray(cl32), C.c_float), 6000, _p(np.asfortranarray(kp32), C.c_float), 12, _p(o6), _p(f32, C.c_float),
-                                   _p(d32, C.c_float), C.byref(V), e, 1024) == 0, e.value
-    wf, wd = pc.getSpacialHistogramDescriptors(cl32.astype(np.float64), kp32.astype(np.float64), opts)
-    v = V.value
-    assert v == len(wf) and v > 0
-    assert np.array_equal(f32.ravel(order="F")[:3 * v].reshape(v, 3, order="F"), wf.astype(np.float32))
-    assert np.array_equal(d32.ravel(order="F")[:980 * v].reshape(v, 980, order="F"), wd.astype(np.float32))
-    pf, pd = pc.getSpacialHistogramDescriptors(cl32, kp32, opts)
-    assert pf.dtype == np.float32 and pd.dtype == np.float32 and np.array_equal(pd, wd.astype(np.float32))
+    for ps, ss in ((1, 1), (1, 0), (0, 1)):
+        pa = np.asfortranarray(cl32 if ps else cloud); ka = np.asfortranarray(kp32 if ss else kp)
+        fo = np.zeros((12, 3), order="F"); do = np.zeros((12, 980), order="F")
+        assert drv.drv_descriptors_classes(pa.ctypes.data_as(C.c_void_p), ps, 6000, ka.ctypes.data_as(C.c_void_p), ss, 12, _p(o6), _p(fo), _p(do),
+                                           C.byref(V), e, 1024) == 0, e.value
+        v = V.value
+        pf, pd = pc.getSpacialHistogramDescriptors(cl32 if ps else cloud, kp32 if ss else kp, opts)      # the Python mirror: same dispatch
+        assert pf.dtype == np.float64 and pd.dtype == np.float64 and v == len(pf) and v > 0
+        assert np.array_equal(fo.ravel(order="F")[:3 * v].reshape(v, 3, order="F"), pf)
+        assert np.array_equal(do.ravel(order="F")[:980 * v].reshape(v, 980, order="F"), pd)
+    # the prepared-model commands: one handle, three surfaces
+    rngm = np.random.default_rng(5)
+    model = (rngm.random((9000, 3)) * [40, 30, 35]).astype(np.float32)
+    surfs = [(model[rngm.choice(9000, 800, replace=False)] + rngm.normal(0, 0.03, (800, 3))).astype(np.float32) for _ in range(3)]
+    flat = np.concatenate([np.asfortranarray(s_).ravel(order="F") for s_ in surfs]).astype(np.float32)
+    pairs = np.zeros(3 * 800 * 2, dtype=np.uint32); Pn = (C.c_int * 3)()
+    assert drv.drv_model_round_trip(_p(np.asfortranarray(model), C.c_float), 9000, _p(flat, C.c_float), 800, 3, C.c_float(0.25), C.c_float(0.8), 1,
+                                    _p(pairs, C.c_uint32), Pn, e, 1024) == 0, e.value
+    for k in range(3):
+        got = pairs[k * 1600:k * 1600 + 2 * Pn[k]].reshape(Pn[k], 2, order="F")
+        assert np.array_equal(got, pc.match_points(surfs[k], model, 0.25, 0.8, True)) and Pn[k] > 100
     assert drv.drv_live_arrays() == 0
 
 
