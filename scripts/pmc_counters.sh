@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash scripts/pmc_counters.sh <tag> <kernel-substring> <out.json (repo-relative)> [VAR=value ...] -- <python script + args>
+# usage: bash scripts/pmc_counters.sh <tag> <kernel-substring> <out.json (repo-relative; on the GPU box only paths under gpurun_out/ travel back -- or re-run scripts/prof_parse.py here on the merged CSVs)> [VAR=value ...] -- <python script + args>
 # SQ / TCP / TCC counters of one kernel, one rocprofv3 --pmc pass per group (no trace options next to --pmc).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; K=$2; OUTJ=$3; shift; shift; shift

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash scripts/pmc_traffic.sh <tag> <out.json (repo-relative)> <16B-reader kernel substrings, comma-separated or ""> -- <python script + args>
+# usage: bash scripts/pmc_traffic.sh <tag> <out.json (repo-relative; on the GPU box only paths under gpurun_out/ travel back -- or re-run scripts/prof_parse.py here on the merged CSVs)> <16B-reader kernel substrings, comma-separated or ""> -- <python script + args>
 # HBM traffic per kernel: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (MI355X_MICROARCH.md's recipe).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; OUTJ=$2; DBL=$3; shift; shift; shift
