@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restr
     if (!seeded) { if (live && sub == 0) gthr[qi] = 0xFFFFFFFFu; return; }       // +inf: no hint
     const int nx = prep->nx, ny = prep->ny, nz = prep->nz;
     const int cx = seed_cell(qx, prep->gx0, prep->inv_h, nx), cy = seed_cell(qy, prep->gy0, prep->inv_h, ny), cz = seed_cell(qz, prep->gz0, prep->inv_h, nz);
-    float d[KC] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    float d[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int c27 = sub + 8 * t;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restr
     unsigned word = 0xFFFFFFFFu;                           // +inf: no hint
     // The 4th-smallest exact distance of the sample bounds the true 4th-nearest distance from above; any rank >= 2 keeps
     // both true neighbours under the threshold (rank 2 was measured in round 2: the kernel's time does not move).
-    const float dk = d[3];
+    const float dk = d[kSeedRank - 1];
     if (dk < INFINITY) {
         const float tx = qx - prep->cx, ty = qy - prep->cy, tz = qz - prep->cz;
         const double r2 = (double)tx * tx + (double)ty * ty + (double)tz * tz;

@@ -7,7 +7,14 @@ namespace pcreg {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int KC = 4;                        // candidates kept per query and chunk
+#ifndef PCREG_KC
+#define PCREG_KC 4
+#endif
+constexpr int KC = PCREG_KC;                 // group entries kept per lane, query and chunk (>= 2: the two nearest points sit in the two best groups)
+#ifndef PCREG_SEED_RANK
+#define PCREG_SEED_RANK 4
+#endif
+constexpr int kSeedRank = PCREG_SEED_RANK;   // the first threshold: the kSeedRank-th smallest exact distance among the seeding grid's points (>= 2)
 constexpr int kMTile = 1024;                 // model points per LDS tile (16 KiB)
 
 // What a PREPARED MODEL carries besides its f16 tiles (model-only quantities: one model, many query sets --
@@ -89,23 +96,7 @@ struct SearchCounters {
 // ---- 2. candidate generation -------------------------------------------------------------
 struct Cand { float s[KC]; int i[KC]; };
 
-__device__ __forceinline__ void cand_insert(Cand& c, float s, int j) {
-    // keep c.s ascending; strict '<' so that, within a lane, earlier (lower) indices win ties
-    if (s < c.s[3]) {
-        if (s < c.s[1]) {
-            c.s[3] = c.s[2]; c.i[3] = c.i[2];
-            c.s[2] = c.s[1]; c.i[2] = c.i[1];
-            if (s < c.s[0]) { c.s[1] = c.s[0]; c.i[1] = c.i[0]; c.s[0] = s; c.i[0] = j; }
-            else { c.s[1] = s; c.i[1] = j; }
-        } else {
-            if (s < c.s[2]) { c.s[3] = c.s[2]; c.i[3] = c.i[2]; c.s[2] = s; c.i[2] = j; }
-            else { c.s[3] = s; c.i[3] = j; }
-        }
-    }
-}
-
-
-// The same insertion without a branch: a four-stage compare-exchange chain that carries (score, index) down the sorted
+// Sorted insertion without a branch: a KC-stage compare-exchange chain that carries (score, index) down the sorted
 // list; `pred` false (or s >= c.s[3]) leaves the list as it is.  Straight-line code for the rare list update of the
 // pipelined f16 kernel: the nested branches of cand_insert cost a lone wave ~3 scalar branch latencies per level.
 __device__ __forceinline__ void cand_insert_branchless(Cand& c, float s, int j, bool pred) {

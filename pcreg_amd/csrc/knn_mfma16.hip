@@ -216,7 +216,7 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
             for (int g = 0; g < QG; ++g) {
                 const int qi = q_base + g * 32 + col;
                 if (qi < Q) {
-                    if (cand[g].s[3] < INFINITY) { unsigned k = f2ord(cand[g].s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
+                    if (cand[g].s[KC - 1] < INFINITY) { unsigned k = f2ord(cand[g].s[KC - 1] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
                     unsigned gv = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     gseen[g] = gv;
                     thr[g] = fminf(fminf(thr[g], ord2f(gv) * sg2), __shfl_xor(thr[g], 32));       // and the sibling half's list
@@ -298,9 +298,9 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
                         const float m4 = fminf(fminf(d[12], d[13]), d[14]);
                         const float mn1 = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), d[15]));
                         cand_insert_branchless(cand[g], mn0[g], jt + sub * 32, mn0[g] < thr[g]);
-                        thr[g] = fminf(thr[g], cand[g].s[3]);
+                        thr[g] = fminf(thr[g], cand[g].s[KC - 1]);
                         cand_insert_branchless(cand[g], mn1, jt + (sub + 1) * 32, mn1 < thr[g]);
-                        thr[g] = fminf(thr[g], cand[g].s[3]);
+                        thr[g] = fminf(thr[g], cand[g].s[KC - 1]);
                     }
                 }
             }
@@ -320,18 +320,18 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
         for (int k = 0; k < KC; ++k) {
             const float os = __shfl_xor(cand[g].s[k], 32);
             const int oi = __shfl_xor(cand[g].i[k], 32);
-            if (oi >= 0 && (os < mine.s[3] || (os == mine.s[3] && (unsigned)oi < (unsigned)mine.i[3]))) {
-                int pos = 3;
+            if (oi >= 0 && (os < mine.s[KC - 1] || (os == mine.s[KC - 1] && (unsigned)oi < (unsigned)mine.i[KC - 1]))) {
+                int pos = KC - 1;
 #pragma unroll
-                for (int t = 2; t >= 0; --t) if (os < mine.s[t] || (os == mine.s[t] && (unsigned)oi < (unsigned)mine.i[t])) pos = t;
+                for (int t = KC - 2; t >= 0; --t) if (os < mine.s[t] || (os == mine.s[t] && (unsigned)oi < (unsigned)mine.i[t])) pos = t;
 #pragma unroll
-                for (int t = 3; t > 0; --t) if (t > pos) { mine.s[t] = mine.s[t - 1]; mine.i[t] = mine.i[t - 1]; }
+                for (int t = KC - 1; t > 0; --t) if (t > pos) { mine.s[t] = mine.s[t - 1]; mine.i[t] = mine.i[t - 1]; }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) if (t == pos) { mine.s[t] = os; mine.i[t] = oi; }
+                for (int t = 0; t < KC; ++t) if (t == pos) { mine.s[t] = os; mine.i[t] = oi; }
             }
         }
         if (qi < Q && half == 0) {
-            if (mine.s[3] < INFINITY) { unsigned k = f2ord(mine.s[3] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
+            if (mine.s[KC - 1] < INFINITY) { unsigned k = f2ord(mine.s[KC - 1] * inv2); if (k < gseen[g]) atomicMin(&gthr[qi], k); }
             int nv = 0;
 #pragma unroll
             for (int k = 0; k < KC; ++k) nv += mine.i[k] >= 0;
