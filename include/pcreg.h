@@ -365,6 +365,27 @@ size_t pcreg_dev_sphere_select_workspace(int V);
 int pcreg_dev_sphere_select(const double* feat, int V, const double centre[3], double R, int32_t* idx,
                             int32_t* n_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* getDescriptorMask for S spheres in one launch (completeExperimentFast.m:109-125 for every sphere of the sweep): the row
+ * list of sphere s is written at idx[seg_off[s] ..], ascending and 0-based; seg_off [S + 1] (device) are the running sums of
+ * pcreg_dev_sphere_counts' counts.  feat_out (or NULL): featCur of every sphere back to back ([seg_off[S]][3] row-major);
+ * n_out (or NULL) [S]: the lengths found (== the counts).  centres [S][3] on the device. */
+int pcreg_dev_sphere_select_batched(const double* feat, int V, const double* centres, int S, double R, const int32_t* seg_off,
+                                    int32_t* idx, double* feat_out, int32_t* n_out, void* stream);
+
+/* getMatches.m:21-59 for S segments in ONE chain of launches: getMatches(descSurface, descModel(rows_s, :), par) for every
+ * segment s, rows_s = seg_rows[seg_off[s] .. seg_off[s+1]) (0-based, ascending) -- the per-sphere calls of the sweep,
+ * completeExperimentFast.m:131-149, which the reference runs under parfor.  descSurface [Q][D], descModel [VM][D] dense
+ * row-major doubles (what the descriptor entry point emits).  total_rows = seg_off[S] and max_rows = the longest segment
+ * are known to the host from the counts.  pairs_all [S][Q][2]: segment s's pairs, 1-based, the model index counting WITHIN
+ * the segment like the per-sphere call's; n_pairs [S]; metric_all [S][Q] or NULL.  The pairs are those of one
+ * pcreg_dev_get_matches call per segment (same arithmetic on the same operands: the appended constant and the row norms
+ * differ per segment, the powered columns do not and are computed once).  Metric SAD only; nothing synchronises. */
+size_t pcreg_dev_get_matches_segmented_workspace(int Q, int VM, int D, int S, int total_rows, int max_rows);
+int pcreg_dev_get_matches_segmented(const double* descSurface, int Q, const double* descModel, int VM, int D, const int32_t* seg_rows,
+                                    const int32_t* seg_off, int S, int total_rows, int max_rows, const pcreg_match_opts* par,
+                                    uint32_t* pairs_all, double* metric_all, int32_t* n_pairs, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* dst(k,:) = src(idx(k),:), k < min(*n, cap): featCur / descCur of completeExperimentFast.m:122-125
  * (row-major, D doubles per row). */
 int pcreg_dev_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap,

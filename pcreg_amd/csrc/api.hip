@@ -753,6 +753,26 @@ int pcreg_dev_sphere_counts(const double* feat, int V, const double* centres, in
     GUARD();
     return launch_sphere_counts(feat, V, centres, S, R, counts, (hipStream_t)stream);
 }
+int pcreg_dev_sphere_select_batched(const double* feat, int V, const double* centres, int S, double R, const int32_t* seg_off,
+                                    int32_t* idx, double* feat_out, int32_t* n_out, void* stream) {
+    PCREG_ARG(feat && centres && seg_off && idx && V >= 0 && S >= 0);
+    GUARD();
+    return launch_sphere_select_batched(feat, V, centres, S, R, seg_off, idx, feat_out, n_out, (hipStream_t)stream);
+}
+size_t pcreg_dev_get_matches_segmented_workspace(int Q, int VM, int D, int S, int total_rows, int max_rows) {
+    return get_matches_segmented_workspace_bytes(Q, VM, D, S, total_rows, max_rows);
+}
+int pcreg_dev_get_matches_segmented(const double* descSurface, int Q, const double* descModel, int VM, int D, const int32_t* seg_rows,
+                                    const int32_t* seg_off, int S, int total_rows, int max_rows, const pcreg_match_opts* par,
+                                    uint32_t* pairs_all, double* metric_all, int32_t* n_pairs, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    PCREG_ARG(descSurface && descModel && seg_rows && seg_off && par && pairs_all && n_pairs && workspace);
+    PCREG_ARG(Q >= 0 && VM >= 0 && D >= 1 && S >= 0 && total_rows >= 0 && max_rows >= 0 && max_rows <= total_rows);
+    if (par->metric != PCREG_METRIC_SAD) { set_error("pcreg_dev_get_matches_segmented: Metric must be SAD (one pcreg_dev_get_matches call per segment handles SSD)"); return PCREG_E_ARG; }
+    GUARD();
+    return launch_get_matches_segmented(descSurface, Q, descModel, VM, D, seg_rows, seg_off, S, total_rows, max_rows, *par, pairs_all,
+                                        metric_all, n_pairs, workspace, workspace_bytes, (hipStream_t)stream);
+}
 size_t pcreg_dev_sphere_select_workspace(int V) { return sphere_select_workspace_bytes(V); }
 int pcreg_dev_sphere_select(const double* feat, int V, const double centre[3], double R, int32_t* idx, int32_t* n_out,
                             void* workspace, size_t workspace_bytes, void* stream) {

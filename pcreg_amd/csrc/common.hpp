@@ -147,6 +147,12 @@ void knn_f16_timing_enable(bool on);
 int knn_f16_timing_read(float* mean_ms, int* launches);
 int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st);
 int launch_widen_rows_u16(const uint16_t* rows, const int32_t* index, int n, int D, double* featmajor, hipStream_t st);   // rows[index[i]] (u16) -> feature-major f64
+int launch_sphere_select_batched(const double* feat, int V, const double* centres, int S, double R, const int32_t* seg_off, int32_t* idx,
+                                 double* feat_out, int32_t* n_out, hipStream_t st);
+size_t get_matches_segmented_workspace_bytes(int Q, int VM, int D, int S, int tot, int n_max);
+int launch_get_matches_segmented(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
+                                 const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
+                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_sweep_plan(const int32_t* n_pairs, int S, int thresh, int32_t* trial_idx, int32_t* offsets, int32_t* n_trials, hipStream_t st);
 int launch_sweep_gather(const uint32_t* pairs_all, int VS, const int32_t* n_pairs, const int32_t* trial_idx, const int32_t* offsets,
                         const int32_t* n_trials, int S, const double* featS, const double* featCur_all, const int64_t* row_off,

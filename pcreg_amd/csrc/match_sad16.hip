@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "select.hpp"
 #include <cmath>
+#include <cfloat>
 #include <cstdlib>
 #include <cstdio>
 #include <algorithm>
@@ -40,6 +41,9 @@ constexpr int KC = 4;
 constexpr int kMaxSplit = 32;                  // S * KC <= 128: two list entries per lane in the finalize wave
 
 struct Range { double fmin, scale, inv_scale; };
+// per-segment element strides of the candidates kernel's arrays (A, B: dwords; P: list entries; live: int32) and the
+// segments' row offsets; all zero / null for the one-segment call
+struct SegZ { size_t A, B, P, live; const int32_t* seg_off; };
 
 // ---- range (two-stage, deterministic) --------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const double* __restrict__ A, int nA, int lda,
@@ -128,7 +132,16 @@ template <bool DRY>
 __global__ __launch_bounds__(kBlock, 3) void sad16_candidates_kernel(const uint32_t* __restrict__ Aq, int nA, int lda,
                                                                   const uint32_t* __restrict__ Bq, int nB, int ldb, int D2p, int chunk,
                                                                   int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s,
-                                                                  unsigned long long* __restrict__ dbg, const int32_t* __restrict__ nA_live) {
+                                                                  unsigned long long* __restrict__ dbg, const int32_t* __restrict__ nA_live,
+                                                                  SegZ sz) {
+    // segmented form (blockIdx.z = segment, section "segmented getMatches" below): every array is strided by the segment,
+    // a segment's B rows are [seg_off[z], seg_off[z + 1]) of the concatenated lists; one segment (sz all zero): unchanged
+    {
+        const size_t z = blockIdx.z;
+        Aq += z * sz.A; Bq += z * sz.B; part_idx += z * sz.P; part_s += z * sz.P;
+        if (nA_live) nA_live += z * sz.live;
+        if (sz.seg_off) nB = sz.seg_off[z + 1] - sz.seg_off[z];
+    }
     if (nA_live && (int)blockIdx.x * BQ >= *nA_live) return;          // a query tile beyond the live rows: nothing to do
     unsigned long long t_start = 0;
     if (dbg) t_start = __builtin_amdgcn_s_memrealtime();
@@ -478,6 +491,434 @@ __global__ void sad_fallback_finish_kernel(const int32_t* __restrict__ list, con
     }
 }
 
+
+// ================================================================================================================
+// Segmented getMatches: ONE surface descriptor set against MANY row subsets of one model set in one chain of launches
+// (the sphere sweep of completeExperimentFast.m:101-150: getMatches(descSurface, descModel(mask_i, :), par) for every
+// sphere i).  blockIdx.z (or .x where a workgroup owns a segment) = segment.
+//
+// What differs between segments is only (a) which model rows take part and (b) the appended constant
+// c_i = norm_factor * mean(vecnorm([descSurface; descCur_i], 1, 2)) (getMatches.m:24-26), hence every row's L2 norm.
+// Everything else is computed ONCE for all segments:
+//   P    = descriptors .^ metric_factor            (getMatches.m:36-37 on the 980 real columns)
+//   l1   = vecnorm(row, 1)                         (ascending feature order, like row_l1_kernel)
+//   s2   = sum of P^2 over the real columns        (ascending, fma: the prefix of normalize_rows_kernel's chain)
+// and per segment: cc_i = c_i ^ metric_factor, nrm_i(row) = sqrt(fma(cc_i, cc_i, s2(row))) -- the same chain, since
+// the constant column comes last.  A normalised value is P / nrm_i(row) (last column cc_i / nrm_i(row)): the SAME IEEE
+// operations on the same operands as the one-segment path (preprocess_kernel, normalize_rows_kernel), so the exact
+// re-rank sees the same bits and the pairs are those of one pcreg_dev_get_matches call per segment.  No normalised
+// double matrix is ever materialised: the u16 operands of the candidates kernel are quantised straight from P, and
+// the re-rank divides the handful of rows it touches on the fly.
+struct SegConst { double cc, fmin, scale, inv_scale; };
+
+constexpr int kPR = 64, kPF = 48;
+// src row-major [n][D] -> P row-major, l1, s2, min / max of P per row (one lane per row keeps the oracle's order)
+__global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restrict__ src, int n, int D, int change_metric, double factor,
+                                                           double* __restrict__ P, double* __restrict__ l1, double* __restrict__ s2,
+                                                           double* __restrict__ pmin, double* __restrict__ pmax) {
+    __shared__ double t_raw[kPF][kPR + 1], t_p[kPF][kPR + 1];
+    const int r0 = blockIdx.x * kPR, rows = min(kPR, n - r0);
+    double a = 0.0, s = 0.0, lo = INFINITY, hi = -INFINITY;
+    for (int d0 = 0; d0 < D; d0 += kPF) {
+        const int dn = min(kPF, D - d0);
+        for (int e = threadIdx.x; e < kPR * kPF; e += kBlock) {
+            const int r = e / kPF, f = e % kPF;
+            double x = 0.0, pv = 0.0;
+            if (r < rows && f < dn) {
+                x = src[(size_t)(r0 + r) * D + d0 + f];
+                pv = change_metric ? pow(x, factor) : x;
+                P[(size_t)(r0 + r) * D + d0 + f] = pv;
+            }
+            t_raw[f][r] = x; t_p[f][r] = pv;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < rows) {
+            const int r = threadIdx.x;
+            for (int f = 0; f < dn; ++f) {
+                const double x = t_raw[f][r], pv = t_p[f][r];
+                a += fabs(x); s = fma(pv, pv, s); lo = fmin(lo, pv); hi = fmax(hi, pv);
+            }
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < rows) { const int r = r0 + threadIdx.x; l1[r] = a; s2[r] = s; pmin[r] = lo; pmax[r] = hi; }
+}
+
+struct SegSets {                // the two descriptor sets after segp_rows_kernel, and the segments
+    const double *PS, *l1S, *s2S, *pminS, *pmaxS;      // surface: Q rows
+    const double *PM, *l1M, *s2M, *pminM, *pmaxM;      // model: every row of the full set
+    const int32_t *seg_rows, *seg_off;                // segment z owns model rows seg_rows[seg_off[z] .. seg_off[z + 1])
+    int Q, D0, Dp;                                    // Dp = D0 + 1 with the appended column
+};
+
+// one workgroup per segment: the appended constant (mean_kernel's order over [l1 of the surface; l1 of the segment's rows]),
+// every row's norm, and the common quantisation range of the segment's normalised values
+__global__ __launch_bounds__(kBlock) void segp_consts_kernel(SegSets S, pcreg_match_opts o, double* __restrict__ nrmS, double* __restrict__ nrmM,
+                                                             SegConst* __restrict__ sc) {
+    __shared__ double s[kBlock];
+    __shared__ double s_lo[kBlock / 64], s_hi[kBlock / 64];
+    const int z = blockIdx.x, off = S.seg_off[z], n = S.seg_off[z + 1] - off, Q = S.Q, tid = threadIdx.x;
+    const int32_t* rows = S.seg_rows + off;
+    double cc = 0.0;
+    if (o.unnormalize) {
+        double a = 0;
+        for (int i = tid; i < Q + n; i += kBlock) a += i < Q ? S.l1S[i] : S.l1M[rows[i - Q]];
+        s[tid] = a;
+        __syncthreads();
+        for (int w = kBlock / 2; w > 0; w >>= 1) { if (tid < w) s[tid] += s[tid + w]; __syncthreads(); }
+        const double c = o.norm_factor * (s[0] / (double)(Q + n));
+        cc = o.change_metric ? pow(c, o.metric_factor) : c;
+    }
+    double lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < Q + n; i += kBlock) {
+        const bool surf = i < Q;
+        const int r = surf ? i : rows[i - Q];
+        const double q2 = surf ? S.s2S[r] : S.s2M[r];
+        double nrm = 1.0;
+        if (!o.prenormalized) {
+            nrm = sqrt(o.unnormalize ? fma(cc, cc, q2) : q2);
+            if (nrm <= (double)FLT_EPSILON) nrm = INFINITY;            // normalizeX: an effectively-zero row becomes zeros
+        }
+        if (surf) nrmS[(size_t)z * Q + i] = nrm; else nrmM[off + i - Q] = nrm;
+        const double a = (surf ? S.pminS[r] : S.pminM[r]) / nrm, b = (surf ? S.pmaxS[r] : S.pmaxM[r]) / nrm;
+        lo = fmin(lo, fmin(a, b)); hi = fmax(hi, fmax(a, b));
+        if (o.unnormalize) { const double c = cc / nrm; lo = fmin(lo, c); hi = fmax(hi, c); }
+    }
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) { lo = fmin(lo, __shfl_xor(lo, w)); hi = fmax(hi, __shfl_xor(hi, w)); }
+    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); }
+        if (!(hi > lo)) hi = lo + 1.0;
+        sc[z] = SegConst{cc, lo, 65535.0 / (hi - lo), (hi - lo) / 65535.0};
+    }
+}
+
+// side 0: the surface rows of segment z (their norms are the segment's); side 1: the segment's model rows.
+// out [segment][D2p][ldq] in quantize_pack_kernel's layout (zero padding in rows and features).
+__global__ __launch_bounds__(kBlock) void segp_quantize_kernel(SegSets S, int side, const double* __restrict__ nrm_all, const SegConst* __restrict__ sc,
+                                                               int D2p, int ldq, uint32_t* __restrict__ out) {
+    __shared__ uint16_t tile[64][66];
+    const int z = blockIdx.z, i0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    int n = S.Q;
+    const int32_t* rows = nullptr;
+    const double* P = S.PS;
+    const double* nrm = nrm_all + (size_t)z * S.Q;
+    if (side) { const int off = S.seg_off[z]; n = S.seg_off[z + 1] - off; rows = S.seg_rows + off; nrm = nrm_all + off; P = S.PM; }
+    const SegConst c = sc[z];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int i = i0 + ty + 4 * k, d = d0 + tx;
+        unsigned q = 0u;
+        if (i < n && d < S.Dp) {
+            const double v = d < S.D0 ? P[(size_t)(rows ? rows[i] : i) * S.D0 + d] : c.cc;
+            const double u = rint((v / nrm[i] - c.fmin) * c.scale);
+            q = (unsigned)fmin(fmax(u, 0.0), 65535.0);
+        }
+        tile[ty + 4 * k][tx] = (uint16_t)q;
+    }
+    __syncthreads();
+    uint32_t* o = out + (size_t)z * D2p * ldq;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int kk = ty + 4 * k, i = i0 + tx;
+        if (i < ldq) o[(size_t)(d0 / 2 + kk) * ldq + i] = (uint32_t)tile[tx][2 * kk] | ((uint32_t)tile[tx][2 * kk + 1] << 16);
+    }
+}
+
+// a row of the segment's normalised matrices, never stored: value(d) = (d < D0 ? p[d] : cc) / nrm
+struct SegRow { const double* p; double nrm; };
+struct SegView { const double *PS, *PM, *nrmS, *nrmM; const int32_t* rows; int D0; double cc; };
+__device__ __forceinline__ SegView seg_view(const SegSets& S, const double* nrmS, const double* nrmM, const SegConst& c, int z) {
+    const int off = S.seg_off[z];
+    return SegView{S.PS, S.PM, nrmS + (size_t)z * S.Q, nrmM + off, S.seg_rows + off, S.D0, c.cc};
+}
+__device__ __forceinline__ SegRow seg_surface_row(const SegView& V, int i) { return SegRow{V.PS + (size_t)i * V.D0, V.nrmS[i]}; }
+__device__ __forceinline__ SegRow seg_model_row(const SegView& V, int j) { return SegRow{V.PM + (size_t)V.rows[j] * V.D0, V.nrmM[j]}; }
+__device__ __forceinline__ double seg_value(const SegView& V, const SegRow& r, int d) {
+    const double v = r.p[min(d, V.D0 - 1)];
+    return (d < V.D0 ? v : V.cc) / r.nrm;
+}
+
+// sad16_finalize_kernel on the segments.  BACK = false: queries = surface rows, candidates = the segment's model rows
+// (local numbers j).  BACK = true (the Unique back-search): queries = the candidates' model rows cand_m[k], k < n_cand,
+// candidates = surface rows.  All per-query arrays are [segment][Q]...
+template <bool BACK>
+__global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
+                                                               const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_m,
+                                                               const int32_t* __restrict__ n_live, const int32_t* __restrict__ part_idx,
+                                                               const uint32_t* __restrict__ part_s, int splits,
+                                                               int32_t* __restrict__ idx, double* __restrict__ dist,
+                                                               int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven) {
+    __shared__ double s_t[kBlock / 64][kNC][kFT];
+    __shared__ int s_j[kBlock / 64][64 * kEPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.z, nA = S.Q, D = S.Dp;
+    const int qi = blockIdx.x * (kBlock / 64) + wave;
+    if (qi >= nA || (BACK && qi >= n_live[z])) return;        // wave-uniform; no block barrier below
+    const SegConst c = sc[z];
+    const SegView V = seg_view(S, nrmS, nrmM, c, z);
+    part_idx += (size_t)z * splits * nA * KC; part_s += (size_t)z * splits * nA * KC;
+    idx += (size_t)z * nA * 2; dist += (size_t)z * nA * 2; flag_list += (size_t)z * nA;
+    const int total = splits * KC;
+    int j[kEPL]; unsigned sq[kEPL];
+    unsigned a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu, g = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < kEPL; ++u) {
+        const int e = lane + 64 * u;
+        j[u] = -1; sq[u] = 0xFFFFFFFFu;
+        if (e < total) { size_t o = ((size_t)(e / KC) * nA + qi) * KC + (e % KC); j[u] = part_idx[o]; sq[u] = part_s[o]; }
+        if (j[u] >= 0) {
+            if (sq[u] < a1) { a2 = a1; a1 = sq[u]; } else if (sq[u] < a2) a2 = sq[u];
+            if ((e % KC) == KC - 1) g = min(g, sq[u]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned b1 = __shfl_xor(a1, o), b2 = __shfl_xor(a2, o);
+        unsigned n1 = min(a1, b1), n2 = min(max(a1, b1), min(a2, b2));
+        a1 = n1; a2 = n2;
+        g = min(g, (unsigned)__shfl_xor((int)g, o));
+    }
+    const unsigned slack = 2u * (unsigned)(D + 1) + 2u;
+    int n_need = 0;
+#pragma unroll
+    for (int u = 0; u < kEPL; ++u) {
+        const bool need = j[u] >= 0 && (a2 == 0xFFFFFFFFu || a2 > 0xFFFFFFFFu - slack || sq[u] <= a2 + slack);
+        const unsigned long long m = __ballot(need);
+        if (need) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = j[u];
+        n_need += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+
+    double d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+    const SegRow a = BACK ? seg_model_row(V, cand_m[(size_t)z * nA + qi]) : seg_surface_row(V, qi);
+    for (int g0 = 0; g0 < n_need; g0 += kNC) {
+        const int nc = min(kNC, n_need - g0);
+        double sum = 0.0;
+        for (int d0 = 0; d0 < D; d0 += kFT) {
+            double av[kFT / 64], bv[kNC][kFT / 64];
+            int dof[kFT / 64];
+#pragma unroll
+            for (int u = 0; u < kFT / 64; ++u) dof[u] = min(d0 + lane + 64 * u, D - 1);
+#pragma unroll
+            for (int u = 0; u < kFT / 64; ++u) av[u] = seg_value(V, a, dof[u]);
+#pragma unroll
+            for (int cnd = 0; cnd < kNC; ++cnd) {
+                const int jc = s_j[wave][min(g0 + cnd, n_need - 1)];
+                const SegRow b = BACK ? seg_surface_row(V, jc) : seg_model_row(V, jc);
+#pragma unroll
+                for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value(V, b, dof[u]);
+            }
+#pragma unroll
+            for (int cnd = 0; cnd < kNC; ++cnd)
+#pragma unroll
+                for (int u = 0; u < kFT / 64; ++u)
+                    s_t[wave][cnd][lane + 64 * u] = (d0 + lane + 64 * u < D) ? fabs(av[u] - bv[cnd][u]) : 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (lane < nc) {
+                const double* t = s_t[wave][lane];
+                for (int k = 0; k < kFT; k += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = t[k + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum += v[u];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < nc) {
+            const int jc = s_j[wave][g0 + lane];
+            if (lexd_lt(sum, jc, d1, i1)) { d2 = d1; i2 = i1; d1 = sum; i1 = jc; }
+            else if (lexd_lt(sum, jc, d2, i2)) { d2 = sum; i2 = jc; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+        int k1 = __shfl_xor(i1, o), k2 = __shfl_xor(i2, o);
+        bool fm = lexd_lt(d1, i1, e1, k1);
+        double w1 = fm ? d1 : e1; int x1 = fm ? i1 : k1;
+        double m2 = fm ? d2 : d1; int y2 = fm ? i2 : i1;
+        double o2 = fm ? e1 : e2; int z2 = fm ? k1 : k2;
+        bool sm = lexd_lt(m2, y2, o2, z2);
+        d1 = w1; i1 = x1; d2 = sm ? m2 : o2; i2 = sm ? y2 : z2;
+    }
+    bool ok;
+    if (g == 0xFFFFFFFFu) ok = true;
+    else {
+        double lower = ((double)g - (double)(D + 1)) * c.inv_scale;
+        ok = (i2 >= 0) && (lower * (1.0 - 1e-12) > d2);
+    }
+    if (force_unproven) ok = false;
+    if (lane == 0) {
+        if (ok) { idx[(size_t)qi * 2] = i1; idx[(size_t)qi * 2 + 1] = i2; dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2; }
+        else { int slot = atomicAdd(&n_flag[z], 1); flag_list[slot] = qi; }
+    }
+}
+
+// unproven queries of every segment, exhaustively and exactly (sad_exact_rows_kernel's order); grid (queries, slices, segments).
+// A workgroup takes one unproven query and one slice of the candidate rows, 256 rows at a time: all threads stage the
+// |a - b| terms of 256 rows x 16 features in LDS (reads coalesced along the features of the row-major P), then every thread
+// adds ITS row's terms in ascending feature order.
+constexpr int kSegFbSlices = 8, kXF = 16;
+template <bool BACK>
+__global__ __launch_bounds__(kBlock) void segp_exact_rows_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
+                                                                 const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_m,
+                                                                 const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag,
+                                                                 int slice_cap, int32_t* __restrict__ part_idx, double* __restrict__ part_dist) {
+    extern __shared__ double s_a[];                           // Dp doubles
+    __shared__ double s_t[kXF][kBlock + 1];
+    __shared__ double s_d[4][2]; __shared__ int s_i[4][2];
+    const int z = blockIdx.z, cap = S.Q, D = S.Dp, tid = threadIdx.x;
+    const int nf = min(n_flag[z], cap);
+    if (nf == 0) return;
+    const SegConst c = sc[z];
+    const SegView V = seg_view(S, nrmS, nrmM, c, z);
+    const int nB = BACK ? S.Q : S.seg_off[z + 1] - S.seg_off[z];
+    const int slice = BACK ? (S.Q + kSegFbSlices - 1) / kSegFbSlices : slice_cap;
+    flag_list += (size_t)z * cap;
+    part_idx += (size_t)z * kSegFbSlices * cap * 2; part_dist += (size_t)z * kSegFbSlices * cap * 2;
+    const int begin = blockIdx.y * slice, end = min(nB, begin + slice);
+    const int f = tid & (kXF - 1), rq = tid >> 4;             // staging role: feature f of rows rq, rq + 16, ...
+    for (int k = blockIdx.x; k < nf; k += gridDim.x) {
+        const int qi = flag_list[k];
+        __syncthreads();
+        const SegRow a = BACK ? seg_model_row(V, cand_m[(size_t)z * cap + qi]) : seg_surface_row(V, qi);
+        for (int d = tid; d < D; d += kBlock) s_a[d] = seg_value(V, a, d);
+        __syncthreads();
+        double d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
+        for (int j0 = begin; j0 < end; j0 += kBlock) {
+            SegRow br[kBlock / kXF];
+#pragma unroll
+            for (int u = 0; u < kBlock / kXF; ++u) {
+                const int jr = min(j0 + rq + (kBlock / kXF) * u, end - 1);
+                br[u] = BACK ? seg_surface_row(V, jr) : seg_model_row(V, jr);
+            }
+            double s = 0.0;
+            for (int d0 = 0; d0 < D; d0 += kXF) {
+                const int d = d0 + f;
+#pragma unroll
+                for (int u = 0; u < kBlock / kXF; ++u)
+                    s_t[f][rq + (kBlock / kXF) * u] = d < D ? fabs(s_a[min(d, D - 1)] - seg_value(V, br[u], min(d, D - 1))) : 0.0;
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < kXF; ++e) s += s_t[e][tid];          // terms past D are +0.0: a non-negative sum is unchanged
+                __syncthreads();
+            }
+            const int j = j0 + tid;
+            if (j < end) { if (s < d1) { d2 = d1; i2 = i1; d1 = s; i1 = j; } else if (s < d2) { d2 = s; i2 = j; } }   // ascending j: strict
+        }
+        auto merge = [&](double e1, int k1, double e2, int k2) {
+            bool fm = lexd_lt(d1, i1, e1, k1);
+            double w1 = fm ? d1 : e1; int x1 = fm ? i1 : k1;
+            double m2 = fm ? d2 : d1; int y2 = fm ? i2 : i1;
+            double o2 = fm ? e1 : e2; int z2 = fm ? k1 : k2;
+            bool sm = lexd_lt(m2, y2, o2, z2);
+            d1 = w1; i1 = x1; d2 = sm ? m2 : o2; i2 = sm ? y2 : z2;
+        };
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) merge(__shfl_xor(d1, o), __shfl_xor(i1, o), __shfl_xor(d2, o), __shfl_xor(i2, o));
+        const int wv = tid >> 6;
+        if ((tid & 63) == 0) { s_d[wv][0] = d1; s_d[wv][1] = d2; s_i[wv][0] = i1; s_i[wv][1] = i2; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) merge(s_d[w][0], s_i[w][0], s_d[w][1], s_i[w][1]);
+            size_t o = ((size_t)blockIdx.y * cap + k) * 2;
+            part_idx[o] = i1; part_idx[o + 1] = i2; part_dist[o] = d1; part_dist[o + 1] = d2;
+        }
+    }
+}
+__global__ void segp_fallback_finish_kernel(const int32_t* __restrict__ flag_list, const int32_t* __restrict__ n_flag, int cap,
+                                            const int32_t* __restrict__ part_idx, const double* __restrict__ part_dist,
+                                            int32_t* __restrict__ idx, double* __restrict__ dist) {
+    const int z = blockIdx.z;
+    const int nf = min(n_flag[z], cap);
+    flag_list += (size_t)z * cap; idx += (size_t)z * cap * 2; dist += (size_t)z * cap * 2;
+    part_idx += (size_t)z * kSegFbSlices * cap * 2; part_dist += (size_t)z * kSegFbSlices * cap * 2;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nf; k += gridDim.x * blockDim.x) {
+        Top2T<double> t{INFINITY, INFINITY, -1, -1};
+        for (int sl = 0; sl < kSegFbSlices; ++sl) {
+            const size_t o = ((size_t)sl * cap + k) * 2;
+            top2_insert_lex_t(t, part_dist[o], part_idx[o]);
+            top2_insert_lex_t(t, part_dist[o + 1], part_idx[o + 1]);
+        }
+        const int qi = flag_list[k];
+        idx[(size_t)qi * 2] = t.i1; idx[(size_t)qi * 2 + 1] = t.i2;
+        dist[(size_t)qi * 2] = t.d1; dist[(size_t)qi * 2 + 1] = t.d2;
+    }
+}
+
+// threshold + ratio + ordered compaction of a segment's surviving queries (filter_compact_kernel, one workgroup per segment);
+// also clears the back-search's fallback counter
+__global__ __launch_bounds__(kCompactThreads) void segp_filter_kernel(const int32_t* __restrict__ idx, const double* __restrict__ dist, int Q,
+                                                                      const int32_t* __restrict__ seg_off, double thr, double ratio,
+                                                                      int32_t* __restrict__ cand_q, int32_t* __restrict__ cand_m,
+                                                                      int32_t* __restrict__ n_cand, int32_t* __restrict__ n_flag) {
+    __shared__ int s_wave[kCompactThreads / 64];
+    const int z = blockIdx.x, M_total = seg_off[z + 1] - seg_off[z];
+    idx += (size_t)z * Q * 2; dist += (size_t)z * Q * 2; cand_q += (size_t)z * Q; cand_m += (size_t)z * Q;
+    const int per = (Q + kCompactThreads - 1) / kCompactThreads;
+    const int lo = min(Q, (int)threadIdx.x * per), hi = min(Q, lo + per);
+    int cnt = 0;
+    for (int qi = lo; qi < hi; ++qi) cnt += filter_keep<double>(idx, dist, qi, M_total, thr, ratio);
+    int total;
+    int o = block_exclusive_scan_1024(cnt, s_wave, &total);
+    for (int qi = lo; qi < hi; ++qi)
+        if (filter_keep<double>(idx, dist, qi, M_total, thr, ratio)) { cand_q[o] = qi; cand_m[o] = idx[(size_t)qi * 2]; ++o; }
+    if (threadIdx.x == 0) { n_cand[z] = total; n_flag[z] = 0; }
+}
+
+// the back-search's query operand: column cand_m[k] of the segment's quantised model rows, k < n_cand (zero past it)
+__global__ __launch_bounds__(kBlock) void segp_gather_q_kernel(const uint32_t* __restrict__ Bq, int ldqb, const int32_t* __restrict__ cand_m,
+                                                               const int32_t* __restrict__ n_cand, int Q, int D2p, int ldqa,
+                                                               uint32_t* __restrict__ Cq) {
+    const int z = blockIdx.z, n = n_cand[z];
+    Bq += (size_t)z * D2p * ldqb; Cq += (size_t)z * D2p * ldqa; cand_m += (size_t)z * Q;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ldqa || k >= (n + BQ - 1) / BQ * BQ) return;          // only the query tiles the candidates kernel will read
+    const int j = k < n ? cand_m[k] : -1;
+    for (int kk = blockIdx.y; kk < D2p; kk += gridDim.y) Cq[(size_t)kk * ldqa + k] = j >= 0 ? Bq[(size_t)kk * ldqb + j] : 0u;
+}
+
+// Unique (keep candidate k iff the best surface row of its model row is its own query) + ordered emission of the
+// 1-based pairs; one workgroup per segment (unique_flag_kernel + emit_pairs_kernel)
+__global__ __launch_bounds__(kBlock) void segp_emit_kernel(const int32_t* __restrict__ cand_q, const int32_t* __restrict__ cand_m,
+                                                           const int32_t* __restrict__ n_cand, const int32_t* __restrict__ back_idx, int unique,
+                                                           const double* __restrict__ dist, int Q, uint32_t* __restrict__ pairs,
+                                                           double* __restrict__ metric, int32_t* __restrict__ n_pairs) {
+    __shared__ int s_cnt[kBlock / 64];
+    __shared__ int s_base;
+    const int z = blockIdx.x, P = n_cand[z];
+    cand_q += (size_t)z * Q; cand_m += (size_t)z * Q; back_idx += (size_t)z * Q * 2; dist += (size_t)z * Q * 2;
+    pairs += (size_t)z * Q * 2; if (metric) metric += (size_t)z * Q;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < P; k0 += kBlock) {
+        const int k = k0 + threadIdx.x;
+        const bool kp = k < P && (!unique || back_idx[(size_t)k * 2] == cand_q[k]);
+        const unsigned long long b = __ballot(kp);
+        if (lane == 0) s_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wave; ++w) base += s_cnt[w];
+        if (kp) {
+            const int o = base + __popcll(b & ((1ull << lane) - 1ull));
+            pairs[(size_t)o * 2] = (uint32_t)cand_q[k] + 1u;
+            pairs[(size_t)o * 2 + 1] = (uint32_t)cand_m[k] + 1u;
+            if (metric) metric[o] = dist[(size_t)cand_q[k] * 2];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kBlock / 64; ++w) t += s_cnt[w]; s_base += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_pairs[z] = s_base;
+}
+
 }  // namespace
 
 // out [n][D] (row-major) = f (n x D, feature-major, leading dimension ld).  The reverse direction is
@@ -582,9 +1023,9 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     const char* tl = PCREG_EXP_STR("PCREG_SAD_TIMELINE");      // debug: dump per-block (start, end, HW_ID, XCC_ID) to this file
     if (tl) PCREG_HIP(hipMalloc(&dbg, (size_t)n_tiles * S * 4 * sizeof(unsigned long long)));
     if (PCREG_EXP_ENV("PCREG_SAD_DRY", 0))      // timing experiment only: list maintenance compiled out, results invalid
-        hipLaunchKernelGGL(sad16_candidates_kernel<true>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live);
+        hipLaunchKernelGGL(sad16_candidates_kernel<true>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr});
     else
-        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live);
+        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr});
     const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
     if (dbg) {
         std::vector<unsigned long long> h((size_t)n_tiles * S * 4);
@@ -620,6 +1061,112 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
                            fpi, fpd, idx, dist);
         PCREG_HIP(hipGetLastError());
     }
+    return PCREG_OK;
+}
+
+
+// ---- segmented getMatches: host side --------------------------------------------------------------------------
+// workspace: [once] P, l1, s2, pmin, pmax of both sets | [per segment] constants, norms, the three quantised operands,
+// candidate lists, top-2, filters, fallback partials
+namespace {
+struct SegLayout {
+    size_t PS, PM, rowS, rowM, sc, nrmS, nrmM, Aq, Bq, Cq, part_idx, part_s, idx, dist, bidx, bdist, cand_q, cand_m, n_cand, n_flag, flag_list, fpi, fpd, total;
+    int D2p, ldqa, ldqb, splits, chunk;
+};
+SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
+    SegLayout L{};
+    const size_t q = (size_t)std::max(Q, 1), vm = (size_t)std::max(VM, 1), ns = (size_t)std::max(S, 1);
+    L.D2p = (int)align_up((size_t)(Dp + 1) / 2, DK2);
+    L.ldqa = (int)align_up(q, BQ); L.ldqb = (int)align_up((size_t)std::max(n_max, 1), BQ);
+    // splits of the model rows: enough workgroups for the chip (3 per CU), as few lists per query as possible
+    const int n_tiles = (Q + BQ - 1) / BQ, row_tiles = std::max(1, (std::max(n_max, Q) + BM - 1) / BM);
+    // as MANY chunks as the finalize wave can read (kMaxSplit): the certificate compares the exact 2nd-best with the 4th-best
+    // integer score of every chunk, and only short chunks put that 4th-best clear of it (one chunk per segment left most
+    // queries of the sweep's shape unproven)
+    const int sp = std::min(kMaxSplit, row_tiles);
+    const int ct = (row_tiles + sp - 1) / sp;
+    L.splits = (row_tiles + ct - 1) / ct; L.chunk = ct * BM;
+    size_t b = 0;
+    auto take = [&](size_t bytes) { size_t o = b; b += align_up(bytes, 256); return o; };
+    L.PS = take(q * D * 8); L.PM = take(vm * D * 8);
+    L.rowS = take(4 * q * 8); L.rowM = take(4 * vm * 8);
+    L.sc = take(ns * sizeof(SegConst));
+    L.nrmS = take(ns * q * 8); L.nrmM = take((size_t)std::max(tot, 1) * 8);
+    L.Aq = take(ns * L.D2p * L.ldqa * 4); L.Bq = take(ns * L.D2p * L.ldqb * 4); L.Cq = take(ns * L.D2p * L.ldqa * 4);
+    L.part_idx = take(ns * L.splits * q * KC * 4); L.part_s = take(ns * L.splits * q * KC * 4);
+    L.idx = take(ns * q * 2 * 4); L.dist = take(ns * q * 2 * 8); L.bidx = take(ns * q * 2 * 4); L.bdist = take(ns * q * 2 * 8);
+    L.cand_q = take(ns * q * 4); L.cand_m = take(ns * q * 4); L.n_cand = take(ns * 4); L.n_flag = take(ns * 4);
+    L.flag_list = take(ns * q * 4);
+    L.fpi = take(ns * kSegFbSlices * q * 2 * 4); L.fpd = take(ns * kSegFbSlices * q * 2 * 8);
+    L.total = b;
+    return L;
+}
+}  // namespace
+
+size_t get_matches_segmented_workspace_bytes(int Q, int VM, int D, int S, int tot, int n_max) {
+    return seg_layout(Q, VM, D, D + 1, S, tot, n_max).total;
+}
+
+// descS [Q][D], descM [VM][D] row-major doubles; segment z = model rows seg_rows[seg_off[z] .. seg_off[z + 1]) (0-based, ascending;
+// seg_off [S + 1] on the device, tot = seg_off[S] and n_max = the longest segment known to the host).  pairs_all [S][Q][2]
+// (1-based; the model index counts within the segment), n_pairs [S], metric_all [S][Q] or null.  SAD only.
+int launch_get_matches_segmented(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
+                                 const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
+                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (S <= 0) return PCREG_OK;
+    if (Q <= 0 || n_max <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, (size_t)S * sizeof(int32_t), st)); return PCREG_OK; }
+    const int Dp = D + (o.unnormalize ? 1 : 0);
+    const SegLayout L = seg_layout(Q, VM, D, D + 1, S, tot, n_max);
+    if (ws_bytes < L.total) { set_error("segmented get_matches workspace too small: %zu < %zu", ws_bytes, L.total); return PCREG_E_WORKSPACE; }
+    if (L.splits * KC > 64 * kEPL) { set_error("segmented get_matches: %d list entries per query exceed the finalize wave", L.splits * KC); return PCREG_E_ARG; }
+    char* w = (char*)ws;
+    double *PS = (double*)(w + L.PS), *PM = (double*)(w + L.PM), *rS = (double*)(w + L.rowS), *rM = (double*)(w + L.rowM);
+    SegConst* sc = (SegConst*)(w + L.sc);
+    double *nrmS = (double*)(w + L.nrmS), *nrmM = (double*)(w + L.nrmM);
+    uint32_t *Aq = (uint32_t*)(w + L.Aq), *Bq = (uint32_t*)(w + L.Bq), *Cq = (uint32_t*)(w + L.Cq);
+    int32_t* part_idx = (int32_t*)(w + L.part_idx); uint32_t* part_s = (uint32_t*)(w + L.part_s);
+    int32_t *idx = (int32_t*)(w + L.idx), *bidx = (int32_t*)(w + L.bidx); double *dist = (double*)(w + L.dist), *bdist = (double*)(w + L.bdist);
+    int32_t *cand_q = (int32_t*)(w + L.cand_q), *cand_m = (int32_t*)(w + L.cand_m), *n_cand = (int32_t*)(w + L.n_cand), *n_flag = (int32_t*)(w + L.n_flag);
+    int32_t* flag_list = (int32_t*)(w + L.flag_list); int32_t* fpi = (int32_t*)(w + L.fpi); double* fpd = (double*)(w + L.fpd);
+    const size_t q = (size_t)Q, vm = (size_t)VM;
+
+    hipLaunchKernelGGL(segp_rows_kernel, dim3((Q + kPR - 1) / kPR), dim3(kBlock), 0, st, descS, Q, D, o.change_metric, o.metric_factor, PS, rS, rS + q, rS + 2 * q, rS + 3 * q);
+    hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM, VM, D, o.change_metric, o.metric_factor, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm);
+    const SegSets sets{PS, rS, rS + q, rS + 2 * q, rS + 3 * q, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, seg_rows, seg_off, Q, D, Dp};
+    hipLaunchKernelGGL(segp_consts_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, nrmS, nrmM, sc);
+    hipLaunchKernelGGL(segp_quantize_kernel, dim3(L.ldqa / 64, L.D2p / 32, S), dim3(kBlock), 0, st, sets, 0, nrmS, sc, L.D2p, L.ldqa, Aq);
+    hipLaunchKernelGGL(segp_quantize_kernel, dim3(L.ldqb / 64, L.D2p / 32, S), dim3(kBlock), 0, st, sets, 1, nrmM, sc, L.D2p, L.ldqb, Bq);
+    PCREG_HIP(hipMemsetAsync(n_flag, 0, (size_t)S * sizeof(int32_t), st));
+    PCREG_HIP(hipGetLastError());
+    const int n_tiles = (Q + BQ - 1) / BQ;
+    const size_t zP = (size_t)L.splits * q * KC;
+    const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
+    // forward: every surface row against its segment's model rows
+    hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, L.splits, S), dim3(kBlock), 0, st, Aq, Q, L.ldqa, Bq, n_max, L.ldqb, L.D2p, L.chunk,
+                       part_idx, part_s, (unsigned long long*)nullptr, (const int32_t*)nullptr, SegZ{(size_t)L.D2p * L.ldqa, (size_t)L.D2p * L.ldqb, zP, 0, seg_off});
+    hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force);
+    const int slice_f = (n_max + kSegFbSlices - 1) / kSegFbSlices;
+    hipLaunchKernelGGL(segp_exact_rows_kernel<false>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
+                       (const int32_t*)nullptr, flag_list, n_flag, slice_f, fpi, fpd);
+    hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag_list, n_flag, Q, fpi, fpd, idx, dist);
+    const double maxval = 2.0 * sqrt((double)Dp);                 // percentToLevel, SAD
+    const double thr = (o.matchThreshold * 0.01) * maxval;
+    hipLaunchKernelGGL(segp_filter_kernel, dim3(S), dim3(kCompactThreads), 0, st, idx, dist, Q, seg_off, thr, o.maxRatio, cand_q, cand_m, n_cand, n_flag);
+    PCREG_HIP(hipGetLastError());
+    if (o.unique) {
+        // back: the candidates' model rows against every surface row (the operands of the forward search, roles swapped)
+        hipLaunchKernelGGL(segp_gather_q_kernel, dim3(L.ldqa / kBlock + (L.ldqa % kBlock != 0), 16, S), dim3(kBlock), 0, st, Bq, L.ldqb, cand_m, n_cand, Q, L.D2p, L.ldqa, Cq);
+        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, L.splits, S), dim3(kBlock), 0, st, Cq, Q, L.ldqa, Aq, Q, L.ldqa, L.D2p, L.chunk,
+                           part_idx, part_s, (unsigned long long*)nullptr, n_cand, SegZ{(size_t)L.D2p * L.ldqa, (size_t)L.D2p * L.ldqa, zP, 1, nullptr});
+        hipLaunchKernelGGL(segp_finalize_kernel<true>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, cand_m, n_cand,
+                           part_idx, part_s, L.splits, bidx, bdist, flag_list, n_flag, force);
+        hipLaunchKernelGGL(segp_exact_rows_kernel<true>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
+                           cand_m, flag_list, n_flag, 0, fpi, fpd);
+        hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag_list, n_flag, Q, fpi, fpd, bidx, bdist);
+    }
+    hipLaunchKernelGGL(segp_emit_kernel, dim3(S), dim3(kBlock), 0, st, cand_q, cand_m, n_cand, bidx, o.unique ? 1 : 0, dist, Q, pairs_all, metric_all, n_pairs);
+    PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
 

@@ -57,6 +57,42 @@ __global__ __launch_bounds__(256) void sphere_scatter_kernel(const int32_t* __re
     if (in) idx[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
 }
 
+// getDescriptorMask for ALL spheres in one launch: one workgroup per sphere walks the keypoints in order and writes the
+// ascending 0-based row list of sphere s at idx[seg_off[s] ..] (seg_off from sphere_counts: the same predicate, so the
+// lengths agree; a longer list would be cut) and, optionally, featCur = feat(mask, :) beside it.
+__global__ __launch_bounds__(1024) void sphere_select_batched_kernel(const double* __restrict__ feat, int V, const double* __restrict__ centres,
+                                                                     double R, const int32_t* __restrict__ seg_off, int32_t* __restrict__ idx,
+                                                                     double* __restrict__ feat_out, int32_t* __restrict__ n_out) {
+    __shared__ int sc[16];
+    __shared__ int s_base;
+    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double cx = centres[(size_t)s * 3], cy = centres[(size_t)s * 3 + 1], cz = centres[(size_t)s * 3 + 2];
+    const int off = seg_off[s], cap = seg_off[s + 1] - off;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < V; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < V && in_sphere(feat, i, cx, cy, cz, R);
+        const unsigned long long b = __ballot(in);
+        if (lane == 0) sc[wave] = __popcll(b);
+        __syncthreads();
+        int base = s_base, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) base += sc[w]; tot += sc[w]; }
+        const int o = base + __popcll(b & ((1ull << lane) - 1ull));
+        if (in && o < cap) {
+            idx[off + o] = i;
+            if (feat_out) {
+                feat_out[(size_t)(off + o) * 3] = feat[(size_t)i * 3]; feat_out[(size_t)(off + o) * 3 + 1] = feat[(size_t)i * 3 + 1];
+                feat_out[(size_t)(off + o) * 3 + 2] = feat[(size_t)i * 3 + 2];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && n_out) n_out[s] = s_base;
+}
+
 // dst[k][:] = src[idx[k]][:] for k < *n (row-major, D doubles per row); one workgroup per row
 __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double* __restrict__ src, int D, const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ n, int cap, double* __restrict__ dst) {
@@ -145,6 +181,13 @@ int launch_sphere_select(const double* feat, int V, const double c[3], double R,
     return PCREG_OK;
 }
 
+int launch_sphere_select_batched(const double* feat, int V, const double* centres, int S, double R, const int32_t* seg_off, int32_t* idx,
+                                 double* feat_out, int32_t* n_out, hipStream_t st) {
+    if (S <= 0) return PCREG_OK;
+    hipLaunchKernelGGL(sphere_select_batched_kernel, dim3(S), dim3(1024), 0, st, feat, V, centres, R, seg_off, idx, feat_out, n_out);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
 int launch_gather_rows_f64(const double* src, int D, const int32_t* idx, const int32_t* n, int cap, double* dst, hipStream_t st) {
     if (cap <= 0 || D <= 0) return PCREG_OK;
     hipLaunchKernelGGL(gather_rows_f64_kernel, dim3(std::min(cap, 8192)), dim3(256), 0, st, src, D, idx, n, cap, dst);

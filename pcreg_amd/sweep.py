@@ -111,8 +111,109 @@ class SphereSweep:
                     statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
 
     def run(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
-            putative_thresh: int = 170, seed: int = 0, n_streams: int = 8) -> dict:
-        """completeExperimentFast.m:46-224 as ONE enqueue chain with TWO host synchronisations for the whole sweep.
+            putative_thresh: int = 170, seed: int = 0) -> dict:
+        """completeExperimentFast.m:46-224 with every per-sphere loop as ONE launch chain over all spheres, TWO host
+        synchronisations for the whole sweep.
+
+        (sync 1) the descriptor counts of all candidate centres fix the valid spheres and every buffer size (:52-64).
+        Then, with nothing read back in between: getDescriptorMask of every valid sphere as one launch writing the row
+        lists and featCur back to back (:109-125, pcreg_dev_sphere_select_batched); getMatches of the surface against every
+        sphere's rows as ONE segmented chain of ~18 launches (:131-149, pcreg_dev_get_matches_segmented: the powered
+        columns are computed once, the appended constant and the row norms per sphere); the putative threshold as a device
+        list of trial spheres (:175, pcreg_dev_sweep_plan); the matched keypoints of all trials packed back to back
+        (:205-206, pcreg_dev_sweep_gather); ONE batched ransac launch over the trial capacity (:201-216,
+        pcreg_dev_ransac_batched, seed + trial ordinal).  (sync 2) counts, pairs, rows and result structs come back
+        together.  Same outputs as run_streams() / run_serial(); SSD (never used by the reference's drivers) takes
+        run_streams()."""
+        from ._lib import DevRansacResult
+        if str(par.get("Metric", "SSD")).upper() != "SAD":
+            return self.run_streams(par, options, R_desc, d_spheres, min_pts, putative_thresh, seed)
+        L = lib()
+        dev = self.dev
+        centres = self.sphere_centres(d_spheres)
+        valid, counts = self.valid_spheres(centres, R_desc, min_pts)                     # ---- sync 1
+        centres = centres[valid]
+        num_desc = counts[valid].astype(np.int64)
+        S = len(centres)
+        if S == 0:
+            return dict(centres=centres, num_desc=num_desc, num_putative=np.zeros(0, np.int64), matches=[], model_rows=[], trial=np.zeros(0, np.int64),
+                        statsPutative=np.zeros(0, np.int64), statsSuccess=np.zeros(0, np.int64), statsInliers=np.zeros(0, np.int64),
+                        statsRatio=np.zeros(0), transforms=[])
+        i32, f64 = torch.int32, torch.float64
+        row_off = np.zeros(S + 1, dtype=np.int64); row_off[1:] = np.cumsum(num_desc)
+        tot, n_max = int(row_off[-1]), int(num_desc.max())
+        if tot >= 2**31:
+            raise ValueError("sphere sweep: more than 2^31 rows over all spheres")
+        VS, sp = self.VS, _stream()
+        seg_off = torch.from_numpy(row_off.astype(np.int32)).to(dev)
+        cen = torch.from_numpy(np.ascontiguousarray(centres, dtype=np.float64)).to(dev)
+        rows_all = torch.empty(tot, dtype=i32, device=dev)
+        feat_all = torch.empty((tot, 3), dtype=f64, device=dev)
+        n_sel = torch.zeros(S, dtype=i32, device=dev)
+        check(L.pcreg_dev_sphere_select_batched(_p(self.featM), self.VM, _p(cen), S, C.c_double(R_desc), _p(seg_off), _p(rows_all), _p(feat_all),
+                                                _p(n_sel), sp))                                                         # :109-125
+        pairs_all = torch.zeros((S, max(VS, 1), 2), dtype=i32, device=dev)
+        n_pairs = torch.zeros(S, dtype=i32, device=dev)
+        o = _match_opts(par)
+        wsb = L.pcreg_dev_get_matches_segmented_workspace(VS, self.VM, self.D, S, tot, n_max)
+        if getattr(self, "_seg_ws", None) is None or self._seg_ws.numel() < wsb:
+            self._seg_ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+        check(L.pcreg_dev_get_matches_segmented(_p(self.descS), VS, _p(self.descM), self.VM, self.D, _p(rows_all), _p(seg_off), S, tot, n_max,
+                                                C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws), C.c_size_t(self._seg_ws.numel()), sp))   # :131-149
+        return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed)
+
+    def _finish_sweep(self, centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed) -> dict:
+        """:166-224 on the current stream + the sweep's second (last) host synchronisation."""
+        from ._lib import DevRansacResult
+        L = lib()
+        dev = self.dev
+        S = len(centres)
+        i32, f64 = torch.int32, torch.float64
+        sp = _stream()
+        trial_idx = torch.empty(S, dtype=i32, device=dev); offsets = torch.empty(S + 1, dtype=i32, device=dev)
+        n_trials = torch.zeros(1, dtype=i32, device=dev)
+        check(L.pcreg_dev_sweep_plan(_p(n_pairs), S, int(putative_thresh), _p(trial_idx), _p(offsets), _p(n_trials), sp))
+        ld = S * max(self.VS, 1)                                    # capacity of the packed correspondences (Unique: <= VS pairs per sphere)
+        p1 = torch.zeros((3, ld), dtype=f64, device=dev); p2 = torch.zeros((3, ld), dtype=f64, device=dev)
+        roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
+        check(L.pcreg_dev_sweep_gather(_p(pairs_all), self.VS, _p(n_pairs), _p(trial_idx), _p(offsets), _p(n_trials), S, _p(self.featS),
+                                       _p(feat_all), _p(roff_dev), _p(p1), _p(p2), ld, sp))
+        o = RansacOpts(int(options["minPtNum"]), int(options["iterNum"]), float(options["thDist"]), float(options["thInlrRatio"]),
+                       int(bool(options["REFINE"])), 0, int(seed))
+        rs = C.sizeof(DevRansacResult)
+        results = torch.zeros((S, rs), dtype=torch.uint8, device=dev)
+        inliers = torch.empty(ld, dtype=i32, device=dev)
+        wsb = L.pcreg_dev_ransac_batched_workspace(self.VS, o.iterNum, S)
+        if getattr(self, "_rs_ws", None) is None or self._rs_ws.numel() < wsb:
+            self._rs_ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+        check(L.pcreg_dev_ransac_batched(_p(p1), _p(p2), ld, _p(offsets), S, self.VS, C.byref(o), _p(results), _p(inliers), _p(self._rs_ws),
+                                         C.c_size_t(self._rs_ws.numel()), sp))
+        # ---- sync 2: everything comes back together
+        npr = n_pairs.cpu().numpy().astype(np.int64)
+        nt = int(n_trials.item())
+        trial = trial_idx[:nt].cpu().numpy().astype(np.int64)
+        raw = results[:max(nt, 1)].cpu().numpy()
+        pairs_host = pairs_all.cpu().numpy()
+        rows_host = rows_all.cpu().numpy().astype(np.int64)
+        nsel = n_sel.cpu().numpy()
+        assert np.array_equal(nsel, num_desc), "sphere_select disagrees with sphere_counts"
+        sp_, ss, si, sr, tf = [], [], [], [], []
+        for t in range(nt):
+            r = DevRansacResult.from_buffer_copy(raw[t].tobytes())
+            P = int(npr[trial[t]])
+            sp_.append(P); ss.append(r.num_success); si.append(r.max_inliers)
+            sr.append(100.0 * r.max_inliers / P if not r.failed else 0.0)
+            tf.append(None if r.failed else np.array(r.T[:]).reshape(4, 4, order="F"))
+        return dict(centres=centres, num_desc=num_desc, num_putative=npr,
+                    matches=[pairs_host[i, :npr[i]].astype(np.uint32) for i in range(S)],
+                    model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)], trial=trial,
+                    statsPutative=np.array(sp_, dtype=np.int64), statsSuccess=np.array(ss, dtype=np.int64),
+                    statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
+
+    def run_streams(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
+                    putative_thresh: int = 170, seed: int = 0, n_streams: int = 8) -> dict:
+        """Round 2's batched form, kept as the cross-check of run() and for SSD: one getMatches CHAIN per sphere,
+        round-robin on `n_streams` HIP streams, then the same plan / gather / batched ransac.
 
         The reference runs the per-sphere getMatches under parfor (:131-149) and the per-trial ransac under a second
         parfor (:201-216).  Here: (sync 1) the descriptor counts of all candidate centres, which fix the valid spheres
@@ -167,46 +268,7 @@ class SphereSweep:
                            ws_cap=(self.VS, n_max))                                                                       # getMatches, :141
         for st, _, _ in self._lanes[:ns]:
             cur.wait_stream(st)
-        # ---- :166-224 on the main stream
-        sp = _stream()
-        trial_idx = torch.empty(S, dtype=i32, device=dev); offsets = torch.empty(S + 1, dtype=i32, device=dev)
-        n_trials = torch.zeros(1, dtype=i32, device=dev)
-        check(L.pcreg_dev_sweep_plan(_p(n_pairs), S, int(putative_thresh), _p(trial_idx), _p(offsets), _p(n_trials), sp))
-        ld = S * max(self.VS, 1)                                    # capacity of the packed correspondences (Unique: <= VS pairs per sphere)
-        p1 = torch.zeros((3, ld), dtype=f64, device=dev); p2 = torch.zeros((3, ld), dtype=f64, device=dev)
-        roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
-        check(L.pcreg_dev_sweep_gather(_p(pairs_all), self.VS, _p(n_pairs), _p(trial_idx), _p(offsets), _p(n_trials), S, _p(self.featS),
-                                       _p(feat_all), _p(roff_dev), _p(p1), _p(p2), ld, sp))
-        o = RansacOpts(int(options["minPtNum"]), int(options["iterNum"]), float(options["thDist"]), float(options["thInlrRatio"]),
-                       int(bool(options["REFINE"])), 0, int(seed))
-        rs = C.sizeof(DevRansacResult)
-        results = torch.zeros((S, rs), dtype=torch.uint8, device=dev)
-        inliers = torch.empty(ld, dtype=i32, device=dev)
-        wsb = L.pcreg_dev_ransac_batched_workspace(self.VS, o.iterNum, S)
-        ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
-        check(L.pcreg_dev_ransac_batched(_p(p1), _p(p2), ld, _p(offsets), S, self.VS, C.byref(o), _p(results), _p(inliers), _p(ws),
-                                         C.c_size_t(ws.numel()), sp))
-        # ---- sync 2: everything comes back together
-        npr = n_pairs.cpu().numpy().astype(np.int64)
-        nt = int(n_trials.item())
-        trial = trial_idx[:nt].cpu().numpy().astype(np.int64)
-        raw = results[:max(nt, 1)].cpu().numpy()
-        pairs_host = pairs_all.cpu().numpy()
-        rows_host = rows_all.cpu().numpy().astype(np.int64)
-        nsel = n_sel.cpu().numpy()
-        assert np.array_equal(nsel, num_desc), "sphere_select disagrees with sphere_counts"
-        sp_, ss, si, sr, tf = [], [], [], [], []
-        for t in range(nt):
-            r = DevRansacResult.from_buffer_copy(raw[t].tobytes())
-            P = int(npr[trial[t]])
-            sp_.append(P); ss.append(r.num_success); si.append(r.max_inliers)
-            sr.append(100.0 * r.max_inliers / P if not r.failed else 0.0)
-            tf.append(None if r.failed else np.array(r.T[:]).reshape(4, 4, order="F"))
-        return dict(centres=centres, num_desc=num_desc, num_putative=npr,
-                    matches=[pairs_host[i, :npr[i]].astype(np.uint32) for i in range(S)],
-                    model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)], trial=trial,
-                    statsPutative=np.array(sp_, dtype=np.int64), statsSuccess=np.array(ss, dtype=np.int64),
-                    statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
+        return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed)
 
 
 def quickTF_dev(pts_soa: torch.Tensor, TF: np.ndarray) -> torch.Tensor:

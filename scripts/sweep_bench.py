@@ -23,12 +23,19 @@ opt = dict(minPtNum=3, iterNum=10000, thDist=0.3, thInlrRatio=0.08, REFINE=True,
 kw = dict(R_desc=9.0, d_spheres=5.0, min_pts=1400, putative_thresh=170, seed=0)
 sw = SphereSweep(featM, descM, featS, descS, device=dev)
 NS = int(os.environ.get("SWEEP_STREAMS", "8"))
-out = sw.run(par, opt, n_streams=NS, **kw)                       # warm-up (allocations)
-torch.cuda.synchronize(); t0 = time.perf_counter(); out = sw.run(par, opt, n_streams=NS, **kw); torch.cuda.synchronize(); tb = time.perf_counter() - t0
-torch.cuda.synchronize(); t0 = time.perf_counter(); ser = sw.run_serial(par, opt, **kw); torch.cuda.synchronize(); ts = time.perf_counter() - t0
-same = all(np.array_equal(out[k], ser[k]) for k in ("num_putative", "trial", "statsSuccess", "statsInliers"))
+def timed(fn, reps=3):
+    fn(); ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return out, min(ts)
+out, tb = timed(lambda: sw.run(par, opt, **kw))                                   # segmented: one launch chain for all spheres
+strm, tst = timed(lambda: sw.run_streams(par, opt, n_streams=NS, **kw), reps=2)    # round 2: one chain per sphere on NS streams
+ser, ts = timed(lambda: sw.run_serial(par, opt, **kw), reps=1)
+same = all(np.array_equal(out[k], o2[k]) for o2 in (strm, ser) for k in ("num_putative", "trial", "statsSuccess", "statsInliers")) and \
+       all(np.array_equal(a, b) for o2 in (strm, ser) for a, b in zip(out["matches"], o2["matches"]))
 S = len(out["centres"])
 print(json.dumps({"workload": f"sphere sweep: {S} valid spheres (of a {VM}-keypoint model, {int(out['num_desc'].mean())} descriptors per sphere on average), "
                               f"surface {VS} keypoints, D {D}, {len(out['trial'])} trial spheres x RANSAC(3,1e4,0.3,0.08,REFINE)",
-                  "batched_ms": round(tb * 1e3, 1), "batched_spheres_per_s": round(S / tb, 1), "serial_ms": round(ts * 1e3, 1),
-                  "serial_spheres_per_s": round(S / ts, 1), "same_results": bool(same), "host_syncs_batched": 2, "streams": NS}), flush=True)
+                  "segmented_ms": round(tb * 1e3, 1), "segmented_spheres_per_s": round(S / tb, 1),
+                  "streams_ms": round(tst * 1e3, 1), "streams_spheres_per_s": round(S / tst, 1), "streams": NS,
+                  "serial_ms": round(ts * 1e3, 1), "serial_spheres_per_s": round(S / ts, 1), "same_results": bool(same), "host_syncs": 2}), flush=True)

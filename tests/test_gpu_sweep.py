@@ -35,10 +35,14 @@ def test_sphere_sweep_equals_oracle_driver(oracle_c, oracle_py):
     sw = SphereSweep(featM, descM, featS, descS)
     got = sw.run(PAR, OPT, **kw)                                            # batched: two host syncs for the whole sweep
     ser = sw.run_serial(PAR, OPT, **kw)                                     # one sphere at a time
-    for k in ("num_desc", "num_putative", "trial", "statsPutative", "statsSuccess", "statsInliers"):
-        np.testing.assert_array_equal(got[k], ser[k])
-    for a, b in zip(got["transforms"], ser["transforms"]):
-        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+    strm = sw.run_streams(PAR, OPT, n_streams=3, **kw)                       # one getMatches chain per sphere, on streams
+    for other in (ser, strm):
+        for k in ("num_desc", "num_putative", "trial", "statsPutative", "statsSuccess", "statsInliers"):
+            np.testing.assert_array_equal(got[k], other[k])
+        for a, b in zip(got["matches"], other["matches"]):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(got["transforms"], other["transforms"]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
     np.testing.assert_array_equal(got["centres"], ref["centres"])
     np.testing.assert_array_equal(got["num_desc"], ref["num_desc"])
     np.testing.assert_array_equal(got["num_putative"], ref["num_putative"])
@@ -130,3 +134,79 @@ def test_batched_sweep_counts_its_host_syncs(monkeypatch):
     assert S >= 4
     # sync 1 = featM (once, cached) + the counts; sync 2 = the final block of reads; nothing scales with S
     assert len(calls) <= 10, calls
+
+
+def _segments_direct(descS, descM, rows_list, par, metric=False):
+    """pcreg_dev_get_matches_segmented on explicit row lists -> per-segment (pairs, metric)."""
+    import ctypes as C
+    import torch
+    from pcreg_amd._lib import check, lib
+    from pcreg_amd.api import _match_opts
+    dev = torch.device("cuda", 0)
+    L = lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    Q, D = descS.shape
+    VM = descM.shape[0]
+    S = len(rows_list)
+    off = np.zeros(S + 1, dtype=np.int32); off[1:] = np.cumsum([len(r) for r in rows_list])
+    tot, n_max = int(off[-1]), max([len(r) for r in rows_list] + [0])
+    dS = torch.from_numpy(np.ascontiguousarray(descS, dtype=np.float64)).to(dev)
+    dM = torch.from_numpy(np.ascontiguousarray(descM, dtype=np.float64)).to(dev)
+    rows = torch.from_numpy(np.concatenate([np.asarray(r, dtype=np.int32) for r in rows_list] + [np.zeros(0, np.int32)])).to(dev)
+    if rows.numel() == 0:
+        rows = torch.zeros(1, dtype=torch.int32, device=dev)
+    seg_off = torch.from_numpy(off).to(dev)
+    pairs = torch.zeros((S, Q, 2), dtype=torch.int32, device=dev)
+    met = torch.zeros((S, Q), dtype=torch.float64, device=dev)
+    n_pairs = torch.full((S,), -1, dtype=torch.int32, device=dev)
+    o = _match_opts(par)
+    wsb = L.pcreg_dev_get_matches_segmented_workspace(Q, VM, D, S, tot, n_max)
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+    check(L.pcreg_dev_get_matches_segmented(p(dS), Q, p(dM), VM, D, p(rows), p(seg_off), S, tot, n_max, C.byref(o), p(pairs),
+                                            p(met) if metric else None, p(n_pairs), p(ws), C.c_size_t(ws.numel()),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    n = n_pairs.cpu().numpy()
+    ph, mh = pairs.cpu().numpy().astype(np.uint32), met.cpu().numpy()
+    return [(ph[z, :n[z]], mh[z, :n[z]]) for z in range(S)]
+
+
+@pytest.mark.parametrize("par_over", [dict(), dict(Unique=False), dict(UNNORMALIZE=False), dict(CHANGE_METRIC=False),
+                                      dict(MatchThreshold=2.0, MaxRatio=0.8)])
+def test_segmented_get_matches_equals_one_call_per_segment(oracle_c, par_over):
+    """Ragged segments (long, short, one row, empty, overlapping rows, the whole model) against pcreg.getMatches per segment and the
+    oracle; with the certificate forced to fail every query takes the exact fallback and the answer must not change."""
+    import os
+    import pcreg_amd as pc
+    rng = np.random.default_rng(11)
+    VM, Q, D = 1500, 300, 120
+    descM = rng.poisson(3.0, (VM, D)).astype(np.float64)
+    pick = rng.choice(VM, Q, replace=False)
+    descS = descM[pick] + rng.poisson(0.2, (Q, D))
+    descS[5] = descS[4]                                     # duplicate surface rows: Unique ties
+    descM[7] = 0.0                                          # an all-zero model row
+    rows_list = [np.sort(rng.choice(VM, 700, replace=False)), np.sort(rng.choice(VM, 130, replace=False)), np.array([7]), np.zeros(0, np.int64),
+                 np.arange(VM), np.sort(rng.choice(VM, 2, replace=False)), np.sort(pick[:200])]
+    par = dict(PAR, **par_over)
+    got = _segments_direct(descS, descM, rows_list, par, metric=True)
+    for z, r in enumerate(rows_list):
+        if len(r) == 0:
+            assert got[z][0].shape[0] == 0
+            continue
+        want = pc.getMatches(descS, descM[r], par)
+        np.testing.assert_array_equal(got[z][0], want, err_msg=f"segment {z}")
+        np.testing.assert_array_equal(want, oracle_c.getMatches(descS, descM[r], par))
+    os.environ["PCREG_MATCH_FORCE_FALLBACK"] = "1"
+    try:
+        forced = _segments_direct(descS, descM, rows_list, par, metric=True)
+    finally:
+        del os.environ["PCREG_MATCH_FORCE_FALLBACK"]
+    for (a, ma), (b, mb) in zip(got, forced):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ma, mb)                # the same exact fp64 distances either way
+
+
+def test_segmented_get_matches_refuses_ssd():
+    from pcreg_amd._lib import PcregError
+    rng = np.random.default_rng(0)
+    with pytest.raises(PcregError):
+        _segments_direct(rng.random((8, 6)), rng.random((20, 6)), [np.arange(10)], dict(PAR, Metric="SSD"))
