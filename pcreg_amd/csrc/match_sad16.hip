@@ -43,7 +43,8 @@ constexpr int kMaxSplit = 32;                  // S * KC <= 128: two list entrie
 struct Range { double fmin, scale, inv_scale; };
 // per-segment element strides of the candidates kernel's arrays (A, B: dwords; P: list entries; live: int32) and the
 // segments' row offsets; all zero / null for the one-segment call
-struct SegZ { size_t A, B, P, live; const int32_t* seg_off; };
+struct SegZ { size_t A, B, P, live; const int32_t* seg_off; uint32_t* mat; int ldm; };
+constexpr int kSadLists = 0, kSadDry = 1, kSadMatrix = 2;     // what the candidates kernel does with a finished 128 x 64 tile of scores
 
 // ---- range (two-stage, deterministic) --------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void minmax_partial_kernel(const double* __restrict__ A, int nA, int lda,
@@ -128,7 +129,7 @@ __device__ __forceinline__ void candu_insert_lex(CandU& c, unsigned s, int j) {
 
 // grid = (ceil(nA/BQ), S).  part_* layout [S][nA][KC].  Empty slots: idx -1, score 0xFFFFFFFF.
 // Aq / Bq are the padded layouts of quantize_pack_kernel (lda / ldb multiples of BQ, D2p of DK2).
-template <bool DRY>
+template <int MODE>
 __global__ __launch_bounds__(kBlock, 3) void sad16_candidates_kernel(const uint32_t* __restrict__ Aq, int nA, int lda,
                                                                   const uint32_t* __restrict__ Bq, int nB, int ldb, int D2p, int chunk,
                                                                   int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s,
@@ -216,10 +217,24 @@ __global__ __launch_bounds__(kBlock, 3) void sad16_candidates_kernel(const uint3
         }
         if (++slab == n_slabs) {                    // a model tile is complete: fold it into the lists
             slab = 0;
+            if (MODE == kSadMatrix) {
+                // the whole tile goes to the score matrix [model row][query] (segmented getMatches: every segment selects from it);
+                // a lane's four consecutive queries are one 16-byte store, 16 lanes cover 256 contiguous bytes of a row
+#pragma unroll
+                for (int c = 0; c < TM; ++c) {
+                    const int j = m0 + ty * TM + c;
+                    if (j < b_end) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            *(uint4*)(sz.mat + (size_t)j * sz.ldm + q0 + h * 64 + tx * 4) = make_uint4(acc[4 * h][c], acc[4 * h + 1][c], acc[4 * h + 2][c], acc[4 * h + 3][c]);
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < TQ; ++r) {
                 unsigned mn = min(min(acc[r][0], acc[r][1]), min(acc[r][2], acc[r][3]));
-                if (DRY) { asm volatile("" :: "v"(mn)); }
+                if (MODE == kSadDry) { asm volatile("" :: "v"(mn)); }
+                else if (MODE == kSadMatrix) {}
                 else if (mn < best[r].s[3]) {
 #pragma unroll
                     for (int c = 0; c < TM; ++c) {
@@ -237,6 +252,7 @@ __global__ __launch_bounds__(kBlock, 3) void sad16_candidates_kernel(const uint3
     }
 #undef PCREG_SAD_DMA
 #undef PCREG_SAD_RANK1
+    if (MODE == kSadMatrix) return;
     // merge the 16 ty-lists of every query (two halves of 64 queries)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -507,18 +523,29 @@ __global__ void sad_fallback_finish_kernel(const int32_t* __restrict__ list, con
 // the constant column comes last.  A normalised value is P / nrm_i(row) (last column cc_i / nrm_i(row)): the SAME IEEE
 // operations on the same operands as the one-segment path (preprocess_kernel, normalize_rows_kernel), so the exact
 // re-rank sees the same bits and the pairs are those of one pcreg_dev_get_matches call per segment.  No normalised
-// double matrix is ever materialised: the u16 operands of the candidates kernel are quantised straight from P, and
-// the re-rank divides the handful of rows it touches on the fly.
-struct SegConst { double cc, fmin, scale, inv_scale; };
+// double matrix is ever materialised: the re-rank divides the handful of rows it touches on the fly.
+//
+// The APPROXIMATE scores are shared by all segments.  The segments' constants differ by ~1e-3 relative (the mean of
+// ~3500 row lengths), so one u16 quantisation under a REFERENCE constant cc_ref (the middle of the segments' constants) scores
+// every (surface row, model row) pair ONCE -- the spheres of the sweep overlap ~8-fold, and the back-search of Unique reads
+// the same matrix.  Segment i relates its true distances to the reference ones: with u(r) = 1 / n_ref(r), w(r) = 1 / n_i(r)
+// and ONE factor rho_i (the ratio n_ref / n_i at a typical row: the constant dominates every norm, so all rows rescale
+// almost alike),
+//     SAD_i(a, b) - rho_i SAD_ref(a, b) = sum_k<D0 (|p_ak w_a - p_bk w_b| - rho_i |p_ak u_a - p_bk u_b|) + (|g_a - g_b| ...)
+//     |.| <= t(a) + t(b) + (max g - min g),   t(r) = sum|P(r)| |w_r - rho_i u_r|,   g(r) = cc_i w_r - rho_i cc_ref u_r
+// (triangle inequality per column; the appended column's two terms differ by at most the spread of g over the rows in play).
+// E_i = max_a t + max_b t + spread(g), evaluated exactly per segment: a few units of the quantisation against the D + 1 = 982
+// the rounding already costs, so the certificate is as strong as the one-segment path's.
+struct SegConst { double cc, fmin, scale, inv_scale, rho; unsigned eunits, slack2; };
 
 constexpr int kPR = 64, kPF = 48;
 // src row-major [n][D] -> P row-major, l1, s2, min / max of P per row (one lane per row keeps the oracle's order)
 __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restrict__ src, int n, int D, int change_metric, double factor,
                                                            double* __restrict__ P, double* __restrict__ l1, double* __restrict__ s2,
-                                                           double* __restrict__ pmin, double* __restrict__ pmax) {
+                                                           double* __restrict__ pmin, double* __restrict__ pmax, double* __restrict__ sp) {
     __shared__ double t_raw[kPF][kPR + 1], t_p[kPF][kPR + 1];
     const int r0 = blockIdx.x * kPR, rows = min(kPR, n - r0);
-    double a = 0.0, s = 0.0, lo = INFINITY, hi = -INFINITY;
+    double a = 0.0, s = 0.0, lo = INFINITY, hi = -INFINITY, ap = 0.0;
     for (int d0 = 0; d0 < D; d0 += kPF) {
         const int dn = min(kPF, D - d0);
         for (int e = threadIdx.x; e < kPR * kPF; e += kBlock) {
@@ -536,27 +563,29 @@ __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restr
             const int r = threadIdx.x;
             for (int f = 0; f < dn; ++f) {
                 const double x = t_raw[f][r], pv = t_p[f][r];
-                a += fabs(x); s = fma(pv, pv, s); lo = fmin(lo, pv); hi = fmax(hi, pv);
+                a += fabs(x); s = fma(pv, pv, s); lo = fmin(lo, pv); hi = fmax(hi, pv); ap += fabs(pv);
             }
         }
         __syncthreads();
     }
-    if ((int)threadIdx.x < rows) { const int r = r0 + threadIdx.x; l1[r] = a; s2[r] = s; pmin[r] = lo; pmax[r] = hi; }
+    if ((int)threadIdx.x < rows) { const int r = r0 + threadIdx.x; l1[r] = a; s2[r] = s; pmin[r] = lo; pmax[r] = hi; sp[r] = ap; }
 }
 
 struct SegSets {                // the two descriptor sets after segp_rows_kernel, and the segments
-    const double *PS, *l1S, *s2S, *pminS, *pmaxS;      // surface: Q rows
-    const double *PM, *l1M, *s2M, *pminM, *pmaxM;      // model: every row of the full set
+    const double *PS, *l1S, *s2S, *pminS, *pmaxS, *spS;      // surface: Q rows
+    const double *PM, *l1M, *s2M, *pminM, *pmaxM, *spM;      // model: every row of the full set (VM)
     const int32_t *seg_rows, *seg_off;                // segment z owns model rows seg_rows[seg_off[z] .. seg_off[z + 1])
-    int Q, D0, Dp;                                    // Dp = D0 + 1 with the appended column
+    int Q, VM, D0, Dp;                                // Dp = D0 + 1 with the appended column
 };
 
-// one workgroup per segment: the appended constant (mean_kernel's order over [l1 of the surface; l1 of the segment's rows]),
-// every row's norm, and the common quantisation range of the segment's normalised values
-__global__ __launch_bounds__(kBlock) void segp_consts_kernel(SegSets S, pcreg_match_opts o, double* __restrict__ nrmS, double* __restrict__ nrmM,
-                                                             SegConst* __restrict__ sc) {
+__device__ __forceinline__ double seg_norm(const pcreg_match_opts& o, double cc, double q2) {
+    if (o.prenormalized) return 1.0;
+    const double nrm = sqrt(o.unnormalize ? fma(cc, cc, q2) : q2);
+    return nrm <= (double)FLT_EPSILON ? INFINITY : nrm;        // normalizeX: an effectively-zero row becomes zeros
+}
+// every segment's appended constant (mean_kernel's order over [l1 of the surface; l1 of the segment's rows]) -> sc[z].cc
+__global__ __launch_bounds__(kBlock) void segp_cc_kernel(SegSets S, pcreg_match_opts o, SegConst* __restrict__ sc) {
     __shared__ double s[kBlock];
-    __shared__ double s_lo[kBlock / 64], s_hi[kBlock / 64];
     const int z = blockIdx.x, off = S.seg_off[z], n = S.seg_off[z + 1] - off, Q = S.Q, tid = threadIdx.x;
     const int32_t* rows = S.seg_rows + off;
     double cc = 0.0;
@@ -569,62 +598,192 @@ __global__ __launch_bounds__(kBlock) void segp_consts_kernel(SegSets S, pcreg_ma
         const double c = o.norm_factor * (s[0] / (double)(Q + n));
         cc = o.change_metric ? pow(c, o.metric_factor) : c;
     }
-    double lo = INFINITY, hi = -INFINITY;
-    for (int i = tid; i < Q + n; i += kBlock) {
-        const bool surf = i < Q;
-        const int r = surf ? i : rows[i - Q];
-        const double q2 = surf ? S.s2S[r] : S.s2M[r];
-        double nrm = 1.0;
-        if (!o.prenormalized) {
-            nrm = sqrt(o.unnormalize ? fma(cc, cc, q2) : q2);
-            if (nrm <= (double)FLT_EPSILON) nrm = INFINITY;            // normalizeX: an effectively-zero row becomes zeros
+    if (tid == 0) sc[z].cc = cc;
+}
+// The reference constant = the middle of the segments' constants (any value works: it only sets how much slack the segments
+// need), every row's norm under it, and the common quantisation range.  One workgroup; ref = sc[n_seg].
+__global__ __launch_bounds__(kBlock) void segp_ref_kernel(SegSets S, pcreg_match_opts o, double* __restrict__ nrefS, double* __restrict__ nrefM,
+                                                          SegConst* __restrict__ sc, int n_seg) {
+    __shared__ double s_lo[kBlock / 64], s_hi[kBlock / 64];
+    __shared__ double s_cc;
+    const int tid = threadIdx.x, n = S.Q + S.VM;
+    {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int z = tid; z < n_seg; z += kBlock) { lo = fmin(lo, sc[z].cc); hi = fmax(hi, sc[z].cc); }
+#pragma unroll
+        for (int w = 32; w > 0; w >>= 1) { lo = fmin(lo, __shfl_xor(lo, w)); hi = fmax(hi, __shfl_xor(hi, w)); }
+        if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < kBlock / 64; ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); }
+            s_cc = 0.5 * (lo + hi);
         }
-        if (surf) nrmS[(size_t)z * Q + i] = nrm; else nrmM[off + i - Q] = nrm;
+        __syncthreads();
+    }
+    const double cc = o.unnormalize ? s_cc : 0.0;
+    SegConst* ref = sc + n_seg;
+    double lo = INFINITY, hi = -INFINITY, q_lo = INFINITY, q_hi = -INFINITY;
+    for (int i = tid; i < n; i += kBlock) {
+        const bool surf = i < S.Q;
+        const int r = surf ? i : i - S.Q;
+        const double q2 = surf ? S.s2S[r] : S.s2M[r];
+        q_lo = fmin(q_lo, q2); q_hi = fmax(q_hi, q2);
+        const double nrm = seg_norm(o, cc, q2);
+        if (surf) nrefS[r] = nrm; else nrefM[r] = nrm;
         const double a = (surf ? S.pminS[r] : S.pminM[r]) / nrm, b = (surf ? S.pmaxS[r] : S.pmaxM[r]) / nrm;
         lo = fmin(lo, fmin(a, b)); hi = fmax(hi, fmax(a, b));
         if (o.unnormalize) { const double c = cc / nrm; lo = fmin(lo, c); hi = fmax(hi, c); }
     }
+    __shared__ double s_q[2][kBlock / 64];
 #pragma unroll
-    for (int w = 32; w > 0; w >>= 1) { lo = fmin(lo, __shfl_xor(lo, w)); hi = fmax(hi, __shfl_xor(hi, w)); }
-    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; }
+    for (int w = 32; w > 0; w >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, w)); hi = fmax(hi, __shfl_xor(hi, w));
+        q_lo = fmin(q_lo, __shfl_xor(q_lo, w)); q_hi = fmax(q_hi, __shfl_xor(q_hi, w));
+    }
+    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; s_q[0][tid >> 6] = q_lo; s_q[1][tid >> 6] = q_hi; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < kBlock / 64; ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); }
+        for (int w = 1; w < kBlock / 64; ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); q_lo = fmin(q_lo, s_q[0][w]); q_hi = fmax(q_hi, s_q[1][w]); }
         if (!(hi > lo)) hi = lo + 1.0;
-        sc[z] = SegConst{cc, lo, 65535.0 / (hi - lo), (hi - lo) / 65535.0};
+        // .rho of the reference slot carries the typical row's sum of squares (the segments derive their factor from it)
+        *ref = SegConst{cc, lo, 65535.0 / (hi - lo), (hi - lo) / 65535.0, 0.5 * (q_lo + q_hi), 0u, 0u};
     }
 }
 
-// side 0: the surface rows of segment z (their norms are the segment's); side 1: the segment's model rows.
-// out [segment][D2p][ldq] in quantize_pack_kernel's layout (zero padding in rows and features).
-__global__ __launch_bounds__(kBlock) void segp_quantize_kernel(SegSets S, int side, const double* __restrict__ nrm_all, const SegConst* __restrict__ sc,
-                                                               int D2p, int ldq, uint32_t* __restrict__ out) {
+// one workgroup per segment: every row's norm under the segment's constant, and E_i in quantisation units (how far the segment's normalised rows are from the reference ones)
+__global__ __launch_bounds__(kBlock) void segp_consts_kernel(SegSets S, pcreg_match_opts o, const double* __restrict__ nrefS,
+                                                             const double* __restrict__ nrefM, double* __restrict__ nrmS,
+                                                             double* __restrict__ nrmM, SegConst* __restrict__ sc, int n_seg) {
+    const int z = blockIdx.x, off = S.seg_off[z], n = S.seg_off[z + 1] - off, Q = S.Q, tid = threadIdx.x;
+    const int32_t* rows = S.seg_rows + off;
+    const SegConst ref = sc[n_seg];
+    const double cc = sc[z].cc;
+    double rho = 1.0;
+    if (o.unnormalize && !o.prenormalized) {
+        const double nr = sqrt(fma(ref.cc, ref.cc, ref.rho)), ni = sqrt(fma(cc, cc, ref.rho));
+        if (nr > 0.0 && ni > 0.0 && nr < INFINITY && ni < INFINITY) rho = nr / ni;
+    }
+    double ts = 0.0, tm = 0.0, g_lo = INFINITY, g_hi = -INFINITY;       // max t over the surface rows / the segment's model rows; range of g
+    for (int i = tid; i < Q + n; i += kBlock) {
+        const bool surf = i < Q;
+        const int r = surf ? i : rows[i - Q];
+        const double nrm = seg_norm(o, cc, surf ? S.s2S[r] : S.s2M[r]);
+        if (surf) nrmS[(size_t)z * Q + i] = nrm; else nrmM[off + i - Q] = nrm;
+        const double wi = 1.0 / nrm, ur = 1.0 / (surf ? nrefS[r] : nrefM[r]);          // 0 for a row that normalizeX zeroes
+        const double t = (surf ? S.spS[r] : S.spM[r]) * fabs(wi - rho * ur);
+        if (surf) ts = fmax(ts, t); else tm = fmax(tm, t);
+        if (o.unnormalize) { const double g = cc * wi - rho * ref.cc * ur; g_lo = fmin(g_lo, g); g_hi = fmax(g_hi, g); }
+    }
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) {
+        ts = fmax(ts, __shfl_xor(ts, w)); tm = fmax(tm, __shfl_xor(tm, w));
+        g_lo = fmin(g_lo, __shfl_xor(g_lo, w)); g_hi = fmax(g_hi, __shfl_xor(g_hi, w));
+    }
+    __shared__ double s_r[4][kBlock / 64];
+    if ((tid & 63) == 0) { s_r[0][tid >> 6] = ts; s_r[1][tid >> 6] = tm; s_r[2][tid >> 6] = g_lo; s_r[3][tid >> 6] = g_hi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) { ts = fmax(ts, s_r[0][w]); tm = fmax(tm, s_r[1][w]); g_lo = fmin(g_lo, s_r[2][w]); g_hi = fmax(g_hi, s_r[3][w]); }
+        double E = ts + tm + (g_hi > g_lo ? g_hi - g_lo : 0.0);
+        // rounding of the fp64 evaluation above is ~1e-16 relative: the factor and the two extra units swamp it.  A NaN / inf
+        // bound (non-finite descriptors) becomes the largest slack: every query of the segment then takes the exact path.
+        const double units = ceil(E * ref.scale * (1.0 + 1e-9)) + 2.0;
+        const unsigned eu = units < 5.0e8 ? (unsigned)units : 500000000u;
+        const double s2 = ceil(2.0 * (double)eu / rho * (1.0 + 1e-9)) + 1.0;
+        sc[z] = SegConst{cc, ref.fmin, ref.scale, ref.inv_scale, rho, eu, s2 < 2.0e9 ? (unsigned)s2 : 2000000000u};
+    }
+}
+
+// rows under the REFERENCE constant -> packed u16 pairs [D2p][ldq] (quantize_pack_kernel's layout, zero padding)
+__global__ __launch_bounds__(kBlock) void segp_quantize_ref_kernel(const double* __restrict__ P, const double* __restrict__ nref, int n, int D0, int Dp,
+                                                                   const SegConst* __restrict__ ref, int D2p, int ldq, uint32_t* __restrict__ out) {
     __shared__ uint16_t tile[64][66];
-    const int z = blockIdx.z, i0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
-    int n = S.Q;
-    const int32_t* rows = nullptr;
-    const double* P = S.PS;
-    const double* nrm = nrm_all + (size_t)z * S.Q;
-    if (side) { const int off = S.seg_off[z]; n = S.seg_off[z + 1] - off; rows = S.seg_rows + off; nrm = nrm_all + off; P = S.PM; }
-    const SegConst c = sc[z];
+    const int i0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+    const SegConst c = *ref;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {
         const int i = i0 + ty + 4 * k, d = d0 + tx;
         unsigned q = 0u;
-        if (i < n && d < S.Dp) {
-            const double v = d < S.D0 ? P[(size_t)(rows ? rows[i] : i) * S.D0 + d] : c.cc;
-            const double u = rint((v / nrm[i] - c.fmin) * c.scale);
+        if (i < n && d < Dp) {
+            const double v = d < D0 ? P[(size_t)i * D0 + d] : c.cc;
+            const double u = rint((v / nref[i] - c.fmin) * c.scale);
             q = (unsigned)fmin(fmax(u, 0.0), 65535.0);
         }
         tile[ty + 4 * k][tx] = (uint16_t)q;
     }
     __syncthreads();
-    uint32_t* o = out + (size_t)z * D2p * ldq;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int kk = ty + 4 * k, i = i0 + tx;
-        if (i < ldq) o[(size_t)(d0 / 2 + kk) * ldq + i] = (uint32_t)tile[tx][2 * kk] | ((uint32_t)tile[tx][2 * kk + 1] << 16);
+        if (i < ldq) out[(size_t)(d0 / 2 + kk) * ldq + i] = (uint32_t)tile[tx][2 * kk] | ((uint32_t)tile[tx][2 * kk + 1] << 16);
+    }
+}
+
+// Candidate lists of every (segment, chunk of its rows, surface row) from the shared score matrix Sc [model row][ldsc]:
+// one wave = 64 surface rows (lanes) x one chunk; the row of a model point is read as 256 contiguous bytes.
+// part_* [segment][chunk][Q][KC] as sad16_candidates_kernel writes them (sorted, ascending row on ties, -1 / 0xFFFFFFFF empty).
+__global__ __launch_bounds__(kBlock) void segp_select_kernel(const uint32_t* __restrict__ Sc, int ldsc, const int32_t* __restrict__ seg_rows,
+                                                             const int32_t* __restrict__ seg_off, int Q, int chunk, int splits,
+                                                             int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int z = blockIdx.z, sidx = blockIdx.y * (kBlock / 64) + wave;
+    if (sidx >= splits) return;
+    const int off = seg_off[z], n = seg_off[z + 1] - off;
+    const int32_t* rows = seg_rows + off;
+    const int qi = blockIdx.x * 64 + lane;                     // < ldsc: the matrix is padded to whole query tiles
+    const int b_begin = sidx * chunk, b_end = min(n, b_begin + chunk);
+    CandU t;
+#pragma unroll
+    for (int k = 0; k < KC; ++k) { t.s[k] = 0xFFFFFFFFu; t.i[k] = -1; }
+    int j = b_begin;
+    for (; j + 8 <= b_end; j += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = Sc[(size_t)rows[j + u] * ldsc + qi];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) candu_insert(t, v[u], j + u);
+    }
+    for (; j < b_end; ++j) candu_insert(t, Sc[(size_t)rows[j] * ldsc + qi], j);
+    if (qi < Q) {
+        const size_t o = (((size_t)z * splits + sidx) * Q + qi) * KC;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { part_idx[o + k] = t.i[k]; part_s[o + k] = t.s[k]; }
+    }
+}
+
+// The back-search's lists: candidate k of segment z is model row rows[cand_m[k]]; its scores against ALL surface rows are one
+// row of the matrix.  One wave per candidate; per chunk of surface rows every lane keeps the best KC of its strided share and
+// KC rounds of a wave-wide (score, row) minimum pull the chunk's sorted list out.
+__global__ __launch_bounds__(kBlock) void segp_select_back_kernel(const uint32_t* __restrict__ Sc, int ldsc, const int32_t* __restrict__ seg_rows,
+                                                                  const int32_t* __restrict__ seg_off, const int32_t* __restrict__ cand_m,
+                                                                  const int32_t* __restrict__ n_cand, int Q, int chunk, int splits,
+                                                                  int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int z = blockIdx.z, k = blockIdx.x * (kBlock / 64) + wave;
+    if (k >= n_cand[z]) return;
+    const uint32_t* row = Sc + (size_t)seg_rows[seg_off[z] + cand_m[(size_t)z * Q + k]] * ldsc;
+    for (int sidx = 0; sidx < splits; ++sidx) {
+        const int a_begin = sidx * chunk, a_end = min(Q, a_begin + chunk);
+        CandU t;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) { t.s[e] = 0xFFFFFFFFu; t.i[e] = -1; }
+        for (int a = a_begin + lane; a < a_end; a += 64) candu_insert(t, row[a], a);
+        const size_t o = (((size_t)z * splits + sidx) * Q + k) * KC;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) {
+            // the smallest (score, row) among the lanes' heads; empty heads are (0xFFFFFFFF, -1): they order last
+            unsigned long long key = ((unsigned long long)t.s[0] << 32) | (unsigned)t.i[0];
+            unsigned long long m = key;
+#pragma unroll
+            for (int w = 32; w > 0; w >>= 1) { const unsigned long long x = __shfl_xor(m, w); m = x < m ? x : m; }
+            if (key == m && t.i[0] >= 0) {                       // the one owner pops its head (rows are distinct)
+#pragma unroll
+                for (int q = 0; q < KC - 1; ++q) { t.s[q] = t.s[q + 1]; t.i[q] = t.i[q + 1]; }
+                t.s[KC - 1] = 0xFFFFFFFFu; t.i[KC - 1] = -1;
+            }
+            if (lane == 0) { part_idx[o + e] = (int)(unsigned)(m & 0xFFFFFFFFull); part_s[o + e] = (unsigned)(m >> 32); }
+        }
     }
 }
 
@@ -682,7 +841,8 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
         a1 = n1; a2 = n2;
         g = min(g, (unsigned)__shfl_xor((int)g, o));
     }
-    const unsigned slack = 2u * (unsigned)(D + 1) + 2u;
+    // the scores were taken under the reference constant: this segment's true distances lie within E_i (c.eunits) of rho_i times them
+    const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
     int n_need = 0;
 #pragma unroll
     for (int u = 0; u < kEPL; ++u) {
@@ -750,7 +910,7 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
     bool ok;
     if (g == 0xFFFFFFFFu) ok = true;
     else {
-        double lower = ((double)g - (double)(D + 1)) * c.inv_scale;
+        double lower = (c.rho * ((double)g - (double)(D + 1)) - (double)c.eunits) * c.inv_scale;
         ok = (i2 >= 0) && (lower * (1.0 - 1e-12) > d2);
     }
     if (force_unproven) ok = false;
@@ -870,18 +1030,6 @@ __global__ __launch_bounds__(kCompactThreads) void segp_filter_kernel(const int3
     for (int qi = lo; qi < hi; ++qi)
         if (filter_keep<double>(idx, dist, qi, M_total, thr, ratio)) { cand_q[o] = qi; cand_m[o] = idx[(size_t)qi * 2]; ++o; }
     if (threadIdx.x == 0) { n_cand[z] = total; n_flag[z] = 0; }
-}
-
-// the back-search's query operand: column cand_m[k] of the segment's quantised model rows, k < n_cand (zero past it)
-__global__ __launch_bounds__(kBlock) void segp_gather_q_kernel(const uint32_t* __restrict__ Bq, int ldqb, const int32_t* __restrict__ cand_m,
-                                                               const int32_t* __restrict__ n_cand, int Q, int D2p, int ldqa,
-                                                               uint32_t* __restrict__ Cq) {
-    const int z = blockIdx.z, n = n_cand[z];
-    Bq += (size_t)z * D2p * ldqb; Cq += (size_t)z * D2p * ldqa; cand_m += (size_t)z * Q;
-    const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= ldqa || k >= (n + BQ - 1) / BQ * BQ) return;          // only the query tiles the candidates kernel will read
-    const int j = k < n ? cand_m[k] : -1;
-    for (int kk = blockIdx.y; kk < D2p; kk += gridDim.y) Cq[(size_t)kk * ldqa + k] = j >= 0 ? Bq[(size_t)kk * ldqb + j] : 0u;
 }
 
 // Unique (keep candidate k iff the best surface row of its model row is its own query) + ordered emission of the
@@ -1022,10 +1170,12 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     unsigned long long* dbg = nullptr;
     const char* tl = PCREG_EXP_STR("PCREG_SAD_TIMELINE");      // debug: dump per-block (start, end, HW_ID, XCC_ID) to this file
     if (tl) PCREG_HIP(hipMalloc(&dbg, (size_t)n_tiles * S * 4 * sizeof(unsigned long long)));
+#ifdef PCREG_EXPERIMENTS
     if (PCREG_EXP_ENV("PCREG_SAD_DRY", 0))      // timing experiment only: list maintenance compiled out, results invalid
-        hipLaunchKernelGGL(sad16_candidates_kernel<true>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr});
+        hipLaunchKernelGGL(sad16_candidates_kernel<kSadDry>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr, nullptr, 0});
     else
-        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr});
+#endif
+        hipLaunchKernelGGL(sad16_candidates_kernel<kSadLists>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr, nullptr, 0});
     const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
     if (dbg) {
         std::vector<unsigned long long> h((size_t)n_tiles * S * 4);
@@ -1048,7 +1198,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
         int32_t nf = 0;
         PCREG_HIP(hipMemcpyAsync(&nf, n_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         PCREG_HIP(hipStreamSynchronize(st));
-        int occ = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sad16_candidates_kernel<false>, kBlock, 0);
+        int occ = -1; (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sad16_candidates_kernel<kSadLists>, kBlock, 0);
         fprintf(stderr, "[pcreg] sad16: nA=%d nB=%d D=%d S=%d unproven=%d (candidates kernel: %d blocks/CU)\n", nA, nB, D, S, nf, occ);
     }
     {   // unproven rows: exact fp64 rows, sliced over B; both kernels read the count on the device
@@ -1066,33 +1216,33 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
 
 
 // ---- segmented getMatches: host side --------------------------------------------------------------------------
-// workspace: [once] P, l1, s2, pmin, pmax of both sets | [per segment] constants, norms, the three quantised operands,
-// candidate lists, top-2, filters, fallback partials
+// workspace: [once] P and five scalars per row of both sets, reference norms, the two quantised operands, the score matrix
+// | [per segment] constants, norms, candidate lists, top-2, filters, fallback partials
 namespace {
 struct SegLayout {
-    size_t PS, PM, rowS, rowM, sc, nrmS, nrmM, Aq, Bq, Cq, part_idx, part_s, idx, dist, bidx, bdist, cand_q, cand_m, n_cand, n_flag, flag_list, fpi, fpd, total;
+    size_t PS, PM, rowS, rowM, nrefS, nrefM, Aq, Bq, Sc, sc, nrmS, nrmM, part_idx, part_s, idx, dist, bidx, bdist, cand_q, cand_m, n_cand, n_flag,
+           flag_list, fpi, fpd, total;
     int D2p, ldqa, ldqb, splits, chunk;
 };
 SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
     SegLayout L{};
     const size_t q = (size_t)std::max(Q, 1), vm = (size_t)std::max(VM, 1), ns = (size_t)std::max(S, 1);
     L.D2p = (int)align_up((size_t)(Dp + 1) / 2, DK2);
-    L.ldqa = (int)align_up(q, BQ); L.ldqb = (int)align_up((size_t)std::max(n_max, 1), BQ);
-    // splits of the model rows: enough workgroups for the chip (3 per CU), as few lists per query as possible
-    const int n_tiles = (Q + BQ - 1) / BQ, row_tiles = std::max(1, (std::max(n_max, Q) + BM - 1) / BM);
+    L.ldqa = (int)align_up(q, BQ); L.ldqb = (int)align_up(vm, BQ);
     // as MANY chunks as the finalize wave can read (kMaxSplit): the certificate compares the exact 2nd-best with the 4th-best
     // integer score of every chunk, and only short chunks put that 4th-best clear of it (one chunk per segment left most
     // queries of the sweep's shape unproven)
+    const int row_tiles = std::max(1, (std::max(n_max, Q) + BM - 1) / BM);
     const int sp = std::min(kMaxSplit, row_tiles);
     const int ct = (row_tiles + sp - 1) / sp;
     L.splits = (row_tiles + ct - 1) / ct; L.chunk = ct * BM;
     size_t b = 0;
     auto take = [&](size_t bytes) { size_t o = b; b += align_up(bytes, 256); return o; };
     L.PS = take(q * D * 8); L.PM = take(vm * D * 8);
-    L.rowS = take(4 * q * 8); L.rowM = take(4 * vm * 8);
-    L.sc = take(ns * sizeof(SegConst));
+    L.rowS = take(5 * q * 8); L.rowM = take(5 * vm * 8); L.nrefS = take(q * 8); L.nrefM = take(vm * 8);
+    L.Aq = take((size_t)L.D2p * L.ldqa * 4); L.Bq = take((size_t)L.D2p * L.ldqb * 4); L.Sc = take((size_t)L.ldqb * L.ldqa * 4);
+    L.sc = take((ns + 1) * sizeof(SegConst));
     L.nrmS = take(ns * q * 8); L.nrmM = take((size_t)std::max(tot, 1) * 8);
-    L.Aq = take(ns * L.D2p * L.ldqa * 4); L.Bq = take(ns * L.D2p * L.ldqb * 4); L.Cq = take(ns * L.D2p * L.ldqa * 4);
     L.part_idx = take(ns * L.splits * q * KC * 4); L.part_s = take(ns * L.splits * q * KC * 4);
     L.idx = take(ns * q * 2 * 4); L.dist = take(ns * q * 2 * 8); L.bidx = take(ns * q * 2 * 4); L.bdist = take(ns * q * 2 * 8);
     L.cand_q = take(ns * q * 4); L.cand_m = take(ns * q * 4); L.n_cand = take(ns * 4); L.n_flag = take(ns * 4);
@@ -1114,36 +1264,44 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
                                  const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
                                  double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st) {
     if (S <= 0) return PCREG_OK;
-    if (Q <= 0 || n_max <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, (size_t)S * sizeof(int32_t), st)); return PCREG_OK; }
+    if (Q <= 0 || n_max <= 0 || VM <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, (size_t)S * sizeof(int32_t), st)); return PCREG_OK; }
     const int Dp = D + (o.unnormalize ? 1 : 0);
     const SegLayout L = seg_layout(Q, VM, D, D + 1, S, tot, n_max);
     if (ws_bytes < L.total) { set_error("segmented get_matches workspace too small: %zu < %zu", ws_bytes, L.total); return PCREG_E_WORKSPACE; }
     if (L.splits * KC > 64 * kEPL) { set_error("segmented get_matches: %d list entries per query exceed the finalize wave", L.splits * KC); return PCREG_E_ARG; }
     char* w = (char*)ws;
     double *PS = (double*)(w + L.PS), *PM = (double*)(w + L.PM), *rS = (double*)(w + L.rowS), *rM = (double*)(w + L.rowM);
+    double *nrefS = (double*)(w + L.nrefS), *nrefM = (double*)(w + L.nrefM);
     SegConst* sc = (SegConst*)(w + L.sc);
     double *nrmS = (double*)(w + L.nrmS), *nrmM = (double*)(w + L.nrmM);
-    uint32_t *Aq = (uint32_t*)(w + L.Aq), *Bq = (uint32_t*)(w + L.Bq), *Cq = (uint32_t*)(w + L.Cq);
+    uint32_t *Aq = (uint32_t*)(w + L.Aq), *Bq = (uint32_t*)(w + L.Bq), *Sc = (uint32_t*)(w + L.Sc);
     int32_t* part_idx = (int32_t*)(w + L.part_idx); uint32_t* part_s = (uint32_t*)(w + L.part_s);
     int32_t *idx = (int32_t*)(w + L.idx), *bidx = (int32_t*)(w + L.bidx); double *dist = (double*)(w + L.dist), *bdist = (double*)(w + L.bdist);
     int32_t *cand_q = (int32_t*)(w + L.cand_q), *cand_m = (int32_t*)(w + L.cand_m), *n_cand = (int32_t*)(w + L.n_cand), *n_flag = (int32_t*)(w + L.n_flag);
     int32_t* flag_list = (int32_t*)(w + L.flag_list); int32_t* fpi = (int32_t*)(w + L.fpi); double* fpd = (double*)(w + L.fpd);
     const size_t q = (size_t)Q, vm = (size_t)VM;
 
-    hipLaunchKernelGGL(segp_rows_kernel, dim3((Q + kPR - 1) / kPR), dim3(kBlock), 0, st, descS, Q, D, o.change_metric, o.metric_factor, PS, rS, rS + q, rS + 2 * q, rS + 3 * q);
-    hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM, VM, D, o.change_metric, o.metric_factor, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm);
-    const SegSets sets{PS, rS, rS + q, rS + 2 * q, rS + 3 * q, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, seg_rows, seg_off, Q, D, Dp};
-    hipLaunchKernelGGL(segp_consts_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, nrmS, nrmM, sc);
-    hipLaunchKernelGGL(segp_quantize_kernel, dim3(L.ldqa / 64, L.D2p / 32, S), dim3(kBlock), 0, st, sets, 0, nrmS, sc, L.D2p, L.ldqa, Aq);
-    hipLaunchKernelGGL(segp_quantize_kernel, dim3(L.ldqb / 64, L.D2p / 32, S), dim3(kBlock), 0, st, sets, 1, nrmM, sc, L.D2p, L.ldqb, Bq);
+    // once for all segments: powers, row scalars, the reference constant, the two quantised operands, ALL approximate scores
+    hipLaunchKernelGGL(segp_rows_kernel, dim3((Q + kPR - 1) / kPR), dim3(kBlock), 0, st, descS, Q, D, o.change_metric, o.metric_factor, PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q);
+    hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM, VM, D, o.change_metric, o.metric_factor, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm);
+    const SegSets sets{PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, seg_rows, seg_off, Q, VM, D, Dp};
+    hipLaunchKernelGGL(segp_cc_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, sc);
+    hipLaunchKernelGGL(segp_ref_kernel, dim3(1), dim3(kBlock), 0, st, sets, o, nrefS, nrefM, sc, S);
+    hipLaunchKernelGGL(segp_quantize_ref_kernel, dim3(L.ldqa / 64, L.D2p / 32), dim3(kBlock), 0, st, PS, nrefS, Q, D, Dp, sc + S, L.D2p, L.ldqa, Aq);
+    hipLaunchKernelGGL(segp_quantize_ref_kernel, dim3(L.ldqb / 64, L.D2p / 32), dim3(kBlock), 0, st, PM, nrefM, VM, D, Dp, sc + S, L.D2p, L.ldqb, Bq);
+    {
+        const int n_tiles = (Q + BQ - 1) / BQ, row_tiles = (VM + BM - 1) / BM;
+        const int sm = std::max(1, std::min(row_tiles, 1536 / std::max(n_tiles, 1)));          // ~2 rounds of resident workgroups
+        const int ct = (row_tiles + sm - 1) / sm, s_eff = (row_tiles + ct - 1) / ct;
+        hipLaunchKernelGGL(sad16_candidates_kernel<kSadMatrix>, dim3(n_tiles, s_eff), dim3(kBlock), 0, st, Aq, Q, L.ldqa, Bq, VM, L.ldqb, L.D2p, ct * BM,
+                           (int32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (const int32_t*)nullptr, SegZ{0, 0, 0, 0, nullptr, Sc, L.ldqa});
+    }
+    // per segment: constants and norms, lists out of the matrix, exact re-rank, exact rows for the unproven
+    hipLaunchKernelGGL(segp_consts_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, nrefS, nrefM, nrmS, nrmM, sc, S);
     PCREG_HIP(hipMemsetAsync(n_flag, 0, (size_t)S * sizeof(int32_t), st));
     PCREG_HIP(hipGetLastError());
-    const int n_tiles = (Q + BQ - 1) / BQ;
-    const size_t zP = (size_t)L.splits * q * KC;
     const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
-    // forward: every surface row against its segment's model rows
-    hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, L.splits, S), dim3(kBlock), 0, st, Aq, Q, L.ldqa, Bq, n_max, L.ldqb, L.D2p, L.chunk,
-                       part_idx, part_s, (unsigned long long*)nullptr, (const int32_t*)nullptr, SegZ{(size_t)L.D2p * L.ldqa, (size_t)L.D2p * L.ldqb, zP, 0, seg_off});
+    hipLaunchKernelGGL(segp_select_kernel, dim3(L.ldqa / 64, (L.splits + 3) / 4, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, Q, L.chunk, L.splits, part_idx, part_s);
     hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
                        part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force);
     const int slice_f = (n_max + kSegFbSlices - 1) / kSegFbSlices;
@@ -1155,10 +1313,8 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     hipLaunchKernelGGL(segp_filter_kernel, dim3(S), dim3(kCompactThreads), 0, st, idx, dist, Q, seg_off, thr, o.maxRatio, cand_q, cand_m, n_cand, n_flag);
     PCREG_HIP(hipGetLastError());
     if (o.unique) {
-        // back: the candidates' model rows against every surface row (the operands of the forward search, roles swapped)
-        hipLaunchKernelGGL(segp_gather_q_kernel, dim3(L.ldqa / kBlock + (L.ldqa % kBlock != 0), 16, S), dim3(kBlock), 0, st, Bq, L.ldqb, cand_m, n_cand, Q, L.D2p, L.ldqa, Cq);
-        hipLaunchKernelGGL(sad16_candidates_kernel<false>, dim3(n_tiles, L.splits, S), dim3(kBlock), 0, st, Cq, Q, L.ldqa, Aq, Q, L.ldqa, L.D2p, L.chunk,
-                           part_idx, part_s, (unsigned long long*)nullptr, n_cand, SegZ{(size_t)L.D2p * L.ldqa, (size_t)L.D2p * L.ldqa, zP, 1, nullptr});
+        // back: every candidate's model row against all surface rows -- a row of the same matrix
+        hipLaunchKernelGGL(segp_select_back_kernel, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, cand_m, n_cand, Q, L.chunk, L.splits, part_idx, part_s);
         hipLaunchKernelGGL(segp_finalize_kernel<true>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, cand_m, n_cand,
                            part_idx, part_s, L.splits, bidx, bdist, flag_list, n_flag, force);
         hipLaunchKernelGGL(segp_exact_rows_kernel<true>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
