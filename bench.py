@@ -85,6 +85,16 @@ def make_crop(model: np.ndarray, Q: int, c: int):
 
 # ---- CPU baseline (the oracle's C restatement; rank 0, N = 1 only) -------------------------------------------------
 
+def kernel_source_hash(files) -> str:
+    """sha256 over the named kernel sources (paths relative to the repo root), in the given order."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def cpu_model() -> str:
     try:
         for ln in open("/proc/cpuinfo"):
@@ -439,6 +449,103 @@ def extra_ransac_cfg1(dev, with_cpu: bool) -> dict:
     return out
 
 
+def extra_ransac_cfg1_batched(dev, with_cpu: bool) -> dict:
+    """cfg 1 as a batch: 256 independent registrations of n = 1000 in ONE launch (pcreg_dev_ransac_batched, the parfor of
+    completeExperimentFast.m:201-216); every registration has its own noise and its own sampler seed."""
+    import torch
+    from pcreg_amd._lib import DevRansacResult, RansacOpts, check, lib
+    B, n, it = 256, 1000, 20000
+    rng = np.random.default_rng(1)
+    pts = rng.uniform([-3, -2, 0], [3, 2, 3], (n, 3))
+    R = eul2rotm_zyx([1.5, -1.2, 0.8]); t = np.array([1.0, 2.0, 3.0])
+    loc1S = pts @ R + t
+    p1h = np.concatenate([pts + np.random.default_rng(100 + b).normal(0, 0.1, pts.shape) for b in range(B)])      # [B*n, 3]
+    p2h = np.tile(loc1S, (B, 1))
+    ld = B * n
+    p1 = torch.from_numpy(np.ascontiguousarray(p1h.T)).to(dev); p2 = torch.from_numpy(np.ascontiguousarray(p2h.T)).to(dev)
+    off = torch.arange(0, (B + 1) * n, n, dtype=torch.int32, device=dev)
+    L = lib()
+    o = RansacOpts(3, it, 0.1, 0.5, 1, 0, 3)
+    rs = C.sizeof(DevRansacResult)
+    res = torch.zeros((B, rs), dtype=torch.uint8, device=dev); inl = torch.empty(ld, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(L.pcreg_dev_ransac_batched_workspace(n, it, B), 256), dtype=torch.uint8, device=dev)
+    p = lambda x: C.c_void_p(x.data_ptr())
+    def run():
+        check(L.pcreg_dev_ransac_batched(p(p1), p(p2), ld, p(off), B, n, C.byref(o), p(res), p(inl), p(ws), C.c_size_t(ws.numel()),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ms = _ev_ms(run, reps=3)
+    raw = res.cpu().numpy()
+    rr = [DevRansacResult.from_buffer_copy(raw[b].tobytes()) for b in range(B)]
+    flops = float(B) * it * n * 76.0
+    return {"workload": f"{B} registrations x (n = {n}, iterNum = {it}, thDist 0.1, thInlrRatio 0.5, REFINE) in one launch (pcreg_dev_ransac_batched)",
+            "ms": round(ms, 3), "registrations_per_s": round(B / ms * 1e3, 1), "failed": int(sum(r.failed for r in rr)),
+            "max_inliers_min": int(min(r.max_inliers for r in rr)),
+            "roofline": {"bound": "valu-fp64", "achieved": round(flops / ms / 1e9, 2), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / ms / 1e9 / PEAK_FP64_TFLOPS, 4), "traffic": None,
+                         "note": "SURVEY 8d's 76 flop per (hypothesis, point); each registration's 48 KB of correspondences sit in LDS"}}
+
+
+def extra_sweep(dev, with_cpu: bool) -> dict:
+    """The sphere sweep of completeExperimentFast.m:46-224 at the reference's shape: a 60 k-keypoint model, ~329 valid spheres of
+    ~1533 descriptors (R_desc 9, spacing 5, >= 1400), a 2000-keypoint surface, D = 980, getMatches per sphere, RANSAC on the
+    spheres with > 170 putative matches.  SphereSweep.run: one segmented launch chain, two host synchronisations."""
+    import torch
+    from pcreg_amd.sweep import SphereSweep
+    VM, VS, D = 60000, 2000, 980
+    rng = np.random.default_rng(0)
+    featM = rng.uniform([0, 0, 0], [60, 50, 40], (VM, 3))
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    descM = torch.poisson(torch.full((VM, D), 3.0, device=dev), generator=g).to(torch.float64)
+    near = np.argsort(np.linalg.norm(featM - np.array([31.0, 24.0, 19.0]), axis=1))[:VS]
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]])
+    featS = featM[near] @ R.T + np.array([2.0, -1.0, 0.5]) + rng.normal(0, 0.02, (VS, 3))
+    descS = (descM[torch.from_numpy(near).to(dev)] + torch.poisson(torch.full((VS, D), 0.15, device=dev), generator=g).to(torch.float64)).contiguous()
+    par = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate", MatchThreshold=10, MaxRatio=0.99,
+               Metric="SAD", Unique=True, VERBOSE=0)
+    opt = dict(minPtNum=3, iterNum=10000, thDist=0.3, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    kw = dict(R_desc=9.0, d_spheres=5.0, min_pts=1400, putative_thresh=170, seed=0)
+    sw = SphereSweep(featM, descM, featS, descS, device=dev)
+    out = sw.run(par, opt, **kw)                                     # warm-up (allocations)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); out = sw.run(par, opt, **kw); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    ms = min(ts) * 1e3
+    S = len(out["centres"]); pairs = float(VS) * float(out["num_desc"].sum())
+    flops = (3.0 * (D + 1) - 1.0) * pairs
+    res = {"workload": f"sphere sweep: {S} valid spheres of a {VM}-keypoint model ({int(out['num_desc'].mean())} descriptors per sphere on average), surface {VS} "
+                       f"keypoints, D {D}, getMatches per sphere (SAD, power 0.6, 10 %, 0.99, Unique), {len(out['trial'])} trial spheres x RANSAC(3,1e4,0.3,0.08,REFINE)",
+           "ms": round(ms, 2), "spheres_per_s": round(S / ms * 1e3, 1), "host_syncs": 2, "trial_spheres": int(len(out["trial"])),
+           "registered": int(sum(t is not None for t in out["transforms"])),
+           "roofline": {"bound": "valu", "achieved": round(flops / ms / 1e9, 1), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                        "note": "SURVEY 8d's (3D-1) flop per (surface row, sphere row) pair of every per-sphere getMatches call, over the WHOLE sweep (sphere "
+                                "selection, matching, plan, batched RANSAC, read-back), against the fp32 vector peak.  The library scores each (surface row, "
+                                "model row) pair once for all spheres (the spheres overlap ~8-fold) and certifies per sphere, so it executes fewer SAD "
+                                "operations than the algorithmic count (DESIGN 4.6)"}}
+    if with_cpu:
+        from oracle import c_oracle
+        import oracle.pcreg_oracle as opy
+        cores = host_cores()
+        fm, dm, ds = featM, descM.cpu().numpy(), descS.cpu().numpy()
+        pick = sorted({0, S // 2, S - 1, int(out["trial"][0]) if len(out["trial"]) else 0})
+        t0 = time.perf_counter(); same = True; n_r = 0
+        for i in pick:
+            idx = np.nonzero(opy.getDescriptorMask(fm, out["centres"][i], kw["R_desc"], 0.0))[0]
+            m = c_oracle.getMatches(ds, dm[idx], par, nthreads=cores)
+            same = same and np.array_equal(m, out["matches"][i]) and np.array_equal(idx, out["model_rows"][i])
+            if len(m) > kw["putative_thresh"]:
+                c_oracle.ransac(featS[m[:, 0].astype(np.int64) - 1], fm[idx][m[:, 1].astype(np.int64) - 1], opt, seed=0); n_r += 1
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(len(pick) / dt, 3), "unit": "spheres/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle: getDescriptorMask + getMatches (OpenMP, {cores} threads) on {len(pick)} of the {S} spheres, ransac (1 thread) on the "
+                                         f"{n_r} of them above the putative threshold, {dt:.1f} s; their matches equal the GPU's: {bool(same)}"}
+        res["same_as_oracle_on_sample"] = bool(same)
+    del sw, descM, descS
+    torch.cuda.empty_cache()
+    return res
+
+
 # ---- main ---------------------------------------------------------------------------------------------------------
 
 def main() -> None:
@@ -508,13 +615,23 @@ def main() -> None:
         alg_tflops = FLOP_PER_PAIR * float(Q) * rows / (kernel_ms * 1e-3) / 1e12
         exe_tflops = FLOP_PER_PAIR_EXECUTED * float(Q) * rows / (kernel_ms * 1e-3) / 1e12
         alg_bytes = 4.0 * 3 * (Q + rows) + 16.0 * Q
-        traffic = None
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is the one
+        # scripts/pmc_traffic.sh measured -- valid only for the kernel sources it was taken from.  profiles/traffic.json records
+        # the content hash of those sources; a build from different sources reports null and says why.
+        traffic, traffic_source = None, "not measured for this shape"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"knn_search:Q{Q}:M{rows}")
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+                ent = tj.get(f"knn_search:Q{Q}:M{rows}")
+                if isinstance(ent, dict):
+                    now = kernel_source_hash(ent.get("sources", []))
+                    if now == ent.get("sources_sha256"):
+                        traffic, traffic_source = ent["bytes"], f"profiles/traffic.json ({ent.get('measured', '?')}; sources sha256 {now[:12]} = this build's)"
+                    else:
+                        traffic_source = f"profiles/traffic.json is stale: taken from sources {str(ent.get('sources_sha256'))[:12]}, this build is {now[:12]}"
+            except Exception as e:
+                traffic_source = f"profiles/traffic.json unreadable: {e}"
         out = {
             "metric": "KNN Gpairs/s end-to-end (search + filters + RANSAC per step; registrations/s = 1000/ms_per_step)",
             "value": round(head["value"], 2), "unit": "Gpairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -532,7 +649,7 @@ def main() -> None:
                                    "(completeExperimentFast.m:131-149); a step = 4 search launches + 1 match launch + the RANSAC chain"},
             "ransac": head["ransac"],
             "roofline": {"bound": "mfma", "achieved": round(alg_tflops, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(alg_tflops / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(alg_tflops / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_flop_per_pair": FLOP_PER_PAIR,
                          "vs_fp32_vector_peak": round(alg_tflops / PEAK_FP32_TFLOPS, 3),
                          "matrix_pipe": {"executed_flop_per_pair": FLOP_PER_PAIR_EXECUTED, "tflops": round(exe_tflops, 1),
@@ -555,7 +672,8 @@ def main() -> None:
         ex = {}
         with_cpu = not args.no_cpu_baseline
         for name, fn in (("getMatches_cfg2", extra_get_matches), ("descriptors_cfg4", extra_descriptors),
-                         ("align_points_knn_batched", extra_align), ("ransac_cfg1", extra_ransac_cfg1)):
+                         ("align_points_knn_batched", extra_align), ("ransac_cfg1", extra_ransac_cfg1),
+                         ("ransac_cfg1_batched", extra_ransac_cfg1_batched), ("sweep", extra_sweep)):
             try:
                 ex[name] = fn(dev, with_cpu)
             except Exception as e:          # an extra must never take the headline down with it

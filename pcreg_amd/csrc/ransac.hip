@@ -2051,6 +2051,7 @@ size_t ransac_workspace_bytes(int iters, int B, int n_cap) {
            staged_extra_bytes(h, B == 1 ? n_cap : 0);
 }
 
+constexpr size_t kLdsPointsMaxBytes = 152 * 1024;     // correspondences of one registration resident in LDS: n_cap <= 3242
 static int launch_ransac_impl(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
                   int n_cap, int B, pcreg_ransac_opts o, const int32_t* sample_idx_dev,
                   pcreg_dev_ransac_result* out, int32_t* inlier_idx, int32_t* iter_inl, int32_t* iter_inl_ref,
@@ -2072,14 +2073,20 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
     long long total = (long long)o.iterNum * B;
     void* sel_ctr = nullptr;              // set by the staged chain: its selection runs on several workgroups
     size_t lds = (size_t)n_cap * 6 * sizeof(double);
-    if (n_cap > 0 && lds <= 64 * 1024) {
-        // small sets: correspondences resident in LDS; hypotheses per wave: fill the chip
+    if (n_cap > 0 && lds <= (offsets ? kLdsPointsMaxBytes : (size_t)64 * 1024)) {
+        // small sets: correspondences resident in LDS (batches: a gfx950 workgroup may take the CU's whole 160 KiB; a batch's capacity
+        // is often far above its registrations' real sizes -- the sweep passes the surface size, its trials hold ~250 pairs --
+        // and a workgroup only stages the n it has); hypotheses per wave: fill the chip
         // first (>= ~2 waves per SIMD), then grow towards 64 so the lane-parallel fits run full
         int hpw = 64;
         while (hpw > 8 && total / hpw < 256LL * 4 * 2) hpw >>= 1;
         a.hpw = hpw;
         int per_block = hpw * kWavesPerBlock;
         dim3 grid((o.iterNum + per_block - 1) / per_block, B);
+        if (lds > 64 * 1024) {
+            static bool raised = false;           // above 64 KiB of dynamic LDS the runtime wants to be told once
+            if (!raised) { PCREG_HIP(hipFuncSetAttribute((const void*)ransac_hyp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPointsMaxBytes)); raised = true; }
+        }
         hipLaunchKernelGGL(ransac_hyp_kernel<true>, grid, dim3(kBlock), lds, st, a);
     } else if (B == 1 && !offsets && n_cap >= kStagedMinN && !(getenv("PCREG_RANSAC_FUSED") && atoi(getenv("PCREG_RANSAC_FUSED")))) {
         // one large registration: the staged chain of lean kernels (see rs_* above)
