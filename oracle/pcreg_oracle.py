@@ -15,6 +15,8 @@ reference checkout, LCJebe/PCReg):
     AlignPoints_KNN     AlignPoints_KNN.m:8-59
     quickTF / invertTF  quickTF.m:5-7 / invertTF.m:5-7
     getLocalPoints      getLocalPoints.m:8-35
+    sphere_sweep        completeExperimentFast.m:46-224
+    final_stage         completeExperimentFast.m:280-394
 
 Pinning status
 --------------
@@ -699,3 +701,54 @@ def refine_by_distance(pts1, pts2, maxDist: float):
     inl = np.nonzero(d1 < maxDist)[0]
     T = estimateTransform(pts1[inl], pts2[inl]) if len(inl) >= 3 else None
     return T, inl
+
+
+def pcRandomUniformSamples(pts, d: float, margin: float, rng=None) -> np.ndarray:
+    """completeExperimentFast.m:416-429: round(volume of the margin-padded bounding box / d^3) uniform random keypoints
+    in that box.  MATLAB's rand stream is unknowable here: `rng` (numpy Generator) stands in, so only the COUNT and the
+    BOX are pinned; the final stage below takes the keypoints as an input for that reason."""
+    pts = np.asarray(pts, dtype=np.float64)
+    lo, hi = pts.min(axis=0), pts.max(axis=0)
+    rng_xyz = (hi - lo) + 2.0 * margin
+    num_pts = matlab_round(float(rng_xyz[0] * rng_xyz[1] * rng_xyz[2]) / (d ** 3))
+    rng = rng or np.random.default_rng(0)
+    return rng.random((num_pts, 3)) * rng_xyz + lo - margin
+
+
+def final_stage(ptsSurface, clusters, sample_pts, featModel_noLRF, descModel_noLRF, R_desc: float, descOpt: dict, par: dict,
+                maxDist: float = 1.5, get_descriptors=None, get_matches=None) -> dict:
+    """completeExperimentFast.m:280-394 on the CPU.  clusters = [(locCur, transCur)]: the middle of every cluster of promising
+    spheres and the RANSAC transform of the sphere closest to it (:283-291; clusterPoints itself is host bookkeeping over a
+    few dozen points and not restated).  sample_pts[i]: the keypoints the script draws at random for cluster i (:297).
+
+    Per cluster (:293-353): quickTF(surface, invertTF(transCur)); descriptors WITHOUT local alignment (ALIGN_POINTS = false);
+    the model descriptors inside the sphere of radius R_desc around locCur; getMatches.  Then (:357-378) the share of
+    matches closer than maxDist, (:381) the cluster with the largest share (MATLAB's max: first maximum, NaN skipped),
+    (:383-394) T_refine = estimateTransform over its close matches and the final surface quickTF(pts_tform, invertTF(T_refine))."""
+    get_descriptors = get_descriptors or getSpacialHistogramDescriptors
+    get_matches = get_matches or getMatches
+    ptsSurface = np.asarray(ptsSurface, dtype=np.float64)
+    featModel_noLRF = np.asarray(featModel_noLRF, dtype=np.float64); descModel_noLRF = np.asarray(descModel_noLRF, dtype=np.float64)
+    opt = dict(descOpt, ALIGN_POINTS=False, VERBOSE=0)                                       # :300 "this false is the key"
+    per = []
+    for (locCur, transCur), kp in zip(clusters, sample_pts):
+        pts_tform = quickTF(ptsSurface, invertTF(np.asarray(transCur, dtype=np.float64)))    # :291
+        feat, desc = get_descriptors(pts_tform, np.asarray(kp, dtype=np.float64), opt)       # :309-310
+        mask = getDescriptorMask(featModel_noLRF, np.asarray(locCur, dtype=np.float64), R_desc, 0.0)   # :319
+        featCur, descCur = featModel_noLRF[mask], descModel_noLRF[mask]
+        if len(feat) and len(featCur):
+            m = get_matches(desc, descCur, dict(par, VERBOSE=0))                             # :344
+        else:
+            m = np.zeros((0, 2), dtype=np.uint32)
+        pts1 = feat[m[:, 0].astype(np.int64) - 1]; pts2 = featCur[m[:, 1].astype(np.int64) - 1]   # :366-367
+        dd = pts1 - pts2
+        d1 = np.sqrt((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2])
+        inl = np.nonzero(d1 < maxDist)[0]                                                    # :369
+        prec = (len(inl) / len(d1) * 100.0) if len(d1) else float("nan")                     # :373 (0/0 = NaN)
+        per.append(dict(pts_tform=pts_tform, feat=feat, featCur=featCur, matches=m, inliers=inl, precision=prec, pts1=pts1, pts2=pts2))
+    precisions = np.array([c["precision"] for c in per], dtype=np.float64)
+    best = 0 if np.all(np.isnan(precisions)) else int(np.nanargmax(precisions))             # :381
+    b = per[best]
+    T_refine = estimateTransform(b["pts1"][b["inliers"]], b["pts2"][b["inliers"]]) if len(b["inliers"]) >= 3 else None   # :391
+    pts_final = quickTF(b["pts_tform"], invertTF(T_refine)) if T_refine is not None else b["pts_tform"]                 # :394
+    return dict(per_cluster=per, precisions=precisions, best=best, T_refine=T_refine, pts_final=pts_final)

@@ -241,7 +241,18 @@ class DescriptorPipeline:
         return t
 
     def describe(self, pts: torch.Tensor, sample_pts: torch.Tensor, options: dict, compact: bool = False, single_mode: int = 0):
-        """-> (feat [S,3], desc, V): rows < V of feat are the surviving keypoints in sample order.
+        """describe_async + the read of the survivor count (one host synchronisation)."""
+        feat, desc, counters = self.describe_async(pts, sample_pts, options, compact, single_mode)
+        V, overflow = (int(v) for v in counters.cpu())
+        if overflow:
+            raise ValueError(f"a support holds {overflow} points: more than an LDS-resident support may have (lower max_pts)")
+        return feat, desc, V
+
+    def describe_async(self, pts: torch.Tensor, sample_pts: torch.Tensor, options: dict, compact: bool = False, single_mode: int = 0,
+                       ws_key: str = "desc"):
+        """-> (feat [S,3], desc, counters): enqueued, nothing read back.  counters (device int32 [2]) = the number V of surviving
+        keypoints and the overflow flag; rows < V of feat are the survivors in sample order.  ws_key: callers that keep several
+        descriptor stages in flight on different streams give each its own workspace.
         compact=False: desc [S,980] float64, rows < V compact (MATLAB's shape).
         compact=True: desc is a U16Rows -- the counts as uint16 rows in KEYPOINT order, written once by the kernel, plus the
         list of the V survivors (a quarter of the bytes and no staging copy; `match` takes it as it is).
@@ -252,7 +263,7 @@ class DescriptorPipeline:
         P, S = pts.shape[1], sample_pts.shape[1]
         feat = torch.empty((S, 3), dtype=torch.float64, device=self.dev)
         counters = torch.zeros(2, dtype=torch.int32, device=self.dev)
-        ws = self._workspace("desc", L.pcreg_dev_spatial_histogram_descriptors_workspace(P, S))
+        ws = self._workspace(ws_key, L.pcreg_dev_spatial_histogram_descriptors_workspace(P, S))
         if compact:
             rows = torch.empty((S, self.ND), dtype=torch.uint16, device=self.dev)
             index = torch.empty(S, dtype=torch.int32, device=self.dev)
@@ -266,10 +277,7 @@ class DescriptorPipeline:
             desc = torch.empty((S, self.ND), dtype=torch.float64, device=self.dev)
             check(L.pcreg_dev_spatial_histogram_descriptors(_p(pts), P, pts.stride(0), _p(sample_pts), S, sample_pts.stride(0), C.byref(o), _p(feat),
                                                             _p(desc), _p(counters), _p(ws), C.c_size_t(ws.numel()), _stream()))
-        V, overflow = (int(v) for v in counters.cpu())
-        if overflow:
-            raise ValueError(f"a support holds {overflow} points: more than an LDS-resident support may have (lower max_pts)")
-        return feat, desc, V
+        return feat, desc, counters
 
     def match(self, descS, VS: int, descM, VM: int, par: dict, pairs_out: torch.Tensor | None = None,
               n_pairs_out: torch.Tensor | None = None, ws_cap: tuple | None = None):

@@ -292,4 +292,90 @@ def refine_by_distance_dev(pts1_soa: torch.Tensor, pts2_soa: torch.Tensor, n: in
     return (None if empty else T16.cpu().numpy().reshape(4, 4, order="F")), cnt
 
 
-__all__ = ["SphereSweep", "pcUniformSamples", "quickTF_dev", "refine_by_distance_dev", "invertTF"]
+class FinalStage:
+    """completeExperimentFast.m:280-394 on the device tier: for every cluster of promising spheres, move the surface by the
+    cluster's RANSAC transform, describe it again WITHOUT local alignment, match against the model's no-LRF descriptors
+    inside the cluster's sphere, keep the matches closer than maxDist; the cluster with the largest share of close matches
+    gives T_refine and the final surface.
+
+    TWO host synchronisations for the whole stage, whatever the number of clusters: (A) the sizes that fix the match
+    grids -- every cluster's surviving keypoint count and descriptor count in its sphere (like the sweep's first read);
+    (B) every cluster's match count, close-match count and refined transform, together.  The final surface
+    quickTF(pts_tform, invertTF(T_refine)) is enqueued after (B) and stays on the device.
+
+    ptsSurface [3, N] float64 on the device; featModel_noLRF [VM, 3] / descModel_noLRF [VM, 980] as for SphereSweep."""
+
+    def __init__(self, ptsSurface: torch.Tensor, featModel_noLRF, descModel_noLRF, device: torch.device | None = None):
+        self.dev = device or ptsSurface.device
+        t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))).to(self.dev).contiguous()
+        self.pts = ptsSurface.to(self.dev)
+        self.featM, self.descM = t(featModel_noLRF), t(descModel_noLRF)
+        self.VM, self.D = self.descM.shape
+        self.pipe = DescriptorPipeline(self.dev)
+
+    def run(self, clusters, sample_pts, descOpt: dict, par: dict, R_desc: float, maxDist: float = 1.5, return_matches: bool = True) -> dict:
+        """clusters = [(locCur [3], transCur [4,4])] (:283-288); sample_pts[i] = the keypoints drawn for cluster i (:297,
+        pcRandomUniformSamples is the caller's: its random stream is not the library's business), [S_i, 3] numpy or [3, S_i]
+        device tensors."""
+        L = lib()
+        dev, K = self.dev, len(clusters)
+        i32, f64 = torch.int32, torch.float64
+        if K == 0:
+            raise ValueError("final stage: no clusters")
+        opt = dict(descOpt, ALIGN_POINTS=False, VERBOSE=0)                                         # :300
+        tf, feats, descs = [], [], []
+        counters = torch.zeros((K, 2), dtype=i32, device=dev)
+        for i, ((loc, T), kp) in enumerate(zip(clusters, sample_pts)):
+            kp = kp if isinstance(kp, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(kp, dtype=np.float64).T)).to(dev)
+            pt = quickTF_dev(self.pts, invertTF(np.asarray(T, dtype=np.float64)))                  # :291
+            f, d, c = self.pipe.describe_async(pt, kp, opt)                                        # :309-310
+            counters[i].copy_(c)
+            tf.append(pt); feats.append(f); descs.append(d)
+        locs = torch.from_numpy(np.ascontiguousarray([np.asarray(c[0], dtype=np.float64) for c in clusters])).to(dev)
+        n_in = torch.zeros(K, dtype=i32, device=dev)
+        check(L.pcreg_dev_sphere_counts(_p(self.featM), self.VM, _p(locs), K, C.c_double(R_desc), _p(n_in), _stream()))
+        cnt = torch.cat([counters.view(-1), n_in]).cpu().numpy()                                   # ---- sync A: sizes only
+        V = cnt[0:2 * K:2].astype(np.int64); over = cnt[1:2 * K:2]; nM = cnt[2 * K:].astype(np.int64)
+        if over.any():
+            raise ValueError(f"a support holds {int(over.max())} points: more than an LDS-resident support may have (lower max_pts)")
+        seg_off_h = np.zeros(K + 1, dtype=np.int32); seg_off_h[1:] = np.cumsum(nM)
+        tot = int(seg_off_h[-1])
+        seg_off = torch.from_numpy(seg_off_h).to(dev)
+        rows_all = torch.empty(max(tot, 1), dtype=i32, device=dev)
+        featCur_all = torch.empty((max(tot, 1), 3), dtype=f64, device=dev)
+        check(L.pcreg_dev_sphere_select_batched(_p(self.featM), self.VM, _p(locs), K, C.c_double(R_desc), _p(seg_off), _p(rows_all), _p(featCur_all),
+                                                None, _stream()))                                  # :319-322, every cluster's sphere
+        n_pairs = torch.zeros(K, dtype=i32, device=dev)
+        info = torch.zeros((K, 2), dtype=i32, device=dev); info[:, 1] = 1
+        T16 = torch.zeros((K, 16), dtype=f64, device=dev)
+        pairs = []
+        n_tot = torch.tensor([tot], dtype=i32, device=dev)
+        for i in range(K):
+            v, n, lo = int(V[i]), int(nM[i]), int(seg_off_h[i])
+            pr = torch.zeros((max(v, 1), 2), dtype=i32, device=dev)
+            pairs.append(pr)
+            if v == 0 or n == 0:
+                continue
+            descCur = torch.empty((n, self.D), dtype=f64, device=dev)
+            check(L.pcreg_dev_gather_rows_f64(_p(self.descM), self.D, _p(rows_all[lo:lo + n]), _p(n_tot), n, _p(descCur), _stream()))
+            self.pipe.match(descs[i][:v], v, descCur, n, par, pairs_out=pr, n_pairs_out=n_pairs[i:i + 1])          # :344
+            p1 = torch.empty((3, v), dtype=f64, device=dev); p2 = torch.empty((3, v), dtype=f64, device=dev)
+            check(L.pcreg_dev_gather_matched_rows(_p(pr), _p(n_pairs[i:i + 1]), v, _p(feats[i]), _p(featCur_all[lo:lo + n]), _p(p1), _p(p2), _stream()))
+            check(L.pcreg_dev_refine_by_distance(_p(p1), _p(p2), _p(n_pairs[i:i + 1]), v, v, C.c_double(maxDist), _p(T16[i]), _p(info[i]),
+                                                 _stream()))                                       # :357-391 for every cluster
+        back = torch.cat([n_pairs.to(f64), info.view(-1).to(f64), T16.view(-1)]).cpu().numpy()     # ---- sync B: the results
+        npr = back[:K].astype(np.int64); inf = back[K:3 * K].reshape(K, 2).astype(np.int64); Ts = back[3 * K:].reshape(K, 16)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            prec = np.where(npr > 0, inf[:, 0] / np.maximum(npr, 1) * 100.0, np.nan)              # :373
+        best = 0 if np.all(np.isnan(prec)) else int(np.nanargmax(prec))                           # :381, MATLAB's max
+        T_refine = None if inf[best, 1] else Ts[best].reshape(4, 4, order="F")
+        pts_final = quickTF_dev(tf[best], invertTF(T_refine)) if T_refine is not None else tf[best]   # :394, stays on the device
+        out = dict(num_keypoints=V, num_desc=nM, num_matches=npr, num_close=inf[:, 0], precisions=prec, best=best, T_refine=T_refine,
+                   pts_final=pts_final, pts_tform=tf, host_syncs=2)
+        if return_matches:                                                                        # a third, optional read (tests, plots)
+            out["matches"] = [pairs[i][:npr[i]].cpu().numpy().astype(np.uint32) for i in range(K)]
+            out["model_rows"] = [rows_all[seg_off_h[i]:seg_off_h[i + 1]].cpu().numpy().astype(np.int64) for i in range(K)]
+        return out
+
+
+__all__ = ["SphereSweep", "FinalStage", "pcUniformSamples", "quickTF_dev", "refine_by_distance_dev", "invertTF"]
