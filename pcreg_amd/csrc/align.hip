@@ -63,7 +63,7 @@ __device__ __forceinline__ int block_sum_iw(int v, int* s_red) {
 #define PCREG_AL_STAMP(k)
 #endif
 template <int PT, int NT>
-__global__ __launch_bounds__(NT, PT <= 8 ? 4 : 2) void align_points_knn_reg_kernel(
+__global__ __launch_bounds__(NT, NT == 128 ? 2 : (NT == 256 && PT > 8 ? 3 : (NT == 1024 ? 2 : (PT <= 8 ? 4 : 2)))) void align_points_knn_reg_kernel(
     const double* __restrict__ pts, int ld, const int32_t* __restrict__ offsets, int C1, int C2,
     double* __restrict__ aligned, int ld_out, double* __restrict__ coeff_out, double* __restrict__ c_out,
     int32_t* __restrict__ status, long long* __restrict__ tstamp) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NT, PT <= 8 ? 4 : 2) void align_points_knn_reg_kern
         double a[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) a[k] = cv[k] / dof;
-        jacobi_sym3(a, s_V);
+        jacobi_sym3(a, s_V);      // V in LDS: on registers the (12, 256) form spills and is 6 % slower, the descriptor kernel does not change
         double ev[3] = {a[0], a[3], a[5]};
         int ord[3] = {0, 1, 2};                                  // descending eigenvalue, stable
         if (ev[ord[1]] > ev[ord[0]]) { int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
@@ -300,7 +300,13 @@ int launch_align_points_knn(const double* pts, int ld, const int32_t* offsets_de
     {
         if (max_n <= 1024) PCREG_AL_LAUNCH(4, 256);
         else if (max_n <= 2048) PCREG_AL_LAUNCH(4, 512);
-        else if (max_n <= 3072) PCREG_AL_LAUNCH(6, 512);
+#ifdef PCREG_EXPERIMENTS
+        else if (max_n <= 3072 && pcreg_env_int("PCREG_ALIGN_SHAPE", 0) == 1) PCREG_AL_LAUNCH(6, 512);
+        else if (max_n <= 3072 && pcreg_env_int("PCREG_ALIGN_SHAPE", 0) == 2) PCREG_AL_LAUNCH(24, 128);
+#endif
+        // four-wave workgroups, three per CU (<= 168 VGPRs): shorter barriers and a third support in flight per CU beat the
+        // eight-wave form (two per CU at 128 VGPRs, spilling) by 1.3 x at 4096 x 3000 (A/B on one box: 0.155 vs 0.204 ms)
+        else if (max_n <= 3072) PCREG_AL_LAUNCH(12, 256);
         else if (max_n <= 4096) PCREG_AL_LAUNCH(8, 512);
         else PCREG_AL_LAUNCH(16, 512);
         PCREG_HIP(hipGetLastError());
