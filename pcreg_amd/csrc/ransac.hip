@@ -910,7 +910,7 @@ constexpr int kSW = 4, kSS = 8;                 // scoring: waves per workgroup,
 constexpr int kSPts = kSW * kSS * 64;           // 2048 correspondences per workgroup
 constexpr int kSMaxPB = 64;                     // point blocks with a partial-count row each
 #ifndef PCREG_MOM_SLOTS
-#define PCREG_MOM_SLOTS 8
+#define PCREG_MOM_SLOTS 40
 #endif
 constexpr int kStagedMinN = 4096;               // one registration of at least this many correspondences runs staged
 constexpr int kMomSlots = PCREG_MOM_SLOTS;                   // lane-per-hypothesis refit: 64-correspondence slots per chunk
@@ -932,12 +932,13 @@ struct StagedArgs {
     double* mom;                 // [iters][27]
     int32_t* part;               // [kSMaxPB][iters]
     int pb;                      // point blocks in use
-    // lane-per-hypothesis refit (rs_moments_lane_kernel): the first scoring pass keeps every hypothesis' inlier
+    // mask-driven refit (rs_moments_mfma_kernel): the first scoring pass keeps every hypothesis' inlier
     // mask, the moments are then sums of per-correspondence records under that mask
     unsigned long long* masks;   // [iters][nslots_cap]: bit (i & 63) of word i / 64 = correspondence i is an inlier
     int nslots_cap;              // ceil(n_cap / kSPts) * kSPts / 64
     double* rec;                 // [nslots_cap * 64][kRec]: d(3) m(3) m (x) d (9) relative to correspondence 0
     double* mpart;               // [chunks][iters][15] partial moments
+    uint4* dig;                  // [nslots_cap * 2 k-steps][4 tiles][64 lanes] x 16 int8: the records' base-128 digits (rs_digits_kernel)
     int32_t* pass_list;          // hypotheses on this path, arrival order
     int32_t* n_pass;
     unsigned char* dense;        // [iters] refit needs rs_moments_kernel (rank not certified, or the N == 3 branch)
@@ -969,10 +970,10 @@ __device__ __forceinline__ void rs_records_body(const StagedArgs& sa, int block)
         P.load(0, o); P.load(i, q);
         m1 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
         m2 = q[3] * q[3] + q[4] * q[4] + q[5] * q[5];
-        if (sa.use_f32) {
+        if (sa.use_f32 || sa.use_lane) {                // bounds of the rows relative to correspondence 0: the fp32 screen's and the digit grid's
             double v[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) { v[c] = q[c] - o[c]; sa.c32[(size_t)c * sa.n32 + i] = (float)v[c]; }
+            for (int c = 0; c < 6; ++c) { v[c] = q[c] - o[c]; if (sa.use_f32) sa.c32[(size_t)c * sa.n32 + i] = (float)v[c]; }
             c1m = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
             c2m = v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
         }
@@ -1467,105 +1468,144 @@ __global__ __launch_bounds__(kTBlock) void rs_moments_kernel(StagedArgs sa) {
     }
 }
 
-typedef int rs_i32x16 __attribute__((ext_vector_type(16)));
-typedef int rs_i32x8 __attribute__((ext_vector_type(8)));
-typedef int rs_i32x4 __attribute__((ext_vector_type(4)));
 typedef int rs_i32x2 __attribute__((ext_vector_type(2)));
-struct RecS { rs_i32x16 a; rs_i32x8 b; rs_i32x4 c; rs_i32x2 d; };     // one record in 30 SGPRs
-// hipcc will not select scalar loads here by itself (it sinks the record loads into the divergent branch and
-// turns them into per-lane loads), so the SMEM traffic is written out: issue, then wait for everything.
-#define PCREG_REC_LOAD(R, BASE, OFF)                                                                                   \
-    asm volatile("s_load_dwordx16 %0, %4, %5\n\ts_load_dwordx8 %1, %4, %6\n\ts_load_dwordx4 %2, %4, %7\n\ts_load_dwordx2 %3, %4, %8" \
-                 : "=&s"(R.a), "=&s"(R.b), "=&s"(R.c), "=&s"(R.d)                                                      \
-                 : "s"(BASE), "n"((OFF)), "n"((OFF) + 64), "n"((OFF) + 96), "n"((OFF) + 112))
-#define PCREG_REC_WAIT(R) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R.a), "+s"(R.b), "+s"(R.c), "+s"(R.d))
 __device__ __forceinline__ double rs_pair(int lo, int hi) { return __builtin_bit_cast(double, rs_i32x2{lo, hi}); }
-#define PCREG_REC_ADD(ACC, R)                                                                                          \
-    {                                                                                                                  \
-        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) ACC[e_] += rs_pair(R.a[2 * e_], R.a[2 * e_ + 1]);             \
-        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) ACC[8 + e_] += rs_pair(R.b[2 * e_], R.b[2 * e_ + 1]);         \
-        ACC[12] += rs_pair(R.c[0], R.c[1]); ACC[13] += rs_pair(R.c[2], R.c[3]); ACC[14] += rs_pair(R.d[0], R.d[1]);    \
-    }
 
-#define PCREG_REC_FMA(ACC, R, F)                                                                                       \
-    {                                                                                                                  \
-        _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) ACC[e_] = __builtin_fma(rs_pair(R.a[2 * e_], R.a[2 * e_ + 1]), F, ACC[e_]);         \
-        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) ACC[8 + e_] = __builtin_fma(rs_pair(R.b[2 * e_], R.b[2 * e_ + 1]), F, ACC[8 + e_]); \
-        ACC[12] = __builtin_fma(rs_pair(R.c[0], R.c[1]), F, ACC[12]); ACC[13] = __builtin_fma(rs_pair(R.c[2], R.c[3]), F, ACC[13]);          \
-        ACC[14] = __builtin_fma(rs_pair(R.d[0], R.d[1]), F, ACC[14]);                                                  \
-    }
+// ---- refit moments on the matrix cores -------------------------------------------------------------------------------
+// A hypothesis' fifteen moments are sums of per-correspondence records under its inlier mask: [hypotheses x points] 0/1 times
+// [points x 15] -- a matrix product whose left factor is EXACT in any number format.  The records are put on a common
+// fixed-point grid per column (2^E_c above the column's bound) and cut into eight balanced base-128 digits (int8); the
+// masks expand to 0/1 bytes; v_mfma_i32_32x32x32_i8 adds digit columns in int32 without any rounding; the eight digit sums
+// of a column are recombined in fp64 (two exact 4-digit halves, ONE rounding).  The result is the correctly rounded
+// masked sum of records truncated at 2^-57 of their column's bound: closer to the true sum than fp64 adds in any order
+// (whose error grows with the 32 k terms), at the int8 matrix rate instead of 15 fp64 FMAs per pair -- the lane-per-
+// hypothesis fp64 kernel this replaces took 247 us of the step's 2.2 ms.
+// eight digits per record column; digit p of column c sits in tile p % 4, column 2 c + p / 4 of the B operand
+constexpr int kMmRows = 64;                   // hypotheses per wave (two 32-row tiles)
+constexpr int kMmWaves = 4;                   // waves per workgroup: 256 hypotheses share every tile of digits
+typedef int rs_v4i __attribute__((ext_vector_type(4)));
+typedef int rs_v16i __attribute__((ext_vector_type(16)));
 
-// Refit moments, kLaneHyps hypotheses per LANE: the correspondence records are wave-uniform (scalar loads, SGPR
-// operands), every lane adds them under its own hypotheses' masks.  No LDS, no cross-lane reduction, and each
-// sum runs in index order.  grid (groups of 64 * kLaneHyps listed hypotheses, chunks of kMomSlots * 64
-// correspondences).  Two hypotheses per lane halve the scalar-cache traffic per accumulated pair.
-constexpr int kLaneHyps = 2;
-__global__ __launch_bounds__(64) void rs_moments_lane_kernel(StagedArgs sa, const double* __restrict__ rec,
-                                                            const unsigned long long* __restrict__ masks) {
+// exponent of the fixed-point grid of record column c: |record| < 2^(E - 1)  (bounds[2], [3] = max |p1 - o1|^2, |p2 - o2|^2)
+__device__ __forceinline__ int rs_rec_exp(const double* __restrict__ bounds, int c) {
+    const double D = sqrt(bounds[2]), M = sqrt(bounds[3]);
+    double b = c < 3 ? D : (c < 6 ? M : D * M);
+    b *= 1.0000001;                           // the records' own rounding
+    return (b > 0.0 && b < INFINITY) ? ilogb(b) + 2 : 0;
+}
+// dig [(kstep * 4 + tile) * 64 + lane] (16 int8): lane = (half << 5) | col; byte b = correspondence kstep * 32 + half * 16 + b
+__global__ __launch_bounds__(256) void rs_digits_kernel(StagedArgs sa, uint4* __restrict__ dig) {
+    const int g = blockIdx.x * 256 + threadIdx.x;               // (kstep, tile, lane)
+    const int lane = g & 63, tile = (g >> 6) & 3, kstep = g >> 8;
+    if (kstep >= sa.nslots_cap * 2) return;
+    const int col = lane & 31, half = lane >> 5;
+    const int c = col >> 1, pd = tile + 4 * (col & 1);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (c < 15) {
+        const int E = rs_rec_exp(sa.bounds, c);
+        const double* r = sa.rec + (size_t)(kstep * 32 + half * 16) * kRec + c;
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) {
+            double y = ldexp(r[(size_t)bb * kRec], -E);         // exact; |y| < 1/2
+            double d = 0.0;
+            for (int q = 0; q <= pd; ++q) { y *= 128.0; d = rint(y); y -= d; }       // every step exact: |d| <= 64
+            w[bb >> 2] |= ((unsigned)(int)d & 0xFFu) << (8 * (bb & 3));
+        }
+    }
+    dig[g] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// grid (groups of 256 listed hypotheses, chunks of kMomSlots * 64 correspondences); mpart [chunk][iters][15]
+__global__ __launch_bounds__(kMmWaves * 64, 2) void rs_moments_mfma_kernel(StagedArgs sa, const uint4* __restrict__ dig,
+                                                                            const unsigned long long* __restrict__ masks) {
+    __shared__ __attribute__((aligned(16))) uint4 s_b[2][16 * 64];               // two stages of 4 k-steps x 4 tiles x 64 lanes
     const RansacArgs& a = sa.a;
-    const int n = __builtin_amdgcn_readfirstlane(staged_n(a));
-    const int np = __builtin_amdgcn_readfirstlane(*sa.n_pass);
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x * 64 * kLaneHyps >= np) return;
+    const int n = staged_n(a), np = *sa.n_pass;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x * kMmWaves * kMmRows >= np) return;
     const int nslots = (n + 63) >> 6;
-    const int s0 = __builtin_amdgcn_readfirstlane((int)blockIdx.y * kMomSlots);
+    const int s0 = (int)blockIdx.y * kMomSlots;
     if (s0 >= nslots) return;
-    const int s1 = __builtin_amdgcn_readfirstlane(min(nslots, s0 + kMomSlots));
-    bool live[kLaneHyps]; int h[kLaneHyps]; const unsigned long long* row[kLaneHyps];
-    double acc[kLaneHyps][15];
-    unsigned long long wn[kLaneHyps];
+    const int s1 = min(nslots, s0 + kMomSlots);
+    const int hrow = lane & 31, half = lane >> 5;
+    int h[2]; bool live[2]; const unsigned long long* row[2];
 #pragma unroll
-    for (int j = 0; j < kLaneHyps; ++j) {
-        const int li = (blockIdx.x * kLaneHyps + j) * 64 + lane;
-        live[j] = li < np;
-        h[j] = live[j] ? sa.pass_list[li] : 0;
-        row[j] = masks + (size_t)h[j] * sa.nslots_cap;
-#pragma unroll
-        for (int e = 0; e < 15; ++e) acc[j][e] = 0.0;
-        wn[j] = live[j] ? row[j][s0] : 0ull;
+    for (int r = 0; r < 2; ++r) {
+        const int li = (blockIdx.x * kMmWaves + wave) * kMmRows + r * 32 + hrow;
+        live[r] = li < np;
+        h[r] = live[r] ? sa.pass_list[li] : sa.pass_list[0];
+        row[r] = masks + (size_t)h[r] * sa.nslots_cap;
     }
-    RecS A, B;
-    const double* base = rec + (size_t)s0 * 64 * kRec;
-    PCREG_REC_LOAD(A, base, 0);
-    for (int s = s0; s < s1; ++s) {
-        unsigned lo[kLaneHyps], hi[kLaneHyps];
+    rs_v16i acc[2][4];
 #pragma unroll
-        for (int j = 0; j < kLaneHyps; ++j) {
-            lo[j] = (unsigned)wn[j]; hi[j] = (unsigned)(wn[j] >> 32);
-            if (s + 1 < s1) wn[j] = live[j] ? row[j][s + 1] : 0ull;
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][t][v] = 0;
+    const int nst = (s1 - s0 + 1) >> 1;                          // stages of two slots = four k-steps (kMomSlots is even)
+    auto stage_load = [&](int st, uint4 (&v)[4]) {
+        const uint4* src = dig + (size_t)(s0 + 2 * st) * 2 * 4 * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = src[k * 256 + tid];
+    };
+    uint4 pre[4];
+    stage_load(0, pre);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_b[0][k * 256 + tid] = pre[k];
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) stage_load(st + 1, pre);
+        // this stage's mask bits: two 64-bit words per row = four k-steps of 32 correspondences; lane half takes 16 of each
+        uint4 mw[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) mw[r] = *(const uint4*)(row[r] + s0 + 2 * st);
+        const uint4* B = s_b[st & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rs_v4i A[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned wj = j == 0 ? mw[r].x : (j == 1 ? mw[r].y : (j == 2 ? mw[r].z : mw[r].w));
+                const unsigned b16 = (wj >> (16 * half)) & 0xFFFFu;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) A[r][q] = (int)((((b16 >> (4 * q)) & 0xFu) * 0x00204081u) & 0x01010101u);   // 4 bits -> 4 bytes of 0 / 1
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint4 bv = B[(j * 4 + t) * 64 + lane];
+                const rs_v4i Bv = {(int)bv.x, (int)bv.y, (int)bv.z, (int)bv.w};
+#pragma unroll
+                for (int r = 0; r < 2; ++r) acc[r][t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[r], Bv, acc[r][t], 0, 0, 0);
+            }
         }
-        const double* nbase = base + 64 * kRec;          // the record array is padded past n
-#define PCREG_REC_USE(K, R)                                                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < kLaneHyps; ++j_) {                              \
-            /* no branch: acc = fma(record, bit ? 1.0 : 0.0, acc) -- the same bits as a masked add (records are finite) */ \
-            const unsigned bit_ = (((K) < 32 ? lo[j_] : hi[j_]) >> ((K) & 31)) & 1u;            \
-            const double f_ = rs_pair(0, (int)((0u - bit_) & 0x3FF00000u));                     \
-            PCREG_REC_FMA(acc[j_], R, f_)                                                       \
+        if (st + 1 < nst) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_b[(st + 1) & 1][k * 256 + tid] = pre[k];
         }
-#define PCREG_REC_STEP(K)                                                                       \
-        PCREG_REC_WAIT(A); PCREG_REC_LOAD(B, base, ((K) + 1) * kRec * 8);                       \
-        PCREG_REC_USE(K, A)                                                                     \
-        PCREG_REC_WAIT(B);                                                                      \
-        if ((K) + 2 < 64) { PCREG_REC_LOAD(A, base, ((K) + 2) * kRec * 8); } else { PCREG_REC_LOAD(A, nbase, 0); } \
-        PCREG_REC_USE((K) + 1, B)
-#define PCREG_REC_STEP4(K) PCREG_REC_STEP(K) PCREG_REC_STEP((K) + 2) PCREG_REC_STEP((K) + 4) PCREG_REC_STEP((K) + 6)
-        PCREG_REC_STEP4(0) PCREG_REC_STEP4(8) PCREG_REC_STEP4(16) PCREG_REC_STEP4(24)
-        PCREG_REC_STEP4(32) PCREG_REC_STEP4(40) PCREG_REC_STEP4(48) PCREG_REC_STEP4(56)
-#undef PCREG_REC_STEP4
-#undef PCREG_REC_STEP
-#undef PCREG_REC_USE
-        base = nbase;
+        __syncthreads();
     }
-    PCREG_REC_WAIT(A);                                    // drain the last prefetch before the wave ends
+    // digits -> doubles.  A lane holds column `hrow` of the four tiles for 16 rows: digits p = 0..3 (even column) or 4..7 (odd)
+    // of record column hrow / 2; the odd neighbour's half is 128^-4 times smaller.
+    const int c = hrow >> 1;
+    const int E = c < 15 ? rs_rec_exp(sa.bounds, c) : 0;
 #pragma unroll
-    for (int j = 0; j < kLaneHyps; ++j) {
-        if (live[j]) {
-            double* out = sa.mpart + ((size_t)blockIdx.y * a.iters + h[j]) * 15;
+    for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int e = 0; e < 15; ++e) out[e] = acc[j][e];
+        for (int v = 0; v < 16; ++v) {
+            // exact: four integers below 2^22 on a 2^-7 ladder span 43 bits
+            double part = (((double)acc[r][3][v] * 0.0078125 + (double)acc[r][2][v]) * 0.0078125 + (double)acc[r][1][v]) * 0.0078125 + (double)acc[r][0][v];
+            const double other = __shfl_xor(part, 1);
+            const int rr = (v >> 2) * 8 + half * 4 + (v & 3);                     // row of this accumulator element
+            const int hh = __shfl(h[r], rr), lv = __shfl((int)live[r], rr);       // lanes 0..31 hold the rows' hypotheses
+            if ((hrow & 1) == 0 && c < 15 && lv) {
+                const double sum = ldexp(part + other * 3.7252902984619140625e-09, E - 7);       // hi + lo * 128^-4, then * 2^E / 128
+                sa.mpart[((size_t)blockIdx.y * a.iters + hh) * 15 + c] = sum;
+            }
         }
     }
 }
+
 
 __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
     const RansacArgs& a = sa.a;
@@ -1581,7 +1621,7 @@ __global__ __launch_bounds__(64) void rs_fit2_kernel(StagedArgs sa) {
         double o[6]; P.load(0, o);
         double mom[27];
         const int c1 = a.cnt1[h];
-        if (!sa.dense[h]) {                         // the chunk partials of rs_moments_lane_kernel, in chunk order
+        if (!sa.dense[h]) {                         // the chunk partials of rs_moments_mfma_kernel, in chunk order
 #pragma unroll
             for (int e = 0; e < 27; ++e) mom[e] = 0.0;
             const int nch = (((n + 63) >> 6) + kMomSlots - 1) / kMomSlots;
@@ -2042,7 +2082,8 @@ static size_t staged_extra_bytes(size_t h, int n_cap) {    // T1 | mom | part | 
     if (n_cap >= kStagedMinN)
         b += align_up(staged_slots_cap(n_cap) * 64 * 6 * sizeof(float), 256) + 2 * align_up(h * 16 * sizeof(float), 256) +
              align_up(h * staged_slots_cap(n_cap) * 8, 256) + align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256) +
-             align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256) + align_up(h * sizeof(int32_t), 256) + 256;
+             align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256) + align_up(h * sizeof(int32_t), 256) + 256 +
+             align_up(staged_slots_cap(n_cap) * 2 * 256 * sizeof(uint4), 256);
     return b;
 }
 size_t ransac_workspace_bytes(int iters, int B, int n_cap) {
@@ -2110,6 +2151,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.rec = (double*)w; w += align_up(staged_slots_cap(n_cap) * 64 * kRec * sizeof(double) + 256, 256);
         sa.mpart = (double*)w; w += align_up(staged_chunks_cap(n_cap) * h * 15 * sizeof(double), 256);
         sa.pass_list = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
+        sa.dig = (uint4*)w; w += align_up(staged_slots_cap(n_cap) * 2 * 256 * sizeof(uint4), 256);
         sa.n_pass = (int32_t*)w; w += 256;
         sa.n32 = (int)staged_slots_cap(n_cap) * 64;
         sa.c32 = (float*)w; w += align_up((size_t)sa.n32 * 6 * sizeof(float), 256);
@@ -2126,11 +2168,12 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.a = a;
         const int it = o.iterNum;
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
-        // 10 launches (round 2: 11 + select): stage1 (sample fits + records), stage2 (maxima + fp32 rows), scoring pass 1,
-        // pass1, lane refit sums, dense refit sums (normally idle), refits, scoring pass 2, finish; then select
+        // 11 launches (round 2: 11 + select): stage1 (sample fits + records), stage2 (maxima + fp32 rows), the records' digits,
+        // scoring pass 1, pass1, refit sums on the matrix cores, dense refit sums (normally idle), refits, scoring pass 2, finish; then select
         const int n_fit = (it + 255) / 256;
         hipLaunchKernelGGL(rs_stage1_kernel, dim3((unsigned)(n_fit + sa.n_rec_blocks)), dim3(256), 0, st, sa, n_fit);
         hipLaunchKernelGGL(rs_stage2_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a);
+        if (sa.use_lane) hipLaunchKernelGGL(rs_digits_kernel, dim3((unsigned)staged_slots_cap(n_cap) * 2), dim3(256), 0, st, sa, sa.dig);
         if (sa.use_f32) {
             if (sa.use_lane)
                 hipLaunchKernelGGL(rs_score32_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1);
@@ -2144,8 +2187,8 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         hipLaunchKernelGGL(rs_pass1_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
         if (a.refine) {
             if (sa.use_lane)
-                hipLaunchKernelGGL(rs_moments_lane_kernel, dim3((it + 64 * kLaneHyps - 1) / (64 * kLaneHyps), (unsigned)staged_chunks_cap(n_cap)), dim3(64), 0, st, sa,
-                                   (const double*)sa.rec, (const unsigned long long*)sa.masks);
+                hipLaunchKernelGGL(rs_moments_mfma_kernel, dim3((it + kMmWaves * kMmRows - 1) / (kMmWaves * kMmRows), (unsigned)staged_chunks_cap(n_cap)), dim3(kMmWaves * 64), 0, st, sa,
+                                   (const uint4*)sa.dig, (const unsigned long long*)sa.masks);
             hipLaunchKernelGGL(rs_moments_kernel, dim3((it + hpw * kTW - 1) / (hpw * kTW)), dim3(kTBlock), 0, st, sa);
             hipLaunchKernelGGL(rs_fit2_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
             if (sa.use_f32)

@@ -139,7 +139,7 @@ def test_ubench_issues_eight_distinct_mfmas_per_iteration(tmp_path):
     assert seen == 5
 
 
-# ---- ransac.hip: inline-asm SCALAR loads (rs_score32_kernel's T32 rows, rs_moments_lane_kernel's records) ---------------
+# ---- ransac.hip: inline-asm SCALAR loads (rs_score32_kernel's T32 rows, (round 2's lane refit kernel did the same with its records; it is gone)) ---------------
 def _sregs(text):
     out = set()
     for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
@@ -191,7 +191,7 @@ def test_no_sgpr_of_an_asm_scalar_load_is_touched_before_its_wait(tmp_path):
     funcs = _functions(open(out).read())
     checked = {}
     for name, ins in funcs.items():
-        if "rs_score32_kernel" not in name and "rs_moments_lane_kernel" not in name:
+        if "rs_score32_kernel" not in name:
             continue
         labels = {s.rstrip(":").split(":")[0]: i for i, s in enumerate(ins) if s.startswith(".LBB")}
         in_asm = False
@@ -207,6 +207,5 @@ def test_no_sgpr_of_an_asm_scalar_load_is_touched_before_its_wait(tmp_path):
                 j = next(k for k in range(i, len(ins)) if ins[k].startswith(";;#ASMEND")) + 1
                 assert _walk_to_wait(ins, labels, j, dst, name) > 0
                 checked[name] = checked.get(name, 0) + 1
-    kinds = {("score32" if "rs_score32" in n else "lane") for n in checked}
-    assert kinds == {"score32", "lane"}, checked
+    assert len(checked) == 2 and all("rs_score32" in n for n in checked), checked            # both instantiations (EMIT = true / false)
     assert all(v >= 2 for v in checked.values()), checked
