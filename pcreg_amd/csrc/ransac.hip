@@ -910,7 +910,7 @@ constexpr int kSW = 4, kSS = 8;                 // scoring: waves per workgroup,
 constexpr int kSPts = kSW * kSS * 64;           // 2048 correspondences per workgroup
 constexpr int kSMaxPB = 64;                     // point blocks with a partial-count row each
 #ifndef PCREG_MOM_SLOTS
-#define PCREG_MOM_SLOTS 40
+#define PCREG_MOM_SLOTS 44
 #endif
 constexpr int kStagedMinN = 4096;               // one registration of at least this many correspondences runs staged
 constexpr int kMomSlots = PCREG_MOM_SLOTS;                   // lane-per-hypothesis refit: 64-correspondence slots per chunk
@@ -1544,22 +1544,22 @@ __global__ __launch_bounds__(kMmWaves * 64, 2) void rs_moments_mfma_kernel(Stage
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[r][t][v] = 0;
     const int nst = (s1 - s0 + 1) >> 1;                          // stages of two slots = four k-steps (kMomSlots is even)
-    auto stage_load = [&](int st, uint4 (&v)[4]) {
-        const uint4* src = dig + (size_t)(s0 + 2 * st) * 2 * 4 * 64;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = src[k * 256 + tid];
-    };
-    uint4 pre[4];
-    stage_load(0, pre);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s_b[0][k * 256 + tid] = pre[k];
+    const uint4* dsrc = dig + (size_t)s0 * 2 * 4 * 64 + tid;    // a stage = 4 k-steps x 256 uint4; thread tid moves element k * 256 + tid
+    uint4 pre0 = dsrc[0], pre1 = dsrc[256], pre2 = dsrc[512], pre3 = dsrc[768];
+    s_b[0][tid] = pre0; s_b[0][256 + tid] = pre1; s_b[0][512 + tid] = pre2; s_b[0][768 + tid] = pre3;
     __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        if (st + 1 < nst) stage_load(st + 1, pre);
-        // this stage's mask bits: two 64-bit words per row = four k-steps of 32 correspondences; lane half takes 16 of each
-        uint4 mw[2];
+    // a stage's mask bits: two 64-bit words per row = four k-steps of 32 correspondences (lane half takes 16 of each); they come
+    // from HBM (40 MB per registration) one row per lane, so the next stage's are requested before this stage's products
+    uint4 mw[2], mwn[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) mw[r] = *(const uint4*)(row[r] + s0 + 2 * st);
+    for (int r = 0; r < 2; ++r) { mw[r] = *(const uint4*)(row[r] + s0); mwn[r] = mw[r]; }
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) {
+            const uint4* nx = dsrc + (size_t)(st + 1) * 1024;
+            pre0 = nx[0]; pre1 = nx[256]; pre2 = nx[512]; pre3 = nx[768];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) mwn[r] = *(const uint4*)(row[r] + s0 + 2 * (st + 1));
+        }
         const uint4* B = s_b[st & 1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1580,15 +1580,19 @@ __global__ __launch_bounds__(kMmWaves * 64, 2) void rs_moments_mfma_kernel(Stage
             }
         }
         if (st + 1 < nst) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s_b[(st + 1) & 1][k * 256 + tid] = pre[k];
+            uint4* nb = s_b[(st + 1) & 1];
+            nb[tid] = pre0; nb[256 + tid] = pre1; nb[512 + tid] = pre2; nb[768 + tid] = pre3;
         }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) mw[r] = mwn[r];
         __syncthreads();
     }
     // digits -> doubles.  A lane holds column `hrow` of the four tiles for 16 rows: digits p = 0..3 (even column) or 4..7 (odd)
-    // of record column hrow / 2; the odd neighbour's half is 128^-4 times smaller.
+    // of record column hrow / 2; the odd neighbour's half is 128^-4 times smaller.  The sums go through LDS (the digit stages are
+    // done with) so that a hypothesis' fifteen doubles leave as one 120-byte run.
     const int c = hrow >> 1;
     const int E = c < 15 ? rs_rec_exp(sa.bounds, c) : 0;
+    double* s_out = (double*)&s_b[0][0] + (size_t)wave * (kMmRows * 15);             // 4 waves x 64 rows x 15 doubles = 30 KB of the 32
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -1597,12 +1601,15 @@ __global__ __launch_bounds__(kMmWaves * 64, 2) void rs_moments_mfma_kernel(Stage
             double part = (((double)acc[r][3][v] * 0.0078125 + (double)acc[r][2][v]) * 0.0078125 + (double)acc[r][1][v]) * 0.0078125 + (double)acc[r][0][v];
             const double other = __shfl_xor(part, 1);
             const int rr = (v >> 2) * 8 + half * 4 + (v & 3);                     // row of this accumulator element
-            const int hh = __shfl(h[r], rr), lv = __shfl((int)live[r], rr);       // lanes 0..31 hold the rows' hypotheses
-            if ((hrow & 1) == 0 && c < 15 && lv) {
-                const double sum = ldexp(part + other * 3.7252902984619140625e-09, E - 7);       // hi + lo * 128^-4, then * 2^E / 128
-                sa.mpart[((size_t)blockIdx.y * a.iters + hh) * 15 + c] = sum;
-            }
+            if ((hrow & 1) == 0 && c < 15)
+                s_out[(r * 32 + rr) * 15 + c] = ldexp(part + other * 3.7252902984619140625e-09, E - 7);   // (hi + lo * 128^-4) * 2^E / 128
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < kMmRows * 15; e += 64) {
+        const int rw = e / 15, cc = e - rw * 15;
+        const int li = (blockIdx.x * kMmWaves + wave) * kMmRows + rw;
+        if (li < np) sa.mpart[((size_t)blockIdx.y * a.iters + sa.pass_list[li]) * 15 + cc] = s_out[e];
     }
 }
 
