@@ -40,6 +40,7 @@ struct RansacArgs {
     int hyp0g;                  // global index of this launch's first hypothesis (hypotheses split over ranks)
     double* TF;                 // [B*iters][12]
     int32_t* cnt1; int32_t* cnt2; unsigned char* has;
+    int n_hi;                   // ransac_hyp_kernel: registrations of up to n_hi correspondences fit the launch's dynamic LDS
 };
 
 // ---------------------------------------------------------------- lane utilities
@@ -465,12 +466,7 @@ __device__ __forceinline__ void sample3(const RansacArgs& a, int b, int p, int n
 
 // ---------------------------------------------------------------- hypothesis kernel
 template <bool LDS_PTS>
-__global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sp[];
-    const int b = blockIdx.y;
-    const int off = a.offsets ? a.offsets[b] : 0;
-    int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
-    n = min(n, a.n_cap);
+__device__ __forceinline__ void ransac_hyp_body(const RansacArgs& a, double* __restrict__ sp, const int b, const int off, const int n) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t hyp0 = (size_t)b * a.iters;
     const int wbase = (blockIdx.x * kWavesPerBlock + wave) * a.hpw;   // first hypothesis of this wave
@@ -648,6 +644,19 @@ __global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
             for (int k = 0; k < 12; ++k) a.TF[(hyp0 + p) * 12 + k] = T2[k];
         }
     }
+}
+
+// The correspondences of a registration sit in LDS when they fit the launch's dynamic LDS (a.n_hi of them); a registration of a
+// batch that does not (the batch's LDS is sized for the common case, not for its capacity: a workgroup that RESERVES 96 KB is
+// alone on its CU) reads them from L2 instead -- the same code on the other point source, chosen per workgroup.
+__global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sp[];
+    const int b = blockIdx.y;
+    const int off = a.offsets ? a.offsets[b] : 0;
+    int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
+    n = min(n, a.n_cap);
+    if (n <= a.n_hi) ransac_hyp_body<true>(a, sp, b, off, n);
+    else ransac_hyp_body<false>(a, sp, b, off, n);
 }
 
 // ---------------------------------------------------------------- hypothesis kernel, large n
@@ -2099,6 +2108,7 @@ size_t ransac_workspace_bytes(int iters, int B, int n_cap) {
            staged_extra_bytes(h, B == 1 ? n_cap : 0);
 }
 
+constexpr size_t kLdsSmallBytes = 32 * 1024;         // batched: registrations up to 682 correspondences share a CU five at a time
 constexpr size_t kLdsPointsMaxBytes = 152 * 1024;     // correspondences of one registration resident in LDS: n_cap <= 3242
 static int launch_ransac_impl(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
                   int n_cap, int B, pcreg_ransac_opts o, const int32_t* sample_idx_dev,
@@ -2114,6 +2124,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
     a.p1 = p1; a.p2 = p2; a.ld = ld; a.offsets = offsets; a.n_dev = n_dev; a.n_cap = n_cap;
     a.iters = o.iterNum; a.m = o.minPtNum; a.thDist = o.thDist; a.ratio = o.thInlrRatio;
     a.refine = o.REFINE != 0; a.seed = o.seed; a.sample_idx = sample_idx_dev; a.hyp0g = hyp_begin;
+    a.n_hi = 0x7FFFFFFF;
     a.TF = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
     a.cnt1 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.cnt2 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
@@ -2133,9 +2144,16 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         dim3 grid((o.iterNum + per_block - 1) / per_block, B);
         if (lds > 64 * 1024) {
             static bool raised = false;           // above 64 KiB of dynamic LDS the runtime wants to be told once
-            if (!raised) { PCREG_HIP(hipFuncSetAttribute((const void*)ransac_hyp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPointsMaxBytes)); raised = true; }
+            if (!raised) { PCREG_HIP(hipFuncSetAttribute((const void*)ransac_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPointsMaxBytes)); raised = true; }
         }
-        hipLaunchKernelGGL(ransac_hyp_kernel<true>, grid, dim3(kBlock), lds, st, a);
+        if (offsets && lds > kLdsSmallBytes) {
+            // A batch's capacity says little about its registrations (the sweep passes the surface size, 2000; its trials hold
+            // ~250 pairs): the launch reserves 32 KB (682 correspondences, five workgroups to a CU by LDS); a larger registration
+            // of the batch runs from L2.
+            lds = kLdsSmallBytes;
+            a.n_hi = (int)(kLdsSmallBytes / (6 * sizeof(double)));
+        }
+        hipLaunchKernelGGL(ransac_hyp_kernel, grid, dim3(kBlock), lds, st, a);
     } else if (B == 1 && !offsets && n_cap >= kStagedMinN && !(getenv("PCREG_RANSAC_FUSED") && atoi(getenv("PCREG_RANSAC_FUSED")))) {
         // one large registration: the staged chain of lean kernels (see rs_* above)
         StagedArgs sa{};
