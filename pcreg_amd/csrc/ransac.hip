@@ -2109,7 +2109,7 @@ size_t ransac_workspace_bytes(int iters, int B, int n_cap) {
 }
 
 constexpr size_t kLdsSmallBytes = 32 * 1024;         // batched: registrations up to 682 correspondences share a CU five at a time
-constexpr size_t kLdsPointsMaxBytes = 152 * 1024;     // correspondences of one registration resident in LDS: n_cap <= 3242
+constexpr size_t kLdsPointsMaxBytes = 152 * 1024;     // batches up to this capacity (n_cap <= 3242) use ransac_hyp_kernel; larger ones the tiled kernel
 static int launch_ransac_impl(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
                   int n_cap, int B, pcreg_ransac_opts o, const int32_t* sample_idx_dev,
                   pcreg_dev_ransac_result* out, int32_t* inlier_idx, int32_t* iter_inl, int32_t* iter_inl_ref,
@@ -2142,14 +2142,11 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         a.hpw = hpw;
         int per_block = hpw * kWavesPerBlock;
         dim3 grid((o.iterNum + per_block - 1) / per_block, B);
-        if (lds > 64 * 1024) {
-            static bool raised = false;           // above 64 KiB of dynamic LDS the runtime wants to be told once
-            if (!raised) { PCREG_HIP(hipFuncSetAttribute((const void*)ransac_hyp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPointsMaxBytes)); raised = true; }
-        }
-        if (offsets && lds > kLdsSmallBytes) {
+        if (offsets && lds > 64 * 1024) {
             // A batch's capacity says little about its registrations (the sweep passes the surface size, 2000; its trials hold
-            // ~250 pairs): the launch reserves 32 KB (682 correspondences, five workgroups to a CU by LDS); a larger registration
-            // of the batch runs from L2.
+            // ~250 pairs): above 64 KB of capacity the launch reserves 32 KB (682 correspondences, five workgroups to a CU by LDS)
+            // and a larger registration of the batch runs from L2; up to 64 KB the capacity itself is reserved (cfg 1's batch of
+            // n = 1000: three workgroups to a CU, all in LDS).
             lds = kLdsSmallBytes;
             a.n_hi = (int)(kLdsSmallBytes / (6 * sizeof(double)));
         }
