@@ -187,3 +187,42 @@ def test_f16_split_midpoints_by_construction(oracle_c):
     oi, od = oracle_c.knn2_points_f32(q, model, nthreads=CORES)
     np.testing.assert_array_equal(gi, oi)
     np.testing.assert_array_equal(gd, od)
+
+
+def test_sphere_sweep_at_the_reference_shape(oracle_c, oracle_py):
+    """completeExperimentFast.m:46-224 at the reference's own shape (a 60 k-keypoint model, ~330 valid spheres of ~1500 descriptors,
+    a 2000-keypoint surface, D = 980): the segmented launch chain against one getMatches chain per sphere -- every sphere's pairs,
+    counts, trial list and transforms identical -- and against the oracle's getDescriptorMask + getMatches on spheres spread over
+    the sweep (first, middle, last, the first trial sphere)."""
+    from pcreg_amd.sweep import SphereSweep
+    VM, VS, D = 60000, 2000, 980
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    featM = rng.uniform([0, 0, 0], [60, 50, 40], (VM, 3))
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    descM = torch.poisson(torch.full((VM, D), 3.0, device=dev), generator=g).to(torch.float64)
+    near = np.argsort(np.linalg.norm(featM - np.array([31.0, 24.0, 19.0]), axis=1))[:VS]
+    c, s = np.cos(0.3), np.sin(0.3)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    featS = featM[near] @ R.T + np.array([2.0, -1.0, 0.5]) + rng.normal(0, 0.02, (VS, 3))
+    descS = (descM[torch.from_numpy(near).to(dev)] + torch.poisson(torch.full((VS, D), 0.15, device=dev), generator=g).to(torch.float64)).contiguous()
+    par = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate", MatchThreshold=10, MaxRatio=0.99,
+               Metric="SAD", Unique=True, VERBOSE=0)
+    opt = dict(minPtNum=3, iterNum=2000, thDist=0.3, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    kw = dict(R_desc=9.0, d_spheres=5.0, min_pts=1400, putative_thresh=170, seed=0)
+    sw = SphereSweep(featM, descM, featS, descS, device=dev)
+    out = sw.run(par, opt, **kw)
+    ref = sw.run_streams(par, opt, n_streams=8, **kw)
+    S = len(out["centres"])
+    assert S >= 300 and len(out["trial"]) >= 50
+    for k in ("num_desc", "num_putative", "trial", "statsPutative", "statsSuccess", "statsInliers"):
+        np.testing.assert_array_equal(out[k], ref[k])
+    for a, b in zip(out["matches"], ref["matches"]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(out["transforms"], ref["transforms"]):
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+    dm, ds = descM.cpu().numpy(), descS.cpu().numpy()
+    for i in sorted({0, S // 2, S - 1, int(out["trial"][0])}):
+        idx = np.nonzero(oracle_py.getDescriptorMask(featM, out["centres"][i], kw["R_desc"], 0.0))[0]
+        np.testing.assert_array_equal(idx, out["model_rows"][i])
+        np.testing.assert_array_equal(oracle_c.getMatches(ds, dm[idx], par, nthreads=0), out["matches"][i])
