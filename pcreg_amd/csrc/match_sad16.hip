@@ -810,7 +810,8 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
                                                                const int32_t* __restrict__ n_live, const int32_t* __restrict__ part_idx,
                                                                const uint32_t* __restrict__ part_s, int splits,
                                                                int32_t* __restrict__ idx, double* __restrict__ dist,
-                                                               int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven) {
+                                                               int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven,
+                                                               int32_t* __restrict__ dbg_hist) {
     __shared__ double s_t[kBlock / 64][kNC][kFT];
     __shared__ int s_j[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -853,6 +854,9 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 
+#ifdef PCREG_EXPERIMENTS
+    if (dbg_hist && lane == 0) atomicAdd(&dbg_hist[min(n_need, 129)], 1);          // PCREG_SEG_DEBUG: candidates re-scored per query
+#endif
     double d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
     const SegRow a = BACK ? seg_model_row(V, cand_m[(size_t)z * nA + qi]) : seg_surface_row(V, qi);
     for (int g0 = 0; g0 < n_need; g0 += kNC) {
@@ -960,10 +964,19 @@ __global__ __launch_bounds__(kBlock) void segp_exact_rows_kernel(SegSets S, cons
             }
             double s = 0.0;
             for (int d0 = 0; d0 < D; d0 += kXF) {
-                const int d = d0 + f;
+                const int d = d0 + f, dc = min(d, D - 1);
+                // sixteen unconditional loads in flight, then the arithmetic: written as one conditional expression per row the
+                // compiler put every load behind its own branch and wait, and a task took 16 x 62 serial round trips (6.9 ms for a
+                // kernel with 141 queries to do)
+                double pv[kBlock / kXF];
 #pragma unroll
-                for (int u = 0; u < kBlock / kXF; ++u)
-                    s_t[f][rq + (kBlock / kXF) * u] = d < D ? fabs(s_a[min(d, D - 1)] - seg_value(V, br[u], min(d, D - 1))) : 0.0;
+                for (int u = 0; u < kBlock / kXF; ++u) pv[u] = br[u].p[min(dc, V.D0 - 1)];
+                const double av = s_a[dc];
+#pragma unroll
+                for (int u = 0; u < kBlock / kXF; ++u) {
+                    const double bvv = (dc < V.D0 ? pv[u] : V.cc) / br[u].nrm;
+                    s_t[f][rq + (kBlock / kXF) * u] = d < D ? fabs(av - bvv) : 0.0;
+                }
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < kXF; ++e) s += s_t[e][tid];          // terms past D are +0.0: a non-negative sum is unchanged
@@ -1302,12 +1315,20 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     PCREG_HIP(hipGetLastError());
     const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
     hipLaunchKernelGGL(segp_select_kernel, dim3(L.ldqa / 64, (L.splits + 3) / 4, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, Q, L.chunk, L.splits, part_idx, part_s);
+    int32_t* dbg_hist = nullptr;
+#ifdef PCREG_EXPERIMENTS
+    if (pcreg_env_int("PCREG_SEG_DEBUG", 0)) { PCREG_HIP(hipMalloc((void**)&dbg_hist, 2 * 130 * sizeof(int32_t))); PCREG_HIP(hipMemsetAsync(dbg_hist, 0, 2 * 130 * sizeof(int32_t), st)); }
+#endif
     hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force);
+                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, dbg_hist);
     const int slice_f = (n_max + kSegFbSlices - 1) / kSegFbSlices;
     hipLaunchKernelGGL(segp_exact_rows_kernel<false>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
                        (const int32_t*)nullptr, flag_list, n_flag, slice_f, fpi, fpd);
     hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag_list, n_flag, Q, fpi, fpd, idx, dist);
+#ifdef PCREG_EXPERIMENTS
+    std::vector<int32_t> dbg_nf_fwd;
+    if (dbg_hist) { dbg_nf_fwd.resize((size_t)S); PCREG_HIP(hipMemcpyAsync(dbg_nf_fwd.data(), n_flag, (size_t)S * 4, hipMemcpyDeviceToHost, st)); }
+#endif
     const double maxval = 2.0 * sqrt((double)Dp);                 // percentToLevel, SAD
     const double thr = (o.matchThreshold * 0.01) * maxval;
     hipLaunchKernelGGL(segp_filter_kernel, dim3(S), dim3(kCompactThreads), 0, st, idx, dist, Q, seg_off, thr, o.maxRatio, cand_q, cand_m, n_cand, n_flag);
@@ -1316,13 +1337,31 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
         // back: every candidate's model row against all surface rows -- a row of the same matrix
         hipLaunchKernelGGL(segp_select_back_kernel, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, cand_m, n_cand, Q, L.chunk, L.splits, part_idx, part_s);
         hipLaunchKernelGGL(segp_finalize_kernel<true>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, cand_m, n_cand,
-                           part_idx, part_s, L.splits, bidx, bdist, flag_list, n_flag, force);
+                           part_idx, part_s, L.splits, bidx, bdist, flag_list, n_flag, force, dbg_hist ? dbg_hist + 130 : nullptr);
         hipLaunchKernelGGL(segp_exact_rows_kernel<true>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
                            cand_m, flag_list, n_flag, 0, fpi, fpd);
         hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag_list, n_flag, Q, fpi, fpd, bidx, bdist);
     }
     hipLaunchKernelGGL(segp_emit_kernel, dim3(S), dim3(kBlock), 0, st, cand_q, cand_m, n_cand, bidx, o.unique ? 1 : 0, dist, Q, pairs_all, metric_all, n_pairs);
     PCREG_HIP(hipGetLastError());
+#ifdef PCREG_EXPERIMENTS
+    if (dbg_hist) {            // candidates re-scored per query (forward, back) and unproven queries: the only host round trip, debugging only
+        std::vector<int32_t> h(2 * 130), nf((size_t)S);
+        PCREG_HIP(hipStreamSynchronize(st));
+        PCREG_HIP(hipMemcpy(h.data(), dbg_hist, h.size() * 4, hipMemcpyDeviceToHost));
+        PCREG_HIP(hipMemcpy(nf.data(), n_flag, nf.size() * 4, hipMemcpyDeviceToHost));
+        (void)hipFree(dbg_hist);
+        for (int dir = 0; dir < 2; ++dir) {
+            long long q = 0, c = 0; for (int k = 0; k < 130; ++k) { q += h[dir * 130 + k]; c += (long long)k * h[dir * 130 + k]; }
+            fprintf(stderr, "[pcreg] segmented %s: %lld queries, %.2f candidates re-scored per query; histogram 0..8:", dir ? "back" : "forward", q, q ? (double)c / q : 0.0);
+            for (int k = 0; k <= 8; ++k) fprintf(stderr, " %d", h[dir * 130 + k]);
+            long long big = 0; for (int k = 9; k < 130; ++k) big += h[dir * 130 + k];
+            fprintf(stderr, " >8: %lld\n", big);
+        }
+        long long f = 0, ff = 0; int mx = 0, nz = 0; for (int z = 0; z < S; ++z) { f += nf[z]; ff += dbg_nf_fwd[z]; mx = std::max(mx, dbg_nf_fwd[z]); nz += dbg_nf_fwd[z] > 0; }
+        fprintf(stderr, "[pcreg] segmented: unproven queries forward %lld (in %d segments, at most %d in one), last search %lld\n", ff, nz, mx, f);
+    }
+#endif
     return PCREG_OK;
 }
 
