@@ -862,6 +862,12 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
     for (int g0 = 0; g0 < n_need; g0 += kNC) {
         const int nc = min(kNC, n_need - g0);
         double sum = 0.0;
+        SegRow brow[kNC];                          // the group's rows, looked up once (index -> row number -> pointer and norm: two dependent
+#pragma unroll                                     // loads that used to sit in front of every feature tile's loads)
+        for (int cnd = 0; cnd < kNC; ++cnd) {
+            const int jc = s_j[wave][min(g0 + cnd, n_need - 1)];
+            brow[cnd] = BACK ? seg_surface_row(V, jc) : seg_model_row(V, jc);
+        }
         for (int d0 = 0; d0 < D; d0 += kFT) {
             double av[kFT / 64], bv[kNC][kFT / 64];
             int dof[kFT / 64];
@@ -871,10 +877,8 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
             for (int u = 0; u < kFT / 64; ++u) av[u] = seg_value(V, a, dof[u]);
 #pragma unroll
             for (int cnd = 0; cnd < kNC; ++cnd) {
-                const int jc = s_j[wave][min(g0 + cnd, n_need - 1)];
-                const SegRow b = BACK ? seg_surface_row(V, jc) : seg_model_row(V, jc);
 #pragma unroll
-                for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value(V, b, dof[u]);
+                for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value(V, brow[cnd], dof[u]);
             }
 #pragma unroll
             for (int cnd = 0; cnd < kNC; ++cnd)
