@@ -1349,17 +1349,23 @@ __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, con
                 b[s] = __ballot(d < thlo);                                                                         \
                 band |= __ballot(d <= thhi) ^ b[s];     /* nested sets: they differ iff somebody is in the band */  \
             }                                                                                                      \
-            if (band != 0ull) {                         /* rare: the whole hypothesis again, fp64 on the raw coordinates */ \
-                double T64[12];                                                                                    \
-                _Pragma("unroll") for (int k = 0; k < 12; ++k) T64[k] = TT[(size_t)(H) * 12 + k];                  \
-                _Pragma("unroll 1") for (int s = 0; s < kSS; ++s) {                                                \
-                    const int i = ibase + s * 64;                                                                  \
+            if (band != 0ull) {      /* 5 % of the (hypothesis, 512 correspondences) units on the benchmark: the SLOTS with somebody in */ \
+                double T64[12];      /* the band (one in 180) again, fp64 on the raw coordinates -- round 2 redid all eight.  The loop stays  */ \
+                _Pragma("unroll") for (int k = 0; k < 12; ++k) T64[k] = TT[(size_t)(H) * 12 + k];   /* rolled (unrolled, its eight branches */ \
+                _Pragma("unroll 1") for (int s = 0; s < kSS; ++s) {      /* pushed the kernel from 75 to 171 VGPRs), so a slot's fp32 values are */ \
+                    const int i = ibase + s * 64;                        /* read again rather than indexed out of q[][] with a runtime s         */ \
                     const bool act = i < n;                                                                        \
                     const int ii = act ? i : 0;                                                                    \
-                    double p[6];                                                                                   \
-                    _Pragma("unroll") for (int c = 0; c < 3; ++c) { p[c] = a.p1[ii + (size_t)c * a.ld]; p[3 + c] = a.p2[ii + (size_t)c * a.ld]; } \
-                    const unsigned long long bb = __ballot((sqdist(p, T64) < th) & act);                           \
-                    _Pragma("unroll") for (int s2 = 0; s2 < kSS; ++s2) if (s2 == s) b[s2] = bb;                    \
+                    float qq[6];                                                                                   \
+                    _Pragma("unroll") for (int c = 0; c < 6; ++c) qq[c] = sa.c32[(size_t)c * sa.n32 + ii];         \
+                    if (!act) qq[0] = __builtin_nanf("");                                                          \
+                    const float d = sqdist32(qq, T);                                                               \
+                    if ((__ballot(d <= thhi) ^ __ballot(d < thlo)) != 0ull) {                /* wave-uniform */     \
+                        double p[6];                                                                               \
+                        _Pragma("unroll") for (int c = 0; c < 3; ++c) { p[c] = a.p1[ii + (size_t)c * a.ld]; p[3 + c] = a.p2[ii + (size_t)c * a.ld]; } \
+                        const unsigned long long bb = __ballot((sqdist(p, T64) < th) & act);                       \
+                        _Pragma("unroll") for (int s2 = 0; s2 < kSS; ++s2) if (s2 == s) b[s2] = bb;                \
+                    }                                                                                              \
                 }                                                                                                  \
             }                                                                                                      \
             int cnt = 0;                                                                                           \
