@@ -210,3 +210,28 @@ def test_segmented_get_matches_refuses_ssd():
     rng = np.random.default_rng(0)
     with pytest.raises(PcregError):
         _segments_direct(rng.random((8, 6)), rng.random((20, 6)), [np.arange(10)], dict(PAR, Metric="SSD"))
+
+
+@pytest.mark.parametrize("case", ["long_surface", "prenormalized", "tiny_d"])
+def test_segmented_get_matches_other_shapes(oracle_c, case):
+    """long_surface: more than 2048 surface rows, so a chunk of the candidate lists spans several 64-row tiles (the back
+    selection's per-lane lists and the wave merge see more than one entry per lane); prenormalized: matchFeatures' flag (no row
+    normalisation, the appended constant still differs per segment); tiny_d: fewer features than one quantisation slab."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(21)
+    if case == "long_surface":
+        VM, Q, D = 2600, 2300, 24
+    elif case == "tiny_d":
+        VM, Q, D = 900, 150, 5
+    else:
+        VM, Q, D = 1200, 260, 64
+    descM = rng.poisson(3.0, (VM, D)).astype(np.float64)
+    pick = rng.choice(VM, Q, replace=Q > VM)
+    descS = descM[pick] + rng.poisson(0.2, (Q, D))
+    par = dict(PAR, Prenormalized=True) if case == "prenormalized" else dict(PAR)
+    rows_list = [np.sort(rng.choice(VM, VM // 2, replace=False)), np.arange(VM), np.sort(rng.choice(VM, 70, replace=False))]
+    got = _segments_direct(descS, descM, rows_list, par, metric=True)
+    for z, r in enumerate(rows_list):
+        want = pc.getMatches(descS, descM[r], par)
+        np.testing.assert_array_equal(got[z][0], want, err_msg=f"{case}, segment {z}")
+        np.testing.assert_array_equal(want, oracle_c.getMatches(descS, descM[r], par))
