@@ -132,6 +132,17 @@ int pcreg_model_destroy(pcreg_model* model);
 int pcreg_model_match_points_f32(pcreg_model* model, const float* q, int Q, int ldq, float thr_abs, float max_ratio,
                                  int unique, uint32_t* pairs, int* P);
 
+/* getMatches for S row subsets of ONE model descriptor set in one call: segment s = getMatches(descSurface,
+ * descModel(rows_s + 1, :), par) with rows_s = seg_rows[seg_off[s] .. seg_off[s+1]) (0-based, ascending, HOST arrays) -- the
+ * per-sphere calls that completeExperimentFast.m:131-149 runs under parfor.  Descriptors as MATLAB holds them (n x D
+ * column-major doubles, ld >= n).  pairs_all [S][Q][2]: segment s's pairs start at pairs_all + s*Q*2, n_pairs[s] of them,
+ * 1-based, the model index counting within the segment like the per-sphere call's.  Same pairs as S calls of
+ * pcreg_get_matches (the powered columns and the approximate scores are computed once for all segments).
+ * Metric SAD; S <= 65535. */
+int pcreg_get_matches_segmented(const double* descSurface, int Q, int ldS, const double* descModel, int VM, int ldM, int D,
+                                const int32_t* seg_rows, const int32_t* seg_off, int S, const pcreg_match_opts* par,
+                                uint32_t* pairs_all, int32_t* n_pairs);
+
 /* getMatches.m:51  matchFeatures(features1, features2, 'Method',..,'MatchThreshold',..,
  * 'MaxRatio',..,'Metric',..,'Unique',..) on Q x D / M x D double features (exact
  * search; 'Approximate' is answered exactly).  Only the matchFeatures fields of opts

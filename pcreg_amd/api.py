@@ -267,6 +267,27 @@ def _match_opts(par: dict) -> MatchOpts:
                      float(par.get("metric_factor", 1.0)))
 
 
+def getMatchesSegmented(descSurface, descModel, rows_list, par: dict) -> list:
+    """[getMatches(descSurface, descModel[rows], par) for rows in rows_list] in ONE library call (pcreg_get_matches_segmented):
+    the per-sphere calls of completeExperimentFast.m:131-149.  rows: 0-based ascending row numbers of descModel."""
+    dS, dM = _fcol(descSurface), _fcol(descModel)
+    if dS.shape[1] != dM.shape[1]:
+        raise ValueError("descriptor lengths differ")
+    Q, D = dS.shape
+    VM = dM.shape[0]
+    S = len(rows_list)
+    off = np.zeros(S + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(r) for r in rows_list])
+    rows = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.int32).ravel() for r in rows_list] + [np.zeros(0, np.int32)]))
+    o = _match_opts(par)
+    pairs = np.zeros((max(S, 1), max(Q, 1), 2), dtype=np.uint32)
+    n_pairs = np.zeros(max(S, 1), dtype=np.int32)
+    check(lib().pcreg_get_matches_segmented(_ptr(dS, C.c_double), Q, max(Q, 1), _ptr(dM, C.c_double), VM, max(VM, 1), D,
+                                            _ptr(rows, C.c_int32) if rows.size else None, _ptr(off, C.c_int32), S, C.byref(o),
+                                            _ptr(pairs, C.c_uint32), _ptr(n_pairs, C.c_int32)))
+    return [pairs[z, :n_pairs[z]].copy() for z in range(S)]
+
+
 def getMatches(descSurface, descModel, par: dict) -> np.ndarray:
     """matches = getMatches(descSurface, descModel, par)  (getMatches.m:1-59):
     P x 2 uint32, 1-based [surfaceIdx, modelIdx], ascending in the first column."""

@@ -439,6 +439,48 @@ int pcreg_get_matches(const double* descSurface, int Q, int ldS, const double* d
     return match_host(descSurface, Q, ldS, descModel, M, ldM, D, par, true, pairs, metric, P);
 }
 
+// getMatches for S row subsets of one model set, host tier (the parfor of completeExperimentFast.m:131-149 as ONE call)
+int pcreg_get_matches_segmented(const double* descSurface, int Q, int ldS, const double* descModel, int VM, int ldM, int D,
+                                const int32_t* seg_rows, const int32_t* seg_off, int S, const pcreg_match_opts* par,
+                                uint32_t* pairs_all, int32_t* n_pairs) {
+    PCREG_ARG(descSurface && descModel && seg_off && par && pairs_all && n_pairs && Q >= 0 && VM >= 0 && D >= 1 && S >= 0 && ldS >= Q && ldM >= VM);
+    PCREG_ARG(S <= 65535);
+    if (par->metric != PCREG_METRIC_SAD) { set_error("pcreg_get_matches_segmented: Metric must be SAD (call pcreg_get_matches per segment for SSD)"); return PCREG_E_ARG; }
+    GUARD();
+    if (S == 0) return PCREG_OK;
+    PCREG_ARG(seg_off[0] == 0);
+    int n_max = 0;
+    for (int z = 0; z < S; ++z) { const int n = seg_off[z + 1] - seg_off[z]; PCREG_ARG(n >= 0); if (n > n_max) n_max = n; }
+    const int tot = seg_off[S];
+    PCREG_ARG(tot == 0 || seg_rows);
+    for (int k = 0; k < tot; ++k) PCREG_ARG(seg_rows[k] >= 0 && seg_rows[k] < VM);
+    if (Q == 0 || VM == 0 || tot == 0) { for (int z = 0; z < S; ++z) n_pairs[z] = 0; return PCREG_OK; }
+    const size_t q = (size_t)Q, vm = (size_t)VM;
+    void *fS, *fM, *rS, *rM, *dr, *doff, *dp, *dn, *ws;
+    TRY(scratch().get(0, sizeof(double) * q * D, &fS));
+    TRY(scratch().get(1, sizeof(double) * vm * D, &fM));
+    TRY(scratch().get(2, sizeof(double) * q * D, &rS));
+    TRY(scratch().get(3, sizeof(double) * vm * D, &rM));
+    TRY(scratch().get(4, sizeof(int32_t) * (size_t)tot, &dr));
+    TRY(scratch().get(5, sizeof(int32_t) * ((size_t)S + 1), &doff));
+    TRY(scratch().get(6, sizeof(uint32_t) * (size_t)S * q * 2, &dp));
+    TRY(scratch().get(7, sizeof(int32_t) * (size_t)S, &dn));
+    const size_t wsb = get_matches_segmented_workspace_bytes(Q, VM, D, S, tot, n_max);
+    TRY(scratch().get(8, wsb, &ws));
+    TRY(upload_cols(descSurface, Q, ldS, D, (double*)fS, g_stream));
+    TRY(upload_cols(descModel, VM, ldM, D, (double*)fM, g_stream));
+    TRY(launch_transpose_rows((const double*)fS, Q, Q, D, (double*)rS, g_stream));          // MATLAB's n x D -> dense rows
+    TRY(launch_transpose_rows((const double*)fM, VM, VM, D, (double*)rM, g_stream));
+    PCREG_HIP(hipMemcpyAsync(dr, seg_rows, sizeof(int32_t) * (size_t)tot, hipMemcpyHostToDevice, g_stream));
+    PCREG_HIP(hipMemcpyAsync(doff, seg_off, sizeof(int32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, g_stream));
+    TRY(launch_get_matches_segmented((const double*)rS, Q, (const double*)rM, VM, D, (const int32_t*)dr, (const int32_t*)doff, S, tot, n_max, *par,
+                                     (uint32_t*)dp, nullptr, (int32_t*)dn, ws, wsb, g_stream));
+    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * q * 2, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    return PCREG_OK;
+}
+
 int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const int32_t* offsets, int B, int C1, int C2,
                                    double* aligned, double* coeff, double* c, int32_t* status) {
     PCREG_ARG(pts && offsets && aligned && coeff && c && status && total >= 0 && ld >= total && B >= 0);
@@ -767,7 +809,7 @@ int pcreg_dev_get_matches_segmented(const double* descSurface, int Q, const doub
                                     uint32_t* pairs_all, double* metric_all, int32_t* n_pairs, void* workspace, size_t workspace_bytes,
                                     void* stream) {
     PCREG_ARG(descSurface && descModel && seg_rows && seg_off && par && pairs_all && n_pairs && workspace);
-    PCREG_ARG(Q >= 0 && VM >= 0 && D >= 1 && S >= 0 && total_rows >= 0 && max_rows >= 0 && max_rows <= total_rows);
+    PCREG_ARG(Q >= 0 && VM >= 0 && D >= 1 && S >= 0 && S <= 65535 && total_rows >= 0 && max_rows >= 0 && max_rows <= total_rows);
     if (par->metric != PCREG_METRIC_SAD) { set_error("pcreg_dev_get_matches_segmented: Metric must be SAD (one pcreg_dev_get_matches call per segment handles SSD)"); return PCREG_E_ARG; }
     GUARD();
     return launch_get_matches_segmented(descSurface, Q, descModel, VM, D, seg_rows, seg_off, S, total_rows, max_rows, *par, pairs_all,

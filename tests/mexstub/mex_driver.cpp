@@ -79,6 +79,25 @@ int drv_get_matches(const double* dS, int Q, const double* dM, int M, int D, con
     return 0;
 }
 
+// rows1: 1-based rows of all segments back to back; off: S + 1 offsets; pairs_colmajor cap S * Q x 2; n_pairs S
+int drv_get_matches_segmented(const double* dS, int Q, const double* dM, int VM, int D, const double* par7, const int32_t* rows1, int tot,
+                              const int32_t* off, int S, uint32_t* pairs_colmajor, int* P_total, int32_t* n_pairs, char* err, int errlen) {
+    mxArray* p = mxCreateStructMatrix(1, 1, 0, nullptr);
+    mxSetField(p, 0, "Metric", mxCreateString("SAD")); mxSetField(p, 0, "Method", mxCreateString("Approximate"));
+    put(p, "MatchThreshold", par7[0]); put(p, "MaxRatio", par7[1]); put(p, "Unique", par7[2]); put(p, "UNNORMALIZE", par7[3]);
+    put(p, "norm_factor", par7[4]); put(p, "CHANGE_METRIC", par7[5]); put(p, "metric_factor", par7[6]); put(p, "VERBOSE", 0);
+    mxArray* r = mxCreateNumericMatrix(tot, 1, mxINT32_CLASS, mxREAL); memcpy(mxGetData(r), rows1, (size_t)tot * 4);
+    mxArray* o = mxCreateNumericMatrix(S + 1, 1, mxINT32_CLASS, mxREAL); memcpy(mxGetData(o), off, (size_t)(S + 1) * 4);
+    std::vector<mxArray*> rhs{mxCreateString("getMatchesSegmented"), dmat(dS, Q, D), dmat(dM, VM, D), r, o, p};
+    mxArray* lhs[2] = {nullptr, nullptr};
+    if (call(2, lhs, rhs, err, errlen)) return 1;
+    *P_total = (int)mxGetM(lhs[0]);
+    memcpy(pairs_colmajor, mxGetData(lhs[0]), (size_t)*P_total * 2 * 4);
+    memcpy(n_pairs, mxGetData(lhs[1]), (size_t)S * 4);
+    mxDestroyArray(lhs[0]); mxDestroyArray(lhs[1]);
+    return 0;
+}
+
 int drv_align_points_knn(const double* pts, int n, int C1, int C2, double* aligned, double* coeff9, double* c3, char* err, int errlen) {
     std::vector<mxArray*> rhs{mxCreateString("AlignPoints_KNN"), dmat(pts, n, 3), mxCreateDoubleScalar(C1), mxCreateDoubleScalar(C2)};
     mxArray* lhs[3] = {nullptr, nullptr, nullptr};

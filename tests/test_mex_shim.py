@@ -106,6 +106,21 @@ def test_shim_round_trips_equal_the_ctypes_path(drv):
     assert drv.drv_get_matches(_p(_d(dS)), 60, _p(_d(dM)), 90, 980, b"SAD", _p(par7), _p(pairs, C.c_uint32), C.byref(P), e, 1024) == 0, e.value
     got = pairs[:2 * P.value].reshape(P.value, 2, order="F")
     assert P.value == len(want) and np.array_equal(got, want)
+    # getMatchesSegmented: three row subsets of the model set in one gateway call == three getMatches calls
+    rows_list = [np.arange(0, 90, 2), np.arange(90), np.array([3, 7, 8, 50])]
+    off = np.zeros(4, dtype=np.int32); off[1:] = np.cumsum([len(r) for r in rows_list])
+    rows1 = (np.concatenate(rows_list) + 1).astype(np.int32)
+    pairs3 = np.zeros(3 * 60 * 2, dtype=np.uint32); npairs = np.zeros(3, dtype=np.int32); Pt = C.c_int()
+    assert drv.drv_get_matches_segmented(_p(_d(dS)), 60, _p(_d(dM)), 90, 980, _p(par7), _p(rows1, C.c_int32), len(rows1), _p(off, C.c_int32), 3,
+                                         _p(pairs3, C.c_uint32), C.byref(Pt), _p(npairs, C.c_int32), e, 1024) == 0, e.value
+    allp = pairs3[:2 * Pt.value].reshape(Pt.value, 2, order="F")
+    seg = pc.getMatchesSegmented(dS, dM, rows_list, par)
+    k = 0
+    for z, r in enumerate(rows_list):
+        wz = pc.getMatches(dS, dM[r], par)
+        assert npairs[z] == len(wz) and np.array_equal(allp[k:k + npairs[z]], wz) and np.array_equal(seg[z], wz)
+        k += npairs[z]
+    assert k == Pt.value
     # AlignPoints_KNN
     X = rng.normal(size=(500, 3)) * [3.0, 1.5, 0.4] + 20
     al = np.zeros((500, 3), order="F"); co = np.zeros(9); c3 = np.zeros(3)
