@@ -321,7 +321,7 @@ def extra_get_matches(dev, with_cpu: bool) -> dict:
     if with_cpu:
         from oracle import c_oracle
         cores = host_cores()
-        qs, msub = 192, 20_000
+        qs, msub = 1024, 50_000
         a, b = dS[:qs].cpu().numpy(), dM[:msub].cpu().numpy()
         t0 = time.perf_counter(); c_oracle.getMatches(a, b, par, nthreads=cores); dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(qs * msub / dt / 1e9, 4), "unit": "Gpairs/s", "cores": cores, "kind": "port",
@@ -372,7 +372,7 @@ def extra_descriptors(dev, with_cpu: bool) -> dict:
     if with_cpu:
         from oracle import c_oracle
         cores = host_cores()
-        ks = 4 * cores
+        ks = 512 * cores
         t0 = time.perf_counter(); c_oracle.getSpacialHistogramDescriptors(pts, kp[:ks], opt, nthreads=cores); dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(ks / dt, 2), "unit": "keypoints/s", "cores": cores, "kind": "port",
                                "sample": f"oracle getSpacialHistogramDescriptors (two brute-force scans per keypoint, OpenMP {cores} threads): {ks} keypoints on the {P}-point cloud, {dt:.1f} s"}
@@ -406,7 +406,7 @@ def extra_align(dev, with_cpu: bool) -> dict:
                         "note": "algorithmic bytes = 24 B read + 24 B written per point (SURVEY 8d)"}}
     if with_cpu:
         from oracle import c_oracle
-        k = 1024
+        k = 4096
         t0 = time.perf_counter()
         for b in range(k):
             c_oracle.AlignPoints_KNN(sup[b * n:(b + 1) * n])
