@@ -48,7 +48,7 @@ Scratch& scratch();
 Scratch& stream_scratch(hipStream_t st);
 
 // Environment switches.  Two kinds:
-//  * result-preserving A/B switches (PCREG_KNN_EXACT, PCREG_UNIQUE_MODE, PCREG_MATCH_EXACT, PCREG_MATCH_FORCE_FALLBACK,
+//  * result-preserving A/B switches (PCREG_KNN_EXACT, PCREG_MATCH_EXACT, PCREG_MATCH_FORCE_FALLBACK,
 //    PCREG_RANSAC_FUSED / _NOLANE / _F64SCORE): always available, read per call (the tests flip them inside one process);
 //    every setting gives the same indices and counts;
 //  * experiment / debug switches that change the launch shape, print, synchronise, write files or INVALIDATE results

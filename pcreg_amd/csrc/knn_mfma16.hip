@@ -350,8 +350,7 @@ __global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_c
 // ---- live timing of the dominant kernel (bench.py's roofline line) --------------------------------
 // When enabled, the candidates kernel of every MAIN search (any size: a 125 k-row shard of an 8-GPU run as much as the
 // 1 M-row model) is bracketed by two HIP events on the launch stream; pcreg_dev_search_kernel_ms() returns the mean over
-// the launches since the last call.  A search the library runs for its own purposes (the Unique back-search of
-// PCREG_UNIQUE_MODE=1) passes timed = false.
+// the launches since the last call.  A caller that searches for its own purposes passes timed = false.
 static bool g_time_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_time_ev;
 static size_t g_time_used = 0;
