@@ -46,6 +46,16 @@ class SphereSweep:
         self._ws_sel = torch.empty(max(L.pcreg_dev_sphere_select_workspace(self.VM), 256), dtype=torch.uint8, device=self.dev)
         self._featM_host = None
 
+    def release(self) -> None:
+        """Drop the cached workspaces (the segmented chain's ~1.4 GB, the batched ransac's, the per-stream pipelines of
+        run_streams()); the next run allocates them again.  The descriptor sets stay resident."""
+        self._seg_ws = None
+        self._rs_ws = None
+        if hasattr(self, "_lanes"):
+            del self._lanes
+        self.pipe = DescriptorPipeline(self.dev)
+        torch.cuda.empty_cache()
+
     # -- :49-50
     def sphere_centres(self, d_spheres: float = 5.0) -> np.ndarray:
         if self._featM_host is None:
