@@ -712,7 +712,7 @@ int pcreg_dev_spatial_histogram_descriptors_rows_u16(const double* pts, int P, i
                               workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-static constexpr int kLayoutRowMajorU16 = 1000;      // internal: dense uint16 rows (pcreg_dev_get_matches_u16)
+static constexpr int kLayoutRowMajorU16 = 1000;      // internal: dense uint16 rows (pcreg_dev_get_matches_rows_u16)
 static size_t dev_get_matches_layout(int Q, int M, int D, int Dp, size_t off[6]) {
     size_t q = (size_t)(Q > 0 ? Q : 1), m = (size_t)(M > 0 ? M : 1), b = 0;
     off[0] = b; b += align_up(q * D * sizeof(double), 256);            // raw surface, feature-major

@@ -1,4 +1,4 @@
-// pcreg_amd/csrc/knn_fast_common.hpp -- device helpers shared by knn_fast.hip and knn_mfma.hip
+// pcreg_amd/csrc/knn_fast_common.hpp -- device helpers shared by knn_fast.hip, knn_mfma16.hip and knn_points.hip
 #pragma once
 #include "common.hpp"
 #include <cmath>

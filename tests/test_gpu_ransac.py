@@ -245,7 +245,7 @@ def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypa
 
 @pytest.mark.parametrize("n,iters,frac", [(4097, 300, 0.3), (8191, 257, 0.0), (140001, 130, 0.2), (5000, 3, 0.0), (4500, 33, 0.3)])
 def test_lane_refit_sizes_and_switch(n, iters, frac, oracle_c, monkeypatch):
-    """rs_moments_lane_kernel (masks kept by the first scoring pass, records added per lane) at ragged sizes,
+    """rs_moments_mfma_kernel (masks kept by the first scoring pass, records added under them on the int8 matrix cores) at ragged sizes,
     past the 64 x 2048 point-block limit of one scoring launch, and against the sweep it replaces
     (PCREG_RANSAC_NOLANE=1): same counts, same inlier set, transforms equal to rounding."""
     import pcreg_amd as pc

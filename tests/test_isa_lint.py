@@ -180,7 +180,7 @@ def _walk_to_wait(ins, labels, start, dst, name):
 
 def test_no_sgpr_of_an_asm_scalar_load_is_touched_before_its_wait(tmp_path):
     """rs_score32_kernel prefetches each hypothesis' row of T32 with inline-asm s_load_dwordx16 and waits in a separate asm
-    statement; rs_moments_lane_kernel does the same with its correspondence records.  The compiler believes an asm output
+    statement.  The compiler believes an asm output
     is ready at once, so a phi copy, an SGPR spill or a re-coalescing between load and wait would read stale registers
     and give wrong inlier counts silently (ADVICE, round 2).  Walk the emitted ISA from every such load along EVERY path
     (branches followed, back edges included) to the wait that drains it."""
