@@ -132,6 +132,16 @@ int pcreg_model_destroy(pcreg_model* model);
 int pcreg_model_match_points_f32(pcreg_model* model, const float* q, int Q, int ldq, float thr_abs, float max_ratio,
                                  int unique, uint32_t* pairs, int* P);
 
+/* getLocalPoints.m:8-35  [pts_sphere, dists] = getLocalPoints(pts, R, c, min_points, max_points): the points of the cloud strictly
+ * inside the open box AND the open ball of radius R around c, RELATIVE to c, in the cloud's order; [] when the box holds fewer
+ * than min_points (:17) or the ball fewer than min_points / more than max_points (:31).  pts: N x 3 column-major (ld >= N).
+ * pts_sphere: capacity N x 3, written as n_out x 3 column-major with leading dimension *n_out; dists (or NULL): capacity N;
+ * *n_out = rows returned, 0 for MATLAB's [].  single_mode as in pcreg_spatial_histogram_descriptors_mixed (0 double; 1 keypoint
+ * single, 2 only the cloud single: MATLAB's element-wise single arithmetic, values passed exactly widened, outputs are those single
+ * values widened). */
+int pcreg_get_local_points(const double* pts, int N, int ld, double R, const double c[3], double min_points, double max_points,
+                           int single_mode, double* pts_sphere, double* dists, int* n_out);
+
 /* getMatches for S row subsets of ONE model descriptor set in one call: segment s = getMatches(descSurface,
  * descModel(rows_s + 1, :), par) with rows_s = seg_rows[seg_off[s] .. seg_off[s+1]) (0-based, ascending, HOST arrays) -- the
  * per-sphere calls that completeExperimentFast.m:131-149 runs under parfor.  Descriptors as MATLAB holds them (n x D

@@ -194,6 +194,37 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             }
             mxDestroyArray(f); mxDestroyArray(d);
         }
+    } else if (!strcmp(cmd, "getLocalPoints")) {              // [pts_sphere, dists] = pcreg_mex('getLocalPoints', pts, R, c, min_points, max_points)
+        if (nrhs != 6 || mxGetN(prhs[1]) != 3) usage = "getLocalPoints: pts (N x 3), R, c (1 x 3), min_points, max_points";
+        else {
+            // a single cloud or centre: MATLAB's element-wise single arithmetic (getLocalPoints.m:8-25) and single results
+            const bool ps = mxIsSingle(prhs[1]), cs = mxIsSingle(prhs[3]);
+            const int mode = cs ? 1 : (ps ? 2 : 0);
+            const int N = (int)mxGetM(prhs[1]);
+            mxArray* wide = mxCreateNumericMatrix(N > 0 ? N : 1, 3, mxDOUBLE_CLASS, mxREAL);
+            if (ps) { const float* f = (const float*)mxGetData(prhs[1]); for (size_t k = 0; k < (size_t)N * 3; ++k) mxGetPr(wide)[k] = (double)f[k]; }
+            else if (N > 0) memcpy(mxGetPr(wide), mxGetPr(prhs[1]), sizeof(double) * 3 * (size_t)N);
+            double c[3];
+            for (int k = 0; k < 3; ++k) c[k] = cs ? (double)((const float*)mxGetData(prhs[3]))[k] : mxGetPr(prhs[3])[k];
+            mxArray* out = mxCreateNumericMatrix(N > 0 ? N : 1, 3, mxDOUBLE_CLASS, mxREAL);
+            mxArray* dd = mxCreateNumericMatrix(N > 0 ? N : 1, 1, mxDOUBLE_CLASS, mxREAL);
+            int n = 0;
+            rc = pcreg_get_local_points(mxGetPr(wide), N, N > 0 ? N : 1, mxGetScalar(prhs[2]), c, mxGetScalar(prhs[4]), mxGetScalar(prhs[5]), mode,
+                                        mxGetPr(out), mxGetPr(dd), &n);
+            if (rc == PCREG_OK) {
+                const mxClassID cls = mode ? mxSINGLE_CLASS : mxDOUBLE_CLASS;
+                plhs[0] = n ? mxCreateNumericMatrix(n, 3, cls, mxREAL) : mxCreateDoubleMatrix(0, 0, mxREAL);          // [] as in the reference
+                if (nlhs > 1) plhs[1] = n ? mxCreateNumericMatrix(n, 1, cls, mxREAL) : mxCreateDoubleMatrix(0, 0, mxREAL);
+                if (n && mode) {
+                    float* o = (float*)mxGetData(plhs[0]); for (size_t k = 0; k < (size_t)n * 3; ++k) o[k] = (float)mxGetPr(out)[k];
+                    if (nlhs > 1) { float* q = (float*)mxGetData(plhs[1]); for (int k = 0; k < n; ++k) q[k] = (float)mxGetPr(dd)[k]; }
+                } else if (n) {
+                    memcpy(mxGetPr(plhs[0]), mxGetPr(out), sizeof(double) * 3 * (size_t)n);
+                    if (nlhs > 1) memcpy(mxGetPr(plhs[1]), mxGetPr(dd), sizeof(double) * (size_t)n);
+                }
+            }
+            mxDestroyArray(wide); mxDestroyArray(out); mxDestroyArray(dd);
+        }
     } else if (!strcmp(cmd, "modelCreate")) {                 // h = pcreg_mex('modelCreate', single(model)): uploaded and prepared ONCE
         if (nrhs != 2 || !mxIsSingle(prhs[1]) || mxGetN(prhs[1]) != 3) usage = "modelCreate: model (single M x 3)";
         else {

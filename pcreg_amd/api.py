@@ -267,6 +267,30 @@ def _match_opts(par: dict) -> MatchOpts:
                      float(par.get("metric_factor", 1.0)))
 
 
+def getLocalPoints(pts, R, c, min_points, max_points):
+    """[pts_sphere, dists] = getLocalPoints(pts, R, c, min_points, max_points)  (getLocalPoints.m:1-35): the points within R of c,
+    RELATIVE to c, or two empty arrays where MATLAB returns [].  A float32 cloud or centre selects MATLAB's single arithmetic
+    (the result is float32 then, as in MATLAB)."""
+    p_single = isinstance(pts, np.ndarray) and pts.dtype == np.float32
+    c_single = isinstance(c, np.ndarray) and c.dtype == np.float32
+    mode = 1 if c_single else (2 if p_single else 0)
+    P = _fcol(pts)
+    if P.shape[1] != 3:
+        raise ValueError("pts must be N x 3")
+    N = P.shape[0]
+    cc = (C.c_double * 3)(*[float(v) for v in np.asarray(c, dtype=np.float64).ravel()[:3]])
+    out = np.zeros((max(N, 1), 3), dtype=np.float64, order="F")
+    dists = np.zeros(max(N, 1), dtype=np.float64)
+    n = C.c_int(0)
+    check(lib().pcreg_get_local_points(_ptr(P, C.c_double), N, max(N, 1), C.c_double(float(R)), cc, C.c_double(float(min_points)),
+                                       C.c_double(float(max_points)), mode, _ptr(out, C.c_double), _ptr(dists, C.c_double), C.byref(n)))
+    k = n.value
+    res = np.ascontiguousarray(out.ravel(order="F")[:3 * k].reshape(k, 3, order="F")), dists[:k].copy()
+    if mode:
+        return res[0].astype(np.float32), res[1].astype(np.float32)
+    return res
+
+
 def getMatchesSegmented(descSurface, descModel, rows_list, par: dict) -> list:
     """[getMatches(descSurface, descModel[rows], par) for rows in rows_list] in ONE library call (pcreg_get_matches_segmented):
     the per-sphere calls of completeExperimentFast.m:131-149.  rows: 0-based ascending row numbers of descModel."""

@@ -439,6 +439,35 @@ int pcreg_get_matches(const double* descSurface, int Q, int ldS, const double* d
     return match_host(descSurface, Q, ldS, descModel, M, ldM, D, par, true, pairs, metric, P);
 }
 
+// getLocalPoints.m:8-35, host tier.  *n_out = rows returned; 0 is MATLAB's [] (a gate failed, or nothing inside)
+int pcreg_get_local_points(const double* pts, int N, int ld, double R, const double c[3], double min_points, double max_points,
+                           int single_mode, double* pts_sphere, double* dists, int* n_out) {
+    PCREG_ARG(pts && c && pts_sphere && n_out && N >= 0 && ld >= N && single_mode >= 0 && single_mode <= 2);
+    GUARD();
+    *n_out = 0;
+    if (N == 0) return PCREG_OK;
+    void *dp, *dout, *dd, *dt, *ws;
+    TRY(scratch().get(0, sizeof(double) * 3 * (size_t)N, &dp));
+    TRY(scratch().get(1, sizeof(double) * 3 * (size_t)N, &dout));
+    TRY(scratch().get(2, sizeof(double) * (size_t)N, &dd));
+    TRY(scratch().get(3, 256, &dt));
+    TRY(scratch().get(4, local_points_workspace_bytes(N), &ws));
+    TRY(upload_cols(pts, N, ld, 3, (double*)dp, g_stream));
+    TRY(launch_local_points((const double*)dp, N, N, R, c, single_mode, (double*)dout, N, (double*)dd, (int32_t*)dt, ws, local_points_workspace_bytes(N), g_stream));
+    int32_t tot[2] = {0, 0};
+    PCREG_HIP(hipMemcpyAsync(tot, dt, sizeof(tot), hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    // :17 the box count against min_points, :31 the sphere count against both gates (comparisons as MATLAB makes them: inf allowed)
+    if ((double)tot[0] < min_points || (double)tot[1] < min_points || (double)tot[1] > max_points || tot[1] == 0) return PCREG_OK;
+    const size_t n = (size_t)tot[1];
+    for (int k = 0; k < 3; ++k)
+        PCREG_HIP(hipMemcpyAsync(pts_sphere + (size_t)k * n, (const double*)dout + (size_t)k * N, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
+    if (dists) PCREG_HIP(hipMemcpyAsync(dists, dd, sizeof(double) * n, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    *n_out = tot[1];
+    return PCREG_OK;
+}
+
 // getMatches for S row subsets of one model set, host tier (the parfor of completeExperimentFast.m:131-149 as ONE call)
 int pcreg_get_matches_segmented(const double* descSurface, int Q, int ldS, const double* descModel, int VM, int ldM, int D,
                                 const int32_t* seg_rows, const int32_t* seg_off, int S, const pcreg_match_opts* par,

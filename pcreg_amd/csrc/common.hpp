@@ -147,6 +147,9 @@ void knn_f16_timing_enable(bool on);
 int knn_f16_timing_read(float* mean_ms, int* launches);
 int launch_transpose_rows(const double* f, int n, int ld, int D, double* out, hipStream_t st);
 int launch_widen_rows_u16(const uint16_t* rows, const int32_t* index, int n, int D, double* featmajor, hipStream_t st);   // rows[index[i]] (u16) -> feature-major f64
+size_t local_points_workspace_bytes(int N);
+int launch_local_points(const double* pts, int N, int ld, double R, const double c[3], int mode, double* out, int ldo, double* dists,
+                        int32_t* totals, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_sphere_select_batched(const double* feat, int V, const double* centres, int S, double R, const int32_t* seg_off, int32_t* idx,
                                  double* feat_out, int32_t* n_out, hipStream_t st);
 size_t get_matches_segmented_workspace_bytes(int Q, int VM, int D, int S, int tot, int n_max);

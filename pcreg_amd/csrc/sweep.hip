@@ -93,6 +93,92 @@ __global__ __launch_bounds__(1024) void sphere_select_batched_kernel(const doubl
     if (threadIdx.x == 0 && n_out) n_out[s] = s_base;
 }
 
+// ---- getLocalPoints.m:8-35 as a function of its own (the descriptor kernel has it folded in) ------------------------------
+// mode 0: double arithmetic.  mode 1 / 2: MATLAB's single arithmetic when the keypoint (1) or only the cloud (2) is single
+// (the values arrive exactly widened): the open box test against single limits (mode 1: c + [-R, R] in single; mode 2: formed in
+// double, rounded for the comparison), pts_cube - c, vecnorm and dists < R in single, one rounding per operation.
+struct LocalArgs { double cx, cy, cz, R; int mode; };
+__device__ __forceinline__ void local_test(const double* __restrict__ pts, int i, int ld, const LocalArgs& a, bool& cube, bool& in, double (&rel)[3],
+                                           double& dist) {
+    const double x = pts[i], y = pts[i + (size_t)ld], z = pts[i + 2 * (size_t)ld];
+    if (a.mode == 0) {
+        cube = x > a.cx - a.R && x < a.cx + a.R && y > a.cy - a.R && y < a.cy + a.R && z > a.cz - a.R && z < a.cz + a.R;       // :8-13, open box
+        rel[0] = x - a.cx; rel[1] = y - a.cy; rel[2] = z - a.cz;                                                                // :23
+        dist = sqrt((rel[0] * rel[0] + rel[1] * rel[1]) + rel[2] * rel[2]);                                                     // :24
+        in = cube && dist < a.R;                                                                                                // :25
+    } else {
+        const float xf = (float)x, yf = (float)y, zf = (float)z, R32 = (float)a.R;
+        const float c0 = (float)a.cx, c1 = (float)a.cy, c2 = (float)a.cz;
+        float lo[3], hi[3];
+        if (a.mode == 1) { lo[0] = c0 + (-R32); hi[0] = c0 + R32; lo[1] = c1 + (-R32); hi[1] = c1 + R32; lo[2] = c2 + (-R32); hi[2] = c2 + R32; }
+        else { lo[0] = (float)(a.cx - a.R); hi[0] = (float)(a.cx + a.R); lo[1] = (float)(a.cy - a.R); hi[1] = (float)(a.cy + a.R);
+               lo[2] = (float)(a.cz - a.R); hi[2] = (float)(a.cz + a.R); }
+        cube = xf > lo[0] && xf < hi[0] && yf > lo[1] && yf < hi[1] && zf > lo[2] && zf < hi[2];
+        const float r0 = xf - c0, r1 = yf - c1, r2 = zf - c2;
+        const float d = sqrtf((r0 * r0 + r1 * r1) + r2 * r2);
+        rel[0] = r0; rel[1] = r1; rel[2] = r2; dist = d;
+        in = cube && d < R32;
+    }
+}
+// per-workgroup counts of the box and of the sphere (cnt [nb][2])
+__global__ __launch_bounds__(256) void local_count_kernel(const double* __restrict__ pts, int N, int ld, LocalArgs a, int32_t* __restrict__ cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool cube = false, in = false; double rel[3], d;
+    if (i < N) local_test(pts, i, ld, a, cube, in, rel, d);
+    __shared__ int sc[4][2];
+    const unsigned long long bc = __ballot(cube), bi = __ballot(in);
+    if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6][0] = __popcll(bc); sc[threadIdx.x >> 6][1] = __popcll(bi); }
+    __syncthreads();
+    if (threadIdx.x < 2) cnt[(size_t)blockIdx.x * 2 + threadIdx.x] = sc[0][threadIdx.x] + sc[1][threadIdx.x] + sc[2][threadIdx.x] + sc[3][threadIdx.x];
+}
+// one workgroup: exclusive scan of the sphere counts in place, totals[0] = box count, totals[1] = sphere count
+__global__ __launch_bounds__(256) void local_scan_kernel(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ totals) {
+    __shared__ int s[256];
+    __shared__ int s_cube[4];
+    int carry = 0, cube = 0;
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb ? cnt[(size_t)i * 2 + 1] : 0;
+        cube += i < nb ? cnt[(size_t)i * 2] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int t = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) cnt[(size_t)i * 2 + 1] = carry + s[threadIdx.x] - v;
+        const int tot = s[255];
+        __syncthreads();
+        carry += tot;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cube += __shfl_xor(cube, o);
+    if ((threadIdx.x & 63) == 0) s_cube[threadIdx.x >> 6] = cube;
+    __syncthreads();
+    if (threadIdx.x == 0) { totals[0] = s_cube[0] + s_cube[1] + s_cube[2] + s_cube[3]; totals[1] = carry; }
+}
+// pts_sphere (n x 3 column-major, leading dimension ldo) and dists in the order of the cloud
+__global__ __launch_bounds__(256) void local_scatter_kernel(const double* __restrict__ pts, int N, int ld, LocalArgs a, const int32_t* __restrict__ cnt,
+                                                            double* __restrict__ out, int ldo, double* __restrict__ dists) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool cube = false, in = false; double rel[3], d = 0.0;
+    if (i < N) local_test(pts, i, ld, a, cube, in, rel, d);
+    __shared__ int sc[4];
+    const unsigned long long b = __ballot(in);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sc[wave] = __popcll(b);
+    __syncthreads();
+    int base = cnt[(size_t)blockIdx.x * 2 + 1];
+    for (int w = 0; w < wave; ++w) base += sc[w];
+    if (in) {
+        const int o = base + __popcll(b & ((1ull << lane) - 1ull));
+        out[o] = rel[0]; out[o + (size_t)ldo] = rel[1]; out[o + 2 * (size_t)ldo] = rel[2];
+        if (dists) dists[o] = d;
+    }
+}
+
 // dst[k][:] = src[idx[k]][:] for k < *n (row-major, D doubles per row); one workgroup per row
 __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double* __restrict__ src, int D, const int32_t* __restrict__ idx,
                                                               const int32_t* __restrict__ n, int cap, double* __restrict__ dst) {
@@ -185,6 +271,21 @@ int launch_sphere_select_batched(const double* feat, int V, const double* centre
                                  double* feat_out, int32_t* n_out, hipStream_t st) {
     if (S <= 0) return PCREG_OK;
     hipLaunchKernelGGL(sphere_select_batched_kernel, dim3(S), dim3(1024), 0, st, feat, V, centres, R, seg_off, idx, feat_out, n_out);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
+size_t local_points_workspace_bytes(int N) { return align_up(((size_t)(N + 255) / 256 + 1) * 2 * sizeof(int32_t), 256) + 256; }
+// counts -> totals[0] = points in the box, totals[1] = points in the sphere; pts_sphere / dists hold totals[1] rows
+int launch_local_points(const double* pts, int N, int ld, double R, const double c[3], int mode, double* out, int ldo, double* dists,
+                        int32_t* totals, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < local_points_workspace_bytes(N)) { set_error("getLocalPoints workspace too small"); return PCREG_E_WORKSPACE; }
+    if (N <= 0) { PCREG_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int32_t), st)); return PCREG_OK; }
+    const int nb = (N + 255) / 256;
+    int32_t* cnt = (int32_t*)ws;
+    const LocalArgs a{c[0], c[1], c[2], R, mode};
+    hipLaunchKernelGGL(local_count_kernel, dim3(nb), dim3(256), 0, st, pts, N, ld, a, cnt);
+    hipLaunchKernelGGL(local_scan_kernel, dim3(1), dim3(256), 0, st, cnt, nb, totals);
+    hipLaunchKernelGGL(local_scatter_kernel, dim3(nb), dim3(256), 0, st, pts, N, ld, a, (const int32_t*)cnt, out, ldo, dists);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }

@@ -98,6 +98,24 @@ int drv_get_matches_segmented(const double* dS, int Q, const double* dM, int VM,
     return 0;
 }
 
+// pts / c in their own classes (single or double); out / dists: capacity n (as doubles); *cls_single = class of the results
+int drv_get_local_points(const void* pts, int pts_single, int n, double R, const void* c, int c_single, double minp, double maxp,
+                         double* out_colmajor, double* dists, int* n_out, int* cls_single, char* err, int errlen) {
+    mxArray* p = mxCreateNumericMatrix(n, 3, pts_single ? mxSINGLE_CLASS : mxDOUBLE_CLASS, mxREAL);
+    memcpy(mxGetData(p), pts, (size_t)n * 3 * (pts_single ? 4 : 8));
+    mxArray* cc = mxCreateNumericMatrix(1, 3, c_single ? mxSINGLE_CLASS : mxDOUBLE_CLASS, mxREAL);
+    memcpy(mxGetData(cc), c, 3 * (c_single ? 4 : 8));
+    std::vector<mxArray*> rhs{mxCreateString("getLocalPoints"), p, mxCreateDoubleScalar(R), cc, mxCreateDoubleScalar(minp), mxCreateDoubleScalar(maxp)};
+    mxArray* lhs[2] = {nullptr, nullptr};
+    if (call(2, lhs, rhs, err, errlen)) return 1;
+    *n_out = (int)mxGetM(lhs[0]);
+    *cls_single = mxIsSingle(lhs[0]) ? 1 : 0;
+    for (size_t k = 0; k < (size_t)*n_out * 3; ++k) out_colmajor[k] = *cls_single ? (double)((const float*)mxGetData(lhs[0]))[k] : mxGetPr(lhs[0])[k];
+    for (int k = 0; k < *n_out; ++k) dists[k] = *cls_single ? (double)((const float*)mxGetData(lhs[1]))[k] : mxGetPr(lhs[1])[k];
+    mxDestroyArray(lhs[0]); mxDestroyArray(lhs[1]);
+    return 0;
+}
+
 int drv_align_points_knn(const double* pts, int n, int C1, int C2, double* aligned, double* coeff9, double* c3, char* err, int errlen) {
     std::vector<mxArray*> rhs{mxCreateString("AlignPoints_KNN"), dmat(pts, n, 3), mxCreateDoubleScalar(C1), mxCreateDoubleScalar(C2)};
     mxArray* lhs[3] = {nullptr, nullptr, nullptr};

@@ -200,3 +200,24 @@ def test_shim_multi_gpu_commands_one_worker(drv):
     assert fl.value == 0 and (ns.value, mi.value) == (nsr, mir) and np.array_equal(inl[:ni.value], np.asarray(inr, dtype=np.float64).ravel())
     assert np.linalg.norm(T.reshape(4, 4, order="F") - Tr) < 1e-12
     assert drv.drv_live_arrays() == 0
+
+
+@pytest.mark.gpu
+def test_shim_get_local_points_keeps_matlabs_classes(drv, oracle_py):
+    """getLocalPoints through the gateway: a single cloud with a double centre is evaluated in single arithmetic and comes back
+    single (getLocalPoints.m:8-25); [] when a gate fails."""
+    rng = np.random.default_rng(3)
+    pts = rng.uniform([0, 0, 0], [40, 30, 20], (5000, 3)).astype(np.float32)
+    c = np.array([20.0, 15.0, 10.0])
+    e = _err()
+    out = np.zeros(5000 * 3); dd = np.zeros(5000); n = C.c_int(); cls = C.c_int()
+    pf = np.asfortranarray(pts)
+    args = (pf.ctypes.data_as(C.c_void_p), 1, 5000, C.c_double(4.0), c.ctypes.data_as(C.c_void_p), 0)
+    tail = (_p(out), _p(dd), C.byref(n), C.byref(cls), e, 1024)
+    assert drv.drv_get_local_points(*args, C.c_double(5), C.c_double(np.inf), *tail) == 0, e.value
+    rp, rd = oracle_py.getLocalPoints(pts, 4.0, c, 5, np.inf, single_mode=2)
+    assert cls.value == 1 and n.value == len(rp) > 50
+    np.testing.assert_array_equal(out[:3 * n.value].reshape(n.value, 3, order="F"), rp)
+    np.testing.assert_array_equal(dd[:n.value], rd)
+    assert drv.drv_get_local_points(*args, C.c_double(len(rp) + 1), C.c_double(np.inf), *tail) == 0 and n.value == 0      # [] (:31)
+    assert drv.drv_live_arrays() == 0
