@@ -35,7 +35,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kT16 = 512;                     // model points per tile: [2 k-halves][512 points][8 f16] = 16 KiB
+#ifndef PCREG_KT16
+#define PCREG_KT16 512
+#endif
+constexpr int kT16 = PCREG_KT16;              // model points per tile: [2 k-halves][512 points][8 f16] = 16 KiB (768 / 1024 measured in round 3: see DESIGN 4.1)
 constexpr int kRefresh = 16;                  // tiles between two looks at the shared threshold words
 
 // The error-free split needs ONE f16 rounding of ONE fp32 value: the stored high part and the high part the
@@ -152,7 +155,7 @@ __device__ void ug_reduce_boxes(const float* __restrict__ part /*[n][6]*/, int n
 // is never loop-carried in flight; it is waited for inside the iteration that issued it and only waited values
 // cross the back edge (tests/test_isa_lint.py checks the emitted ISA for a VGPR read between load and wait).
 template <int QG, bool DRY>   // DRY: timing only (no compare, no lists; PCREG_KNN_VARIANT=41)
-__global__ __launch_bounds__(kBlock, QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)) void knn_candidates_f16_pipe_kernel(
+__global__ __launch_bounds__(kBlock, kT16 > 768 ? 2 : (kT16 > 512 ? 3 : (QG <= 2 ? 5 : (QG <= 4 ? 4 : 2)))) void knn_candidates_f16_pipe_kernel(
     const float* __restrict__ q, int Q, int ldq, const uint4* __restrict__ mt, int n_tiles, int tiles_per_chunk,
     const Prep* __restrict__ prep, unsigned* __restrict__ gthr, uint2* __restrict__ cand_ent, int32_t* __restrict__ cand_cnt,
     int cap, int q_blocks, int xcd_map, int n_chunks, const float* __restrict__ ug_part, int ug_nparts, int ug_cells, UgPrep* __restrict__ ug_prep) {
