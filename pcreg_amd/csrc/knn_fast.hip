@@ -122,11 +122,11 @@ __global__ void model_bbox_final_kernel(const float* __restrict__ part, int npar
 // ---- S1. seeding: a first threshold per query from the model-wide grid ------------------------------------------
 // The candidate kernel only touches its sorted lists when a score beats the query's threshold, and a wave pays that
 // slow path whenever ANY of its lanes does.  Starting from +inf every lane does so O(log n) times; starting from "the
-// 4th-nearest of a few model points around the query" almost never.  The grid remembers up to kSeedSlots points per
+// k-th nearest of a few model points around the query" (k = kSeedRank = 2) almost never.  The grid remembers up to kSeedSlots points per
 // cell (whoever arrived first: the threshold is a hint, results never depend on it); a query looks at the 27 cells
 // around its own (clamped into the grid: any model point's exact distance is a valid upper bound), takes the
-// 4th-smallest EXACT distance d4 and publishes the s-space threshold d4 - |q~|^2 plus twice the score error bound, so
-// that its true four nearest are still below it.  Every point that is later skipped was compared with a word >= the
+// k-th smallest EXACT distance dk and publishes the s-space threshold dk - |q~|^2 plus twice the score error bound, so
+// that its true k nearest are still below it.  Every point that is later skipped was compared with a word >= the
 // final word G, which is all the certificate needs.
 __device__ __forceinline__ int seed_cell(float v, float lo, float inv_h, int n) {
     int c = (int)floorf((v - lo) * inv_h);
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(kBlock) void seed_query_kernel(const float* __restr
     }
     if (!live || sub != 0) return;
     unsigned word = 0xFFFFFFFFu;                           // +inf: no hint
-    // The 4th-smallest exact distance of the sample bounds the true 4th-nearest distance from above; any rank >= 2 keeps
-    // both true neighbours under the threshold (rank 2 was measured in round 2: the kernel's time does not move).
+    // The k-th smallest exact distance of the sample bounds the true k-th nearest distance from above; any rank >= 2 keeps
+    // both true neighbours under the threshold (kSeedRank = 2 since round 3).
     const float dk = d[kSeedRank - 1];
     if (dk < INFINITY) {
         const float tx = qx - prep->cx, ty = qy - prep->cy, tz = qz - prep->cz;

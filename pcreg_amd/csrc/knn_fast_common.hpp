@@ -12,9 +12,10 @@ constexpr int kBlock = 256;
 #endif
 constexpr int KC = PCREG_KC;                 // group entries kept per lane, query and chunk (>= 2: the two nearest points sit in the two best groups)
 #ifndef PCREG_SEED_RANK
-#define PCREG_SEED_RANK 4
+#define PCREG_SEED_RANK 2
 #endif
-constexpr int kSeedRank = PCREG_SEED_RANK;   // the first threshold: the kSeedRank-th smallest exact distance among the seeding grid's points (>= 2)
+constexpr int kSeedRank = PCREG_SEED_RANK;   // the first threshold: the kSeedRank-th smallest exact distance among the seeding grid's points (>= 2;
+                                             // 2 is the tightest valid hint: -1.3 % on the candidates kernel against 4, interleaved A/B in round 3)
 constexpr int kMTile = 1024;                 // model points per LDS tile (16 KiB)
 
 // What a PREPARED MODEL carries besides its f16 tiles (model-only quantities: one model, many query sets --

@@ -39,7 +39,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PCREG_KT16 512
 #endif
 constexpr int kT16 = PCREG_KT16;              // model points per tile: [2 k-halves][512 points][8 f16] = 16 KiB (768 / 1024 measured in round 3: see DESIGN 4.1)
-constexpr int kRefresh = 16;                  // tiles between two looks at the shared threshold words
+#ifndef PCREG_KREFRESH
+#define PCREG_KREFRESH 16
+#endif
+constexpr int kRefresh = PCREG_KREFRESH;       // tiles between two looks at the shared threshold words (a power of two)
 
 // The error-free split needs ONE f16 rounding of ONE fp32 value: the stored high part and the high part the
 // residual is taken against must be the same number.  hipcc folds `(_Float16)fma(a, b, c)` into v_fma_mixlo_f16 (the
