@@ -804,6 +804,73 @@ __device__ __forceinline__ double seg_value(const SegView& V, const SegRow& r, i
 // sad16_finalize_kernel on the segments.  BACK = false: queries = surface rows, candidates = the segment's model rows
 // (local numbers j).  BACK = true (the Unique back-search): queries = the candidates' model rows cand_m[k], k < n_cand,
 // candidates = surface rows.  All per-query arrays are [segment][Q]...
+// The exact re-rank of a query against a list of candidate rows (numbers local to the segment / surface rows), the oracle's
+// order per candidate: the |a - b| terms of up to kNC candidates are computed by the whole wave into LDS, 256 features at a time,
+// then lane c adds candidate c's terms one by one.  Returns the two smallest (distance, row), wave-uniform.
+template <bool BACK>
+__device__ __forceinline__ void seg_rerank(const SegView& V, const SegRow& a, const int* __restrict__ sj, int n_need, int D,
+                                           double (*st)[kFT], double& d1, int& i1, double& d2, int& i2) {
+    const int lane = threadIdx.x & 63;
+    d1 = INFINITY; d2 = INFINITY; i1 = -1; i2 = -1;
+    for (int g0 = 0; g0 < n_need; g0 += kNC) {
+        const int nc = min(kNC, n_need - g0);
+        double sum = 0.0;
+        SegRow brow[kNC];                          // the group's rows, looked up once (index -> row number -> pointer and norm: two dependent
+#pragma unroll                                     // loads that used to sit in front of every feature tile's loads)
+        for (int cnd = 0; cnd < kNC; ++cnd) {
+            const int jc = sj[min(g0 + cnd, n_need - 1)];
+            brow[cnd] = BACK ? seg_surface_row(V, jc) : seg_model_row(V, jc);
+        }
+        for (int d0 = 0; d0 < D; d0 += kFT) {
+            double av[kFT / 64], bv[kNC][kFT / 64];
+            int dof[kFT / 64];
+#pragma unroll
+            for (int u = 0; u < kFT / 64; ++u) dof[u] = min(d0 + lane + 64 * u, D - 1);
+#pragma unroll
+            for (int u = 0; u < kFT / 64; ++u) av[u] = seg_value(V, a, dof[u]);
+#pragma unroll
+            for (int cnd = 0; cnd < kNC; ++cnd) {
+#pragma unroll
+                for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value(V, brow[cnd], dof[u]);
+            }
+#pragma unroll
+            for (int cnd = 0; cnd < kNC; ++cnd)
+#pragma unroll
+                for (int u = 0; u < kFT / 64; ++u)
+                    st[cnd][lane + 64 * u] = (d0 + lane + 64 * u < D) ? fabs(av[u] - bv[cnd][u]) : 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+            if (lane < nc) {
+                // the oracle's order; terms past D are +0.0, which leaves a non-negative sum unchanged
+                const double* t = st[lane];
+                for (int k = 0; k < kFT; k += 16) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = t[k + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum += v[u];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        }
+        if (lane < nc) {
+            const int jc = sj[g0 + lane];
+            if (lexd_lt(sum, jc, d1, i1)) { d2 = d1; i2 = i1; d1 = sum; i1 = jc; }
+            else if (lexd_lt(sum, jc, d2, i2)) { d2 = sum; i2 = jc; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+        int k1 = __shfl_xor(i1, o), k2 = __shfl_xor(i2, o);
+        bool fm = lexd_lt(d1, i1, e1, k1);
+        double w1 = fm ? d1 : e1; int x1 = fm ? i1 : k1;
+        double m2 = fm ? d2 : d1; int y2 = fm ? i2 : i1;
+        double o2 = fm ? e1 : e2; int z2 = fm ? k1 : k2;
+        bool sm = lexd_lt(m2, y2, o2, z2);
+        d1 = w1; i1 = x1; d2 = sm ? m2 : o2; i2 = sm ? y2 : z2;
+    }
+}
+
 template <bool BACK>
 __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
                                                                const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_m,
@@ -857,64 +924,9 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
 #ifdef PCREG_EXPERIMENTS
     if (dbg_hist && lane == 0) atomicAdd(&dbg_hist[min(n_need, 129)], 1);          // PCREG_SEG_DEBUG: candidates re-scored per query
 #endif
-    double d1 = INFINITY, d2 = INFINITY; int i1 = -1, i2 = -1;
     const SegRow a = BACK ? seg_model_row(V, cand_m[(size_t)z * nA + qi]) : seg_surface_row(V, qi);
-    for (int g0 = 0; g0 < n_need; g0 += kNC) {
-        const int nc = min(kNC, n_need - g0);
-        double sum = 0.0;
-        SegRow brow[kNC];                          // the group's rows, looked up once (index -> row number -> pointer and norm: two dependent
-#pragma unroll                                     // loads that used to sit in front of every feature tile's loads)
-        for (int cnd = 0; cnd < kNC; ++cnd) {
-            const int jc = s_j[wave][min(g0 + cnd, n_need - 1)];
-            brow[cnd] = BACK ? seg_surface_row(V, jc) : seg_model_row(V, jc);
-        }
-        for (int d0 = 0; d0 < D; d0 += kFT) {
-            double av[kFT / 64], bv[kNC][kFT / 64];
-            int dof[kFT / 64];
-#pragma unroll
-            for (int u = 0; u < kFT / 64; ++u) dof[u] = min(d0 + lane + 64 * u, D - 1);
-#pragma unroll
-            for (int u = 0; u < kFT / 64; ++u) av[u] = seg_value(V, a, dof[u]);
-#pragma unroll
-            for (int cnd = 0; cnd < kNC; ++cnd) {
-#pragma unroll
-                for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value(V, brow[cnd], dof[u]);
-            }
-#pragma unroll
-            for (int cnd = 0; cnd < kNC; ++cnd)
-#pragma unroll
-                for (int u = 0; u < kFT / 64; ++u)
-                    s_t[wave][cnd][lane + 64 * u] = (d0 + lane + 64 * u < D) ? fabs(av[u] - bv[cnd][u]) : 0.0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-            if (lane < nc) {
-                const double* t = s_t[wave][lane];
-                for (int k = 0; k < kFT; k += 16) {
-                    double v[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) v[u] = t[k + u];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) sum += v[u];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        }
-        if (lane < nc) {
-            const int jc = s_j[wave][g0 + lane];
-            if (lexd_lt(sum, jc, d1, i1)) { d2 = d1; i2 = i1; d1 = sum; i1 = jc; }
-            else if (lexd_lt(sum, jc, d2, i2)) { d2 = sum; i2 = jc; }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        double e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
-        int k1 = __shfl_xor(i1, o), k2 = __shfl_xor(i2, o);
-        bool fm = lexd_lt(d1, i1, e1, k1);
-        double w1 = fm ? d1 : e1; int x1 = fm ? i1 : k1;
-        double m2 = fm ? d2 : d1; int y2 = fm ? i2 : i1;
-        double o2 = fm ? e1 : e2; int z2 = fm ? k1 : k2;
-        bool sm = lexd_lt(m2, y2, o2, z2);
-        d1 = w1; i1 = x1; d2 = sm ? m2 : o2; i2 = sm ? y2 : z2;
-    }
+    double d1, d2; int i1, i2;
+    seg_rerank<BACK>(V, a, s_j[wave], n_need, D, s_t[wave], d1, i1, d2, i2);
     bool ok;
     if (g == 0xFFFFFFFFu) ok = true;
     else {
@@ -922,9 +934,65 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
         ok = (i2 >= 0) && (lower * (1.0 - 1e-12) > d2);
     }
     if (force_unproven) ok = false;
-    if (lane == 0) {
-        if (ok) { idx[(size_t)qi * 2] = i1; idx[(size_t)qi * 2 + 1] = i2; dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2; }
-        else { int slot = atomicAdd(&n_flag[z], 1); flag_list[slot] = qi; }
+    if (lane == 0) {          // an unproven query keeps its provisional pair: segp_refine_kernel starts from it
+        idx[(size_t)qi * 2] = i1; idx[(size_t)qi * 2 + 1] = i2; dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2;
+        if (!ok) { int slot = atomicAdd(&n_flag[z], 1); flag_list[slot] = qi; }
+    }
+}
+
+// An unproven query does not need every row: a row whose reference score s has rho (s - (D + 1)) - E > scale * d2 for the
+// provisional (exact) second distance d2 cannot enter the pair.  One wave per unproven query reads the query's scores of all
+// candidate rows from the score matrix, keeps the rows below that threshold (a few dozen where the exhaustive scan read 1533 rows of
+// 7.8 KB each) and re-ranks them exactly; a query with more than 128 rows under the threshold stays for segp_exact_rows_kernel
+// (flag2 / n_flag2).
+template <bool BACK>
+__global__ __launch_bounds__(kBlock) void segp_refine_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
+                                                             const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_m,
+                                                             const uint32_t* __restrict__ Sc, int ldsc, const int32_t* __restrict__ flag_list,
+                                                             const int32_t* __restrict__ n_flag, int32_t* __restrict__ idx, double* __restrict__ dist,
+                                                             int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip) {
+    __shared__ double s_t[kBlock / 64][kNC][kFT];
+    __shared__ int s_j[kBlock / 64][64 * kEPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.z, nA = S.Q, D = S.Dp;
+    const int nf = min(n_flag[z], nA);
+    const SegConst c = sc[z];
+    const SegView V = seg_view(S, nrmS, nrmM, c, z);
+    flag_list += (size_t)z * nA; flag2 += (size_t)z * nA; idx += (size_t)z * nA * 2; dist += (size_t)z * nA * 2;
+    const int off = S.seg_off[z], nB = BACK ? S.Q : S.seg_off[z + 1] - off;
+    for (int k = blockIdx.x * (kBlock / 64) + wave; k < nf; k += gridDim.x * (kBlock / 64)) {       // wave-uniform
+        const int qi = flag_list[k];
+        const double p1 = dist[(size_t)qi * 2], p2 = dist[(size_t)qi * 2 + 1];
+        const int q1 = idx[(size_t)qi * 2], q2 = idx[(size_t)qi * 2 + 1];
+        // rows that can still matter: reference score <= smax (everything when there is no provisional second yet)
+        unsigned smax = 0xFFFFFFFFu;
+        if (q2 >= 0 && p2 < INFINITY) {
+            const double t = (p2 * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0;
+            if (t < 4.0e9) smax = (unsigned)t;
+        }
+        const int mrow = BACK ? V.rows[cand_m[(size_t)z * nA + qi]] : 0;
+        int n_need = 0; bool over = skip != 0;
+        for (int j0 = 0; j0 < nB && !over; j0 += 64) {
+            const int j = j0 + lane;
+            unsigned sv = 0xFFFFFFFFu;
+            if (j < nB) sv = BACK ? Sc[(size_t)mrow * ldsc + j] : Sc[(size_t)V.rows[j] * ldsc + qi];
+            const bool take = j < nB && sv <= smax;
+            const unsigned long long m = __ballot(take);
+            const int cnt = __popcll(m);
+            if (n_need + cnt > 64 * kEPL) { over = true; break; }
+            if (take) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            n_need += cnt;
+        }
+        if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = qi; } continue; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        const SegRow a = BACK ? seg_model_row(V, cand_m[(size_t)z * nA + qi]) : seg_surface_row(V, qi);
+        double d1, d2; int i1, i2;
+        seg_rerank<BACK>(V, a, s_j[wave], n_need, D, s_t[wave], d1, i1, d2, i2);
+        // the provisional pair was summed exactly too (its rows are under the threshold, so they were summed again: same bits)
+        Top2T<double> t2{d1, d2, i1, i2};
+        top2_insert_lex_t(t2, p1, q1); top2_insert_lex_t(t2, p2, q2);
+        if (lane == 0) { idx[(size_t)qi * 2] = t2.i1; idx[(size_t)qi * 2 + 1] = t2.i2; dist[(size_t)qi * 2] = t2.d1; dist[(size_t)qi * 2 + 1] = t2.d2; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1238,7 +1306,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
 namespace {
 struct SegLayout {
     size_t PS, PM, rowS, rowM, nrefS, nrefM, Aq, Bq, Sc, sc, nrmS, nrmM, part_idx, part_s, idx, dist, bidx, bdist, cand_q, cand_m, n_cand, n_flag,
-           flag_list, fpi, fpd, total;
+           flag_list, flag2, n_flag2, fpi, fpd, total;
     int D2p, ldqa, ldqb, splits, chunk;
 };
 SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
@@ -1263,7 +1331,7 @@ SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
     L.part_idx = take(ns * L.splits * q * KC * 4); L.part_s = take(ns * L.splits * q * KC * 4);
     L.idx = take(ns * q * 2 * 4); L.dist = take(ns * q * 2 * 8); L.bidx = take(ns * q * 2 * 4); L.bdist = take(ns * q * 2 * 8);
     L.cand_q = take(ns * q * 4); L.cand_m = take(ns * q * 4); L.n_cand = take(ns * 4); L.n_flag = take(ns * 4);
-    L.flag_list = take(ns * q * 4);
+    L.flag_list = take(ns * q * 4); L.flag2 = take(ns * q * 4); L.n_flag2 = take(ns * 4);
     L.fpi = take(ns * kSegFbSlices * q * 2 * 4); L.fpd = take(ns * kSegFbSlices * q * 2 * 8);
     L.total = b;
     return L;
@@ -1296,6 +1364,7 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     int32_t *idx = (int32_t*)(w + L.idx), *bidx = (int32_t*)(w + L.bidx); double *dist = (double*)(w + L.dist), *bdist = (double*)(w + L.bdist);
     int32_t *cand_q = (int32_t*)(w + L.cand_q), *cand_m = (int32_t*)(w + L.cand_m), *n_cand = (int32_t*)(w + L.n_cand), *n_flag = (int32_t*)(w + L.n_flag);
     int32_t* flag_list = (int32_t*)(w + L.flag_list); int32_t* fpi = (int32_t*)(w + L.fpi); double* fpd = (double*)(w + L.fpd);
+    int32_t *flag2 = (int32_t*)(w + L.flag2), *n_flag2 = (int32_t*)(w + L.n_flag2);
     const size_t q = (size_t)Q, vm = (size_t)VM;
 
     // once for all segments: powers, row scalars, the reference constant, the two quantised operands, ALL approximate scores
@@ -1317,7 +1386,9 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     hipLaunchKernelGGL(segp_consts_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, nrefS, nrefM, nrmS, nrmM, sc, S);
     PCREG_HIP(hipMemsetAsync(n_flag, 0, (size_t)S * sizeof(int32_t), st));
     PCREG_HIP(hipGetLastError());
-    const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
+    // PCREG_MATCH_FORCE_FALLBACK: 1 = every query counts as unproven (they take the refinement), 2 = and the refinement passes
+    // them all on to the exhaustive kernel
+    const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0, skip_refine = fe && atoi(fe) == 2;
     hipLaunchKernelGGL(segp_select_kernel, dim3(L.ldqa / 64, (L.splits + 3) / 4, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, Q, L.chunk, L.splits, part_idx, part_s);
     int32_t* dbg_hist = nullptr;
 #ifdef PCREG_EXPERIMENTS
@@ -1326,9 +1397,12 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
                        part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, dbg_hist);
     const int slice_f = (n_max + kSegFbSlices - 1) / kSegFbSlices;
+    PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
+    hipLaunchKernelGGL(segp_refine_kernel<false>, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const uint32_t*)Sc, L.ldqa,
+                       (const int32_t*)flag_list, (const int32_t*)n_flag, idx, dist, flag2, n_flag2, skip_refine);
     hipLaunchKernelGGL(segp_exact_rows_kernel<false>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
-                       (const int32_t*)nullptr, flag_list, n_flag, slice_f, fpi, fpd);
-    hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag_list, n_flag, Q, fpi, fpd, idx, dist);
+                       (const int32_t*)nullptr, flag2, n_flag2, slice_f, fpi, fpd);
+    hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag2, n_flag2, Q, fpi, fpd, idx, dist);
 #ifdef PCREG_EXPERIMENTS
     std::vector<int32_t> dbg_nf_fwd;
     if (dbg_hist) { dbg_nf_fwd.resize((size_t)S); PCREG_HIP(hipMemcpyAsync(dbg_nf_fwd.data(), n_flag, (size_t)S * 4, hipMemcpyDeviceToHost, st)); }
@@ -1342,9 +1416,12 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
         hipLaunchKernelGGL(segp_select_back_kernel, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, cand_m, n_cand, Q, L.chunk, L.splits, part_idx, part_s);
         hipLaunchKernelGGL(segp_finalize_kernel<true>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, cand_m, n_cand,
                            part_idx, part_s, L.splits, bidx, bdist, flag_list, n_flag, force, dbg_hist ? dbg_hist + 130 : nullptr);
+        PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
+        hipLaunchKernelGGL(segp_refine_kernel<true>, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)cand_m, (const uint32_t*)Sc, L.ldqa,
+                           (const int32_t*)flag_list, (const int32_t*)n_flag, bidx, bdist, flag2, n_flag2, skip_refine);
         hipLaunchKernelGGL(segp_exact_rows_kernel<true>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
-                           cand_m, flag_list, n_flag, 0, fpi, fpd);
-        hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag_list, n_flag, Q, fpi, fpd, bidx, bdist);
+                           cand_m, flag2, n_flag2, 0, fpi, fpd);
+        hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag2, n_flag2, Q, fpi, fpd, bidx, bdist);
     }
     hipLaunchKernelGGL(segp_emit_kernel, dim3(S), dim3(kBlock), 0, st, cand_q, cand_m, n_cand, bidx, o.unique ? 1 : 0, dist, Q, pairs_all, metric_all, n_pairs);
     PCREG_HIP(hipGetLastError());
