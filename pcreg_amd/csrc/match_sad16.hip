@@ -926,7 +926,56 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
 #endif
     const SegRow a = BACK ? seg_model_row(V, cand_m[(size_t)z * nA + qi]) : seg_surface_row(V, qi);
     double d1, d2; int i1, i2;
-    seg_rerank<BACK>(V, a, s_j[wave], n_need, D, s_t[wave], d1, i1, d2, i2);
+    if (n_need > kNC) {
+        // More candidates than one group holds (5.3 on average at the sweep's shape, inside a slack that must allow the rounding of
+        // BOTH distances compared): sum the kNC with the smallest reference scores first.  Their exact second distance d2' bounds the
+        // true one from above, and a remaining candidate can only matter if its own lower bound does not exceed d2' -- a one-sided
+        // test that usually leaves nothing for a second group.
+        int jk[kEPL]; unsigned sk[kEPL];
+#pragma unroll
+        for (int u = 0; u < kEPL; ++u) {
+            const bool need = j[u] >= 0 && (a2 == 0xFFFFFFFFu || a2 > 0xFFFFFFFFu - slack || sq[u] <= a2 + slack);
+            jk[u] = need ? j[u] : -1; sk[u] = need ? sq[u] : 0xFFFFFFFFu;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < kNC; ++r) {                       // kNC rounds of a wave-wide (score, entry) minimum
+            unsigned long long key = 0xFFFFFFFFFFFFFFFFull;
+#pragma unroll
+            for (int u = 0; u < kEPL; ++u) if (jk[u] >= 0) { const unsigned long long k2 = ((unsigned long long)sk[u] << 32) | (unsigned)(lane + 64 * u); key = k2 < key ? k2 : key; }
+            unsigned long long m = key;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(m, o); m = x < m ? x : m; }
+            const int e = (int)(unsigned)(m & 0xFFFFFFFFull);          // the winning entry (lane + 64 u): unique
+#pragma unroll
+            for (int u = 0; u < kEPL; ++u) if (lane + 64 * u == e && jk[u] >= 0) { s_j[wave][r] = jk[u]; jk[u] = -1; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        seg_rerank<BACK>(V, a, s_j[wave], kNC, D, s_t[wave], d1, i1, d2, i2);
+        unsigned smax = 0xFFFFFFFFu;
+        if (i2 >= 0 && d2 < INFINITY) {
+            const double t = (d2 * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0;
+            if (t < 4.0e9) smax = (unsigned)t;
+        }
+        int n_more = 0;
+#pragma unroll
+        for (int u = 0; u < kEPL; ++u) {
+            const bool more = jk[u] >= 0 && sk[u] <= smax;
+            const unsigned long long m = __ballot(more);
+            if (more) s_j[wave][n_more + __popcll(m & ((1ull << lane) - 1ull))] = jk[u];
+            n_more += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (n_more > 0) {
+            double e1, e2; int k1, k2;
+            seg_rerank<BACK>(V, a, s_j[wave], n_more, D, s_t[wave], e1, k1, e2, k2);
+            Top2T<double> t2{d1, d2, i1, i2};
+            top2_insert_lex_t(t2, e1, k1); top2_insert_lex_t(t2, e2, k2);
+            d1 = t2.d1; d2 = t2.d2; i1 = t2.i1; i2 = t2.i2;
+        }
+    } else {
+        seg_rerank<BACK>(V, a, s_j[wave], n_need, D, s_t[wave], d1, i1, d2, i2);
+    }
     bool ok;
     if (g == 0xFFFFFFFFu) ok = true;
     else {
