@@ -752,41 +752,6 @@ __global__ __launch_bounds__(kBlock) void segp_select_kernel(const uint32_t* __r
     }
 }
 
-// The back-search's lists: candidate k of segment z is model row rows[cand_m[k]]; its scores against ALL surface rows are one
-// row of the matrix.  One wave per candidate; per chunk of surface rows every lane keeps the best KC of its strided share and
-// KC rounds of a wave-wide (score, row) minimum pull the chunk's sorted list out.
-__global__ __launch_bounds__(kBlock) void segp_select_back_kernel(const uint32_t* __restrict__ Sc, int ldsc, const int32_t* __restrict__ seg_rows,
-                                                                  const int32_t* __restrict__ seg_off, const int32_t* __restrict__ cand_m,
-                                                                  const int32_t* __restrict__ n_cand, int Q, int chunk, int splits,
-                                                                  int32_t* __restrict__ part_idx, uint32_t* __restrict__ part_s) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int z = blockIdx.z, k = blockIdx.x * (kBlock / 64) + wave;
-    if (k >= n_cand[z]) return;
-    const uint32_t* row = Sc + (size_t)seg_rows[seg_off[z] + cand_m[(size_t)z * Q + k]] * ldsc;
-    for (int sidx = 0; sidx < splits; ++sidx) {
-        const int a_begin = sidx * chunk, a_end = min(Q, a_begin + chunk);
-        CandU t;
-#pragma unroll
-        for (int e = 0; e < KC; ++e) { t.s[e] = 0xFFFFFFFFu; t.i[e] = -1; }
-        for (int a = a_begin + lane; a < a_end; a += 64) candu_insert(t, row[a], a);
-        const size_t o = (((size_t)z * splits + sidx) * Q + k) * KC;
-#pragma unroll
-        for (int e = 0; e < KC; ++e) {
-            // the smallest (score, row) among the lanes' heads; empty heads are (0xFFFFFFFF, -1): they order last
-            unsigned long long key = ((unsigned long long)t.s[0] << 32) | (unsigned)t.i[0];
-            unsigned long long m = key;
-#pragma unroll
-            for (int w = 32; w > 0; w >>= 1) { const unsigned long long x = __shfl_xor(m, w); m = x < m ? x : m; }
-            if (key == m && t.i[0] >= 0) {                       // the one owner pops its head (rows are distinct)
-#pragma unroll
-                for (int q = 0; q < KC - 1; ++q) { t.s[q] = t.s[q + 1]; t.i[q] = t.i[q + 1]; }
-                t.s[KC - 1] = 0xFFFFFFFFu; t.i[KC - 1] = -1;
-            }
-            if (lane == 0) { part_idx[o + e] = (int)(unsigned)(m & 0xFFFFFFFFull); part_s[o + e] = (unsigned)(m >> 32); }
-        }
-    }
-}
-
 // a row of the segment's normalised matrices, never stored: value(d) = (d < D0 ? p[d] : cc) / nrm
 struct SegRow { const double* p; double nrm; };
 struct SegView { const double *PS, *PM, *nrmS, *nrmM; const int32_t* rows; int D0; double cc; };
@@ -1041,6 +1006,64 @@ __global__ __launch_bounds__(kBlock) void segp_refine_kernel(SegSets S, const do
         Top2T<double> t2{d1, d2, i1, i2};
         top2_insert_lex_t(t2, p1, q1); top2_insert_lex_t(t2, p2, q2);
         if (lane == 0) { idx[(size_t)qi * 2] = t2.i1; idx[(size_t)qi * 2 + 1] = t2.i2; dist[(size_t)qi * 2] = t2.d1; dist[(size_t)qi * 2 + 1] = t2.d2; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The Unique back-check straight from the score matrix.  Candidate k = (surface row q, model row m) asks whether q is the best
+// surface row for m.  Its distance d(q, m) is known exactly (the forward result: the same terms in the same order), so only surface
+// rows whose reference score allows a distance <= d(q, m) can answer "no": one wave per candidate reads m's row of the matrix,
+// keeps those rows (q among them) and re-ranks them exactly -- no candidate lists, no certificate, because nothing is left out.
+// A candidate with more than 128 such rows goes to segp_exact_rows_kernel<true> (flag2 / n_flag2).
+__global__ __launch_bounds__(kBlock) void segp_back_direct_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
+                                                                  const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_q,
+                                                                  const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
+                                                                  const uint32_t* __restrict__ Sc, int ldsc, const double* __restrict__ fdist,
+                                                                  int32_t* __restrict__ bidx, double* __restrict__ bdist,
+                                                                  int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip) {
+    __shared__ double s_t[kBlock / 64][kNC][kFT];
+    __shared__ int s_j[kBlock / 64][64 * kEPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.z, nA = S.Q, D = S.Dp;
+    const int nc = min(n_cand[z], nA);
+    const SegConst c = sc[z];
+    const SegView V = seg_view(S, nrmS, nrmM, c, z);
+    cand_q += (size_t)z * nA; cand_m += (size_t)z * nA; fdist += (size_t)z * nA * 2;
+    bidx += (size_t)z * nA * 2; bdist += (size_t)z * nA * 2; flag2 += (size_t)z * nA;
+    for (int k = blockIdx.x * (kBlock / 64) + wave; k < nc; k += gridDim.x * (kBlock / 64)) {       // wave-uniform
+        const int qi = cand_q[k], jm = cand_m[k];
+        const double dq = fdist[(size_t)qi * 2];
+        unsigned smax = 0xFFFFFFFFu;
+        { const double t = (dq * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0; if (t < 4.0e9) smax = (unsigned)t; }
+        const uint32_t* row = Sc + (size_t)V.rows[jm] * ldsc;
+        // the best reference score of the row bounds the best true distance from above: rows more than the two-sided slack above it
+        // cannot be the best -- if q is one of them the answer is "no" without any exact work (most weak matches end here)
+        unsigned best = 0xFFFFFFFFu;
+        for (int a = lane; a < nA; a += 64) best = min(best, row[a]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+        const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
+        const unsigned bmax = best > 0xFFFFFFFFu - slack ? 0xFFFFFFFFu : best + slack;
+        if (row[qi] > bmax && !skip) {
+            if (lane == 0) { bidx[(size_t)k * 2] = -1; bidx[(size_t)k * 2 + 1] = -1; bdist[(size_t)k * 2] = INFINITY; bdist[(size_t)k * 2 + 1] = INFINITY; }
+            continue;
+        }
+        smax = min(smax, bmax);
+        int n_need = 0; bool over = skip != 0;
+        for (int a0 = 0; a0 < nA && !over; a0 += 64) {
+            const int a = a0 + lane;
+            const bool take = a < nA && row[a] <= smax;
+            const unsigned long long m = __ballot(take);
+            const int cnt = __popcll(m);
+            if (n_need + cnt > 64 * kEPL) { over = true; break; }
+            if (take) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = a;
+            n_need += cnt;
+        }
+        if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = k; } continue; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        double d1, d2; int i1, i2;
+        seg_rerank<true>(V, seg_model_row(V, jm), s_j[wave], n_need, D, s_t[wave], d1, i1, d2, i2);
+        if (lane == 0) { bidx[(size_t)k * 2] = i1; bidx[(size_t)k * 2 + 1] = i2; bdist[(size_t)k * 2] = d1; bdist[(size_t)k * 2 + 1] = d2; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1461,13 +1484,11 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     hipLaunchKernelGGL(segp_filter_kernel, dim3(S), dim3(kCompactThreads), 0, st, idx, dist, Q, seg_off, thr, o.maxRatio, cand_q, cand_m, n_cand, n_flag);
     PCREG_HIP(hipGetLastError());
     if (o.unique) {
-        // back: every candidate's model row against all surface rows -- a row of the same matrix
-        hipLaunchKernelGGL(segp_select_back_kernel, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, cand_m, n_cand, Q, L.chunk, L.splits, part_idx, part_s);
-        hipLaunchKernelGGL(segp_finalize_kernel<true>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, cand_m, n_cand,
-                           part_idx, part_s, L.splits, bidx, bdist, flag_list, n_flag, force, dbg_hist ? dbg_hist + 130 : nullptr);
+        // back: every candidate's model row against the surface rows that can still beat its own query -- a row of the same matrix
         PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
-        hipLaunchKernelGGL(segp_refine_kernel<true>, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)cand_m, (const uint32_t*)Sc, L.ldqa,
-                           (const int32_t*)flag_list, (const int32_t*)n_flag, bidx, bdist, flag2, n_flag2, skip_refine);
+        hipLaunchKernelGGL(segp_back_direct_kernel, dim3(std::max(1, std::min((Q + 3) / 4, 128)), 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc,
+                           (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const double*)dist, bidx, bdist,
+                           flag2, n_flag2, skip_refine);
         hipLaunchKernelGGL(segp_exact_rows_kernel<true>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
                            cand_m, flag2, n_flag2, 0, fpi, fpd);
         hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag2, n_flag2, Q, fpi, fpd, bidx, bdist);
@@ -1481,15 +1502,15 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
         PCREG_HIP(hipMemcpy(h.data(), dbg_hist, h.size() * 4, hipMemcpyDeviceToHost));
         PCREG_HIP(hipMemcpy(nf.data(), n_flag, nf.size() * 4, hipMemcpyDeviceToHost));
         (void)hipFree(dbg_hist);
-        for (int dir = 0; dir < 2; ++dir) {
-            long long q = 0, c = 0; for (int k = 0; k < 130; ++k) { q += h[dir * 130 + k]; c += (long long)k * h[dir * 130 + k]; }
-            fprintf(stderr, "[pcreg] segmented %s: %lld queries, %.2f candidates re-scored per query; histogram 0..8:", dir ? "back" : "forward", q, q ? (double)c / q : 0.0);
-            for (int k = 0; k <= 8; ++k) fprintf(stderr, " %d", h[dir * 130 + k]);
-            long long big = 0; for (int k = 9; k < 130; ++k) big += h[dir * 130 + k];
+        {
+            long long q = 0, c = 0; for (int k = 0; k < 130; ++k) { q += h[k]; c += (long long)k * h[k]; }
+            fprintf(stderr, "[pcreg] segmented forward: %lld queries, %.2f candidates inside the two-sided slack per query; histogram 0..8:", q, q ? (double)c / q : 0.0);
+            for (int k = 0; k <= 8; ++k) fprintf(stderr, " %d", h[k]);
+            long long big = 0; for (int k = 9; k < 130; ++k) big += h[k];
             fprintf(stderr, " >8: %lld\n", big);
         }
         long long f = 0, ff = 0; int mx = 0, nz = 0; for (int z = 0; z < S; ++z) { f += nf[z]; ff += dbg_nf_fwd[z]; mx = std::max(mx, dbg_nf_fwd[z]); nz += dbg_nf_fwd[z] > 0; }
-        fprintf(stderr, "[pcreg] segmented: unproven queries forward %lld (in %d segments, at most %d in one), last search %lld\n", ff, nz, mx, f);
+        fprintf(stderr, "[pcreg] segmented: unproven queries forward %lld (in %d segments, at most %d in one)\n", ff, nz, mx); (void)f;
     }
 #endif
     return PCREG_OK;
