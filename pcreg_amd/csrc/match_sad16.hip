@@ -321,7 +321,10 @@ __device__ __forceinline__ bool lexd_lt(double da, int ia, double db, int ib) { 
 // The |a - b| terms of a candidate are order-free, so the whole wave computes them in parallel into
 // LDS (256 features x up to kNC candidates at a time); only the SUM keeps the oracle's order: lane c
 // adds candidate c's terms one by one, s carried from tile to tile.
-constexpr int kNC = 4, kFT = 256, kEPL = 2;
+#ifndef PCREG_SAD_KFT
+#define PCREG_SAD_KFT 128
+#endif
+constexpr int kNC = 4, kFT = PCREG_SAD_KFT, kEPL = 2;      // candidates per re-rank group, features per LDS tile, list entries per lane
 __global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __restrict__ At, int nA,
                                                                 const double* __restrict__ Bt, int nB, int D,
                                                                 const Range* __restrict__ rp, const int32_t* __restrict__ part_idx,
