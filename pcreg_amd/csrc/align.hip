@@ -30,10 +30,20 @@ namespace {
 // (<= 128 VGPRs, no scratch: the cross-wave sums are butterflies, the Jacobi's V lives in LDS).  Round 1's kernel
 // re-read the support from L2 in five passes (0.29 ms for 4096 x 3000; this one 0.20 ms).
 __device__ __forceinline__ double opaque_f64(double x) { asm volatile("" : "+v"(x)); return x; }
-// N block-wide sums: DPP wave sums (wave_math.hpp), then every wave sums the NW wave partials the same way (lanes
-// >= NW add zeros), so all threads end with the same bits and only N values are live
+// N block-wide sums: DPP wave sums (wave_math.hpp), then every thread adds the NW wave partials as the same pairwise
+// tree (broadcast LDS reads: NW - 1 additions per value instead of a second 30-instruction butterfly), so all threads end
+// with the same bits and only N values are live
+template <int NW>
+__device__ __forceinline__ double tree_sum_lds(const double* s, int stride) {
+    if constexpr (NW == 1) return s[0];
+    else {
+        constexpr int H = NW <= 2 ? 1 : (NW <= 4 ? 2 : (NW <= 8 ? 4 : 8));     // the largest power of two below NW
+        return tree_sum_lds<H>(s, stride) + tree_sum_lds<NW - H>(s + H * stride, stride);
+    }
+}
 template <int NW, int N>
 __device__ __forceinline__ void block_sum_nw(double (&v)[N], double* s_redn /*[NW][N]*/) {
+    static_assert(NW >= 1 && NW <= 16, "one wave partial per wave of a workgroup");
 #pragma unroll
     for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(v[k]);
     const int lane = threadIdx.x & 63;
@@ -43,7 +53,7 @@ __device__ __forceinline__ void block_sum_nw(double (&v)[N], double* s_redn /*[N
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(lane < NW ? s_redn[lane * N + k] : 0.0);
+    for (int k = 0; k < N; ++k) v[k] = tree_sum_lds<NW>(s_redn + k, N);
     __syncthreads();
 }
 template <int NW>
@@ -52,7 +62,9 @@ __device__ __forceinline__ int block_sum_iw(int v, int* s_red) {
     const int lane = threadIdx.x & 63;
     if (lane == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
-    const int t = wave_sum_dpp_i(lane < NW ? s_red[lane] : 0);
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += s_red[w];
     __syncthreads();
     return t;
 }

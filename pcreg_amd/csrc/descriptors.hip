@@ -244,8 +244,9 @@ __global__ void kp_scatter_kernel(const int32_t* __restrict__ kcell, int S, cons
 }
 
 // ---- per-keypoint descriptor ------------------------------------------------------------------
-// block-wide sums of a 256-thread workgroup: DPP wave sums (wave_math.hpp: no LDS crossbar), then every wave adds the
-// four wave partials the same way, so all threads hold the same bits; one barrier pair per call
+// block-wide sums of a 256-thread workgroup: DPP wave sums (wave_math.hpp: no LDS crossbar), then every thread adds the
+// four wave partials in the same order, (w0 + w1) + (w2 + w3) (broadcast LDS reads), so all threads hold the same bits;
+// one barrier pair per call
 template <int N>
 __device__ __forceinline__ void bsum_n(double (&v)[N], double* s_redn /*[4][N]*/) {
 #pragma unroll
@@ -257,7 +258,7 @@ __device__ __forceinline__ void bsum_n(double (&v)[N], double* s_redn /*[4][N]*/
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wave_sum_dpp(lane < 4 ? s_redn[lane * N + k] : 0.0);
+    for (int k = 0; k < N; ++k) v[k] = (s_redn[k] + s_redn[N + k]) + (s_redn[2 * N + k] + s_redn[3 * N + k]);
     __syncthreads();
 }
 __device__ __forceinline__ int bsum_i(int v, int* s_red) {
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     int slot = blockIdx.x;
     if (xcd_chunk > 0) { slot = (blockIdx.x & 7) * xcd_chunk + (blockIdx.x >> 3); if ((int)(blockIdx.x >> 3) >= xcd_chunk || slot >= S) return; }
     const int s = perm[slot];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // an SGPR: the loops over a wave's chunks are scalar
     const double cx = kp[s], cy = kp[s + (size_t)ldk], cz = kp[s + 2 * (size_t)ldk];
     const double R = o.R;
     // the keypoint in the frame of the fp32 copies: SM 0: relative to the grid's origin (screening), SM 1: the single value itself
@@ -393,25 +394,41 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         s_cp[nrows] = run;
     }
     __syncthreads();
-    const int n_chunks = s_cp[nrows];
-    // pass 1 streams the candidates ONCE (four 64-point chunks = twelve 4-byte loads in flight per wave) and keeps
-    // every chunk's ballot; pass 2 replays the ballots, so it touches no global memory
-    constexpr int kMaskCap = 160;                   // chunks per wave whose ballot is kept (beyond: re-tested)
+    const int n_chunks = __builtin_amdgcn_readfirstlane(s_cp[nrows]);
+    // pass 1 streams the candidates ONCE (four 64-point chunks = twelve loads in flight per wave) and keeps every chunk's
+    // ballot; pass 2 replays the ballots, so it touches no global memory.  The kernel is bound by VALU issue
+    // (profiles/r03_pmc_desc_kernel.json), so the loop is written for few vector instructions per chunk: chunk numbers and
+    // ranges live in SGPRs, the ballots of a wave's chunks sit in the lanes of three register pairs (v_writelane / v_readlane:
+    // no LDS traffic), the cloud is addressed as scalar base + 32-bit byte offset, the centroid's sums run under the ballot as
+    // the exec mask (a branch, not six v_cndmask per chunk).
+    constexpr int kMaskCap = 192;                   // chunks per wave whose ballot is kept (beyond: re-tested)
     __shared__ unsigned long long s_mask[4][kMaskCap];
+    int blo = 0, bhi = 0;                           // lane l: the ballot of the wave's chunk 64 round + l (flushed to s_mask per round)
+    auto keep_ballot = [&](int ch /* scalar */, unsigned long long bal) {
+        // (value and lane select both in SGPRs exceed gfx9's one-scalar-operand limit: the lane select goes through m0)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // "m0 is reserved": it is, and this statement says that it overwrites it
+        asm volatile("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                     : "+v"(blo), "+v"(bhi) : "s"((int)(unsigned)bal), "s"((int)(unsigned)(bal >> 32)), "s"(ch & 63) : "m0");
+#pragma clang diagnostic pop
+    };
+    auto flush_ballots = [&](int round /* scalar */) {
+        if (round * 64 < kMaskCap) s_mask[wave][round * 64 + lane] = ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo;
+    };
     // chunk c -> (first position, end of its row).  The lookup walks two LDS tables, and doing it inside the streaming loop
     // put ~4 dependent LDS round trips in front of every chunk's loads (the collection took 1.7 ms per 100 k keypoints for
     // 0.3 ms worth of loads and tests).  Every lane therefore resolves ONE chunk of its wave up front -- lane l owns the
-    // wave's l-th chunk, chunks wave + 4 l -- and the loop reads the pair with v_readlane (a wave meets at most
-    // kMaskCap + ... chunks; beyond 64 per wave a second, third ... round of lookups follows).
+    // wave's l-th chunk, chunks wave + 4 l -- and the loop reads the pair with v_readlane (beyond 64 chunks per wave a
+    // second, third ... round of lookups follows).
     auto chunk_lookup = [&](int c, int& j0, int& end) {
         int rp = 0;
         while (c >= s_cp[rp + 1]) ++rp;
         j0 = s_rowb[rp] + ((c - s_cp[rp]) << 6); end = s_rowe[rp];
     };
     int my_j0 = 0, my_end = 0, my_round = -1;
-    auto chunk_range = [&](int ord /* the wave's ord-th chunk: wave-uniform */, int& j0, int& end) {
+    auto chunk_range = [&](int ord /* the wave's ord-th chunk: scalar */, int& j0, int& end) {
         const int round = ord >> 6;
-        if (round != my_round) {                       // wave-uniform
+        if (round != my_round) {                       // scalar
             my_round = round;
             const int c = wave + 4 * (round * 64 + lane);
             my_j0 = 0; my_end = 0;
@@ -419,97 +436,91 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         }
         j0 = __builtin_amdgcn_readlane(my_j0, ord & 63); end = __builtin_amdgcn_readlane(my_end, ord & 63);
     };
+    // the cloud through a scalar base and a 32-bit byte offset (global_load ... v_off, s[base]: no 64-bit address arithmetic
+    // per load; the launcher refuses clouds of 2^28 points or more)
+    auto ldd = [](const double* __restrict__ base, unsigned off) -> double { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + off); };
+    auto ldf4 = [&](unsigned off8 /* 8 j */) -> float4 { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(f4) + 2u * off8); };
     // is candidate j inside?  SM 1: (X, Y, Z) the single point, (x, y, z) = pts_cube - c in single (getLocalPoints.m:8-25 as
     // MATLAB runs it for single data); SM 0: the fp64 test on the double coordinates
-    auto inside = [&](int j, float X, float Y, float Z, float x, float y, float z) -> bool {
+    auto inside = [&](unsigned off, float X, float Y, float Z, float x, float y, float z) -> bool {
         if (SM) {
             const bool box = X > xlo && X < xhi && Y > ylo32 && Y < yhi32 && Z > zlo32 && Z < zhi32;
             return box && sqrtf((x * x + y * y) + z * z) < R32;
         }
-        const double ex = sx[j] - cx, ey = sy[j] - cy, ez = sz[j] - cz;
+        const double ex = ldd(sx, off) - cx, ey = ldd(sy, off) - cy, ez = ldd(sz, off) - cz;
         return ex * ex + ey * ey + ez * ez < R2T;                          // getLocalPoints.m:23-25 (see R2T)
     };
     double a3[3] = {0, 0, 0};
     {
-        int cnt = 0, ch = 0;                         // ch: running chunk number of this wave
+        int cnt = 0;                                 // scalar: popcounts of ballots
         // SM 0 streams the DOUBLE coordinates once (test + centroid sums from the same registers).  A form that screened
         // the test on the fp32 copy and fetched the doubles of the inside lanes only was 1.6 ms per 100 k keypoints slower:
         // with 40 % of the candidates inside, every sector of the double arrays is touched anyway, on top of the copy.
-        if constexpr (SM == 0) {
-            constexpr int kD = 4;                    // chunks in flight per wave: 12 eight-byte loads per lane
-            for (int c0 = wave; c0 < n_chunks; c0 += 4 * kD) {
-                double X[kD], Y[kD], Z[kD]; int J0[kD], E[kD];
+        constexpr int kD = SM ? kDC : 4;             // chunks in flight per wave
+        static_assert(64 % kD == 0, "a round of 64 chunks is a whole number of groups");
+        for (int c0 = wave, ch0 = 0; c0 < n_chunks; c0 += 4 * kD, ch0 += kD) {
+            if (ch0 != 0 && (ch0 & 63) == 0) flush_ballots((ch0 >> 6) - 1);      // scalar
+            double X[SM ? 1 : kD], Y[SM ? 1 : kD], Z[SM ? 1 : kD]; float Xf[SM ? kD : 1], Yf[SM ? kD : 1], Zf[SM ? kD : 1];
+            int J0[kD], E[kD];
 #pragma unroll
-                for (int u = 0; u < kD; ++u) {
-                    const int c = c0 + 4 * u;
-                    J0[u] = 0; E[u] = 0;
-                    if (c < n_chunks) chunk_range((c - wave) >> 2, J0[u], E[u]);  // wave-uniform
-                    const int j = max(min(J0[u] + lane, E[u] - 1), 0);
-                    X[u] = sx[j]; Y[u] = sy[j]; Z[u] = sz[j];
-                }
-#pragma unroll
-                for (int u = 0; u < kD; ++u) {
-                    if (c0 + 4 * u < n_chunks) {         // wave-uniform
-                        const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
-                        const bool in = (J0[u] + lane < E[u]) && x * x + y * y + z * z < R2T;   // getLocalPoints.m:23-25 (see R2T)
-                        if (in) { a3[0] += x; a3[1] += y; a3[2] += z; }        // the local centroid's sums ride along (:80)
-                        const unsigned long long bal = __ballot(in);
-                        if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
-                        ++ch;
-                        cnt += __popcll(bal);
-                    }
-                }
+            for (int u = 0; u < kD; ++u) {
+                J0[u] = 0; E[u] = 0;
+                if (c0 + 4 * u < n_chunks) chunk_range(ch0 + u, J0[u], E[u]);        // scalar
+                const unsigned off = (unsigned)max(min(J0[u] + lane, E[u] - 1), 0) << 3;
+                if constexpr (SM == 0) { X[u] = ldd(sx, off); Y[u] = ldd(sy, off); Z[u] = ldd(sz, off); }
+                else { const float4 t4 = ldf4(off); Xf[u] = t4.x; Yf[u] = t4.y; Zf[u] = t4.z; }
             }
-        } else {
-            for (int c0 = wave; c0 < n_chunks; c0 += 4 * kDC) {
-                float X[kDC], Y[kDC], Z[kDC]; int J0[kDC], E[kDC];
 #pragma unroll
-                for (int u = 0; u < kDC; ++u) {
-                    const int c = c0 + 4 * u;
-                    J0[u] = 0; E[u] = 0;
-                    if (c < n_chunks) chunk_range((c - wave) >> 2, J0[u], E[u]);  // wave-uniform
-                    const int j = max(min(J0[u] + lane, E[u] - 1), 0);
-                    const float4 t4 = f4[j]; X[u] = t4.x; Y[u] = t4.y; Z[u] = t4.z;
-                }
-#pragma unroll
-                for (int u = 0; u < kDC; ++u) {
-                    if (c0 + 4 * u < n_chunks) {         // wave-uniform
-                        const int j = J0[u] + lane;
-                        const float x = X[u] - cxf, y = Y[u] - cyf, z = Z[u] - czf;
-                        const bool in = j < E[u] && inside(j, X[u], Y[u], Z[u], x, y, z);
-                        if (in) { a3[0] += (double)x; a3[1] += (double)y; a3[2] += (double)z; }   // MATLAB's single pts_rel values (:80 sums them)
-                        const unsigned long long bal = __ballot(in);
-                        if (lane == 0 && ch < kMaskCap) s_mask[wave][ch] = bal;
-                        ++ch;
-                        cnt += __popcll(bal);
+            for (int u = 0; u < kD; ++u) {
+                if (c0 + 4 * u < n_chunks) {         // scalar
+                    unsigned long long bal;
+                    if constexpr (SM == 0) {
+                        const double x = X[u] - cx, y = Y[u] - cy, z = Z[u] - cz;
+                        // lanes past the end of the row tested a clamped (repeated) point: masked out in the scalar unit
+                        const int live = E[u] - J0[u];
+                        const unsigned long long lanes = live >= 64 ? ~0ull : (1ull << live) - 1ull;
+                        bal = __builtin_amdgcn_ballot_w64(x * x + y * y + z * z < R2T) & lanes;   // getLocalPoints.m:23-25 (see R2T)
+                        if (__builtin_amdgcn_inverse_ballot_w64(bal)) { asm volatile("" ::: "memory"); a3[0] += x; a3[1] += y; a3[2] += z; }   // the local centroid's sums ride along (:80)
+                    } else {
+                        const float x = Xf[u] - cxf, y = Yf[u] - cyf, z = Zf[u] - czf;
+                        const int live = E[u] - J0[u];
+                        const unsigned long long lanes = live >= 64 ? ~0ull : (1ull << live) - 1ull;
+                        bal = __builtin_amdgcn_ballot_w64(inside(0u, Xf[u], Yf[u], Zf[u], x, y, z)) & lanes;
+                        if (__builtin_amdgcn_inverse_ballot_w64(bal)) { asm volatile("" ::: "memory"); a3[0] += (double)x; a3[1] += (double)y; a3[2] += (double)z; }   // MATLAB's single pts_rel values (:80 sums them)
                     }
+                    keep_ballot(ch0 + u, bal);
+                    cnt += __builtin_popcountll(bal);
                 }
             }
         }
+        if (n_chunks > wave) flush_ballots(((n_chunks - wave + 3) / 4 - 1) >> 6);     // the last (partial) round
         if (lane == 0) s_wtot[wave] = cnt;
     }
     __syncthreads();
     int n_total = 0, my_base = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { if (w == wave) my_base = n_total; n_total += s_wtot[w]; }
+    for (int w = 0; w < 4; ++w) { const int t = __builtin_amdgcn_readfirstlane(s_wtot[w]); if (w == wave) my_base = n_total; n_total += t; }
     const int n = n_total;
     if (n < 1 || n < o.min_pts || n > o.max_pts) return;                   // getLocalPoints.m:17,31
     if (n > cap) { if (tid == 0) atomicMax(err, n); return; }              // support larger than the LDS list
     {
-        int ch = 0, pos = my_base;
-        for (int c = wave; c < n_chunks; c += 4, ++ch) {
+        int pos = my_base;                           // scalar
+        for (int c = wave, ch = 0; c < n_chunks; c += 4, ++ch) {
             int j0, end;
             chunk_range(ch, j0, end);
             unsigned long long bal;
-            if (ch < kMaskCap) bal = s_mask[wave][ch];
+            if ((ch & 63) == 0 && ch < kMaskCap) { const unsigned long long t = s_mask[wave][ch + lane]; blo = (int)(unsigned)t; bhi = (int)(unsigned)(t >> 32); }   // scalar
+            if (ch < kMaskCap) bal = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(bhi, ch & 63) << 32) | (unsigned)__builtin_amdgcn_readlane(blo, ch & 63);
             else {
-                const int j = j0 + lane, jc = max(min(j, end - 1), 0);
+                const int j = j0 + lane; const unsigned off = (unsigned)max(min(j, end - 1), 0) << 3;
                 float X = 0.0f, Y = 0.0f, Z = 0.0f;
-                if (SM) { const float4 t4 = f4[jc]; X = t4.x; Y = t4.y; Z = t4.z; }
-                bal = __ballot(j < end && inside(jc, X, Y, Z, X - cxf, Y - cyf, Z - czf));
+                if (SM) { const float4 t4 = ldf4(off); X = t4.x; Y = t4.y; Z = t4.z; }
+                bal = __builtin_amdgcn_ballot_w64(j < end && inside(off, X, Y, Z, X - cxf, Y - cyf, Z - czf));
             }
-            if ((bal >> lane) & 1ull) lpos[pos + __popcll(bal & ((1ull << lane) - 1ull))] = j0 + lane;
-            pos += __popcll(bal);
+            // the list holds BYTE offsets into the double columns (8 x the sorted position)
+            if (__builtin_amdgcn_inverse_ballot_w64(bal))
+                lpos[pos + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (j0 + lane) << 3;
+            pos += __builtin_popcountll(bal);
         }
     }
     __syncthreads();
@@ -520,9 +531,9 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     // (bit r of selmask).  Four entries' gathers are issued before the first is used: the sorted cloud sits in the L2 /
     // Infinity Cache, so the passes are latency-bound and memory-level parallelism is what they need.
     unsigned selmask = 0xFFFFFFFFu;                  // cap <= 8191 -> r < 32
-#define PCREG_LOAD_REL(j_, X_, Y_, Z_)                                                               \
-    if (SM) { const float4 t4_ = f4[j_]; X_ = (double)(t4_.x - cxf); Y_ = (double)(t4_.y - cyf); Z_ = (double)(t4_.z - czf); } \
-    else { X_ = sx[j_] - cx; Y_ = sy[j_] - cy; Z_ = sz[j_] - cz; }
+#define PCREG_LOAD_REL(j_ /* byte offset into the double columns */, X_, Y_, Z_)                      \
+    if (SM) { const float4 t4_ = ldf4((unsigned)(j_)); X_ = (double)(t4_.x - cxf); Y_ = (double)(t4_.y - cyf); Z_ = (double)(t4_.z - czf); } \
+    else { X_ = ldd(sx, (unsigned)(j_)) - cx; Y_ = ldd(sy, (unsigned)(j_)) - cy; Z_ = ldd(sz, (unsigned)(j_)) - cz; }
 #define PCREG_MY_PTS(...)                                                                            \
     for (int i0_ = tid, r0_ = 0; i0_ < n; i0_ += kD64 * kBlock, r0_ += kD64) {                       \
         double X_[kD64], Y_[kD64], Z_[kD64];                                                         \
@@ -576,11 +587,10 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         _Pragma("unroll") for (int pq_ = 0; pq_ < 4; ++pq_) { const int pr = pg_ * 4 + pq_; const int i = tid + pr * kBlock; if (i < n) { const unsigned long long k = kreg[pr]; (void)i; __VA_ARGS__ } } } }
         // K-th smallest by ONE 256-bin histogram over [min, max] (the bin index is monotone in the
         // key), then an exact rank inside the bin that holds it; bisection only if that bin is crowded
-        unsigned long long lo = ~0ull, hi = 0ull;
-        PCREG_MY_KEYS(lo = k < lo ? k : lo; hi = k > hi ? k : hi;)
-        // the keys are bit patterns of non-negative doubles: reduce them as doubles (DPP, wave_math.hpp)
-        lo = kth_key(wave_min_dpp(lo == ~0ull ? DBL_MAX : __longlong_as_double((long long)lo)));
-        hi = kth_key(wave_max_dpp(__longlong_as_double((long long)hi)));
+        // the keys are bit patterns of non-negative doubles: min / max as doubles (v_min_f64 / v_max_f64, DPP in wave_math.hpp)
+        double lo_d = DBL_MAX, hi_d = 0.0;
+        PCREG_MY_KEYS(const double kd = __longlong_as_double((long long)k); lo_d = fmin(lo_d, kd); hi_d = fmax(hi_d, kd);)
+        unsigned long long lo = kth_key(wave_min_dpp(lo_d)), hi = kth_key(wave_max_dpp(hi_d));
         if (lane == 0) { s_u64[wave] = lo; s_u64[4 + wave] = hi; }
         for (int i = tid; i < 256; i += kBlock) s_hist[i] = 0;
         if (tid == 0) { s_nsmall = 0; s_vk = 0ull; }
@@ -646,32 +656,51 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         }
         __syncthreads();
         const unsigned long long t_lo = s_tlo, t_hi = s_thi;
-        int c1 = 0, c2 = 0;
-        PCREG_MY_KEYS(c1 += k < t_lo; c2 += (k >= t_lo && k < t_hi);)
-        const int n_less = bsum_i(c1, s_redi), n_eq = bsum_i(c2, s_redi);
+        // n_less = #{d2 < t_lo}, n_eq = #{d2 in the tie group}.  The bin index is monotone in the key: when the whole tie group
+        // lies in the K-th's bin (always, but for a group that straddles a bin border), the keys of the lower bins are all
+        // below t_lo, those of the higher bins all >= t_hi, and the counts follow from the bin's <= 256 entries in s_small --
+        // one entry per thread, two ballots -- instead of another pass over every key and two block reductions.
+        int n_less, n_eq;
+        if (m <= kSmall && bin_of(t_lo > lo ? t_lo : lo) == bstar && bin_of(t_hi - 1ull < hi ? t_hi - 1ull : hi) == bstar) {   // block-uniform
+            static_assert(kSmall <= kBlock, "one s_small entry per thread");
+            const unsigned long long ks = tid < m ? s_small[tid] : ~0ull;
+            const unsigned long long b1 = __builtin_amdgcn_ballot_w64(ks < t_lo), b2 = __builtin_amdgcn_ballot_w64(ks >= t_lo && ks < t_hi);
+            if (lane == 0) s_redi[wave] = __builtin_popcountll(b1) | (__builtin_popcountll(b2) << 16);
+            __syncthreads();
+            const int t = s_redi[0] + s_redi[1] + s_redi[2] + s_redi[3];
+            __syncthreads();
+            n_less = below + (t & 0xFFFF); n_eq = t >> 16;
+        } else {
+            int c1 = 0, c2 = 0;
+            PCREG_MY_KEYS(c1 += k < t_lo; c2 += (k >= t_lo && k < t_hi);)
+            n_less = bsum_i(c1, s_redi); n_eq = bsum_i(c2, s_redi);
+        }
         if (dbg_stop == 6) return;
         const int take_eq = K - n_less;
         // ties at the K-th distance: the stable sort keeps the lowest ORIGINAL indices
         unsigned sm = 0u;
+        if (n_eq == take_eq) {                       // the whole tie group is kept (nearly always a group of one): one comparison per key
+            PCREG_MY_KEYS(sm |= (k < t_hi ? 1u : 0u) << pr;)
+        } else {
         PCREG_MY_KEYS(
             const unsigned long long key = k;
             bool sel = key < t_lo;
             if (key >= t_lo && key < t_hi) {
-                if (n_eq == take_eq) sel = true;
-                else {
-                    const int me = sorted_idx[lpos[i]];
+                {
+                    const int me = sorted_idx[lpos[i] >> 3];
                     int rank = 0;
                     for (int t = 0; t < n; ++t) {
                         const int jt = lpos[t];
                         double tx, ty, tz;
                         PCREG_LOAD_REL(jt, tx, ty, tz)
                         const unsigned long long kt = PCREG_KEY(tx, ty, tz);
-                        if (kt >= t_lo && kt < t_hi && sorted_idx[jt] < me) ++rank;
+                        if (kt >= t_lo && kt < t_hi && sorted_idx[jt >> 3] < me) ++rank;
                     }
                     sel = rank < take_eq;
                 }
             }
             sm |= (sel ? 1u : 0u) << pr;)
+        }
         selmask = sm;
 #undef PCREG_KEY
 #undef PCREG_MY_KEYS
@@ -746,24 +775,30 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     //    when t keeps its integer part under the error of d2 (the rounded edges sit 1e-16 off this formula: inside the margin);
     //  * the theta edges are symmetric about pi / 2 (cos(pi - x) = -cos x): three comparisons of z^2 with cos^2(edge) d2
     //    count the edges between the point and its pole, the sign of z picks the side (near z = 0 both sides give bin 4).
+    //  * one v_rsq_f32 gives r = d2 / sqrt(d2) and every RELATIVE error term (e / r): no IEEE square root (15 instructions) and
+    //    no IEEE division (11) per point; explicit fma chains (fewer roundings than the bounds assume).
     const float k3 = (float)((double)NR / (R * R * R));
+    const int base_pos = lp_pos > 0 ? NR * NT * (lp_pos - 1) : -(1 << 20), base_neg = lp_neg > 0 ? NR * NT * (lp_neg - 1) : -(1 << 20);
+    const float e2_rot = e_rot * e_rot, e_rot2 = 2.0f * e_rot;
     auto bin_fast32 = [&](float x, float y, float z, bool& safe) -> int {
-        const float xy2 = x * x + y * y; const float d2 = xy2 + z * z;
-        const float r = sqrtf(d2);
-        const float e_d2 = 3.5f * r * e_rot + 3.0f * e_rot * e_rot + 6.0f * u32 * d2;     // |d2 - exact|
-        const float t = d2 * r * k3;                                                        // NR (r / R)^3
-        const float e_t = t * (1.5f * e_d2 / d2 + 12.0f * u32) + 2e-6f;                    // d(r^3) / r^3 = 1.5 d(d2) / d2
-        const float fr = t - floorf(t);
-        safe = fabsf(y) > e_rot && fr > e_t && fr < 1.0f - e_t && t < (float)NR - e_t && d2 > e_d2;
-        const int lr = (int)t + 1;
         const float a = z * z;
-        const float e_a = 2.0f * r * e_rot + e_rot * e_rot + e_d2 + 4.0f * u32 * d2;        // |(z^2 - c^2 d2) - exact|, c^2 <= 1
+        const float d2 = fmaf(x, x, fmaf(y, y, a));
+        const float rinv = __builtin_amdgcn_rsqf(d2);                                      // 1 ulp; d2 = 0: inf -> NaN bounds -> deferred
+        const float r = d2 * rinv;                                                          // sqrt(d2) to 3 u
+        const float q = e_rot * rinv;
+        // |d2 - exact| / d2 <= rel: 2 sqrt(3) r e + 3 e^2 from the inputs, 6 u d2 from the three products and two sums
+        const float rel = fmaf(q, fmaf(q, 3.0f, 3.7f), 6.0f * u32);
+        const float t = d2 * r * k3;                                                        // NR (r / R)^3
+        const float e_t = fmaf(t, fmaf(rel, 1.5f, 12.0f * u32), 2e-6f);                     // d(r^3) / r^3 = 1.5 d(d2) / d2
+        const float fr = __builtin_amdgcn_fractf(t);
+        safe = fabsf(y) > e_rot && fr > e_t && fr + e_t < 1.0f && t + e_t < (float)NR && rel < 1.0f;
+        // |(z^2 - c^2 d2) - exact| <= e_a, c^2 <= 1
+        const float e_a = fmaf(d2, rel + 4.0f * u32, fmaf(r, e_rot2, e2_rot));
         int m = 0;
 #pragma unroll
-        for (int jj = 1; jj <= 3; ++jj) { const float dl = a - e32.cts[jj] * d2; safe = safe && fabsf(dl) > e_a; m += dl < 0.0f; }
-        const int lt = z >= 0.0f ? 1 + m : 7 - m;
-        const int lp = y > 0.0f ? lp_pos : lp_neg;
-        return (lr >= 1 && lr <= NR && lp > 0) ? (lr - 1) + NR * (lt - 1) + NR * NT * (lp - 1) : -1;
+        for (int jj = 1; jj <= 3; ++jj) { const float dl = fmaf(-e32.cts[jj], d2, a); safe = safe && fabsf(dl) > e_a; m += dl < 0.0f; }
+        const int ltm = z >= 0.0f ? m : 6 - m;                                              // lt - 1
+        return (int)t + NR * ltm + (y > 0.0f ? base_pos : base_neg);                        // (lr - 1) + NR (lt - 1) + NR NT (lp - 1); lr <= NR when safe
     };
     // a deferred point is first binned with the fp64 images (no transcendental); only inside THEIR 1e-12 band -- where the
     // computed acos could land on the other side of an edge -- it takes the literal path
@@ -796,7 +831,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         float X_[kD32], Y_[kD32], Z_[kD32];                                                          \
         _Pragma("unroll") for (int u_ = 0; u_ < kD32; ++u_) {                                        \
             const int j_ = lpos[min(i0_ + u_ * kBlock, n - 1)];                                      \
-            { const float4 t4_ = f4[j_]; X_[u_] = t4_.x; Y_[u_] = t4_.y; Z_[u_] = t4_.z; }                  \
+            { const float4 t4_ = ldf4((unsigned)j_); X_[u_] = t4_.x; Y_[u_] = t4_.y; Z_[u_] = t4_.z; }       \
         }                                                                                            \
         _Pragma("unroll") for (int u_ = 0; u_ < kD32; ++u_) {                                        \
             const int i = i0_ + u_ * kBlock, pr = r0_ + u_;                                          \
@@ -814,20 +849,21 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         const double c1x = cu[1] * det0, c1y = cu[4] * det0, c1z = cu[7] * det0;
         const float f0 = (float)cu[0], f3 = (float)cu[3], f6 = (float)cu[6], f2 = (float)cu[2], f5 = (float)cu[5], f8 = (float)cu[8];
         const float g1x = (float)c1x, g1y = (float)c1y, g1z = (float)c1z;
-        const float mxf = (float)mx, myf = (float)my, mzf = (float)mz;
-        // a vote's dot product runs on (p - mean): one more fp32 rounding per coordinate on values up to 2 R
-        const float e_vote = 3.0f * (dlt + 4.0f * u32 * R32) + 12.0f * u32 * (2.0f * R32);
+        // a vote is the sign of (p - mean) . column = p . column - mean . column: the first term is the rotated coordinate the
+        // histogram needs anyway (error e_rot), the second a constant per keypoint (fp64, rounded once: u R), their
+        // difference one more rounding on values up to 2 R
+        const float m0f = (float)(mx * cu[0] + my * cu[3] + mz * cu[6]), m2f = (float)(mx * cu[2] + my * cu[5] + mz * cu[8]);
+        const float e_vote = e_rot + 4.0f * u32 * R32;
         int votes = 0;                              // vx | vz << 16 (K <= n <= 8191)
         PCREG_MY_PTS32(
+            const float x0 = fmaf(az, f6, fmaf(ay, f3, ax * f0)), y0 = fmaf(az, g1z, fmaf(ay, g1y, ax * g1x)), z0 = fmaf(az, f8, fmaf(ay, f5, ax * f2));
             bool need = false;
             if (psel) {
-                const float x = ax - mxf, y = ay - myf, z = az - mzf;
-                const float vx = x * f0 + y * f3 + z * f6, vz = x * f2 + y * f5 + z * f8;
+                const float vx = x0 - m0f, vz = z0 - m2f;
                 if (fabsf(vx) > e_vote && fabsf(vz) > e_vote) votes += (vx > 0.0f ? 1 : 0) + (vz > 0.0f ? 1 << 16 : 0);
                 else need = true;
             }
             if (need) { const int qv = atomicAdd(&s_nvdef, 1); if (qv < kDef) s_vdef[qv] = i; }
-            const float x0 = ax * f0 + ay * f3 + az * f6, y0 = ax * g1x + ay * g1y + az * g1z, z0 = ax * f2 + ay * f5 + az * f8;
             bool safe; const int bb = bin_fast32(x0, y0, z0, safe);
             if (safe) { if (bb >= 0) atomicAdd(&s_cnt[bb], 1u); }
             else { const int q = atomicAdd(&s_ndef, 1); if (q < kDef) s_def[q] = i; })
@@ -880,7 +916,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     if (permuted) {
         // the deferred points: literally, in the final frame, into the bins of the UNPERMUTED histogram's image
         const int ndef = s_ndef;
-        unsigned* s_fin = reinterpret_cast<unsigned*>(&s_mask[0][0]);     // the collection's ballots are dead: 5 KiB >= 980 words
+        unsigned* s_fin = reinterpret_cast<unsigned*>(&s_mask[0][0]);     // the collection's ballots are dead: 6 KiB >= 980 words
         static_assert(sizeof(unsigned long long) * 4 * kMaskCap >= sizeof(unsigned) * ND, "s_fin aliases s_mask");
         for (int i = tid; i < ND; i += kBlock) {
             const int lr1 = i % NR, lt1 = (i / NR) % NT, lp1 = i / (NR * NT);
@@ -1001,6 +1037,8 @@ int launch_descriptors(const double* pts, int P, int ld, const double* kp, int S
     PCREG_HIP(hipMemsetAsync(V_dev, 0, sizeof(int32_t), st));
     PCREG_HIP(hipMemsetAsync(err_dev, 0, sizeof(int32_t), st));
     if (S == 0 || P == 0) return PCREG_OK;
+    // desc_kernel addresses the sorted cloud as scalar base + 32-bit byte offset (16 P bytes of float4 copies)
+    if (P >= (1 << 28)) { set_error("descriptors: clouds of 2^28 points or more are not supported (got %d)", P); return PCREG_E_ARG; }
     size_t need = descriptors_workspace_bytes(P, S);
     if (ws_bytes < need) { set_error("descriptor workspace too small: %zu < %zu", ws_bytes, need); return PCREG_E_WORKSPACE; }
     size_t p = (size_t)P, s = (size_t)S;

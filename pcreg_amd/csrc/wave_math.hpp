@@ -20,8 +20,9 @@ namespace pcreg {
 template <int CTRL>
 __device__ __forceinline__ double dpp_partner_f64(double v) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // every lane of these permutations has a source lane: no `old` operand, so no register copy in front of the v_mov_b32_dpp
+    const int lo2 = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    const int hi2 = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi2, lo2);
 }
 
@@ -61,10 +62,10 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
 }
 
 __device__ __forceinline__ int wave_sum_dpp_i(int v) {
-    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
            __builtin_amdgcn_readlane(v, 48);
 }

@@ -18,7 +18,9 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT" \
            "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+           "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
+           "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" \
+           "SQ_IFETCH SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d "$OUT/g$i" -o p -- python3 "$ROOT/$1" "${@:2}" > "$OUT/g$i.log" 2>&1 || echo "group $i failed (see $OUT/g$i.log): $grp"
 done
