@@ -133,8 +133,9 @@ __global__ __launch_bounds__(NT, NT == 128 ? 2 : (NT == 256 && PT > 8 ? 3 : (NT 
     for (int i = tid; i < 256; i += NT) s_hist[i] = 0;
     if (tid == 0) { s_nsmall = 0; s_vk = 0ull; s_nless = 0; s_neq = 0; }
     __syncthreads();
-    const double dlo = wave_min_dpp(lane < NW ? __longlong_as_double((long long)s_u64[lane]) : DBL_MAX);
-    const double dhi = wave_max_dpp(lane < NW ? __longlong_as_double((long long)s_u64[NW + lane]) : 0.0);
+    double dlo = __longlong_as_double((long long)s_u64[0]), dhi = __longlong_as_double((long long)s_u64[NW]);     // broadcast reads
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { dlo = fmin(dlo, __longlong_as_double((long long)s_u64[w])); dhi = fmax(dhi, __longlong_as_double((long long)s_u64[NW + w])); }
     const unsigned long long lo = kth_key(dlo), hi = kth_key(dhi);
     const double scale = dhi > dlo ? 256.0 / (dhi - dlo) : 0.0;
     auto bin_of = [&](double d) -> int { const int bb = (int)((d - dlo) * scale); return bb > 255 ? 255 : bb; };
@@ -145,9 +146,7 @@ __global__ __launch_bounds__(NT, NT == 128 ? 2 : (NT == 256 && PT > 8 ? 3 : (NT 
         int c4[4], run = 0;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) { c4[q4] = s_hist[lane * 4 + q4]; run += c4[q4]; }
-        int incl = run;
-#pragma unroll
-        for (int ofs = 1; ofs < 64; ofs <<= 1) { const int t = __shfl_up(incl, ofs); if (lane >= ofs) incl += t; }
+        const int incl = wave_scan_incl_i(run);
         int before = incl - run, mybin = -1, mybelow = 0;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {

@@ -569,11 +569,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         unsigned long long kreg[32];
 #pragma unroll
         for (int t_ = 0; t_ < 32 / kD64; ++t_) {
-            if (t_ * kD64 * kBlock >= n) {             // block-uniform: the unrolled loop is sized for 8191 entries, a typical support holds half
-#pragma unroll
-                for (int u_ = 0; u_ < kD64; ++u_) kreg[t_ * kD64 + u_] = 0ull;
-                continue;
-            }
+            if (t_ * kD64 * kBlock >= n) continue;     // block-uniform: the unrolled loop is sized for 8191 entries, a typical support holds half (PCREG_MY_KEYS never reads the slots past n)
             double X_[kD64], Y_[kD64], Z_[kD64];
 #pragma unroll
             for (int u_ = 0; u_ < kD64; ++u_) {
@@ -605,16 +601,15 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
             return bb > 255 ? 255 : bb;
         };
         if (dbg_stop == 4) return;
-        PCREG_MY_KEYS(atomicAdd(&s_hist[bin_of(k)], 1);)
+        unsigned kb[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};         // the keys' bins, four to a register (the second look costs a bit-field extract)
+        PCREG_MY_KEYS(const int bb = bin_of(k); atomicAdd(&s_hist[bb], 1); kb[pr >> 2] |= (unsigned)bb << (8 * (pr & 3));)
         __syncthreads();
         if (dbg_stop == 5) return;
         if (wave == 0) {                             // the bin of the K-th and the number of entries below that bin
             int c4[4], run = 0;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) { c4[q4] = s_hist[lane * 4 + q4]; run += c4[q4]; }
-            int incl = run;
-#pragma unroll
-            for (int ofs = 1; ofs < 64; ofs <<= 1) { const int t = __shfl_up(incl, ofs); if (lane >= ofs) incl += t; }
+            const int incl = wave_scan_incl_i(run);
             int before = incl - run;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -624,7 +619,7 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         }
         __syncthreads();
         const int bstar = s_bin, below = s_below;
-        PCREG_MY_KEYS(if (bin_of(k) == bstar) { const int q = atomicAdd(&s_nsmall, 1); if (q < kSmall) s_small[q] = k; })
+        PCREG_MY_KEYS(if ((int)((kb[pr >> 2] >> (8 * (pr & 3))) & 255u) == bstar) { const int q = atomicAdd(&s_nsmall, 1); if (q < kSmall) s_small[q] = k; })
         __syncthreads();
         const int m = s_nsmall, Kp = K - below;
         unsigned long long vK;
@@ -918,12 +913,13 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         const int ndef = s_ndef;
         unsigned* s_fin = reinterpret_cast<unsigned*>(&s_mask[0][0]);     // the collection's ballots are dead: 6 KiB >= 980 words
         static_assert(sizeof(unsigned long long) * 4 * kMaskCap >= sizeof(unsigned) * ND, "s_fin aliases s_mask");
-        for (int i = tid; i < ND; i += kBlock) {
-            const int lr1 = i % NR, lt1 = (i / NR) % NT, lp1 = i / (NR * NT);
+        if (tid < NT * NP) {                         // one (theta, phi) run of NR radial bins per thread: no division per bin
+            const int lt1 = tid % NT, lp1 = tid / NT;
             const int st = zs < 0.0 ? NT - 1 - lt1 : lt1;
             int sp = lp1;
             if (xs * zs < 0.0) sp = lp1 == lp_pos - 1 ? lp_neg - 1 : (lp1 == lp_neg - 1 ? lp_pos - 1 : lp1);
-            s_fin[i] = s_cnt[lr1 + NR * st + NR * NT * sp];
+#pragma unroll
+            for (int lr1 = 0; lr1 < NR; ++lr1) s_fin[lr1 + NR * tid] = s_cnt[lr1 + NR * st + NR * NT * sp];
         }
         __syncthreads();
         for (int q = tid; q < ndef; q += kBlock) {
@@ -937,8 +933,11 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
         }
         __syncthreads();
         // ONE write of the finished row, in its final type (u16 rows: counts <= max_pts <= 65535)
-        if (rows_u16) { uint16_t* row = (uint16_t*)rows_out + (size_t)s * ND; for (int i = tid; i < ND; i += kBlock) row[i] = (uint16_t)s_fin[i]; }
-        else { uint32_t* row = (uint32_t*)rows_out + (size_t)s * ND; for (int i = tid; i < ND; i += kBlock) row[i] = s_fin[i]; }
+        if (rows_u16) {                              // two counts per 4-byte store (a row is 1960 bytes: 4-byte aligned)
+            static_assert(ND % 2 == 0, "u16 rows are written as pairs");
+            uint32_t* row = reinterpret_cast<uint32_t*>((uint16_t*)rows_out + (size_t)s * ND);
+            for (int i = tid; i < ND / 2; i += kBlock) row[i] = (s_fin[2 * i] & 0xFFFFu) | (s_fin[2 * i + 1] << 16);
+        } else { uint32_t* row = (uint32_t*)rows_out + (size_t)s * ND; for (int i = tid; i < ND; i += kBlock) row[i] = s_fin[i]; }
     } else {
         PCREG_MY_PTS(
             double x = px; double y = py; double z = pz;

@@ -70,6 +70,18 @@ __device__ __forceinline__ int wave_sum_dpp_i(int v) {
            __builtin_amdgcn_readlane(v, 48);
 }
 
+// inclusive prefix sum over the 64 lanes: four row_shr steps inside each row of 16, then row_bcast:15 / row_bcast:31 carry the
+// row totals (lanes without a source lane add the `old` operand, 0) -- six DPP adds instead of six ds_bpermute round trips
+__device__ __forceinline__ int wave_scan_incl_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 // a = {a00, a01, a02, a11, a12, a22} (in/out: the diagonal ends up in a[0], a[3], a[5]); V row-major 3 x 3, columns =
 // eigenvectors.  V may live in LDS: its addresses are compile-time constants here.
 __device__ __forceinline__ void jacobi_sym3(double (&a)[6], double* V) {

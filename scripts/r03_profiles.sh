@@ -17,6 +17,10 @@ bash scripts/prof_stats.sh r03_sweep 2 -- scripts/sweep_prof.py 2 > gpurun_out/r
 echo "== align counters"
 bash scripts/pmc_counters.sh r03_align align_points_knn_reg gpurun_out/r03_pmc_align.json -- scripts/align_dev_bench.py > gpurun_out/r03_align_counters.txt 2>&1 || exit 1
 bash scripts/pmc_traffic.sh r03_align gpurun_out/r03_pmc_align_traffic.json "" -- scripts/align_dev_bench.py > gpurun_out/r03_align_traffic.txt 2>&1 || exit 1
+echo "== descriptors at cfg 4 (1 M keypoints on a 1 M-point cloud): kernel stats, counters, traffic"
+bash scripts/prof_stats.sh r03_desc_1m 1 -m desc_kernel -- scripts/desc_dev_bench.py 1000000 1000000 > gpurun_out/r03_desc_1m_stats.txt 2>&1 || exit 1
+bash scripts/pmc_counters.sh r03_desc desc_kernel gpurun_out/r03_pmc_desc_kernel.json -- scripts/desc_dev_bench.py 1000000 1000000 > gpurun_out/r03_desc_counters.txt 2>&1 || exit 1
+bash scripts/pmc_traffic.sh r03_desc gpurun_out/r03_pmc_desc_traffic.json "" -- scripts/desc_dev_bench.py 1000000 1000000 > gpurun_out/r03_desc_traffic.txt 2>&1 || exit 1
 echo "== sweep bench"
 python scripts/sweep_bench.py > gpurun_out/r03_sweep_bench.json 2> gpurun_out/r03_sweep_bench.err || exit 1
 echo "== full bench line"
