@@ -1,6 +1,8 @@
 """Randomised parity sweeps of the certified paths against the exhaustive C oracle: whatever the
 geometry does to the seeding grid, the f16 split or the certificate, the answer must be the oracle's
 bits (unproven queries fall back to the exact kernels)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -27,6 +29,10 @@ def _cloud(rng, n, kind):
 
 
 KINDS = ["uniform", "blobs", "plane", "line", "offset", "tiny", "dupes"]
+
+
+# PCREG_FUZZ_SCALE=n runs n times as many seeds of the descriptor and AlignPoints_KNN fuzzers (a soak after kernel changes)
+_SCALE = max(1, int(os.environ.get("PCREG_FUZZ_SCALE", "1")))
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -73,7 +79,7 @@ def test_match_features_sad_fuzz(seed, oracle_c):
             np.testing.assert_array_equal(met, rm)
 
 
-@pytest.mark.parametrize("seed", range(3))
+@pytest.mark.parametrize("seed", range(3 * _SCALE))
 def test_align_points_knn_fuzz(seed, oracle_c):
     """Supports with heavy ties at the K-th distance (lattices, duplicates, shells), tiny and large sizes:
     the selection (histogram + exact rank, crowded-bin bisection, tie ranks) must pick the oracle's rows."""
@@ -108,12 +114,17 @@ def test_align_points_knn_fuzz(seed, oracle_c):
         cc = X.mean(0); K = int(np.floor(len(X) * 0.85 + 0.5))
         sub = X[np.argsort(np.linalg.norm(X - cc, axis=1), kind="stable")[:K]]
         ev = np.linalg.eigvalsh(np.cov((sub - sub.mean(0)).T)) if K > 1 else np.zeros(3)
+        # pca's sign convention (largest-magnitude entry of a column positive) is decided by rounding noise when a column's
+        # two largest entries are equal in magnitude (e.g. (1, 0, 1) / sqrt 2 on a symmetric 5-point support)
+        top2 = np.sort(np.abs(rco), axis=0)[-2:]
+        if np.min(top2[1] - top2[0]) < 1e-9:
+            continue
         if ev.min() > 1e-9 and np.min(np.diff(np.sort(ev))) > 1e-6 * ev.max():
             assert np.abs(co[b] - rco).max() < 1e-7, (b, len(X))
             assert np.abs(al[b] - ral).max() < 1e-6 * (1 + np.abs(X).max()), (b, len(X))
 
 
-@pytest.mark.parametrize("seed", range(2))
+@pytest.mark.parametrize("seed", range(2 * _SCALE))
 def test_descriptors_fuzz(seed, oracle_c):
     """Descriptor counts vs the oracle on clouds with duplicated points (ties at the K-th distance) and
     different densities / option sets."""
