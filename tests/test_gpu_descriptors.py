@@ -146,3 +146,22 @@ def test_k_nearest_boundary_where_square_roots_collide(oracle_c):
         assert len(rfeat) == 4
         np.testing.assert_array_equal(feat, rfeat)
         np.testing.assert_array_equal(desc, rdesc)
+
+
+def test_more_candidate_chunks_than_the_kept_ballots(oracle_c):
+    """Two far outliers stretch the bounding box, so the grid (at most 65 536 cells) is coarse and a keypoint's rows hold the
+    whole dense strip: more than 4 x 192 chunks of 64 candidates per keypoint -- the chunks past the ballots a wave keeps are
+    re-tested by the list pass -- and several flushes of the ballot registers before that."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(77)
+    n = 100000
+    x = rng.uniform(0, 150, n); y = rng.uniform(-1.2, 1.2, n); z = 10 + 0.05 * x + rng.normal(0, 0.2, n)
+    pts = np.vstack([np.column_stack([x, y, z]), [[30000.0, 20000.0, 15000.0], [-30000.0, -20000.0, -15000.0]]])
+    kx = rng.uniform(5, 145, 12)
+    kp = np.column_stack([kx, rng.uniform(-0.8, 0.8, 12), 10 + 0.05 * kx])
+    opt = dict(OPT, min_pts=100, max_pts=8000)
+    feat, desc = pc.getSpacialHistogramDescriptors(pts, kp, opt)
+    rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(pts, kp, opt)
+    assert len(rfeat) >= 6 and rdesc.sum(axis=1).max() < 8000          # supports fit the list; the CANDIDATES are the 100 000
+    np.testing.assert_array_equal(feat, rfeat)
+    np.testing.assert_array_equal(desc, rdesc)
