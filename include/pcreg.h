@@ -204,7 +204,10 @@ typedef struct pcreg_desc_opts {
  * sample_pts: S x 3 (column-major).  Outputs are ROW-major with capacity S rows:
  * feat [V][3], desc [V][980] (counts, r fastest / then theta / then phi, i.e. MATLAB's
  * reshape(counts,[],1)); *V = number of surviving keypoints, in input order.
- * The O(S*P) brute-force radius search of the reference is replaced by a uniform grid. */
+ * The O(S*P) brute-force radius search of the reference is replaced by a uniform grid.
+ * Limits: a support of more than 8191 points (possible only with options.max_pts > 8190;
+ * it lives in LDS) and a cloud of 2^28 points or more (the kernel addresses the sorted
+ * cloud with 32-bit byte offsets) are refused with PCREG_E_ARG. */
 int pcreg_spatial_histogram_descriptors(const double* pts, int P, int ld, const double* sample_pts, int S, int lds,
                                         const pcreg_desc_opts* options, double* feat, double* desc, int* V);
 
