@@ -45,6 +45,7 @@ class SphereSweep:
         self._n = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._ws_sel = torch.empty(max(L.pcreg_dev_sphere_select_workspace(self.VM), 256), dtype=torch.uint8, device=self.dev)
         self._featM_host = None
+        self._centres = {}
 
     def release(self) -> None:
         """Drop the cached workspaces (the segmented chain's ~1.4 GB, the batched ransac's, the per-stream pipelines of
@@ -58,9 +59,15 @@ class SphereSweep:
 
     # -- :49-50
     def sphere_centres(self, d_spheres: float = 5.0) -> np.ndarray:
-        if self._featM_host is None:
-            self._featM_host = self.featM.cpu().numpy()
-        return pcUniformSamples(self._featM_host, d_spheres)
+        """The model is fixed for the life of this object (one model, many surfaces: completeExperimentFast.m's shape), so its
+        candidate centres are computed once per spacing (the bounding box of 60 000 keypoints + the mesh: ~2 ms of host time
+        that a 19-ms sweep would otherwise spend with the GPU idle)."""
+        key = float(d_spheres)
+        if key not in self._centres:
+            if self._featM_host is None:
+                self._featM_host = self.featM.cpu().numpy()
+            self._centres[key] = pcUniformSamples(self._featM_host, d_spheres)
+        return self._centres[key].copy()
 
     # -- :52-64
     def valid_spheres(self, centres: np.ndarray, R_desc: float, min_pts: int = 1400, max_pts: float = float("inf")):
@@ -155,8 +162,11 @@ class SphereSweep:
         if tot >= 2**31:
             raise ValueError("sphere sweep: more than 2^31 rows over all spheres")
         VS, sp = self.VS, _stream()
+        # every host-to-device copy before the first launch: a pageable copy waits for the stream's earlier work, and one placed
+        # after the matching chain would hold back the launches behind it until that chain has run
         seg_off = torch.from_numpy(row_off.astype(np.int32)).to(dev)
         cen = torch.from_numpy(np.ascontiguousarray(centres, dtype=np.float64)).to(dev)
+        roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
         rows_all = torch.empty(tot, dtype=i32, device=dev)
         feat_all = torch.empty((tot, 3), dtype=f64, device=dev)
         n_sel = torch.zeros(S, dtype=i32, device=dev)
@@ -170,9 +180,9 @@ class SphereSweep:
             self._seg_ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
         check(L.pcreg_dev_get_matches_segmented(_p(self.descS), VS, _p(self.descM), self.VM, self.D, _p(rows_all), _p(seg_off), S, tot, n_max,
                                                 C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws), C.c_size_t(self._seg_ws.numel()), sp))   # :131-149
-        return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed)
+        return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev)
 
-    def _finish_sweep(self, centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed) -> dict:
+    def _finish_sweep(self, centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev=None) -> dict:
         """:166-224 on the current stream + the sweep's second (last) host synchronisation."""
         from ._lib import DevRansacResult
         L = lib()
@@ -185,7 +195,8 @@ class SphereSweep:
         check(L.pcreg_dev_sweep_plan(_p(n_pairs), S, int(putative_thresh), _p(trial_idx), _p(offsets), _p(n_trials), sp))
         ld = S * max(self.VS, 1)                                    # capacity of the packed correspondences (Unique: <= VS pairs per sphere)
         p1 = torch.zeros((3, ld), dtype=f64, device=dev); p2 = torch.zeros((3, ld), dtype=f64, device=dev)
-        roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
+        if roff_dev is None:
+            roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
         check(L.pcreg_dev_sweep_gather(_p(pairs_all), self.VS, _p(n_pairs), _p(trial_idx), _p(offsets), _p(n_trials), S, _p(self.featS),
                                        _p(feat_all), _p(roff_dev), _p(p1), _p(p2), ld, sp))
         o = RansacOpts(int(options["minPtNum"]), int(options["iterNum"]), float(options["thDist"]), float(options["thInlrRatio"]),
@@ -203,7 +214,8 @@ class SphereSweep:
         nt = int(n_trials.item())
         trial = trial_idx[:nt].cpu().numpy().astype(np.int64)
         raw = results[:max(nt, 1)].cpu().numpy()
-        pairs_host = pairs_all.cpu().numpy()
+        m_pairs = max(int(npr.max()) if S else 0, 1)                # only the columns that hold pairs cross the bus
+        pairs_host = pairs_all[:, :m_pairs].contiguous().cpu().numpy().astype(np.uint32)     # one conversion; the per-sphere lists are views of it
         rows_host = rows_all.cpu().numpy().astype(np.int64)
         nsel = n_sel.cpu().numpy()
         assert np.array_equal(nsel, num_desc), "sphere_select disagrees with sphere_counts"
@@ -215,7 +227,7 @@ class SphereSweep:
             sr.append(100.0 * r.max_inliers / P if not r.failed else 0.0)
             tf.append(None if r.failed else np.array(r.T[:]).reshape(4, 4, order="F"))
         return dict(centres=centres, num_desc=num_desc, num_putative=npr,
-                    matches=[pairs_host[i, :npr[i]].astype(np.uint32) for i in range(S)],
+                    matches=[pairs_host[i, :npr[i]] for i in range(S)],
                     model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)], trial=trial,
                     statsPutative=np.array(sp_, dtype=np.int64), statsSuccess=np.array(ss, dtype=np.int64),
                     statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
