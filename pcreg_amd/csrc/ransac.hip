@@ -54,6 +54,35 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// wave_sum of 27 values at once, the same bits as 27 calls.  wave_sum's butterfly adds lane l and lane l ^ o for o = 32, 16, ..., 1;
+// after every step the two partners hold the same bits (fp addition commutes), so only ONE of them needs to go on with a given
+// value: at distance 32 the lower half-wave keeps values 0-13 and the upper one 14-26, each sending the other its remaining
+// half, and so on down -- 14 + 7 + 4 + 2 + 1 + 1 = 29 exchanged doubles instead of 27 x 6 = 162.  Value k ends in the lanes whose
+// bits 5..1 spell its path (k = 14 b5 + 7 b4 + 4 b3 + 2 b2 + b1) and is broadcast from there with v_readlane.
+__device__ __forceinline__ void wave_sum27(double (&v)[27]) {
+    const int lane = threadIdx.x & 63;
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    double k1[14], k2[8], k3[4], k4[2];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const double hi = 14 + j < 27 ? v[14 + j < 27 ? 14 + j : 26] : 0.0;
+        k1[j] = (b5 ? hi : v[j]) + __shfl_xor(b5 ? v[j] : hi, 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) k2[j] = (b4 ? k1[7 + j] : k1[j]) + __shfl_xor(b4 ? k1[j] : k1[7 + j], 16);
+    k2[7] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k3[j] = (b3 ? k2[4 + j] : k2[j]) + __shfl_xor(b3 ? k2[j] : k2[4 + j], 8);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) k4[j] = (b2 ? k3[2 + j] : k3[j]) + __shfl_xor(b2 ? k3[j] : k3[2 + j], 4);
+    double k5 = (b1 ? k4[1] : k4[0]) + __shfl_xor(b1 ? k4[0] : k4[1], 2);
+    k5 += __shfl_xor(k5, 1);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const int c5 = k >= 14, r5 = k - 14 * c5, c4 = r5 >= 7, r4 = r5 - 7 * c4, c3 = r4 >= 4, r3 = r4 - 4 * c3, c2 = r3 >= 2, c1 = r3 - 2 * c2;
+        v[k] = rdlane(k5, 32 * c5 + 16 * c4 + 8 * c3 + 4 * c2 + 2 * c1);
+    }
+}
 __device__ __forceinline__ double ulp_at(double x) {   // MATLAB eps(x)
     x = fabs(x);
     return __longlong_as_double(__double_as_longlong(x) + 1) - x;
@@ -595,11 +624,9 @@ __device__ __forceinline__ void ransac_hyp_body(const RansacArgs& a, double* __r
             double q[6]; P.load(act ? i : n - 1, q);
             if (act && sqdist(q, T) < a.thDist) mom_accumulate(acc, q, o);
         }
+        wave_sum27(acc);
 #pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            double tot = wave_sum(acc[k]);
-            if (lane == h) mom[k] = tot;
-        }
+        for (int k = 0; k < 27; ++k) if (lane == h) mom[k] = acc[k];
     }
 
     // ---- phase 3: refit, one hypothesis per lane (estimateTransform on the inliers)
@@ -836,11 +863,9 @@ __global__ __launch_bounds__(kTBlock) void ransac_hyp_tiled_kernel(RansacArgs a)
                 }
             PCREG_TILE_SWEEP_END
             if (want && ch != 3) {
+                wave_sum27(acc);
 #pragma unroll
-                for (int e = 0; e < 27; ++e) {
-                    double tot = wave_sum(acc[e]);
-                    if (lane == 0) s_mom[wave][k][e] = tot;
-                }
+                for (int e = 0; e < 27; ++e) if (lane == 0) s_mom[wave][k][e] = acc[e];
             }
         }
         // s_mom was written by this wave only (after the sweep's last barrier)
@@ -1473,11 +1498,9 @@ __global__ __launch_bounds__(kTBlock) void rs_moments_kernel(StagedArgs sa) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (want[k] && ch[k] != 3) {
+                wave_sum27(acc[k]);
 #pragma unroll
-                for (int e = 0; e < 27; ++e) {
-                    double tot = wave_sum(acc[k][e]);
-                    if (lane == 0) sa.mom[(size_t)(wbase + hs[k]) * 27 + e] = tot;
-                }
+                for (int e = 0; e < 27; ++e) if (lane == 0) sa.mom[(size_t)(wbase + hs[k]) * 27 + e] = acc[k][e];
             }
         }
     }
@@ -1978,8 +2001,9 @@ __global__ __launch_bounds__(64) void estimate_transform_kernel(const double* p1
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc[k] = 0.0;
         for (int i = lane; i < n; i += 64) { double q[6]; P.load(i, q); mom_accumulate(acc, q, o); }
+        wave_sum27(acc);
 #pragma unroll
-        for (int k = 0; k < 27; ++k) mom[k] = wave_sum(acc[k]);
+        for (int k = 0; k < 27; ++k) mom[k] = acc[k];
         // rank(pts1) >= 3 and rank(pts2) >= 2 (estimateTransform.m:11): from the Grams where they can tell, from the points
         // themselves (one more pass along the deciding eigenvector) where the Gram's noise floor hides the answer
         const double g1[6] = {mom[15], mom[16], mom[17], mom[18], mom[19], mom[20]};
@@ -2060,8 +2084,9 @@ __global__ __launch_bounds__(64) void refine_by_distance_kernel(const double* p1
             ok = fit_3pt(A1, A2, T);
         } else if (cnt > 3) {
             double mom[27];
+            wave_sum27(acc);
 #pragma unroll
-            for (int k = 0; k < 27; ++k) mom[k] = wave_sum(acc[k]);
+            for (int k = 0; k < 27; ++k) mom[k] = acc[k];
             ok = fit_moments(cnt, mom, o, T);
         }
     }
