@@ -541,12 +541,27 @@ __global__ void sad_fallback_finish_kernel(const int32_t* __restrict__ list, con
 // the rounding already costs, so the certificate is as strong as the one-segment path's.
 struct SegConst { double cc, fmin, scale, inv_scale, rho; unsigned eunits, slack2; };
 
-constexpr int kPR = 64, kPF = 48;
+#ifndef PCREG_SEG_PR
+#define PCREG_SEG_PR 64
+#endif
+#ifndef PCREG_SEG_PF
+#define PCREG_SEG_PF 48
+#endif
+constexpr int kPR = PCREG_SEG_PR, kPF = PCREG_SEG_PF;
 // src row-major [n][D] -> P row-major, l1, s2, min / max of P per row (one lane per row keeps the oracle's order)
 __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restrict__ src, int n, int D, int change_metric, double factor,
                                                            double* __restrict__ P, double* __restrict__ l1, double* __restrict__ s2,
                                                            double* __restrict__ pmin, double* __restrict__ pmax, double* __restrict__ sp) {
     __shared__ double t_raw[kPF][kPR + 1], t_p[kPF][kPR + 1];
+    // The descriptors are COUNTS (getSpacialHistogramDescriptors: integers, a few units per bin): their powers come from a table
+    // of this very pow -- same bits -- that each workgroup fills first (kPowTab fp64 pow calls against the 62 720 of its rows);
+    // anything that is not a small integer takes pow itself.
+    constexpr int kPowTab = 512;
+    __shared__ double s_pow[kPowTab];
+    if (change_metric) {
+        for (int e = threadIdx.x; e < kPowTab; e += kBlock) s_pow[e] = pow((double)e, factor);
+        __syncthreads();
+    }
     const int r0 = blockIdx.x * kPR, rows = min(kPR, n - r0);
     double a = 0.0, s = 0.0, lo = INFINITY, hi = -INFINITY, ap = 0.0;
     for (int d0 = 0; d0 < D; d0 += kPF) {
@@ -556,7 +571,10 @@ __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restr
             double x = 0.0, pv = 0.0;
             if (r < rows && f < dn) {
                 x = src[(size_t)(r0 + r) * D + d0 + f];
-                pv = change_metric ? pow(x, factor) : x;
+                if (change_metric) {
+                    const int xi = (x >= 0.0 && x < (double)kPowTab) ? (int)x : -1;
+                    pv = (xi >= 0 && (double)xi == x) ? s_pow[xi] : pow(x, factor);
+                } else pv = x;
                 P[(size_t)(r0 + r) * D + d0 + f] = pv;
             }
             t_raw[f][r] = x; t_p[f][r] = pv;
