@@ -864,7 +864,7 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
                                                                const uint32_t* __restrict__ part_s, int splits,
                                                                int32_t* __restrict__ idx, double* __restrict__ dist,
                                                                int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven,
-                                                               int32_t* __restrict__ dbg_hist) {
+                                                               double match_thr, double max_ratio, int32_t* __restrict__ dbg_hist) {
     __shared__ double s_t[kBlock / 64][kNC][kFT];
     __shared__ int s_j[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -894,6 +894,23 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
         unsigned n1 = min(a1, b1), n2 = min(max(a1, b1), min(a2, b2));
         a1 = n1; a2 = n2;
         g = min(g, (unsigned)__shfl_xor((int)g, o));
+    }
+    // A query that cannot pass filter_keep needs no exact sums.  Every row's exact distance lies within
+    // [rho (s - (D + 1)) - E, rho (s + (D + 1)) + E] / scale of its reference score s, so with the two smallest scores a1 <= a2:
+    // d1 >= lower(a1) and d2 <= upper(a2) (two rows at least are that close).  No pair if lower(a1) > thr (d1 <= thr fails) or if
+    // lower(a1) / upper(a2) > maxRatio (the ratio test fails: most queries of a sphere that does not hold their partner -- their
+    // nearest and second-nearest rows are random neighbours a fraction of a percent apart).
+    if (!BACK && !force_unproven && a1 != 0xFFFFFFFFu) {
+        const double lower1 = (c.rho * ((double)a1 - (double)(D + 1)) - (double)c.eunits) * c.inv_scale * (1.0 - 1e-12);
+        bool none = lower1 > match_thr;
+        if (!none && a2 != 0xFFFFFFFFu && S.seg_off[z + 1] - S.seg_off[z] > 1) {
+            const double upper2 = (c.rho * ((double)a2 + (double)(D + 1)) + (double)c.eunits) * c.inv_scale * (1.0 + 1e-12);
+            none = upper2 >= 1e-6 && lower1 > max_ratio * upper2 * (1.0 + 1e-12);
+        }
+        if (none) {                                                                 // wave-uniform
+            if (lane == 0) { idx[(size_t)qi * 2] = -1; idx[(size_t)qi * 2 + 1] = -1; dist[(size_t)qi * 2] = INFINITY; dist[(size_t)qi * 2 + 1] = INFINITY; }
+            return;
+        }
     }
     // the scores were taken under the reference constant: this segment's true distances lie within E_i (c.eunits) of rho_i times them
     const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
@@ -1488,7 +1505,7 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     if (pcreg_env_int("PCREG_SEG_DEBUG", 0)) { PCREG_HIP(hipMalloc((void**)&dbg_hist, 2 * 130 * sizeof(int32_t))); PCREG_HIP(hipMemsetAsync(dbg_hist, 0, 2 * 130 * sizeof(int32_t), st)); }
 #endif
     hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, dbg_hist);
+                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, dbg_hist);
     const int slice_f = (n_max + kSegFbSlices - 1) / kSegFbSlices;
     PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
     hipLaunchKernelGGL(segp_refine_kernel<false>, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const uint32_t*)Sc, L.ldqa,
