@@ -1098,6 +1098,12 @@ __global__ __launch_bounds__(kBlock) void segp_back_direct_kernel(SegSets S, con
             n_need += cnt;
         }
         if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = k; } continue; }
+        // q itself always passes (smax bounds its own score from above, and it was not rejected against bmax); every row left out
+        // is STRICTLY farther than d(q, m).  If q is alone, it is the best surface row of m: nothing to sum.
+        if (n_need == 1) {
+            if (lane == 0) { bidx[(size_t)k * 2] = qi; bidx[(size_t)k * 2 + 1] = -1; bdist[(size_t)k * 2] = dq; bdist[(size_t)k * 2 + 1] = INFINITY; }
+            continue;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         double d1, d2; int i1, i2;
         seg_rerank<true>(V, seg_model_row(V, jm), s_j[wave], n_need, D, s_t[wave], d1, i1, d2, i2);
