@@ -363,10 +363,12 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
     constexpr int kRowsMax = 25;
     __shared__ int s_rowb[kRowsMax], s_rowe[kRowsMax], s_cp[kRowsMax + 1], s_wtot[4];
     const int nyo = g.fy, nzo = g.fz, wy = 2 * nyo + 1, nrows = wy * (2 * nzo + 1);
-    if (tid < nrows) {
+    static_assert(kRowsMax < 64, "the rows of a keypoint are resolved by the lanes of wave 0");
+    if (wave == 0) {
+        int b = 0, e = 0;
+        if (tid < nrows) {
         const int ky = cell_coord(cy, g.oy, g.invy, g.ny), kz = cell_coord(cz, g.oz, g.invz, g.nz);
         const int zz = kz + tid / wy - nzo, yy = ky + tid % wy - nyo;
-        int b = 0, e = 0;
         // a keypoint outside the cloud's box by more than R has no neighbours: all its rows are then farther than R
         if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny) {
             // the row's slab in y and z keeps every point at least (gy, gz) away from the keypoint: what is left of R^2
@@ -385,13 +387,13 @@ __global__ __launch_bounds__(kBlock, 4) void desc_kernel(
                 b = cell_start[(zz * g.ny + yy) * g.nx + x0]; e = cell_start[(zz * g.ny + yy) * g.nx + x1 + 1];   // x-adjacent cells are contiguous
             }
         }
-        s_rowb[tid] = b; s_rowe[tid] = e;
-    }
-    __syncthreads();
-    if (tid == 0) {                                  // chunk prefix over the rows
-        int run = 0;
-        for (int r = 0; r < nrows; ++r) { s_cp[r] = run; run += (s_rowe[r] - s_rowb[r] + 63) >> 6; }
-        s_cp[nrows] = run;
+        }
+        // chunk prefix over the rows: one DPP scan over wave 0's lanes (a serial loop by one thread cost ~50 dependent LDS round
+        // trips at the start of every keypoint)
+        const int cnt = (e - b + 63) >> 6;              // 0 for the lanes past nrows
+        const int incl = wave_scan_incl_i(cnt);
+        if (tid < nrows) { s_rowb[tid] = b; s_rowe[tid] = e; s_cp[tid] = incl - cnt; }
+        if (tid == 63) s_cp[nrows] = incl;
     }
     __syncthreads();
     const int n_chunks = __builtin_amdgcn_readfirstlane(s_cp[nrows]);
