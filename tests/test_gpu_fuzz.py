@@ -31,11 +31,11 @@ def _cloud(rng, n, kind):
 KINDS = ["uniform", "blobs", "plane", "line", "offset", "tiny", "dupes"]
 
 
-# PCREG_FUZZ_SCALE=n runs n times as many seeds of the descriptor and AlignPoints_KNN fuzzers (a soak after kernel changes)
+# PCREG_FUZZ_SCALE=n runs n times as many seeds of every fuzzer (a soak after kernel changes)
 _SCALE = max(1, int(os.environ.get("PCREG_FUZZ_SCALE", "1")))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * _SCALE))
 def test_knn2_fuzz(seed, oracle_c):
     import pcreg_amd as pc
     rng = np.random.default_rng(1000 + seed)
@@ -56,7 +56,7 @@ def test_knn2_fuzz(seed, oracle_c):
         np.testing.assert_array_equal(dist, rdist, err_msg=f"{kind} {src} Q={Q} M={M}")
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(4 * _SCALE))
 def test_match_features_sad_fuzz(seed, oracle_c):
     """Descriptor matching: counts, constants, duplicates, heavy ties, tiny D, Q > M and Q < M."""
     import pcreg_amd as pc
