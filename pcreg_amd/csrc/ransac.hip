@@ -521,6 +521,8 @@ __device__ __forceinline__ void ransac_hyp_body(const RansacArgs& a, double* __r
     }
     double o[6];
     P.load(0, o);   // fixed origin for the refit moments
+#pragma unroll
+    for (int c = 0; c < 6; ++c) o[c] = rdlane(o[c], 0);     // the same six numbers in every lane: SGPRs, not 12 of the kernel's 177 VGPRs
 
     // ---- phase 0: minimal-sample fit, one hypothesis per lane (ransac.m:42-45)
     double T1[12];
