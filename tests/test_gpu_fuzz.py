@@ -141,3 +141,28 @@ def test_descriptors_fuzz(seed, oracle_c):
         rfeat, rdesc = oracle_c.getSpacialHistogramDescriptors(pts, kp, opt)
         np.testing.assert_array_equal(feat, rfeat)
         np.testing.assert_array_equal(desc, rdesc)
+
+
+@pytest.mark.parametrize("seed", range(3 * _SCALE))
+def test_ransac_fuzz(seed, oracle_c):
+    """Random sizes, outlier shares, iteration counts and thresholds: per-iteration counts, numSuccess, maxInliers and the inlier set
+    are the oracle's bits whatever kernel the size selects (LDS-resident, tiled or staged) and however many hypotheses refit."""
+    import pcreg_amd as pc
+    from conftest import rigid_case
+    from test_gpu_ransac import _cmp
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(4):
+        n = int(rng.choice([12, 40, 150, 600, 1300, 1400, 2500, 4200, 6000]))
+        iters = int(rng.integers(60, 900))
+        frac = float(rng.choice([0.0, 0.2, 0.5, 0.8]))
+        refine = bool(rng.random() < 0.8)
+        p1, p2, _ = rigid_case(n, int(rng.integers(0, 10 ** 6)), noise=float(rng.choice([0.005, 0.02, 0.05])), outlier_frac=frac)
+        coef = dict(minPtNum=3, iterNum=iters, thDist=float(rng.choice([0.01, 0.05, 0.3])), thInlrRatio=float(rng.choice([0.05, 0.1, 0.3])),
+                    REFINE=refine, VERBOSE=0)
+        ref = oracle_c.ransac(p1, p2, coef, seed=seed)
+        if ref["failed"]:
+            T = pc.ransac(p1, p2, coef, pc.estimateTransform, pc.calcDists, seed=seed)[0]
+            assert T is None or np.size(T) == 0
+            continue
+        res = pc.ransac(p1, p2, coef, pc.estimateTransform, pc.calcDists, seed=seed, return_iter_counts=True)
+        _cmp(res, ref, n)
