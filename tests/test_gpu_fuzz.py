@@ -166,3 +166,34 @@ def test_ransac_fuzz(seed, oracle_c):
             continue
         res = pc.ransac(p1, p2, coef, pc.estimateTransform, pc.calcDists, seed=seed, return_iter_counts=True)
         _cmp(res, ref, n)
+
+
+@pytest.mark.parametrize("seed", range(2 * _SCALE))
+def test_segmented_get_matches_fuzz(seed):
+    """Random segment structures and matchFeatures settings: the segmented chain (shared scores, per-segment certificates, the
+    queries skipped on the strength of their score bounds, the Unique back-check's shortcuts) gives the pairs of one getMatches
+    call per segment."""
+    import pcreg_amd as pc
+    from test_gpu_sweep import PAR, _segments_direct
+    rng = np.random.default_rng(6000 + seed)
+    for _ in range(3):
+        VM, Q, D = int(rng.integers(200, 2500)), int(rng.integers(40, 500)), int(rng.choice([6, 24, 64, 160]))
+        lam = float(rng.choice([0.5, 3.0, 12.0]))
+        descM = rng.poisson(lam, (VM, D)).astype(np.float64)
+        pick = rng.choice(VM, Q, replace=Q > VM)
+        descS = descM[pick] + rng.poisson(float(rng.choice([0.05, 0.3, 1.0])), (Q, D))
+        if rng.random() < 0.5:
+            descS[rng.integers(0, Q)] = descS[rng.integers(0, Q)]          # duplicate surface rows: Unique ties
+        rows_list = []
+        for _s in range(int(rng.integers(2, 7))):
+            k = int(rng.choice([0, 1, 2, 5, VM // 7, VM // 2, VM]))
+            rows_list.append(np.sort(rng.choice(VM, k, replace=False)) if k else np.zeros(0, np.int64))
+        par = dict(PAR, Unique=bool(rng.random() < 0.7), MaxRatio=float(rng.choice([0.6, 0.9, 0.99, 1.0])),
+                   MatchThreshold=float(rng.choice([1.0, 5.0, 10.0, 40.0, 100.0])), UNNORMALIZE=bool(rng.random() < 0.8),
+                   CHANGE_METRIC=bool(rng.random() < 0.8))
+        got = _segments_direct(descS, descM, rows_list, par, metric=True)
+        for z, r in enumerate(rows_list):
+            if len(r) == 0:
+                assert got[z][0].shape[0] == 0
+                continue
+            np.testing.assert_array_equal(got[z][0], pc.getMatches(descS, descM[r], par), err_msg=f"seed {seed}, segment {z}, {par}")
