@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = 4;
-constexpr int HB = 2;   // hypotheses sharing one pass over the points
+constexpr int HB = 4;   // hypotheses sharing one pass over the points (2 until round 3: 4 halves the LDS reads per score, +4 % on batched cfg 1)
 
 struct RansacArgs {
     const double* p1; const double* p2; int ld;
