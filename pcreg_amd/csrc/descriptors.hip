@@ -35,7 +35,7 @@ namespace {
 #define PCREG_DESC_DC 8
 #endif
 #ifndef PCREG_DESC_D64
-#define PCREG_DESC_D64 4
+#define PCREG_DESC_D64 2
 #endif
 #ifndef PCREG_DESC_D32
 #define PCREG_DESC_D32 8
