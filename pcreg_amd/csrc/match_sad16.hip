@@ -1493,7 +1493,7 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     hipLaunchKernelGGL(segp_quantize_ref_kernel, dim3(L.ldqb / 64, L.D2p / 32), dim3(kBlock), 0, st, PM, nrefM, VM, D, Dp, sc + S, L.D2p, L.ldqb, Bq);
     {
         const int n_tiles = (Q + BQ - 1) / BQ, row_tiles = (VM + BM - 1) / BM;
-        const int sm = std::max(1, std::min(row_tiles, 1536 / std::max(n_tiles, 1)));          // ~2 rounds of resident workgroups
+        const int sm = std::max(1, std::min(row_tiles, 6144 / std::max(n_tiles, 1)));          // ~8 rounds of resident workgroups (measured: 2 rounds 2.38 ms, 4: 2.28, 8: 2.24, 16: 2.22)
         const int ct = (row_tiles + sm - 1) / sm, s_eff = (row_tiles + ct - 1) / ct;
         hipLaunchKernelGGL(sad16_candidates_kernel<kSadMatrix>, dim3(n_tiles, s_eff), dim3(kBlock), 0, st, Aq, Q, L.ldqa, Bq, VM, L.ldqb, L.D2p, ct * BM,
                            (int32_t*)nullptr, (uint32_t*)nullptr, (unsigned long long*)nullptr, (const int32_t*)nullptr, SegZ{0, 0, 0, 0, nullptr, Sc, L.ldqa});
