@@ -41,6 +41,8 @@ struct RansacArgs {
     double* TF;                 // [B*iters][12]
     int32_t* cnt1; int32_t* cnt2; unsigned char* has;
     int n_hi;                   // ransac_hyp_kernel: registrations of up to n_hi correspondences fit the launch's dynamic LDS
+    int n_lo;                   // this launch serves registrations of n_lo < n (<= n_hi from LDS) correspondences
+    double* msc;                // ransac_hyp32_kernel: [B*iters][16] the fifteen refit sums of a hypothesis
 };
 
 // ---------------------------------------------------------------- lane utilities
@@ -494,15 +496,15 @@ __device__ __forceinline__ void sample3(const RansacArgs& a, int b, int p, int n
 }
 
 // ---------------------------------------------------------------- hypothesis kernel
-template <bool LDS_PTS>
+template <bool LDS_PTS, int NW = kWavesPerBlock>
 __device__ __forceinline__ void ransac_hyp_body(const RansacArgs& a, double* __restrict__ sp, const int b, const int off, const int n) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t hyp0 = (size_t)b * a.iters;
-    const int wbase = (blockIdx.x * kWavesPerBlock + wave) * a.hpw;   // first hypothesis of this wave
+    const int wbase = (blockIdx.x * NW + wave) * a.hpw;   // first hypothesis of this wave
     const double* g1 = a.p1 + off; const double* g2 = a.p2 + off;
 
     if (LDS_PTS) {
-        for (int i = threadIdx.x; i < n; i += kBlock) {
+        for (int i = threadIdx.x; i < n; i += NW * 64) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) { sp[c * n + i] = g1[i + (size_t)c * a.ld]; sp[(3 + c) * n + i] = g2[i + (size_t)c * a.ld]; }
         }
@@ -684,6 +686,7 @@ __global__ __launch_bounds__(kBlock) void ransac_hyp_kernel(RansacArgs a) {
     const int off = a.offsets ? a.offsets[b] : 0;
     int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
     n = min(n, a.n_cap);
+    if (n <= a.n_lo) return;                                    // ransac_hyp32_kernel serves it
     if (n <= a.n_hi) ransac_hyp_body<true>(a, sp, b, off, n);
     else ransac_hyp_body<false>(a, sp, b, off, n);
 }
@@ -1259,7 +1262,7 @@ __global__ __launch_bounds__(kSW * 64) void rs_score_kernel(StagedArgs sa, const
 // the fp64 sqdist on the raw coordinates -- so every count and every mask is the fp64 one.  E > thDist / 2 or a
 // non-finite E sends everything to fp64.
 __device__ __forceinline__ void make_t32(const double (&T)[12], const double (&o)[6], double A, double B, double th,
-                                         float* __restrict__ out /*16*/) {
+                                         float* __restrict__ out /*16*/, const bool resident = false /* sqdist32r's operation order */) {
     const double u = 5.9604644775390625e-08;
     double rho = 0.0, tau = 0.0;
 #pragma unroll
@@ -1270,7 +1273,7 @@ __device__ __forceinline__ void make_t32(const double (&T)[12], const double (&o
         out[r * 3] = (float)T[r * 4]; out[r * 3 + 1] = (float)T[r * 4 + 1]; out[r * 3 + 2] = (float)T[r * 4 + 2];
         out[9 + r] = (float)tp;
     }
-    const double e1 = u * (A + 5.1 * (B * rho + tau));
+    const double e1 = resident ? 6.1 * u * (A + B * rho + tau) : u * (A + 5.1 * (B * rho + tau));
     const double E = 1.5 * (2.0 * 1.7320508075688774 * sqrt(4.0 * th) * e1 + 3.0 * e1 * e1 + 5.2 * u * 4.0 * th);
     float lo = -INFINITY, hi = INFINITY;
     if (E == E && E <= 0.5 * th && th > 0.0 && tau < 1e30 && A < 1e15 && B < 1e15) {
@@ -1433,6 +1436,539 @@ __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, con
         for (int w = 0; w < kSW; ++w) c += s_cnt[w][hl];
         sa.part[(size_t)blockIdx.x * a.iters + h0 + hl] = c;
     }
+}
+
+// ================================================================ hypothesis kernel, fp32-screened (LDS-resident)
+// ransac_hyp_kernel's arithmetic with rs_score32_kernel's screen in front of both scoring passes (round 4): the registrations
+// the reference really runs (n = 170 - 2000 putative matches, completeExperimentFast.m:166,205-206) stay in LDS and were scored
+// in fp64 only.  Per workgroup the correspondences are staged ONCE, relative to correspondence 0 (a = p1 - o1, b = p2 - o2):
+//   c64[np / 64][6][64]      the fp64 differences (exactly mom_core's d', m': the refit sums read them back),
+//   c32[np / 128][6][2][64]  their fp32 roundings (the screen's operands), a pad lane holds NaN and scores nothing,
+// np = n rounded up to 128.  A wave owns up to 64 hypotheses (sample fits one per lane as before) and walks them four at a
+// time: the four fp32 transforms sit in SGPRs, every lane screens two 64-point slots per trip (15 packed-fp32 operations per
+// pair and two compares), the "proven inlier" ballots are counted AND kept -- ballot of slot s in lane s of a VGPR pair per
+// hypothesis -- so that the refit pass does not evaluate a single distance: it runs under those ballots as EXEC masks
+// (inverse_ballot -> s_and_saveexec) over the fp64 differences, two hypotheses per read of the points, fifteen sums each (the
+// rank of the inlier set is certified from the sample as in rs_fit1_body; an uncertified or three-inlier refit takes the old
+// 27-sum path on the raw coordinates from L2).  A hypothesis that meets ANY distance inside the band thDist +- E is re-scored
+// slot by slot and the slots concerned decided by the fp64 sqdist on the raw coordinates, so counts and masks are the fp64 ones.
+// The fifteen wave sums of a refit leave the lanes through two levels of v_permlane32/16_swap and four DPP levels (65 vector
+// instructions where 15 shuffle butterflies took 270 and the LDS pipe) and land, one value per lane, in a 128-byte row of
+// scratch per hypothesis; the lane-parallel refit reads its row back.  Sample fits and refits are parked in their output
+// rows (a.TF) instead of 24 VGPRs.
+constexpr int kHB32 = 4;                       // hypotheses per pass over the points
+typedef unsigned rs_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// (A, B) -> A + B after v_permlane32_swap: lanes 0-31 hold A(l) + A(l + 32), lanes 32-63 hold B(l - 32) + B(l)
+__device__ __forceinline__ double swap32_add(double A, double B) {
+    const rs_u32x2 r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(A), (unsigned)__double2loint(B), false, false);
+    const rs_u32x2 r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(A), (unsigned)__double2hiint(B), false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// the same one level down: even 16-lane rows end with A(l) + A(l + 16), odd rows with B(l - 16) + B(l)
+__device__ __forceinline__ double swap16_add(double A, double B) {
+    const rs_u32x2 r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(A), (unsigned)__double2loint(B), false, false);
+    const rs_u32x2 r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(A), (unsigned)__double2hiint(B), false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// Wave sums of fifteen values, scattered: lane l returns the sum over the wave of v[k(l)], k(l) = 8 b5 + 4 b4 + 2 b3 + b2 of l
+// (k = 15: zero; bits 1 and 0 of the lane do not matter).  The additions of one value form a fixed tree over the lanes, so the
+// result depends on the hypothesis alone, not on the wave or rank that owns it.
+__device__ __forceinline__ double wave_sum15_scatter(const double (&v)[15]) {
+    const int lane = threadIdx.x & 63;
+    double r1[8], r2[4], r3[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r1[j] = swap32_add(v[j], j < 7 ? v[j < 7 ? 8 + j : 14] : 0.0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r2[j] = swap16_add(r1[j], r1[4 + j]);
+    const bool b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) r3[j] = (b3 ? r2[2 + j] : r2[j]) + dpp_f64<0x128>(b3 ? r2[j] : r2[2 + j]);             // row_ror:8 = lane ^ 8
+    double r = (b2 ? r3[1] : r3[0]) + dpp_f64<0x1B>(dpp_f64<0x141>(b2 ? r3[0] : r3[1]));    // row_half_mirror then quad reverse = lane ^ 4
+    r += dpp_f64<0x4E>(r);                                                                    // quad_perm [2,3,0,1] = lane ^ 2
+    r += dpp_f64<0xB1>(r);                                                                    // quad_perm [1,0,3,2] = lane ^ 1
+    return r;
+}
+__device__ __forceinline__ void mom15_add(double (&m)[15], const double (&q)[6]) {      // mom_core on stored differences
+    m[0] += q[0]; m[1] += q[1]; m[2] += q[2]; m[3] += q[3]; m[4] += q[4]; m[5] += q[5];
+    m[6]  = fma(q[3], q[0], m[6]);  m[7]  = fma(q[3], q[1], m[7]);  m[8]  = fma(q[3], q[2], m[8]);
+    m[9]  = fma(q[4], q[0], m[9]);  m[10] = fma(q[4], q[1], m[10]); m[11] = fma(q[4], q[2], m[11]);
+    m[12] = fma(q[5], q[0], m[12]); m[13] = fma(q[5], q[1], m[13]); m[14] = fma(q[5], q[2], m[14]);
+}
+// estimateTransform for N > 3 correspondences of certified rank, from the fifteen sums about (o1, o2)
+__device__ bool fit_moments15(int N, const double (&mom)[15], const double (&o)[6], double (&T)[12]) {
+    if (N < 4) return false;
+    const double inv = 1.0 / (double)N;
+    const double cdp[3] = {mom[0] * inv, mom[1] * inv, mom[2] * inv};
+    const double cmp_[3] = {mom[3] * inv, mom[4] * inv, mom[5] * inv};
+    double H[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) H[i][j] = mom[6 + i * 3 + j] - (double)N * cmp_[i] * cdp[j];
+    const double cd[3] = {cdp[0] + o[0], cdp[1] + o[1], cdp[2] + o[2]};
+    const double cm[3] = {cmp_[0] + o[3], cmp_[1] + o[4], cmp_[2] + o[5]};
+    return polar_to_T(H, cd, cm, T);
+}
+// a value another lane of this wave stored (after a wavefront-scope release): read at the coherent level, not from the CU's L1
+__device__ __forceinline__ double ld_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct Hyp32Lds { const double* c64; const float* c32; int np; int ns; };
+typedef float rs_f32x2 __attribute__((ext_vector_type(2)));
+
+// The screen's arithmetic, written so that every operation reads ONE scalar operand (a VALU instruction of this chip reads one SGPR):
+//     u_c = a_c - t'_c;   u_c = fma(b_z, -R_c2, u_c);   u_c = fma(b_y, -R_c1, u_c);   u_c = fma(b_x, -R_c0, u_c);   c = x, y, z
+//     d   = fma(u_z, u_z, fma(u_y, u_y, u_x * u_x))
+// Rounding: the inputs carry u |a|, u |t'| and 2.01 u |R_c| |b| <= 2.01 u rho B, the subtraction and the three FMAs four roundings of
+// a running value bounded by A + tau + rho B, so every u_c is within e1 = 6.1 u (A + rho B + tau) of the exact residual component,
+// and |d32 - d| <= 2 sqrt(3) sqrt(d) e1 + 3 e1^2 + 3.1 u d -- make_t32's E with this e1 (its `resident` flag).
+__device__ __forceinline__ float sqdist32r(const float (&q)[6], const float (&T)[12]) {      // T: R rows (9), t' (3)
+    float ux = q[0] - T[9], uy = q[1] - T[10], uz = q[2] - T[11];
+    ux = __builtin_fmaf(q[5], -T[2], ux); uy = __builtin_fmaf(q[5], -T[5], uy); uz = __builtin_fmaf(q[5], -T[8], uz);
+    ux = __builtin_fmaf(q[4], -T[1], ux); uy = __builtin_fmaf(q[4], -T[4], uy); uz = __builtin_fmaf(q[4], -T[7], uz);
+    ux = __builtin_fmaf(q[3], -T[0], ux); uy = __builtin_fmaf(q[3], -T[3], uy); uz = __builtin_fmaf(q[3], -T[6], uz);
+    return __builtin_fmaf(uz, uz, __builtin_fmaf(uy, uy, ux * ux));
+}
+// sqdist32r of the correspondences of TWO slots (the halves of q[c]) under one hypothesis: fifteen packed-fp32 instructions, the
+// transform in six SGPR pairs P = (t'x, t'y) (t'z, R02) (R12, R22) (R01, R11) (R21, R00) (R10, R20), each operation broadcasting one
+// half of a pair to both lanes of the packed instruction (op_sel / op_sel_hi) -- the compiler's own packing duplicated every
+// coefficient into a pair of its own (96 SGPRs for four hypotheses: spilled, and re-read inside the loop).
+__device__ __forceinline__ rs_f32x2 sqdist32r_x2(const rs_f32x2 (&q)[6], const rs_f32x2 (&P)[6]) {
+    rs_f32x2 ux, uy, uz, d;
+    asm("v_pk_add_f32 %0, %4, %10 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %5, %10 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %6, %11 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %9, %11, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %9, %12, %1 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %2, %9, %12, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %8, %13, %0 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %8, %13, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %2, %8, %14, %2 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %7, %14, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %7, %15, %1 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %2, %7, %15, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_mul_f32 %3, %0, %0\n\t"
+        "v_pk_fma_f32 %3, %1, %1, %3\n\t"
+        "v_pk_fma_f32 %3, %2, %2, %3"
+        : "=&v"(ux), "=&v"(uy), "=&v"(uz), "=&v"(d)
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "s"(P[0]), "s"(P[1]), "s"(P[2]), "s"(P[3]), "s"(P[4]), "s"(P[5]));
+    return d;
+}
+// own := 2 own + (this lane's bit of the ballot): v_addc_co_u32 shifts and inserts in one instruction
+__device__ __forceinline__ void push_bit(unsigned& own, unsigned long long ballot) {
+    unsigned long long carry_out;
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(own), "=s"(carry_out) : "s"(ballot));
+}
+// ballot of the lanes' top bits, and w := 2 w: v_add_co_u32's carry-out is the predicate, as a wave mask
+__device__ __forceinline__ unsigned long long pop_bit(unsigned& w) {
+    unsigned long long carry_out;
+    asm("v_add_co_u32 %0, %1, %0, %0" : "+v"(w), "=s"(carry_out));
+    return carry_out;
+}
+__device__ __forceinline__ float rdlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// One screened pass of up to kHB32 hypotheses (lanes hs[k] of T32) over the staged correspondences.  cnt[k]: inliers.
+// EMIT: own[k] = this LANE's inlier bits, slot s at bit ns - 1 - s (ns <= 32).  TFwave: the wave's rows of fp64 transforms.
+template <bool EMIT>
+__device__ __forceinline__ void score32_group(const RansacArgs& a, const Hyp32Lds& L, const double* g1, const double* g2, const int n,
+                                              const int lane, const float (&T32)[14], const double* __restrict__ TFwave,
+                                              const int (&hs)[kHB32], int (&cnt)[kHB32], unsigned (&own)[kHB32]) {
+    rs_f32x2 P[kHB32][6];
+    float thlo[kHB32], thhi[kHB32];             // wave-uniform, but kept in VGPRs: the 48 SGPRs of the transforms leave no room for them
+    unsigned bandbits = 0u;                     // bit k: hypothesis k met a distance inside its band
+#pragma unroll
+    for (int k = 0; k < kHB32; ++k) {
+        const int h = hs[k];
+        P[k][0] = rs_f32x2{rdlane_f(T32[9], h), rdlane_f(T32[10], h)}; P[k][1] = rs_f32x2{rdlane_f(T32[11], h), rdlane_f(T32[2], h)};
+        P[k][2] = rs_f32x2{rdlane_f(T32[5], h), rdlane_f(T32[8], h)};  P[k][3] = rs_f32x2{rdlane_f(T32[1], h), rdlane_f(T32[4], h)};
+        P[k][4] = rs_f32x2{rdlane_f(T32[7], h), rdlane_f(T32[0], h)};  P[k][5] = rs_f32x2{rdlane_f(T32[3], h), rdlane_f(T32[6], h)};
+        thlo[k] = rdlane_f(T32[12], h); thhi[k] = rdlane_f(T32[13], h);
+        asm volatile("" : "+v"(thlo[k]), "+v"(thhi[k]));
+        cnt[k] = 0; own[k] = 0u;
+    }
+    for (int s = 0; s < L.ns; s += 2) {
+        rs_f32x2 q[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) q[c] = rs_f32x2{L.c32[s * 384 + c * 128 + lane], L.c32[s * 384 + c * 128 + 64 + lane]};      // one address, constant offsets
+#pragma unroll
+        for (int k = 0; k < kHB32; ++k) {
+            const rs_f32x2 d = sqdist32r_x2(q, P[k]);
+            const unsigned long long b0 = __ballot(d.x < thlo[k]), b1 = __ballot(d.y < thlo[k]);
+            if (((__ballot(d.x <= thhi[k]) ^ b0) | (__ballot(d.y <= thhi[k]) ^ b1)) != 0ull) bandbits |= 1u << k;     // nested sets: they differ iff somebody is in the band
+            cnt[k] += __popcll(b0) + __popcll(b1);
+            if (EMIT) { push_bit(own[k], b0); push_bit(own[k], b1); }
+        }
+    }
+    // somebody inside the band: that hypothesis again, slot by slot, the slots concerned in fp64 on the raw coordinates
+#pragma unroll 1
+    for (int k = 0; k < kHB32; ++k) {
+        if (!((bandbits >> k) & 1u)) continue;                                    // wave-uniform
+        int hk = hs[0];
+#pragma unroll
+        for (int kk = 1; kk < kHB32; ++kk) hk = kk == k ? hs[kk] : hk;
+        float Tk[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) Tk[j] = rdlane_f(T32[j], hk);
+        const float lo = rdlane_f(T32[12], hk), hi = rdlane_f(T32[13], hk);
+        double T64[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) T64[j] = ld_coherent(TFwave + (size_t)hk * 12 + j);
+        int nc = 0; unsigned nown = 0u;
+#pragma unroll 1
+        for (int s = 0; s < L.ns; ++s) {
+            float q[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) q[c] = L.c32[(s >> 1) * 768 + c * 128 + (s & 1) * 64 + lane];
+            const float d = sqdist32r(q, Tk);
+            unsigned long long bb = __ballot(d < lo);
+            if ((__ballot(d <= hi) ^ bb) != 0ull) {                               // wave-uniform
+                const int i = s * 64 + lane;
+                const bool act = i < n;
+                const int ii = act ? i : 0;
+                double p[6];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { p[c] = g1[ii + (size_t)c * a.ld]; p[3 + c] = g2[ii + (size_t)c * a.ld]; }
+                bb = __ballot((sqdist(p, T64) < a.thDist) & act);
+            }
+            nc += __popcll(bb);
+            if (EMIT) push_bit(nown, bb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < kHB32; ++kk) {
+            if (kk == k) { cnt[kk] = nc; if (EMIT) own[kk] = nown; }
+        }
+    }
+}
+
+// The old 27-sum refit pass of ONE hypothesis on the raw coordinates (uncertified rank, or exactly three inliers), then its
+// refit ON ONE LANE: rare by construction (a sample whose points are not inliers of their own fit seldom reaches thInlr), and
+// keeping these sums per lane for a lane-parallel refit would cost the whole kernel a wave of occupancy.
+__device__ __forceinline__ bool dense_refit(const RansacArgs& a, const Pts<false>& P, const int n, const int lane, const int h, const int ch,
+                                            const double (&T)[12], const double (&o)[6], double (&T2)[12]) {
+    double mom[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+    if (ch == 3) {          // estimateTransform's N == 3 branch needs the points themselves (estimateTransform.m:18-37)
+        int k = 0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < n;
+            double q[6]; P.load(act ? i : n - 1, q);
+            unsigned long long bal = __ballot(act && sqdist(q, T) < a.thDist);
+            while (bal) {
+                const int Ln = __builtin_ctzll(bal);
+                bal &= bal - 1;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double v = rdlane(q[c], Ln);
+                    if (k == 0) mom[c] = v; else if (k == 1) mom[6 + c] = v; else if (k == 2) mom[12 + c] = v;
+                }
+                ++k;
+            }
+        }
+    } else {
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            const bool act = i < n;
+            double q[6]; P.load(act ? i : n - 1, q);
+            if (act && sqdist(q, T) < a.thDist) mom_accumulate(mom, q, o);
+        }
+        wave_sum27(mom);
+    }
+    bool v2 = false;
+    if (lane == h) {
+        if (ch == 3) {
+            double A1[3][3], A2[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { A1[j][c] = mom[j * 6 + c]; A2[j][c] = mom[j * 6 + 3 + c]; }
+            v2 = fit_3pt(A1, A2, T2);
+        } else {
+            v2 = fit_moments(ch, mom, o, T2);
+        }
+    }
+    return v2;
+}
+
+template <int NW, bool REFINE>
+__device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __restrict__ smem, const int b, const int off, const int n) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t hyp0 = (size_t)b * a.iters;
+    const int wbase = (blockIdx.x * NW + wave) * a.hpw;
+    const double* g1 = a.p1 + off; const double* g2 = a.p2 + off;
+    const int np = (n + 127) / 128 * 128;
+    double* c64 = (double*)smem;
+    float* c32 = (float*)(c64 + (size_t)6 * np);
+    double* s_mx = (double*)(c32 + (size_t)6 * np);          // [NW][4]
+    if (n < a.m || n < 3) {   // randperm(ptNum)(1:minPtNum) would throw; report nothing found
+        const int p = wbase + lane;
+        if (wbase < a.iters && lane < min(a.hpw, a.iters - wbase)) { a.cnt1[hyp0 + p] = 0; a.cnt2[hyp0 + p] = 0; a.has[hyp0 + p] = 0; }
+        return;
+    }
+    Pts<false> P{g1, g2, a.ld, nullptr, n};
+    // ---- stage the differences, their fp32 roundings and the four maxima the screen and the rank certificate need
+    {
+        double o[6];
+        P.load(0, o);
+        double mx[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < np; i += NW * 64) {
+            double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (i < n) {
+                double q[6]; P.load(i, q);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) v[c] = q[c] - o[c];
+                mx[0] = fmax(mx[0], q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+                mx[1] = fmax(mx[1], q[3] * q[3] + q[4] * q[4] + q[5] * q[5]);
+                mx[2] = fmax(mx[2], v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                mx[3] = fmax(mx[3], v[3] * v[3] + v[4] * v[4] + v[5] * v[5]);
+            }
+            // slot-major layouts: c64[slot][6][64], c32[slot pair][6][2][64] -- a pass over the points moves ONE address, the six
+            // coordinates (and the pair's second slot) sit at constant offsets of it
+            const int sl = i >> 6, ln = i & 63;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { c64[sl * 384 + c * 64 + ln] = v[c]; c32[(sl >> 1) * 768 + c * 128 + (sl & 1) * 64 + ln] = (float)v[c]; }
+            if (i >= n) c32[(sl >> 1) * 768 + (sl & 1) * 64 + ln] = __builtin_nanf("");          // a pad scores NaN: neither screen test holds for it
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int o_ = 32; o_ > 0; o_ >>= 1) mx[k] = fmax(mx[k], __shfl_xor(mx[k], o_));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_mx[wave * 4 + k] = mx[k];
+        }
+    }
+    __syncthreads();
+    if (wbase >= a.iters) return;
+    // the workgroup's maxima: sqrt(max |p1 row|^2), sqrt(max |p2 row|^2) (rank certificate), the same of the differences (screen).
+    // Folded where they are used (three places) rather than kept in eight SGPRs across the scoring loops; likewise correspondence 0.
+    auto bound = [&](int k) {
+        double m = s_mx[k];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) m = fmax(m, s_mx[w * 4 + k]);
+        return sqrt(m) * (1.0 + 1e-12);
+    };
+    const Hyp32Lds L{c64, c32, np, np / 64};
+    const int nh = min(a.hpw, a.iters - wbase);
+    const int p = wbase + lane;
+    const bool mine = lane < nh;
+    const int thInlr = matlab_round_i(a.ratio * (double)n);                   // ransac.m:28
+    double* const TFwave = a.TF + (hyp0 + wbase) * 12;                         // this wave's output rows: lane h's transform in row h
+    double* const MSwave = a.msc + (hyp0 + wbase) * 16;                        // ... and its refit sums
+
+    // ---- phase 0: minimal-sample fit, one hypothesis per lane (ransac.m:42-45); the fit is parked in its output row
+    float T32[14];
+    bool v1 = false, cert = false;
+    {
+        double T1[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T1[k] = 0.0;
+        if (mine) {
+            if (a.m == 3) {
+                int s[3]; sample3(a, b, p, n, s);
+                double A1[3][3], A2[3][3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double q[6]; P.load(s[j], q);
+                    A1[j][0] = q[0]; A1[j][1] = q[1]; A1[j][2] = q[2];
+                    A2[j][0] = q[3]; A2[j][1] = q[4]; A2[j][2] = q[5];
+                }
+                // the rank certificate of rs_fit1_body / rs_pass1_body; its two quantities are taken BEFORE the fit so that the
+                // eighteen coordinates do not stay live across it (they are read again for the "sample points are inliers" test)
+                bool cq = false;
+                if (REFINE) {
+                    const double nn = (double)n, tolf = 4.0 * nn * sqrt(nn) * 2.220446049250313e-16;
+                    double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { f1 = fma(A1[j][c], A1[j][c], f1); f2 = fma(A2[j][c], A2[j][c], f2); }
+                    const double det1 = A1[0][0] * (A1[1][1] * A1[2][2] - A1[1][2] * A1[2][1]) - A1[0][1] * (A1[1][0] * A1[2][2] - A1[1][2] * A1[2][0])
+                                      + A1[0][2] * (A1[1][0] * A1[2][1] - A1[1][1] * A1[2][0]);
+                    double mm = 0.0;
+#pragma unroll
+                    for (int r0 = 0; r0 < 3; ++r0)
+#pragma unroll
+                        for (int c0 = 0; c0 < 3; ++c0) {
+                            const int r1 = (r0 + 1) % 3, c1_ = (c0 + 1) % 3;
+                            mm = fmax(mm, fabs(A2[r0][c0] * A2[r1][c1_] - A2[r0][c1_] * A2[r1][c0]));
+                        }
+                    cq = f1 > 0.0 && f2 > 0.0 && 2.0 * fabs(det1) / (f1 * tolf) > bound(0) && mm / (sqrt(f2) * tolf) > bound(1);
+                }
+                v1 = fit_3pt(A1, A2, T1);
+                if (v1 && cq) {
+                    bool all_in = true;
+#pragma unroll 1
+                    for (int j = 0; j < 3; ++j) {
+                        double q[6]; P.load(s[j], q);
+                        all_in = all_in && sqdist(q, T1) < a.thDist;
+                    }
+                    cert = all_in;
+                }
+            } else {   // minPtNum > 3: general estimateTransform path on the sample
+                double mom[27];
+#pragma unroll
+                for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+                const int32_t* t = a.sample_idx + ((size_t)hyp0 + p) * a.m;
+                double os[6];
+                for (int j = 0; j < a.m; ++j) {
+                    int idx = min(max(t[j] - 1, 0), n - 1);
+                    double q[6]; P.load(idx, q);
+                    if (j == 0) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) os[c] = q[c];
+                    }
+                    mom_accumulate(mom, q, os);
+                }
+                v1 = fit_moments(a.m, mom, os, T1);
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) TFwave[(size_t)lane * 12 + k] = T1[k];
+        }
+        float t16[16];
+        double o[6];
+        P.load(0, o);
+        make_t32(T1, o, bound(2), bound(3), a.thDist, t16, true);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) T32[k] = t16[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+
+    // ---- phases 1 + 2, four hypotheses at a time: screened scores (ransac.m:48-50), then the refit sums of those that pass (:53-55)
+    int c1 = 0;
+    bool onlane = false;                       // this lane's hypothesis has its fifteen sums in MSwave
+    const int v1c = (v1 ? 1 : 0) | (cert ? 2 : 0);
+    for (int h = 0; h < nh; h += kHB32) {
+        int hs[kHB32], cnt[kHB32];
+        unsigned own[kHB32];
+#pragma unroll
+        for (int k = 0; k < kHB32; ++k) hs[k] = min(h + k, nh - 1);
+        score32_group<REFINE>(a, L, g1, g2, n, lane, T32, TFwave, hs, cnt, own);
+        bool lp[kHB32];
+#pragma unroll
+        for (int k = 0; k < kHB32; ++k) {
+            if (lane == h + k) c1 = cnt[k];
+            lp[k] = REFINE && h + k < nh && __builtin_amdgcn_readlane(v1c, hs[k]) == 3 && cnt[k] >= thInlr && cnt[k] >= 4;
+            if (lp[k] && lane == hs[k]) onlane = true;
+        }
+        if (!REFINE) continue;
+#ifndef NO_MOM
+#pragma unroll
+        for (int kp = 0; kp < kHB32; kp += 2) {
+            if (!(lp[kp] || lp[kp + 1])) continue;                               // wave-uniform
+            double accA[15], accB[15];
+#pragma unroll
+            for (int e = 0; e < 15; ++e) { accA[e] = 0.0; accB[e] = 0.0; }
+            // this lane's inlier bits, slot 0 at the top: every v_add_co_u32 hands the next slot's predicate out as a wave mask
+            unsigned wA = lp[kp] ? own[kp] << (32 - L.ns) : 0u, wB = lp[kp + 1] ? own[kp + 1] << (32 - L.ns) : 0u;
+            for (int s = 0; s < L.ns; ++s) {
+                double q[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) q[c] = L.c64[s * 384 + c * 64 + lane];
+                const unsigned long long wa = pop_bit(wA), wb = pop_bit(wB);
+                if (__builtin_amdgcn_inverse_ballot_w64(wa)) mom15_add(accA, q);
+                if (__builtin_amdgcn_inverse_ballot_w64(wb)) mom15_add(accB, q);
+            }
+            const int kq = 8 * ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
+            if (lp[kp]) { const double r = wave_sum15_scatter(accA); if ((lane & 3) == 0 && kq < 15) MSwave[(size_t)hs[kp] * 16 + kq] = r; }
+            if (lp[kp + 1]) { const double r = wave_sum15_scatter(accB); if ((lane & 3) == 0 && kq < 15) MSwave[(size_t)hs[kp + 1] * 16 + kq] = r; }
+        }
+#endif
+    }
+    if (!v1) c1 = 0;   // empty transform: scores 0 (deviation documented in DESIGN.md)
+    const bool pass1 = mine && v1 && c1 >= thInlr;                              // ransac.m:53
+    if (!REFINE) {                                                              // ransac.m:62-64: the sample fit is already in its row
+        if (mine) { a.cnt1[hyp0 + p] = c1; a.cnt2[hyp0 + p] = 0; a.has[hyp0 + p] = pass1; }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+
+    // ---- phase 3: refit, one hypothesis per lane (estimateTransform on the inliers)
+    bool v2 = false;
+    {
+        double o[6];
+        P.load(0, o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) o[c] = rdlane(o[c], 0);
+#ifdef NO_DENSE
+        unsigned long long dense = 0;
+#else
+        unsigned long long dense = __ballot(pass1 && !onlane);
+#endif
+        while (dense) {                   // rank not certified from the sample, or the N == 3 branch: the 27-sum pass on the raw coordinates,
+            const int h = __builtin_ctzll(dense);       // the refit on lane h alone, parked in its row at once (nothing of it stays live)
+            dense &= dense - 1;
+            double T[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T[k] = rdlane(ld_coherent(TFwave + (size_t)h * 12 + k), 0);
+            double Td[12];
+            if (dense_refit(a, P, n, lane, h, __builtin_amdgcn_readlane(c1, h), T, o, Td)) {      // true on lane h only
+                v2 = true;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) TFwave[(size_t)lane * 12 + k] = Td[k];
+            }
+        }
+        double T2[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T2[k] = 0.0;
+        if (onlane) {
+            double mom[15];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) mom[k] = ld_coherent(MSwave + (size_t)lane * 16 + k);
+            v2 = fit_moments15(c1, mom, o, T2);
+            if (v2) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) TFwave[(size_t)lane * 12 + k] = T2[k];
+            }
+        } else if (v2) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T2[k] = TFwave[(size_t)lane * 12 + k];     // this lane's own store
+        }
+        float t16[16];
+        make_t32(T2, o, bound(2), bound(3), a.thDist, t16, true);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) T32[k] = t16[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+
+    // ---- phase 4: rescore the refined transforms (ransac.m:56-58)
+    int c2 = 0;
+    unsigned long long mask = __ballot(v2);
+    while (mask) {
+        int hs[kHB32], cnt[kHB32];
+        unsigned own[kHB32];
+#pragma unroll
+        for (int k = 0; k < kHB32; ++k) {
+            hs[k] = mask ? __builtin_ctzll(mask) : hs[k > 0 ? k - 1 : 0];
+            if (mask) mask &= mask - 1;
+        }
+        score32_group<false>(a, L, g1, g2, n, lane, T32, TFwave, hs, cnt, own);
+#pragma unroll
+        for (int k = 0; k < kHB32; ++k) if (lane == hs[k]) c2 = cnt[k];
+    }
+    if (mine) {
+        const bool keep = v2 && c2 >= thInlr;                                   // ransac.m:59-61
+        a.cnt1[hyp0 + p] = c1; a.cnt2[hyp0 + p] = v2 ? c2 : 0; a.has[hyp0 + p] = keep;
+    }
+}
+
+template <int NW, bool REFINE>
+__global__ __launch_bounds__(NW * 64) void ransac_hyp32_kernel(RansacArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem32[];
+    const int b = blockIdx.y;
+    const int off = a.offsets ? a.offsets[b] : 0;
+    int n = a.offsets ? (a.offsets[b + 1] - off) : (a.n_dev ? *a.n_dev : a.n_cap);
+    n = min(n, a.n_cap);
+    if (n <= a.n_lo) return;                                    // a smaller launch class serves it
+    if (n <= a.n_hi) ransac_hyp32_body<NW, REFINE>(a, smem32, b, off, n);   // above every class: ransac_hyp_kernel, fp64 from L2 (a launch of its own)
 }
 
 // Refit moments: the tiled kernel's phase 2, two passing hypotheses of every wave per sweep.
@@ -2138,11 +2674,29 @@ static size_t staged_extra_bytes(size_t h, int n_cap) {    // T1 | mom | part | 
 size_t ransac_workspace_bytes(int iters, int B, int n_cap) {
     size_t h = (size_t)iters * (size_t)B;
     return align_up(h * 12 * sizeof(double), 256) + 2 * align_up(h * sizeof(int32_t), 256) + align_up(h, 256) +
-           staged_extra_bytes(h, B == 1 ? n_cap : 0);
+           align_up(h * 16 * sizeof(double), 256) /* ransac_hyp32_kernel's refit sums */ + staged_extra_bytes(h, B == 1 ? n_cap : 0);
 }
 
-constexpr size_t kLdsSmallBytes = 32 * 1024;         // batched: registrations up to 682 correspondences share a CU five at a time
-constexpr size_t kLdsPointsMaxBytes = 152 * 1024;     // batches up to this capacity (n_cap <= 3242) use ransac_hyp_kernel; larger ones the tiled kernel
+// ransac_hyp32_kernel: launch classes by correspondences per registration (LDS = 72 B per correspondence, rounded up to 128 of
+// them).  The kernel holds 126 VGPRs, four waves per SIMD, so a CU takes sixteen waves: two 8-wave workgroups of up to 1024
+// correspondences (74 KB each), or one 16-wave workgroup of up to 2048 (148 KB of the CU's 160).
+constexpr int kHyp32NClasses = 2;
+constexpr int kHyp32Classes[kHyp32NClasses] = {1024, 2048};
+constexpr int kHyp32Waves[kHyp32NClasses] = {8, 16};
+constexpr int kHyp32BatchCap = 3242;            // batches of a larger capacity run on the tiled kernel, as before round 4
+static size_t hyp32_lds_bytes(int n, int nw) { return (size_t)((n + 127) / 128 * 128) * 72 + (size_t)nw * 4 * sizeof(double); }
+template <int NW>
+static int launch_hyp32(const RansacArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PCREG_HIP(hipFuncSetAttribute((const void*)ransac_hyp32_kernel<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PCREG_HIP(hipFuncSetAttribute((const void*)ransac_hyp32_kernel<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    if (a.refine) hipLaunchKernelGGL((ransac_hyp32_kernel<NW, true>), grid, dim3(NW * 64), lds, st, a);
+    else hipLaunchKernelGGL((ransac_hyp32_kernel<NW, false>), grid, dim3(NW * 64), lds, st, a);
+    return PCREG_OK;
+}
 static int launch_ransac_impl(const double* p1, const double* p2, int ld, const int32_t* offsets, const int32_t* n_dev,
                   int n_cap, int B, pcreg_ransac_opts o, const int32_t* sample_idx_dev,
                   pcreg_dev_ransac_result* out, int32_t* inlier_idx, int32_t* iter_inl, int32_t* iter_inl_ref,
@@ -2157,33 +2711,39 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
     a.p1 = p1; a.p2 = p2; a.ld = ld; a.offsets = offsets; a.n_dev = n_dev; a.n_cap = n_cap;
     a.iters = o.iterNum; a.m = o.minPtNum; a.thDist = o.thDist; a.ratio = o.thInlrRatio;
     a.refine = o.REFINE != 0; a.seed = o.seed; a.sample_idx = sample_idx_dev; a.hyp0g = hyp_begin;
-    a.n_hi = 0x7FFFFFFF;
+    a.n_hi = 0x7FFFFFFF; a.n_lo = -1;
     a.TF = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
     a.cnt1 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.cnt2 = (int32_t*)w; w += align_up(h * sizeof(int32_t), 256);
     a.has = (unsigned char*)w; w += align_up(h, 256);
     long long total = (long long)o.iterNum * B;
     void* sel_ctr = nullptr;              // set by the staged chain: its selection runs on several workgroups
-    size_t lds = (size_t)n_cap * 6 * sizeof(double);
-    if (n_cap > 0 && lds <= (offsets ? kLdsPointsMaxBytes : (size_t)64 * 1024)) {
-        // small sets: correspondences resident in LDS (batches: a gfx950 workgroup may take the CU's whole 160 KiB; a batch's capacity
-        // is often far above its registrations' real sizes -- the sweep passes the surface size, its trials hold ~250 pairs --
-        // and a workgroup only stages the n it has); hypotheses per wave: fill the chip
-        // first (>= ~2 waves per SIMD), then grow towards 64 so the lane-parallel fits run full
+    if (n_cap > 0 && n_cap <= (offsets ? kHyp32BatchCap : kHyp32Classes[kHyp32NClasses - 1])) {
+        // correspondences resident in LDS, scored through the fp32 screen (ransac_hyp32_kernel).  A workgroup reserves the LDS of
+        // its launch CLASS, not of the batch's capacity (the sweep passes the surface size, 2000; its trials hold ~250 pairs): one
+        // launch per class that the capacity reaches, a workgroup returns at once when its registration belongs to another class
+        // (n is read from the offsets on the device), and the last launch also takes what is above every class (fp64 from L2).
+        // Hypotheses per wave: fill the chip first (>= ~2 waves per SIMD), then grow towards 64 so the lane-parallel fits run full.
         int hpw = 64;
         while (hpw > 8 && total / hpw < 256LL * 4 * 2) hpw >>= 1;
         a.hpw = hpw;
-        int per_block = hpw * kWavesPerBlock;
-        dim3 grid((o.iterNum + per_block - 1) / per_block, B);
-        if (offsets && lds > 64 * 1024) {
-            // A batch's capacity says little about its registrations (the sweep passes the surface size, 2000; its trials hold
-            // ~250 pairs): above 64 KB of capacity the launch reserves 32 KB (682 correspondences, five workgroups to a CU by LDS)
-            // and a larger registration of the batch runs from L2; up to 64 KB the capacity itself is reserved (cfg 1's batch of
-            // n = 1000: three workgroups to a CU, all in LDS).
-            lds = kLdsSmallBytes;
-            a.n_hi = (int)(kLdsSmallBytes / (6 * sizeof(double)));
+        a.msc = (double*)w; w += align_up(h * 16 * sizeof(double), 256);
+        int lo = -1;
+        for (int c = 0; c < kHyp32NClasses; ++c) {
+            const bool last = c == kHyp32NClasses - 1 || n_cap <= kHyp32Classes[c];
+            a.n_lo = lo; a.n_hi = last ? std::min(n_cap, kHyp32Classes[c]) : kHyp32Classes[c];
+            const int nw = kHyp32Waves[c], per_block = hpw * nw;
+            const dim3 grid((o.iterNum + per_block - 1) / per_block, B);
+            const int rc = nw == 8 ? launch_hyp32<8>(a, grid, hyp32_lds_bytes(a.n_hi, nw), st) : launch_hyp32<16>(a, grid, hyp32_lds_bytes(a.n_hi, nw), st);
+            if (rc != PCREG_OK) return rc;
+            lo = a.n_hi;
+            if (last) break;
         }
-        hipLaunchKernelGGL(ransac_hyp_kernel, grid, dim3(kBlock), lds, st, a);
+        if (n_cap > lo) {     // registrations of a batch above every class: the fp64 kernel on the raw coordinates from L2
+            a.n_lo = lo; a.n_hi = -1;
+            const int pb4 = hpw * kWavesPerBlock;
+            hipLaunchKernelGGL(ransac_hyp_kernel, dim3((o.iterNum + pb4 - 1) / pb4, B), dim3(kBlock), 0, st, a);
+        }
     } else if (B == 1 && !offsets && n_cap >= kStagedMinN && !(getenv("PCREG_RANSAC_FUSED") && atoi(getenv("PCREG_RANSAC_FUSED")))) {
         // one large registration: the staged chain of lean kernels (see rs_* above)
         StagedArgs sa{};

@@ -373,3 +373,110 @@ def test_estimate_transform_rank_decision_near_planar(n, ratio):
     got = pc.estimateTransform(rng.uniform(-40, 40, size=(n, 3)), line)
     if want is None or ratio >= 1e-11:      # below ~1e-12 H has ONE usable singular pair: MATLAB returns a T made of rounding
         assert (got.size == 0) == (want is None)    # noise there, this library []
+
+
+# ---- round 4: the LDS-resident kernel with the fp32 screen (ransac_hyp32_kernel), the reference's real sizes ----------------
+
+@pytest.mark.parametrize("n", [1000, 1365])
+@pytest.mark.parametrize("big_offset", [False, True])
+def test_fp32_screen_band_is_decided_in_fp64_resident(n, big_offset, oracle_c):
+    """Resident twin of test_fp32_screen_band_is_decided_in_fp64: n = 1000 (first launch class, two workgroups to a CU) and
+    n = 1365 (second class).  Half of the correspondences sit 1e-7 .. 1e-4 (relative) off thDist -- inside the fp32 band,
+    far outside fp64 rounding -- so nearly every hypothesis of ransac_hyp32_kernel goes through its fp64 slot re-score; the
+    per-iteration counts (both passes), numSuccess, maxInliers and the inlier set must be the oracle's bits."""
+    import pcreg_amd as pc
+    iters, th = 600, 0.05
+    p1, p2, _ = rigid_case(n, 4321 + n, noise=0.0, outlier_frac=0.0)
+    rng = np.random.default_rng(98)
+    delta = rng.choice([-1.0, 1.0], n // 2) * 10.0 ** rng.uniform(-7, -4, n // 2)
+    v = rng.normal(size=(n // 2, 3)); v *= (np.sqrt(th * (1.0 + delta)) / np.linalg.norm(v, axis=1))[:, None]
+    p1 = p1.copy(); p1[:2 * (n // 2):2] += v
+    if big_offset:
+        p1 = p1 + 4000.0; p2 = p2 + np.array([3900.0, -4100.0, 4050.0])
+    coef = dict(minPtNum=3, iterNum=iters, thDist=th, thInlrRatio=0.2, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=11)
+    res = pc.ransac(p1, p2, coef, seed=11, return_iter_counts=True)
+    near = np.abs(np.asarray(ref["inlrNum"]) - n // 2) < n // 4          # hypotheses that split the cloud at the boundary
+    assert near.sum() > 10
+    _cmp(res, ref, n)
+
+
+@pytest.mark.parametrize("n", [3, 4, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 2047, 2048, 2049])
+@pytest.mark.parametrize("refine", [True, False])
+def test_resident_kernel_slot_and_class_edges(n, refine, oracle_c):
+    """Slot (64), slot-pair (128) and launch-class (1024 / 2048) edges of ransac_hyp32_kernel; 2049 is the first size on the tiled kernel."""
+    import pcreg_amd as pc
+    p1, p2, _ = rigid_case(n, 7000 + n, outlier_frac=0.3 if n > 20 else 0.0)
+    coef = dict(minPtNum=3, iterNum=257, thDist=0.05, thInlrRatio=0.1, REFINE=refine, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=5)
+    if ref["failed"]:
+        T = pc.ransac(p1, p2, coef, seed=5)[0]
+        assert T is None or np.size(T) == 0
+        return
+    _cmp(pc.ransac(p1, p2, coef, seed=5, return_iter_counts=True), ref, n)
+
+
+@pytest.mark.parametrize("case", ["three_inliers", "min4", "planar_pts1", "planar_pts2", "loose_sample"])
+def test_resident_kernel_uncertified_refits(case, oracle_c):
+    """The refits ransac_hyp32_kernel cannot run from the fifteen masked sums -- exactly three inliers (estimateTransform's
+    N == 3 branch), minPtNum = 4 (no rank certificate), planar point sets, and samples whose own points are NOT inliers of
+    their fit (thDist far below the noise) -- take the 27-sum pass on the raw coordinates; same bits as the oracle."""
+    import pcreg_amd as pc
+    n, iters = 900, 500
+    p1, p2, _ = rigid_case(n, 4243, noise=0.02, outlier_frac=0.6 if case == "three_inliers" else 0.05)
+    coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)
+    table = None
+    if case == "min4":
+        rng = np.random.default_rng(8)
+        table = np.stack([rng.permutation(n)[:4] + 1 for _ in range(iters)]).astype(np.int32)
+        coef["minPtNum"] = 4
+    if case == "three_inliers":
+        from oracle import pcreg_oracle as o
+        rng = np.random.default_rng(9)
+        iters = n // 3
+        p2 = rng.uniform(-50, 50, (n, 3)); p1 = np.empty_like(p2)
+        for g in range(n // 3):
+            R = o.eul2rotm(rng.uniform(-1, 1, 3)); t = rng.uniform(-20, 20, 3)
+            p1[3 * g:3 * g + 3] = p2[3 * g:3 * g + 3] @ R + t
+        table = (np.arange(iters)[:, None] * 3 + np.arange(3)[None, :] + 1).astype(np.int32)
+        coef.update(thDist=1e-6, thInlrRatio=0.003, iterNum=iters)
+    if case == "planar_pts1":
+        p1 = p1.copy(); p1[:, 2] = 0.0
+    if case == "planar_pts2":
+        p2 = p2.copy(); p2[:, 2] = 0.0
+    if case == "loose_sample":            # noise 0.02 -> squared residuals ~1e-3; thDist 2e-4 keeps ~10 % and the sample points mostly out
+        coef.update(thDist=2e-4, thInlrRatio=0.02)
+    ref = oracle_c.ransac(p1, p2, coef, sample_idx=table, seed=21)
+    res = pc.ransac(p1, p2, coef, sample_idx=table, seed=21, return_iter_counts=True)
+    np.testing.assert_array_equal(res[5], ref["inlrNum"])
+    np.testing.assert_array_equal(res[6], ref["inlrNum_refined"])
+    assert res[2] == ref["numSuccess"] and res[3] == ref["maxInliers"]
+    if ref["failed"]:
+        assert res[0] is None or np.size(res[0]) == 0
+    else:
+        np.testing.assert_array_equal(np.asarray(res[1]).astype(np.int64), ref["inlierIdx"])
+        assert np.linalg.norm(res[0] - ref["T"]) < T_TOL
+    if case == "three_inliers":
+        assert (ref["inlrNum"] == 3).sum() > 100
+    if case == "loose_sample":
+        assert ref["numSuccess"] > 0
+
+
+def test_ransac_batched_across_launch_classes(oracle_c):
+    """One batch whose registrations fall into both launch classes of ransac_hyp32_kernel (<= 1024, <= 2048) and above them
+    (the fp64 kernel on the raw coordinates from L2), plus the degenerate sizes 0-2."""
+    import pcreg_amd as pc
+    sizes = [2, 170, 1024, 1025, 2048, 2500, 640, 3000, 33]
+    cases = [rigid_case(max(n, 3), 900 + i)[:2] for i, n in enumerate(sizes)]
+    cases = [(c[0][:n], c[1][:n]) for c, n in zip(cases, sizes)]
+    coef = dict(minPtNum=3, iterNum=300, thDist=0.05, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    out = pc.ransac_batched([c[0] for c in cases], [c[1] for c in cases], coef, seed=70)
+    for b, (p1, p2) in enumerate(cases):
+        T, inl, ns, mi, _ = out[b]
+        if sizes[b] < 3:
+            assert T is None or np.size(T) == 0
+            continue
+        ref = oracle_c.ransac(p1, p2, coef, seed=70 + b)
+        np.testing.assert_array_equal(inl.astype(np.int64), ref["inlierIdx"])
+        assert ns == ref["numSuccess"] and mi == ref["maxInliers"]
+        assert np.linalg.norm(T - ref["T"]) < T_TOL
