@@ -74,6 +74,12 @@ const char* pcreg_version(void);
 int  pcreg_device_count(int* count);
 int  pcreg_set_device(int ordinal);          /* one process per GPU: call once per rank */
 int  pcreg_device_name(char* buf, int cap);  /* e.g. "gfx950:..."                       */
+/* Test hook, not part of the reference's interface: selects the OTHER side of a certified fast path (process-wide), so that
+ * the parity tests can run both sides inside one process.  Every setting returns the same indices and counts.  Keys:
+ * "knn_exact", "match_exact", "match_force_fallback" (1, 2), "ransac_fused", "ransac_nolane", "ransac_f64score",
+ * "ransac_resident_f64", "align_times", "align_shape", "seg_debug"; value 0 restores the default.  The library reads NO
+ * environment variable (tests/test_abi.py greps the binary).  PCREG_E_ARG for an unknown key. */
+int  pcreg_debug_set(const char* key, int value);
 
 /* ---- host tier ------------------------------------------------------------------ */
 

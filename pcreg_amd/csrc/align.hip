@@ -305,15 +305,15 @@ int launch_align_points_knn(const double* pts, int ld, const int32_t* offsets_de
                                                    aligned, ld_out, coeff, c, status, tstamp)
     long long* tstamp = nullptr;
 #ifdef PCREG_EXPERIMENTS
-    if (pcreg_env_int("PCREG_ALIGN_TIMES", 0)) { PCREG_HIP(hipMalloc((void**)&tstamp, (size_t)B * 16 * 8)); PCREG_HIP(hipMemsetAsync(tstamp, 0, (size_t)B * 16 * 8, st)); }
+    if (debug_flag(kDbgAlignTimes)) { PCREG_HIP(hipMalloc((void**)&tstamp, (size_t)B * 16 * 8)); PCREG_HIP(hipMemsetAsync(tstamp, 0, (size_t)B * 16 * 8, st)); }
 #endif
     if (max_n > 8192) { set_error("AlignPoints_KNN support of %d points exceeds the register-resident limit (8192)", max_n); return PCREG_E_ARG; }
     {
         if (max_n <= 1024) PCREG_AL_LAUNCH(4, 256);
         else if (max_n <= 2048) PCREG_AL_LAUNCH(4, 512);
 #ifdef PCREG_EXPERIMENTS
-        else if (max_n <= 3072 && pcreg_env_int("PCREG_ALIGN_SHAPE", 0) == 1) PCREG_AL_LAUNCH(6, 512);
-        else if (max_n <= 3072 && pcreg_env_int("PCREG_ALIGN_SHAPE", 0) == 2) PCREG_AL_LAUNCH(24, 128);
+        else if (max_n <= 3072 && debug_flag(kDbgAlignShape) == 1) PCREG_AL_LAUNCH(6, 512);
+        else if (max_n <= 3072 && debug_flag(kDbgAlignShape) == 2) PCREG_AL_LAUNCH(24, 128);
 #endif
         // four-wave workgroups, three per CU (<= 168 VGPRs): shorter barriers and a third support in flight per CU beat the
         // eight-wave form (two per CU at 128 VGPRs, spilling) by 1.3 x at 4096 x 3000 (A/B on one box: 0.155 vs 0.204 ms)

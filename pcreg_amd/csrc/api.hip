@@ -6,6 +6,7 @@
 // this file: without a gfx950 device every compute entry point fails with
 // PCREG_E_NODEVICE.
 #include "common.hpp"
+#include <atomic>
 #include <cstdarg>
 #include <cmath>
 #include <map>
@@ -86,7 +87,22 @@ using namespace pcreg;
     do { int rc__ = ensure_device(); if (rc__) return rc__; } while (0)
 #define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 
+namespace pcreg {
+static std::atomic<int> g_debug[kDbgCount];
+int debug_flag(DebugKey k) { return g_debug[k].load(std::memory_order_relaxed); }
+}
+
 extern "C" {
+
+int pcreg_debug_set(const char* key, int value) {
+    static const char* const names[pcreg::kDbgCount] = {"knn_exact", "match_exact", "match_force_fallback", "ransac_fused", "ransac_nolane",
+                                                        "ransac_f64score", "ransac_resident_f64", "align_times", "align_shape", "seg_debug"};
+    PCREG_ARG(key != nullptr);
+    for (int k = 0; k < pcreg::kDbgCount; ++k)
+        if (!strcmp(key, names[k])) { pcreg::g_debug[k].store(value, std::memory_order_relaxed); return PCREG_OK; }
+    pcreg::set_error("pcreg_debug_set: unknown key '%s'", key);
+    return PCREG_E_ARG;
+}
 
 const char* pcreg_last_error(void) { return g_err; }
 const char* pcreg_version(void) { return "pcreg-hip 0.1 (gfx950)"; }

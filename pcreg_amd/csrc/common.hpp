@@ -47,16 +47,32 @@ Scratch& scratch();
 // (a stream runs its own kernels in order, which makes the reuse within it safe)
 Scratch& stream_scratch(hipStream_t st);
 
-// Environment switches.  Two kinds:
-//  * result-preserving A/B switches (PCREG_KNN_EXACT, PCREG_MATCH_EXACT, PCREG_MATCH_FORCE_FALLBACK,
-//    PCREG_RANSAC_FUSED / _NOLANE / _F64SCORE): always available, read per call (the tests flip them inside one process);
-//    every setting gives the same indices and counts;
+// Switches.  Two kinds, and NEITHER reads the environment in the default build (a stray variable in a MATLAB worker's
+// environment must not change which kernels run):
+//  * result-preserving A/B switches (the direct-form search, the exhaustive fp64 SAD, the forced fallback of the certified
+//    matcher, the fused / fp64-only RANSAC kernels, ...): process-wide integers set through pcreg_debug_set(key, value) --
+//    the entry the parity tests call to run both sides of a certified path inside one process; every setting gives the same
+//    indices and counts;
 //  * experiment / debug switches that change the launch shape, print, synchronise, write files or INVALIDATE results
-//    (timing-only kernels): they exist only in a build with -DPCREG_EXPERIMENTS (`make EXPERIMENTS=1`); the default
-//    library compiles them to their default value, so a stray variable in a user's environment cannot change anything.
+//    (timing-only kernels): environment variables that exist only in a build with -DPCREG_EXPERIMENTS (`make EXPERIMENTS=1`);
+//    the default library compiles them to their default value.
+enum DebugKey {
+    kDbgKnnExact = 0,          // "knn_exact": direct-form fp32 search instead of the certified f16 matrix-core path
+    kDbgMatchExact,            // "match_exact": exhaustive fp64 SAD instead of the certified u16 path
+    kDbgMatchForceFallback,    // "match_force_fallback": 1 = every query takes the exact fallback, 2 = also skip the refine
+    kDbgRansacFused,           // "ransac_fused": n >= 4096 on the fused tiled kernel instead of the staged chain
+    kDbgRansacNoLane,          // "ransac_nolane": refit sums by the fp64 sweep kernel instead of the int8 matrix-core kernel
+    kDbgRansacF64Score,        // "ransac_f64score": no fp32 screen in the staged chain
+    kDbgRansacResidentF64,     // "ransac_resident_f64": the round-3 fp64 LDS-resident kernel instead of ransac_hyp32_kernel
+    kDbgAlignTimes,            // "align_times": per-phase timestamps of align_points_knn (host read-back)
+    kDbgAlignShape,            // "align_shape": launch-shape override of align_points_knn
+    kDbgSegDebug,              // "seg_debug": histogram dump of the segmented matcher
+    kDbgCount
+};
+int debug_flag(DebugKey k);
+#ifdef PCREG_EXPERIMENTS
 static inline int pcreg_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static inline const char* pcreg_env_str(const char* name) { return getenv(name); }
-#ifdef PCREG_EXPERIMENTS
 #define PCREG_EXP_ENV(name, dflt) pcreg_env_int(name, dflt)
 #define PCREG_EXP_STR(name) pcreg_env_str(name)
 #else

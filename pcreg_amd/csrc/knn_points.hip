@@ -402,9 +402,9 @@ int launch_knn2_points_exact_list(const float* q, int Q, int ldq, const float* m
     return knn2_exact_impl(q, Q, ldq, m, M, ldm, idx_base, qlist, n_list, min_active, idx, dist, ws, ws_bytes, st);
 }
 
-// PCREG_KNN_EXACT=1 forces the direct-form kernel (tuning / A-B runs); the default is the
+// pcreg_debug_set("knn_exact", 1) forces the direct-form kernel (tuning / A-B runs); the default is the
 // certified fast path of knn_fast.hip, which returns the same bits.
-static bool use_exact_only() { return pcreg_env_int("PCREG_KNN_EXACT", 0) != 0; }
+static bool use_exact_only() { return debug_flag(kDbgKnnExact) != 0; }
 
 size_t knn2_points_workspace_bytes(int Q, int M) {
     size_t a = knn2_points_exact_workspace_bytes(Q, M), b = knn2_points_fast_workspace_bytes(Q, M);

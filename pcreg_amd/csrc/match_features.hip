@@ -315,10 +315,9 @@ size_t sad16_workspace_bytes(int nA, int nB, int D);
 int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, int ldb, int D,
                    int32_t* idx, double* dist, void* ws, size_t ws_bytes, hipStream_t st, const int32_t* nA_live = nullptr);
 
-// SAD runs on the certified u16 path unless PCREG_MATCH_EXACT=1 (identical results either way)
+// SAD runs on the certified u16 path unless pcreg_debug_set("match_exact", 1) (identical results either way)
 static bool use_sad16(int metric) {
-    const char* e = getenv("PCREG_MATCH_EXACT");
-    return metric == PCREG_METRIC_SAD && !(e && atoi(e) != 0);
+    return metric == PCREG_METRIC_SAD && debug_flag(kDbgMatchExact) == 0;
 }
 
 // workspace layout of launch_match_features (all sizes for capacity Q):

@@ -1377,7 +1377,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     else
 #endif
         hipLaunchKernelGGL(sad16_candidates_kernel<kSadLists>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr, nullptr, 0});
-    const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0;
+    const int force = debug_flag(kDbgMatchForceFallback) != 0;
     if (dbg) {
         std::vector<unsigned long long> h((size_t)n_tiles * S * 4);
         PCREG_HIP(hipStreamSynchronize(st));
@@ -1504,11 +1504,11 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     PCREG_HIP(hipGetLastError());
     // PCREG_MATCH_FORCE_FALLBACK: 1 = every query counts as unproven (they take the refinement), 2 = and the refinement passes
     // them all on to the exhaustive kernel
-    const char* fe = getenv("PCREG_MATCH_FORCE_FALLBACK"); const int force = fe && atoi(fe) != 0, skip_refine = fe && atoi(fe) == 2;
+    const int force = debug_flag(kDbgMatchForceFallback) != 0, skip_refine = debug_flag(kDbgMatchForceFallback) == 2;
     hipLaunchKernelGGL(segp_select_kernel, dim3(L.ldqa / 64, (L.splits + 3) / 4, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, Q, L.chunk, L.splits, part_idx, part_s);
     int32_t* dbg_hist = nullptr;
 #ifdef PCREG_EXPERIMENTS
-    if (pcreg_env_int("PCREG_SEG_DEBUG", 0)) { PCREG_HIP(hipMalloc((void**)&dbg_hist, 2 * 130 * sizeof(int32_t))); PCREG_HIP(hipMemsetAsync(dbg_hist, 0, 2 * 130 * sizeof(int32_t), st)); }
+    if (debug_flag(kDbgSegDebug)) { PCREG_HIP(hipMalloc((void**)&dbg_hist, 2 * 130 * sizeof(int32_t))); PCREG_HIP(hipMemsetAsync(dbg_hist, 0, 2 * 130 * sizeof(int32_t), st)); }
 #endif
     hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
                        part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, dbg_hist);

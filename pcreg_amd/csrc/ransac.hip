@@ -2718,7 +2718,17 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
     a.has = (unsigned char*)w; w += align_up(h, 256);
     long long total = (long long)o.iterNum * B;
     void* sel_ctr = nullptr;              // set by the staged chain: its selection runs on several workgroups
-    if (n_cap > 0 && n_cap <= (offsets ? kHyp32BatchCap : kHyp32Classes[kHyp32NClasses - 1])) {
+    if (debug_flag(kDbgRansacResidentF64) && n_cap > 0 && (size_t)n_cap * 48 <= (offsets ? (size_t)152 * 1024 : (size_t)64 * 1024)) {
+        // A/B and parity switch: the round-3 kernel, fp64 scoring on the raw coordinates in LDS (up to 32 KB per registration of a
+        // batch of large capacity, the rest from L2)
+        size_t lds = (size_t)n_cap * 48;
+        int hpw = 64;
+        while (hpw > 8 && total / hpw < 256LL * 4 * 2) hpw >>= 1;
+        a.hpw = hpw;
+        if (offsets && lds > 64 * 1024) { lds = 32 * 1024; a.n_hi = (int)(lds / 48); }
+        const int pb4 = hpw * kWavesPerBlock;
+        hipLaunchKernelGGL(ransac_hyp_kernel, dim3((o.iterNum + pb4 - 1) / pb4, B), dim3(kBlock), lds, st, a);
+    } else if (n_cap > 0 && n_cap <= (offsets ? kHyp32BatchCap : kHyp32Classes[kHyp32NClasses - 1])) {
         // correspondences resident in LDS, scored through the fp32 screen (ransac_hyp32_kernel).  A workgroup reserves the LDS of
         // its launch CLASS, not of the batch's capacity (the sweep passes the surface size, 2000; its trials hold ~250 pairs): one
         // launch per class that the capacity reaches, a workgroup returns at once when its registration belongs to another class
@@ -2744,7 +2754,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
             const int pb4 = hpw * kWavesPerBlock;
             hipLaunchKernelGGL(ransac_hyp_kernel, dim3((o.iterNum + pb4 - 1) / pb4, B), dim3(kBlock), 0, st, a);
         }
-    } else if (B == 1 && !offsets && n_cap >= kStagedMinN && !(getenv("PCREG_RANSAC_FUSED") && atoi(getenv("PCREG_RANSAC_FUSED")))) {
+    } else if (B == 1 && !offsets && n_cap >= kStagedMinN && !debug_flag(kDbgRansacFused)) {
         // one large registration: the staged chain of lean kernels (see rs_* above)
         StagedArgs sa{};
         sa.T1 = (double*)w; w += align_up(h * 12 * sizeof(double), 256);
@@ -2772,8 +2782,8 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.c32 = (float*)w; w += align_up((size_t)sa.n32 * 6 * sizeof(float), 256);
         sa.T32a = (float*)w; w += align_up(h * 16 * sizeof(float), 256);
         sa.T32b = (float*)w; w += align_up(h * 16 * sizeof(float), 256);
-        sa.use_lane = a.refine && !(getenv("PCREG_RANSAC_NOLANE") && atoi(getenv("PCREG_RANSAC_NOLANE")));
-        sa.use_f32 = !(getenv("PCREG_RANSAC_F64SCORE") && atoi(getenv("PCREG_RANSAC_F64SCORE")));
+        sa.use_lane = a.refine && !debug_flag(kDbgRansacNoLane);
+        sa.use_f32 = !debug_flag(kDbgRansacF64Score);
         int pb = (n_cap + kSPts - 1) / kSPts; if (pb > kSMaxPB) pb = kSMaxPB; if (pb < 1) pb = 1;
         sa.pb = pb;
         int hpw = (int)((total + 250LL * kTW - 1) / (250LL * kTW));

@@ -39,6 +39,21 @@ def oracle_c():
     return c_oracle
 
 
+@pytest.fixture
+def debug_set():
+    """pcreg_debug_set(key, value) for the duration of one test: selects the other side of a certified fast path (the library
+    reads no environment variable); every key touched is reset to 0 afterwards."""
+    from pcreg_amd._lib import check, lib
+    touched = []
+
+    def _set(key: str, value: int = 1):
+        check(lib().pcreg_debug_set(key.encode(), int(value)))
+        touched.append(key)
+    yield _set
+    for key in touched:
+        lib().pcreg_debug_set(key.encode(), 0)
+
+
 @pytest.fixture(scope="session")
 def oracle_py():
     from oracle import pcreg_oracle

@@ -81,3 +81,21 @@ def test_default_library_carries_no_experiment_switches():
     blob = open(_lib.LIB_PATH, "rb").read()
     for name in (b"PCREG_KNN_VARIANT", b"PCREG_DESC_STOP", b"PCREG_SAD_DRY", b"PCREG_KNN_F16_QG", b"PCREG_ALIGN_TIMES", b"PCREG_DESC_SUBDIV"):
         assert name not in blob, name.decode()
+
+
+def test_default_library_reads_no_environment_variable():
+    """ADVICE / VERDICT r3: the A/B switches the parity tests flip (exact search, exhaustive SAD, forced fallback, fused /
+    fp64-only RANSAC) are pcreg_debug_set keys, not environment variables: the shipped library neither imports getenv nor
+    contains any PCREG_* variable name, and an unknown key is an argument error."""
+    import re
+    import subprocess
+    from pcreg_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"PCREG_(?:KNN|MATCH|RANSAC|ALIGN|SEG|SAD|DESC_S|DESC_X)[A-Z0-9_]*", blob))      # PCREG_METRIC_SAD etc. are enum names in messages
+    assert not names, names
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert not re.search(r"\b(secure_)?getenv\b", nm), "libpcreg_hip.so imports getenv"
+    L = _lib.lib()
+    assert L.pcreg_debug_set(b"match_exact", 0) == _lib.PCREG_OK
+    assert L.pcreg_debug_set(b"no_such_key", 1) == _lib.PCREG_E_ARG
+    assert b"no_such_key" in L.pcreg_last_error()

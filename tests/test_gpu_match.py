@@ -94,14 +94,14 @@ def test_get_matches_empty_and_verbose(capsys):
 
 @pytest.mark.parametrize("mode", ["fast", "exact", "fallback"])
 @pytest.mark.parametrize("Q,M,D", [(700, 2500, 981), (257, 130, 33), (3, 2, 5)])
-def test_sad_fast_path_is_the_exact_search(Q, M, D, mode, oracle_c, monkeypatch):
+def test_sad_fast_path_is_the_exact_search(Q, M, D, mode, oracle_c, debug_set):
     """The certified u16 SAD path (match_sad16.hip), the exhaustive fp64 kernel and the
     all-queries-unproven fallback return the same pairs AND the same fp64 metric values."""
     import pcreg_amd as pc
     if mode == "exact":
-        monkeypatch.setenv("PCREG_MATCH_EXACT", "1")
+        debug_set("match_exact")
     if mode == "fallback":
-        monkeypatch.setenv("PCREG_MATCH_FORCE_FALLBACK", "1")
+        debug_set("match_force_fallback")
     dS, dM = _descs(Q, M, D, Q + M + D)
     dM[M // 2] = dM[0]                                  # duplicate model rows: ties go to the lowest index
     if M > 100:

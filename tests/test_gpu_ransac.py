@@ -192,8 +192,8 @@ def test_generic_handles_run_on_host():
 
 
 @pytest.mark.parametrize("case", ["clean", "outliers", "norefine", "min4", "three_inliers", "planar_pts1", "planar_pts2"])
-def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypatch):
-    """n >= 4096 runs the staged chain (rs_fit1 / rs_score / rs_moments / rs_fit2); PCREG_RANSAC_FUSED=1
+def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, debug_set):
+    """n >= 4096 runs the staged chain (rs_fit1 / rs_score / rs_moments / rs_fit2); pcreg_debug_set("ransac_fused", 1)
     selects the fused tiled kernel.  Both must reproduce the oracle's counts and inlier set."""
     import pcreg_amd as pc
     n, iters = 6000, 700
@@ -224,7 +224,7 @@ def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypa
     out = {}
     for mode in ("staged", "fused"):
         if mode == "fused":
-            monkeypatch.setenv("PCREG_RANSAC_FUSED", "1")
+            debug_set("ransac_fused")
         out[mode] = pc.ransac(p1, p2, coef, sample_idx=table, seed=21, return_iter_counts=True)
     for mode, res in out.items():
         np.testing.assert_array_equal(res[5], ref["inlrNum"], err_msg=mode)
@@ -244,16 +244,16 @@ def test_staged_pipeline_equals_fused_kernel_and_oracle(case, oracle_c, monkeypa
 
 
 @pytest.mark.parametrize("n,iters,frac", [(4097, 300, 0.3), (8191, 257, 0.0), (140001, 130, 0.2), (5000, 3, 0.0), (4500, 33, 0.3)])
-def test_lane_refit_sizes_and_switch(n, iters, frac, oracle_c, monkeypatch):
+def test_lane_refit_sizes_and_switch(n, iters, frac, oracle_c, debug_set):
     """rs_moments_mfma_kernel (masks kept by the first scoring pass, records added under them on the int8 matrix cores) at ragged sizes,
     past the 64 x 2048 point-block limit of one scoring launch, and against the sweep it replaces
-    (PCREG_RANSAC_NOLANE=1): same counts, same inlier set, transforms equal to rounding."""
+    (pcreg_debug_set("ransac_nolane", 1)): same counts, same inlier set, transforms equal to rounding."""
     import pcreg_amd as pc
     p1, p2, _ = rigid_case(n, 31 + n, noise=0.02, outlier_frac=frac)
     coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)
     ref = oracle_c.ransac(p1, p2, coef, seed=3)
     res = pc.ransac(p1, p2, coef, seed=3, return_iter_counts=True)
-    monkeypatch.setenv("PCREG_RANSAC_NOLANE", "1")
+    debug_set("ransac_nolane")
     res_sweep = pc.ransac(p1, p2, coef, seed=3, return_iter_counts=True)
     assert not ref["failed"] and ref["numSuccess"] > 0
     for r in (res, res_sweep):
@@ -266,13 +266,13 @@ def test_lane_refit_sizes_and_switch(n, iters, frac, oracle_c, monkeypatch):
 
 
 @pytest.mark.parametrize("big_offset", [False, True])
-def test_fp32_screen_band_is_decided_in_fp64(big_offset, oracle_c, monkeypatch):
+def test_fp32_screen_band_is_decided_in_fp64(big_offset, oracle_c, debug_set):
     """rs_score32_kernel screens distances in fp32 and re-scores a hypothesis in fp64 when any distance falls
     within its certified band around thDist.  Here half of the correspondences sit 1e-7 .. 1e-4 (relative) off the
     threshold (offset by a vector of squared length thDist (1 +- delta), no noise): deep inside the fp32 band, far
     outside fp64 rounding, so nearly every hypothesis goes through the band and fp64 must decide it; with
     big_offset the coordinates are ~4000 and the band is wide.  Counts, inlier sets and the fp64-only run
-    (PCREG_RANSAC_F64SCORE=1) must agree with the oracle exactly."""
+    (pcreg_debug_set("ransac_f64score", 1)) must agree with the oracle exactly."""
     import pcreg_amd as pc
     n, iters, th = 6000, 400, 0.05
     p1, p2, _ = rigid_case(n, 1234, noise=0.0, outlier_frac=0.0)
@@ -285,7 +285,7 @@ def test_fp32_screen_band_is_decided_in_fp64(big_offset, oracle_c, monkeypatch):
     coef = dict(minPtNum=3, iterNum=iters, thDist=th, thInlrRatio=0.2, REFINE=True, VERBOSE=0)
     ref = oracle_c.ransac(p1, p2, coef, seed=11)
     res = pc.ransac(p1, p2, coef, seed=11, return_iter_counts=True)
-    monkeypatch.setenv("PCREG_RANSAC_F64SCORE", "1")
+    debug_set("ransac_f64score")
     res64 = pc.ransac(p1, p2, coef, seed=11, return_iter_counts=True)
     assert not ref["failed"]
     near = np.abs(np.asarray(ref["inlrNum"]) - n // 2) < n // 4          # hypotheses that split the cloud at the boundary
@@ -379,7 +379,7 @@ def test_estimate_transform_rank_decision_near_planar(n, ratio):
 
 @pytest.mark.parametrize("n", [1000, 1365])
 @pytest.mark.parametrize("big_offset", [False, True])
-def test_fp32_screen_band_is_decided_in_fp64_resident(n, big_offset, oracle_c):
+def test_fp32_screen_band_is_decided_in_fp64_resident(n, big_offset, oracle_c, debug_set):
     """Resident twin of test_fp32_screen_band_is_decided_in_fp64: n = 1000 (first launch class, two workgroups to a CU) and
     n = 1365 (second class).  Half of the correspondences sit 1e-7 .. 1e-4 (relative) off thDist -- inside the fp32 band,
     far outside fp64 rounding -- so nearly every hypothesis of ransac_hyp32_kernel goes through its fp64 slot re-score; the
@@ -399,6 +399,10 @@ def test_fp32_screen_band_is_decided_in_fp64_resident(n, big_offset, oracle_c):
     near = np.abs(np.asarray(ref["inlrNum"]) - n // 2) < n // 4          # hypotheses that split the cloud at the boundary
     assert near.sum() > 10
     _cmp(res, ref, n)
+    debug_set("ransac_resident_f64")                                      # the round-3 kernel: fp64 only, raw coordinates in LDS
+    res64 = pc.ransac(p1, p2, coef, seed=11, return_iter_counts=True)
+    _cmp(res64, ref, n)
+    assert np.abs(res[0] - res64[0]).max() < 1e-10
 
 
 @pytest.mark.parametrize("n", [3, 4, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 2047, 2048, 2049])

@@ -172,7 +172,7 @@ def _segments_direct(descS, descM, rows_list, par, metric=False):
 
 @pytest.mark.parametrize("par_over", [dict(), dict(Unique=False), dict(UNNORMALIZE=False), dict(CHANGE_METRIC=False),
                                       dict(MatchThreshold=2.0, MaxRatio=0.8)])
-def test_segmented_get_matches_equals_one_call_per_segment(oracle_c, par_over):
+def test_segmented_get_matches_equals_one_call_per_segment(oracle_c, par_over, debug_set):
     """Ragged segments (long, short, one row, empty, overlapping rows, the whole model) against pcreg.getMatches per segment and the
     oracle; with the certificate forced to fail every query takes the refinement (and, at level 2, the exhaustive exact kernel) and the
     answer must not change."""
@@ -196,12 +196,9 @@ def test_segmented_get_matches_equals_one_call_per_segment(oracle_c, par_over):
         want = pc.getMatches(descS, descM[r], par)
         np.testing.assert_array_equal(got[z][0], want, err_msg=f"segment {z}")
         np.testing.assert_array_equal(want, oracle_c.getMatches(descS, descM[r], par))
-    for level in ("1", "2"):          # 1: every query through the score-filtered refinement; 2: and on to the exhaustive exact kernel
-        os.environ["PCREG_MATCH_FORCE_FALLBACK"] = level
-        try:
-            forced = _segments_direct(descS, descM, rows_list, par, metric=True)
-        finally:
-            del os.environ["PCREG_MATCH_FORCE_FALLBACK"]
+    for level in (1, 2):              # 1: every query through the score-filtered refinement; 2: and on to the exhaustive exact kernel
+        debug_set("match_force_fallback", level)
+        forced = _segments_direct(descS, descM, rows_list, par, metric=True)
         for (a, ma), (b, mb) in zip(got, forced):
             np.testing.assert_array_equal(a, b)
             np.testing.assert_array_equal(ma, mb)                # the same exact fp64 distances either way
