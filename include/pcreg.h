@@ -77,9 +77,15 @@ int  pcreg_device_name(char* buf, int cap);  /* e.g. "gfx950:..."               
 /* Test hook, not part of the reference's interface: selects the OTHER side of a certified fast path (process-wide), so that
  * the parity tests can run both sides inside one process.  Every setting returns the same indices and counts.  Keys:
  * "knn_exact", "match_exact", "match_force_fallback" (1, 2), "ransac_fused", "ransac_nolane", "ransac_f64score",
- * "ransac_resident_f64", "align_times", "align_shape", "seg_debug"; value 0 restores the default.  The library reads NO
+ * "ransac_resident_f64", "align_times", "align_shape", "seg_debug", "match_stats"; value 0 restores the default.  The library reads NO
  * environment variable (tests/test_abi.py greps the binary).  PCREG_E_ARG for an unknown key. */
 int  pcreg_debug_set(const char* key, int value);
+/* With pcreg_debug_set("match_stats", 1): the counters of the certified SAD matcher summed over the calls since the last
+ * reset -- out[0] queries finalised, [1] candidates re-scored exactly (fp64), [2] queries the certificate left unproven,
+ * [3] queries handed to the exhaustive exact-rows kernel, [4] Unique back-check items (segmented form), [5] back-check items
+ * handed to the exhaustive kernel, [6] matcher calls, [7] segments.  Synchronises the device.  bench.py reports them so that
+ * a throughput figure says how much of it the certificates carried. */
+int  pcreg_debug_match_stats(long long out[8], int reset);
 
 /* ---- host tier ------------------------------------------------------------------ */
 

@@ -90,18 +90,40 @@ using namespace pcreg;
 namespace pcreg {
 static std::atomic<int> g_debug[kDbgCount];
 int debug_flag(DebugKey k) { return g_debug[k].load(std::memory_order_relaxed); }
+static unsigned long long* g_match_stats = nullptr;
+unsigned long long* match_stats_dev() {
+    if (!debug_flag(kDbgMatchStats)) return nullptr;
+    if (!g_match_stats) {
+        if (hipMalloc((void**)&g_match_stats, 8 * sizeof(unsigned long long)) != hipSuccess) { g_match_stats = nullptr; return nullptr; }
+        (void)hipMemset(g_match_stats, 0, 8 * sizeof(unsigned long long));
+    }
+    return g_match_stats;
+}
 }
 
 extern "C" {
 
 int pcreg_debug_set(const char* key, int value) {
     static const char* const names[pcreg::kDbgCount] = {"knn_exact", "match_exact", "match_force_fallback", "ransac_fused", "ransac_nolane",
-                                                        "ransac_f64score", "ransac_resident_f64", "align_times", "align_shape", "seg_debug"};
+                                                        "ransac_f64score", "ransac_resident_f64", "align_times", "align_shape", "seg_debug",
+                                                        "match_stats"};
     PCREG_ARG(key != nullptr);
     for (int k = 0; k < pcreg::kDbgCount; ++k)
         if (!strcmp(key, names[k])) { pcreg::g_debug[k].store(value, std::memory_order_relaxed); return PCREG_OK; }
     pcreg::set_error("pcreg_debug_set: unknown key '%s'", key);
     return PCREG_E_ARG;
+}
+
+int pcreg_debug_match_stats(long long out[8], int reset) {
+    PCREG_ARG(out != nullptr);
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    if (!pcreg::g_match_stats) return PCREG_OK;               // "match_stats" was never on
+    PCREG_HIP(hipDeviceSynchronize());
+    unsigned long long h[8];
+    PCREG_HIP(hipMemcpy(h, pcreg::g_match_stats, sizeof h, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) out[k] = (long long)h[k];
+    if (reset) PCREG_HIP(hipMemset(pcreg::g_match_stats, 0, sizeof h));
+    return PCREG_OK;
 }
 
 const char* pcreg_last_error(void) { return g_err; }

@@ -31,6 +31,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -59,11 +60,25 @@ Scratch g_cs;                       // the sharded entry points' own device buff
 
 // ---- host-staged transport -----------------------------------------------------------------------------------------
 constexpr size_t kHsSlot = 64u << 20;               // bytes per rank (sparse: only touched pages exist)
-struct HsHeader { std::atomic<int> count; std::atomic<int> sense; std::atomic<int> attached; int world; };
+// The segment's header.  Rank 0 always makes a FRESH segment (shm_unlink, then O_CREAT | O_EXCL: a new inode, zero-filled),
+// fills the header and publishes `magic` last; the other ranks only open what exists.  A segment a crashed run left behind
+// (attached == world, sense == 1, count != 0 ...) is therefore never reused by rank 0, and a rank that opened it before rank
+// 0 replaced it finds out: either it is turned away at once (attached was already at world) or, while it waits for `ready`,
+// it sees the name point at another inode and starts over.  The last rank to leave unlinks the name (if it is still ours).
+constexpr unsigned long long kHsMagic = 0x70637265675f6873ull;      // "pcreg_hs"
+struct HsHeader {
+    std::atomic<unsigned long long> magic;     // kHsMagic once rank 0 has initialised the header
+    std::atomic<int> world;
+    std::atomic<int> attached;                 // ranks that have mapped this segment and been admitted
+    std::atomic<int> ready;                    // rank 0: everybody is attached, the barrier may be used
+    std::atomic<int> detached;
+    std::atomic<int> count; std::atomic<int> sense;      // the sense-reversing barrier
+};
 struct HostStaged {
     bool on = false;
     std::string name;
     void* base = nullptr; size_t bytes = 0;
+    ino_t ino = 0;                      // the segment this process mapped
     int local_sense = 0;
     std::vector<char> tmp;
     HsHeader* hdr() const { return (HsHeader*)base; }
@@ -189,20 +204,71 @@ int pcreg_comm_init_host_staged(int rank, int world, const char* name) {
     std::lock_guard<std::mutex> lock(g_cmu);
     if (g_open) { set_error("pcreg_comm_init_host_staged: a communicator is already open (pcreg_comm_destroy first)"); return PCREG_E_ARG; }
     const size_t bytes = 4096 + (size_t)world * kHsSlot;
-    int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) { set_error("shm_open(%s) failed", name); return PCREG_E_HIP; }
-    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); set_error("ftruncate(%s) failed", name); return PCREG_E_HIP; }     // a fresh segment is zero-filled
-    void* base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (base == MAP_FAILED) { set_error("mmap(%s) failed", name); return PCREG_E_HIP; }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto timed_out = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120); };
+    auto name_ino = [&](ino_t* out) {            // the inode the name refers to NOW (false: no such segment)
+        int f = shm_open(name, O_RDWR, 0600);
+        if (f < 0) return false;
+        struct stat sb; const bool ok = fstat(f, &sb) == 0;
+        close(f);
+        if (ok) *out = sb.st_ino;
+        return ok;
+    };
+    void* base = MAP_FAILED; ino_t ino = 0;
+    if (rank == 0) {
+        (void)shm_unlink(name);                  // whatever a previous run left under this name is not ours
+        int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) { set_error("shm_open(%s, O_CREAT | O_EXCL) failed: %s", name, strerror(errno)); return PCREG_E_HIP; }
+        struct stat sb;
+        if (ftruncate(fd, (off_t)bytes) != 0 || fstat(fd, &sb) != 0) { close(fd); shm_unlink(name); set_error("ftruncate(%s) failed", name); return PCREG_E_HIP; }   // zero-filled
+        base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (base == MAP_FAILED) { shm_unlink(name); set_error("mmap(%s) failed", name); return PCREG_E_HIP; }
+        ino = sb.st_ino;
+        HsHeader* h = (HsHeader*)base;
+        h->world.store(world); h->attached.store(1); h->ready.store(0); h->detached.store(0); h->count.store(0); h->sense.store(0);
+        h->magic.store(kHsMagic, std::memory_order_release);
+    } else {
+        for (;;) {                               // open what rank 0 made; never create
+            if (timed_out()) { set_error("host-staged communicator: rank %d found no live segment %s within 120 s", rank, name); return PCREG_E_HIP; }
+            int fd = shm_open(name, O_RDWR, 0600);
+            struct stat sb;
+            if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) { if (fd >= 0) close(fd); sched_yield(); continue; }
+            base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (base == MAP_FAILED) { set_error("mmap(%s) failed", name); return PCREG_E_HIP; }
+            ino = sb.st_ino;
+            HsHeader* h = (HsHeader*)base;
+            bool stale = false;
+            while (h->magic.load(std::memory_order_acquire) != kHsMagic && !stale) {      // rank 0 is still filling the header -- or this is debris
+                sched_yield();
+                ino_t now; stale = timed_out() || (name_ino(&now) && now != ino);
+            }
+            // admitted only while there is room: a complete segment of an earlier run (attached == world) turns the newcomer away
+            if (!stale && h->world.load() == world && h->attached.fetch_add(1, std::memory_order_acq_rel) < world) {
+                while (!h->ready.load(std::memory_order_acquire) && !stale) {              // rank 0 of THIS run has seen everybody
+                    sched_yield();
+                    ino_t now; stale = timed_out() || !name_ino(&now) || now != ino;       // ... unless the name has moved on: debris
+                }
+                if (!stale) break;
+            }
+            munmap(base, bytes); base = MAP_FAILED;
+            sched_yield();
+        }
+    }
     int rc = open_common(rank, world);
-    if (rc) { munmap(base, bytes); return rc; }
-    g_hs.on = true; g_hs.name = name; g_hs.base = base; g_hs.bytes = bytes; g_hs.local_sense = 0;
-    g_hs.hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
-    const auto t0 = std::chrono::steady_clock::now();                       // every rank is attached before anybody uses the barrier
-    while (g_hs.hdr()->attached.load(std::memory_order_acquire) < world) {
-        sched_yield();
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) { set_error("host-staged communicator: %d of %d ranks attached", g_hs.hdr()->attached.load(), world); return PCREG_E_HIP; }
+    if (rc) { munmap(base, bytes); if (rank == 0) shm_unlink(name); return rc; }
+    g_hs.on = true; g_hs.name = name; g_hs.base = base; g_hs.bytes = bytes; g_hs.ino = ino; g_hs.local_sense = 0;
+    if (rank == 0) {
+        while (g_hs.hdr()->attached.load(std::memory_order_acquire) < world) {
+            sched_yield();
+            if (timed_out()) {
+                set_error("host-staged communicator: %d of %d ranks attached", g_hs.hdr()->attached.load(), world);
+                munmap(base, bytes); shm_unlink(name); g_hs = HostStaged{}; close_common();
+                return PCREG_E_HIP;
+            }
+        }
+        g_hs.hdr()->ready.store(1, std::memory_order_release);
     }
     return PCREG_OK;
 }
@@ -220,8 +286,16 @@ int pcreg_comm_destroy(void) {
     if (g_cstream) (void)hipStreamSynchronize(g_cstream);
     if (g_comm) { (void)g_rccl.CommDestroy(g_comm); g_comm = nullptr; }
     if (g_hs.on) {
+        // the last rank to leave removes the name -- if it still refers to the segment this process mapped
+        const bool last = g_hs.hdr()->detached.fetch_add(1, std::memory_order_acq_rel) + 1 >= g_world;
         munmap(g_hs.base, g_hs.bytes);
-        if (g_rank == 0) shm_unlink(g_hs.name.c_str());
+        if (last) {
+            int f = shm_open(g_hs.name.c_str(), O_RDWR, 0600);
+            struct stat sb;
+            const bool ours = f >= 0 && fstat(f, &sb) == 0 && sb.st_ino == g_hs.ino;
+            if (f >= 0) close(f);
+            if (ours) shm_unlink(g_hs.name.c_str());
+        }
         g_hs = HostStaged{};
     }
     close_common();

@@ -67,9 +67,15 @@ enum DebugKey {
     kDbgAlignTimes,            // "align_times": per-phase timestamps of align_points_knn (host read-back)
     kDbgAlignShape,            // "align_shape": launch-shape override of align_points_knn
     kDbgSegDebug,              // "seg_debug": histogram dump of the segmented matcher
+    kDbgMatchStats,            // "match_stats": the certified matcher counts what it proves / re-scores / hands on (pcreg_debug_match_stats)
     kDbgCount
 };
 int debug_flag(DebugKey k);
+// Device counters of the certified SAD matcher (match_sad16.hip), or null while "match_stats" is off:
+//   [0] queries finalised   [1] candidates re-scored exactly (fp64)   [2] queries the certificate left unproven
+//   [3] queries handed to the exhaustive exact-rows kernel   [4] Unique back-check items (segmented form)
+//   [5] back-check items handed to the exhaustive kernel   [6] matcher calls   [7] segments
+unsigned long long* match_stats_dev();
 #ifdef PCREG_EXPERIMENTS
 static inline int pcreg_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static inline const char* pcreg_env_str(const char* name) { return getenv(name); }

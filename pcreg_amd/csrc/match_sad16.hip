@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __
                                                                 const uint32_t* __restrict__ part_s, int S,
                                                                 int32_t* __restrict__ idx, double* __restrict__ dist,
                                                                 int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven,
-                                                                const int32_t* __restrict__ nA_live) {
+                                                                const int32_t* __restrict__ nA_live, unsigned long long* __restrict__ stats) {
     __shared__ double s_t[kBlock / 64][kNC][kFT];          // 32 KiB
     __shared__ int s_j[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -436,8 +436,14 @@ __global__ __launch_bounds__(kBlock) void sad16_finalize_kernel(const double* __
     if (lane == 0) {
         if (ok) { idx[(size_t)qi * 2] = i1; idx[(size_t)qi * 2 + 1] = i2; dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2; }
         else { int slot = atomicAdd(n_flag, 1); flag_list[slot] = qi; }
+        if (stats) {          // pcreg_debug_set("match_stats", 1): what the certificate proved, re-scored, handed on
+            atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)n_need);
+            if (!ok) { atomicAdd(&stats[2], 1ull); atomicAdd(&stats[3], 1ull); }
+        }
     }
 }
+
+__global__ void stats_bump_kernel(unsigned long long* stats, int k, unsigned long long v) { atomicAdd(&stats[k], v); }
 
 // ---- fallback: unproven queries, exhaustively, exact ---------------------------------------------
 // grid (nf, SC): block = one unproven query x one slice of B; the query row sits in LDS, each thread
@@ -864,7 +870,8 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
                                                                const uint32_t* __restrict__ part_s, int splits,
                                                                int32_t* __restrict__ idx, double* __restrict__ dist,
                                                                int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven,
-                                                               double match_thr, double max_ratio, int32_t* __restrict__ dbg_hist) {
+                                                               double match_thr, double max_ratio, int32_t* __restrict__ dbg_hist,
+                                                               unsigned long long* __restrict__ stats) {
     __shared__ double s_t[kBlock / 64][kNC][kFT];
     __shared__ int s_j[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -989,6 +996,7 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
     if (lane == 0) {          // an unproven query keeps its provisional pair: segp_refine_kernel starts from it
         idx[(size_t)qi * 2] = i1; idx[(size_t)qi * 2 + 1] = i2; dist[(size_t)qi * 2] = d1; dist[(size_t)qi * 2 + 1] = d2;
         if (!ok) { int slot = atomicAdd(&n_flag[z], 1); flag_list[slot] = qi; }
+        if (stats) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)n_need); if (!ok) atomicAdd(&stats[2], 1ull); }
     }
 }
 
@@ -1002,7 +1010,8 @@ __global__ __launch_bounds__(kBlock) void segp_refine_kernel(SegSets S, const do
                                                              const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_m,
                                                              const uint32_t* __restrict__ Sc, int ldsc, const int32_t* __restrict__ flag_list,
                                                              const int32_t* __restrict__ n_flag, int32_t* __restrict__ idx, double* __restrict__ dist,
-                                                             int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip) {
+                                                             int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip,
+                                                             unsigned long long* __restrict__ stats) {
     __shared__ double s_t[kBlock / 64][kNC][kFT];
     __shared__ int s_j[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1035,7 +1044,7 @@ __global__ __launch_bounds__(kBlock) void segp_refine_kernel(SegSets S, const do
             if (take) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = j;
             n_need += cnt;
         }
-        if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = qi; } continue; }
+        if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = qi; if (stats) atomicAdd(&stats[3], 1ull); } continue; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         const SegRow a = BACK ? seg_model_row(V, cand_m[(size_t)z * nA + qi]) : seg_surface_row(V, qi);
         double d1, d2; int i1, i2;
@@ -1058,7 +1067,8 @@ __global__ __launch_bounds__(kBlock) void segp_back_direct_kernel(SegSets S, con
                                                                   const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
                                                                   const uint32_t* __restrict__ Sc, int ldsc, const double* __restrict__ fdist,
                                                                   int32_t* __restrict__ bidx, double* __restrict__ bdist,
-                                                                  int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip) {
+                                                                  int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip,
+                                                                  unsigned long long* __restrict__ stats) {
     __shared__ double s_t[kBlock / 64][kNC][kFT];
     __shared__ int s_j[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1097,7 +1107,8 @@ __global__ __launch_bounds__(kBlock) void segp_back_direct_kernel(SegSets S, con
             if (take) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = a;
             n_need += cnt;
         }
-        if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = k; } continue; }
+        if (stats && lane == 0) atomicAdd(&stats[4], 1ull);
+        if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = k; if (stats) atomicAdd(&stats[5], 1ull); } continue; }
         // q itself always passes (smax bounds its own score from above, and it was not rejected against bmax); every row left out
         // is STRICTLY farther than d(q, m).  If q is alone, it is the best surface row of m: nothing to sum.
         if (n_need == 1) {
@@ -1378,6 +1389,8 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
 #endif
         hipLaunchKernelGGL(sad16_candidates_kernel<kSadLists>, dim3(n_tiles, S), dim3(kBlock), 0, st, Aq, nA, ldqa, Bq, nB, ldqb, D2p, chunk, part_idx, part_s, dbg, nA_live, SegZ{0, 0, 0, 0, nullptr, nullptr, 0});
     const int force = debug_flag(kDbgMatchForceFallback) != 0;
+    unsigned long long* stats = match_stats_dev();
+    if (stats) hipLaunchKernelGGL(stats_bump_kernel, dim3(1), dim3(1), 0, st, stats, 6, 1ull);
     if (dbg) {
         std::vector<unsigned long long> h((size_t)n_tiles * S * 4);
         PCREG_HIP(hipStreamSynchronize(st));
@@ -1393,7 +1406,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
     hipLaunchKernelGGL(transpose_rows_kernel, dim3((nA + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, A, nA, lda, D, At, nA_live);
     hipLaunchKernelGGL(transpose_rows_kernel, dim3((nB + 63) / 64, (D + 63) / 64), dim3(kBlock), 0, st, B, nB, ldb, D, Bt, (const int32_t*)nullptr);
     hipLaunchKernelGGL(sad16_finalize_kernel, dim3((nA + 3) / 4), dim3(kBlock), 0, st, At, nA, Bt, nB, D, range,
-                       part_idx, part_s, S, idx, dist, flag_list, n_flag, force, nA_live);
+                       part_idx, part_s, S, idx, dist, flag_list, n_flag, force, nA_live, stats);
     PCREG_HIP(hipGetLastError());
     if (PCREG_EXP_ENV("PCREG_MATCH_DEBUG", 0)) {                       // the only host round trip of the call, debugging only
         int32_t nf = 0;
@@ -1507,15 +1520,17 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
     const int force = debug_flag(kDbgMatchForceFallback) != 0, skip_refine = debug_flag(kDbgMatchForceFallback) == 2;
     hipLaunchKernelGGL(segp_select_kernel, dim3(L.ldqa / 64, (L.splits + 3) / 4, S), dim3(kBlock), 0, st, Sc, L.ldqa, seg_rows, seg_off, Q, L.chunk, L.splits, part_idx, part_s);
     int32_t* dbg_hist = nullptr;
+    unsigned long long* stats = match_stats_dev();
+    if (stats) { hipLaunchKernelGGL(stats_bump_kernel, dim3(1), dim3(1), 0, st, stats, 6, 1ull); hipLaunchKernelGGL(stats_bump_kernel, dim3(1), dim3(1), 0, st, stats, 7, (unsigned long long)S); }
 #ifdef PCREG_EXPERIMENTS
     if (debug_flag(kDbgSegDebug)) { PCREG_HIP(hipMalloc((void**)&dbg_hist, 2 * 130 * sizeof(int32_t))); PCREG_HIP(hipMemsetAsync(dbg_hist, 0, 2 * 130 * sizeof(int32_t), st)); }
 #endif
     hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, dbg_hist);
+                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, dbg_hist, stats);
     const int slice_f = (n_max + kSegFbSlices - 1) / kSegFbSlices;
     PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
     hipLaunchKernelGGL(segp_refine_kernel<false>, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const uint32_t*)Sc, L.ldqa,
-                       (const int32_t*)flag_list, (const int32_t*)n_flag, idx, dist, flag2, n_flag2, skip_refine);
+                       (const int32_t*)flag_list, (const int32_t*)n_flag, idx, dist, flag2, n_flag2, skip_refine, stats);
     hipLaunchKernelGGL(segp_exact_rows_kernel<false>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
                        (const int32_t*)nullptr, flag2, n_flag2, slice_f, fpi, fpd);
     hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag2, n_flag2, Q, fpi, fpd, idx, dist);
@@ -1532,7 +1547,7 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
         PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
         hipLaunchKernelGGL(segp_back_direct_kernel, dim3(std::max(1, std::min((Q + 3) / 4, 128)), 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc,
                            (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const double*)dist, bidx, bdist,
-                           flag2, n_flag2, skip_refine);
+                           flag2, n_flag2, skip_refine, stats);
         hipLaunchKernelGGL(segp_exact_rows_kernel<true>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
                            cand_m, flag2, n_flag2, 0, fpi, fpd);
         hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag2, n_flag2, Q, fpi, fpd, bidx, bdist);

@@ -61,16 +61,61 @@ def test_one_rank_communicator_equals_single_gpu(oracle_c):
     assert L.pcreg_comm_rank(C.byref(r), C.byref(w)) != 0             # closed
 
 
+def _run_two_ranks(name, stagger=0.0):
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = {}
+    for r in (1, 0):                        # rank 1 first: with `stagger` it meets whatever lies under the name before rank 0 replaces it
+        procs[r] = subprocess.Popen([sys.executable, os.path.join(root, "scripts", "cabi_two_ranks_one_gpu.py"), str(r), "2", name],
+                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=root)
+        if r == 1 and stagger:
+            time.sleep(stagger)
+    try:
+        for r in (0, 1):
+            o = procs[r].communicate(timeout=600)[0]
+            assert procs[r].returncode == 0 and f"rank {r}: cabi_world2_ok=True" in o, o[-3000:]
+    finally:
+        for pr in procs.values():
+            if pr.poll() is None:
+                pr.kill()
+        try:
+            os.unlink("/dev/shm" + name)    # a failed run leaks its segment (the last rank to leave unlinks it otherwise)
+        except FileNotFoundError:
+            pass
+    assert not os.path.exists("/dev/shm" + name)
+
+
 def test_two_ranks_through_the_c_abi_on_one_gpu():
     """The N > 1 path of comm.hip with two PROCESSES on cuda:0 (host-staged communicator): rank strides of the gathered
     top-2, one contributor per table column, empty shards, uneven / empty hypothesis shares, reuse of the scratch."""
     import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    name = f"/pcreg_test_{os.getpid()}"
-    procs = [subprocess.Popen([sys.executable, os.path.join(root, "scripts", "cabi_two_ranks_one_gpu.py"), str(r), "2", name],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=root) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"rank {r}: cabi_world2_ok=True" in o, o[-3000:]
+    _run_two_ranks(f"/pcreg_test_{os.getpid()}")
+
+
+@pytest.mark.parametrize("debris", ["complete_run", "crashed_mid_attach", "garbage"])
+def test_host_staged_communicator_ignores_a_dirty_segment(debris):
+    """a segment left under the same name by a crashed run -- every rank attached, sense = 1, a
+    half-counted barrier; or a run that died while attaching; or garbage -- must not be trusted.  Rank 0 unlinks and
+    creates exclusively, rank 1 (started first, so it opens the debris) is turned away or notices the name moving on.
+    The world-2 protocol then has to give the oracle's results as usual."""
+    import os
+    import struct
+    name = f"/pcreg_dirty_{os.getpid()}_{debris}"
+    path = "/dev/shm" + name
+    fd = os.open(path, os.O_CREAT | os.O_RDWR, 0o600)
+    try:
+        os.ftruncate(fd, 4096 + 2 * (64 << 20))
+        magic = 0x70637265675f6873
+        if debris == "complete_run":       # magic, world, attached, ready, detached, count, sense
+            os.pwrite(fd, struct.pack("<Qiiiiii", magic, 2, 2, 1, 0, 1, 1), 0)
+        elif debris == "crashed_mid_attach":
+            os.pwrite(fd, struct.pack("<Qiiiiii", magic, 2, 1, 0, 0, 0, 0), 0)
+        else:
+            os.pwrite(fd, bytes(range(256)) * 16, 0)
+        os.pwrite(fd, b"\xff" * 4096, 4096)                       # stale slot contents
+    finally:
+        os.close(fd)
+    _run_two_ranks(name, stagger=1.5)
