@@ -274,7 +274,7 @@ def run_batch_cfg5(ctx: Ctx, n_crops: int, M: int, Q: int) -> dict:
                        f"match + RANSAC(3,1e4,0.3,0.08,REFINE) per crop",
            "ms": round(best * 1e3, 3), "registrations_per_s": round(n_crops / best, 2), "failed": int(sum(r["failed"] for r in res)),
            "min_inliers": int(min(r["n_inliers"] for r in res)), "scaling": "strong (fixed batch)", "n_gpus": ctx.world,
-           "roofline": {"note": "composite of the headline step; its dominant kernel is the headline's (see roofline there)"}}
+           "roofline": {"note": "composite of the headline step (its dominant kernel is the headline's)"}}
     del br, model_soa, surfaces
     torch.cuda.empty_cache()
     return out
@@ -316,8 +316,7 @@ def extra_get_matches(dev, with_cpu: bool) -> dict:
            "ms": round(ms, 2), "gpairs_per_s": round(Q * M / ms / 1e6, 1), "pairs_found": n_pairs,
            "roofline": {"bound": "valu", "achieved": round(flops / ms / 1e9, 1), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                        "note": "SURVEY 8d: (3D-1) flop per pair against the fp32 vector peak; the kernel accumulates |a-b| on u16 pairs "
-                                "with v_sad_u16 (certified, exact re-rank in fp64)"}}
+                        "note": "(3D-1) flop/pair vs fp32 vector peak; v_sad_u16 + exact fp64 re-rank"}}
     if with_cpu:
         from oracle import c_oracle
         cores = host_cores()
@@ -366,9 +365,7 @@ def extra_descriptors(dev, with_cpu: bool) -> dict:
            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / ms / 1e6, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(alg_bytes / ms / 1e6 / PEAK_HBM_GBPS, 4), "traffic": None,
                         "algorithmic_bytes": int(alg_bytes), "algorithmic_bytes_matlab_double_rows": int(alg_bytes_f64),
-                        "note": "algorithmic bytes = cloud + keypoints read once, V x (980 uint16 + feat + index) written; SURVEY 8d's figure for "
-                                "MATLAB-shaped double rows is given beside it.  The kernel is bound by its dependent passes over each support "
-                                "(L2 gathers + fp64 moments, DESIGN 4.5), not by HBM"}}
+                        "note": "cloud + keypoints read, V x (980 u16 + feat + index) written; not HBM-bound"}}
     if with_cpu:
         from oracle import c_oracle
         cores = host_cores()
@@ -437,7 +434,7 @@ def extra_ransac_cfg1(dev, with_cpu: bool) -> dict:
            "ms": round(ms, 4), "registrations_per_s": round(1e3 / ms, 1), "max_inliers": res["maxInliers"], "failed": res["failed"],
            "roofline": {"bound": "valu-fp64", "achieved": round(flops / ms / 1e9, 2), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flops / ms / 1e9 / PEAK_FP64_TFLOPS, 4), "traffic": None,
-                        "note": "48 KB of correspondences resident in LDS; one small registration is latency-bound: batches of registrations fill the chip (cfg 5)"}}
+                        "note": "one small registration is latency-bound; see ransac_cfg1_batched"}}
     if with_cpu:
         from oracle import c_oracle
         t0 = time.perf_counter()
@@ -477,12 +474,19 @@ def extra_ransac_cfg1_batched(dev, with_cpu: bool) -> dict:
     raw = res.cpu().numpy()
     rr = [DevRansacResult.from_buffer_copy(raw[b].tobytes()) for b in range(B)]
     flops = float(B) * it * n * 76.0
+    # What the launch executes per (hypothesis, correspondence) now (ransac_hyp32_kernel, every hypothesis refits on this data): two
+    # screened scoring passes = 2 x 15 packed-fp32 operations (78.6 T lane-op/s) + 2 x 2 compares (39.3 T/s), and 15 fp64 operations
+    # of the refit sums (39.3 T/s); the time those take at the issue peaks is the floor the kernel is measured against.
+    pairs = float(B) * it * n
+    floor_ms = pairs * (30.0 / 78.6e12 + 4.0 / 39.3e12 + 15.0 / 39.3e12) * 1e3
     return {"workload": f"{B} registrations x (n = {n}, iterNum = {it}, thDist 0.1, thInlrRatio 0.5, REFINE) in one launch (pcreg_dev_ransac_batched)",
             "ms": round(ms, 3), "registrations_per_s": round(B / ms * 1e3, 1), "failed": int(sum(r.failed for r in rr)),
             "max_inliers_min": int(min(r.max_inliers for r in rr)),
-            "roofline": {"bound": "valu-fp64", "achieved": round(flops / ms / 1e9, 2), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "valu", "achieved": round(flops / ms / 1e9, 2), "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flops / ms / 1e9 / PEAK_FP64_TFLOPS, 4), "traffic": None,
-                         "note": "SURVEY 8d's 76 flop per (hypothesis, point); each registration's 48 KB of correspondences sit in LDS"}}
+                         "executed": {"per_pair": "30 packed-fp32 + 4 compares + 15 fp64 (two screened passes, masked refit sums)",
+                                      "floor_ms_at_issue_peaks": round(floor_ms, 3), "frac_of_floor": round(floor_ms / ms, 4)},
+                         "note": "76 flop per (hypothesis, point) of SURVEY 8d vs fp64 peak; `executed`: issue floor"}}
 
 
 def extra_sweep(dev, with_cpu: bool) -> dict:
@@ -511,18 +515,19 @@ def extra_sweep(dev, with_cpu: bool) -> dict:
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter(); out = sw.run(par, opt, **kw); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     ms = min(ts) * 1e3
-    S = len(out["centres"]); pairs = float(VS) * float(out["num_desc"].sum())
-    flops = (3.0 * (D + 1) - 1.0) * pairs
+    S = len(out["centres"])
+    union = int(len(np.unique(np.concatenate(out["model_rows"])))) if S else 0
+    pairs_dedup = float(VS) * float(union)                       # every (surface row, model row that lies in SOME sphere) pair once
+    pairs_per_sphere_calls = float(VS) * float(out["num_desc"].sum())
+    flops = (3.0 * (D + 1) - 1.0) * pairs_dedup
     res = {"workload": f"sphere sweep: {S} valid spheres of a {VM}-keypoint model ({int(out['num_desc'].mean())} descriptors per sphere on average), surface {VS} "
                        f"keypoints, D {D}, getMatches per sphere (SAD, power 0.6, 10 %, 0.99, Unique), {len(out['trial'])} trial spheres x RANSAC(3,1e4,0.3,0.08,REFINE)",
            "ms": round(ms, 2), "spheres_per_s": round(S / ms * 1e3, 1), "host_syncs": 2, "trial_spheres": int(len(out["trial"])),
            "registered": int(sum(t is not None for t in out["transforms"])),
            "roofline": {"bound": "valu", "achieved": round(flops / ms / 1e9, 1), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                        "note": "SURVEY 8d's (3D-1) flop per (surface row, sphere row) pair of every per-sphere getMatches call, over the WHOLE sweep (sphere "
-                                "selection, matching, plan, batched RANSAC, read-back), against the fp32 vector peak.  The library scores each (surface row, "
-                                "model row) pair once for all spheres (the spheres overlap ~8-fold) and certifies per sphere, so it executes fewer SAD "
-                                "operations than the algorithmic count (DESIGN 4.6)"}}
+                        "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None, "dedup_model_rows": union,
+                        "sphere_overlap": round(pairs_per_sphere_calls / max(pairs_dedup, 1.0), 2),
+                        "note": "(3D-1) flop per de-duplicated pair; kernel split: docs/BENCH_NOTES.md"}}
     if with_cpu:
         from oracle import c_oracle
         import oracle.pcreg_oracle as opy
@@ -546,6 +551,203 @@ def extra_sweep(dev, with_cpu: bool) -> dict:
     return res
 
 
+def _ridge_volume(P: int, S: int, seed: int = 5):
+    """A 60 x 50 x 40 mm block of 48 undulating ridges (strips 2.4 mm wide, 6 mm apart in y, 6.5 mm in z): R = 3.5 supports hold
+    ~1000-2000 points and are elongated, so keypoints pass getSpacialHistogramDescriptors' eigenvalue-ratio test (thVar [3, 1.5]);
+    a sphere of R_desc = 9 takes in ~9 ridges -- the shape of the reference's CT surfaces as far as the path is concerned."""
+    rng = np.random.default_rng(seed)
+    ny, nz = 8, 6
+
+    def on_ridges(n, half_w, dz):
+        r = rng.integers(0, ny * nz, n); iy, iz = r % ny, r // ny
+        x = rng.uniform(0, 60, n)
+        return np.column_stack([x, 4 + 6 * iy + rng.uniform(-half_w, half_w, n), 3.5 + 6.5 * iz + 0.8 * np.sin(0.5 * x + 0.7 * iy + 1.3 * iz) + dz(n)])
+    pts = on_ridges(P, 1.2, lambda n: rng.normal(0, 0.25, n))
+    kp = on_ridges(S, 1.0, lambda n: rng.uniform(-0.4, 0.4, n))
+    return pts, kp
+
+
+DESC_OPT = dict(min_pts=500, max_pts=6000, R=3.5, thVar=[3, 1.5], k=0.85, ALIGN_POINTS=True, VERBOSE=0)
+MATCH_PAR = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate", MatchThreshold=10, MaxRatio=0.99,
+                 Metric="SAD", Unique=True, VERBOSE=0)
+
+
+def desc_chain_data(dev, n_model_kp: int, n_surface_kp: int, P: int = 600_000, compact: bool = True):
+    """cfg 4 -> cfg 2 on rows the descriptor kernel produces: a model cloud with n_model_kp keypoints, and a SURFACE that is a
+    moved, noisy crop of it (the n_surface_kp model keypoints nearest to a centre, jittered; the cloud around them with its own
+    noise), both described by pcreg_dev_spatial_histogram_descriptors[_rows_u16].  -> dict with the device tensors and timings."""
+    import torch
+    from pcreg_amd.device import DescriptorPipeline
+    cloud, kpM = _ridge_volume(P, n_model_kp)
+    c0 = np.array([30.0, 25.0, 20.0])
+    rng = np.random.default_rng(77)
+    dk = np.linalg.norm(kpM - c0, axis=1)
+    near = np.sort(np.argpartition(dk, n_surface_kp - 1)[:n_surface_kp])
+    r_s = float(dk[near].max())
+    crop = cloud[np.linalg.norm(cloud - c0, axis=1) < r_s + 4.5]
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1.0]]); t = np.array([2.0, -1.0, 0.5])
+    move = lambda x: (x - c0) @ R.T + c0 + t
+    surf = move(crop + rng.normal(0, 0.02, crop.shape))
+    kpS = move(kpM[near] + rng.normal(0, 0.05, (n_surface_kp, 3)))
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(dev)
+    dp = DescriptorPipeline(dev)
+    tm, tkm, ts, tks = tt(cloud), tt(kpM), tt(surf), tt(kpS)
+    dp.describe(tm[:, :50_000].contiguous(), tkm[:, :1000].contiguous(), DESC_OPT, compact=compact)           # warm-up (allocations)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    featM, descM, VM = dp.describe(tm, tkm, DESC_OPT, compact=compact)
+    torch.cuda.synchronize(); ms_m = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    featS, descS, VS = dp.describe(ts, tks, DESC_OPT, compact=compact)
+    torch.cuda.synchronize(); ms_s = (time.perf_counter() - t0) * 1e3
+    return dict(dp=dp, cloud=cloud, kpM=kpM, surf=surf, kpS=kpS, near=near, featM=featM, descM=descM, VM=VM, featS=featS, descS=descS, VS=VS,
+                describe_model_ms=ms_m, describe_surface_ms=ms_s, R=R, t=t, c0=c0)
+
+
+def _match_stats(reset: bool = True) -> dict:
+    from pcreg_amd._lib import check, lib
+    out = (C.c_longlong * 8)()
+    check(lib().pcreg_debug_match_stats(out, 1 if reset else 0))
+    q = max(int(out[0]), 1)
+    return {"queries": int(out[0]), "rescored_per_query": round(out[1] / q, 2), "unproven": int(out[2]), "to_exhaustive": int(out[3]),
+            "back_items": int(out[4]), "back_to_exhaustive": int(out[5]), "calls": int(out[6])}
+
+
+def extra_desc_chain(dev, with_cpu: bool) -> dict:
+    """getMatches and the sphere sweep on rows that the repo's own descriptor kernel produces (sparse, spatially
+    correlated spherical histograms of overlapping supports, getSpacialHistogramDescriptors.m:150-171) instead of i.i.d. Poisson
+    rows.  (a) 200 k model keypoints, 20 k surface keypoints: describe -> pcreg_dev_get_matches_rows_u16; (b) the reference's
+    sweep shape, 60 k / 2 k: describe -> SphereSweep.run.  Each with the certified matcher's counters."""
+    import torch
+    from pcreg_amd._lib import check, lib
+    from pcreg_amd.sweep import SphereSweep
+    L = lib()
+    res = {}
+    # ---- (a) cfg 4 -> cfg 2
+    d = desc_chain_data(dev, 200_000, 20_000)
+    dp, VM, VS = d["dp"], d["VM"], d["VS"]
+    ms = _ev_ms(lambda: dp.match(d["descS"], VS, d["descM"], VM, MATCH_PAR), reps=2)
+    check(L.pcreg_debug_set(b"match_stats", 1)); _match_stats()
+    pairs, n_pairs = dp.match(d["descS"], VS, d["descM"], VM, MATCH_PAR)
+    st = _match_stats(); check(L.pcreg_debug_set(b"match_stats", 0))
+    P_ = int(n_pairs.item())
+    pr = pairs[:P_].cpu().numpy().astype(np.int64)
+    # a pair is right when the surface keypoint's model original is the matched model keypoint (both sets keep keypoint order)
+    iS = d["descS"].index[:VS].cpu().numpy(); iM = d["descM"].index[:VM].cpu().numpy()
+    right = int(np.sum(d["near"][iS[pr[:, 0] - 1]] == iM[pr[:, 1] - 1])) if P_ else 0
+    flops = (3.0 * 981 - 1.0) * VS * VM
+    res["get_matches"] = {"workload": f"describe {d['kpM'].shape[0]} + {d['kpS'].shape[0]} keypoints -> getMatches rows_u16 {VS} x {VM}, D 981",
+                          "describe_model_ms": round(d["describe_model_ms"], 2), "describe_surface_ms": round(d["describe_surface_ms"], 2),
+                          "ms": round(ms, 2), "gpairs_per_s": round(VS * VM / ms / 1e6, 1), "pairs_found": P_, "pairs_right": right, "stats": st,
+                          "roofline": {"bound": "valu", "achieved": round(flops / ms / 1e9, 1), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None}}
+    del d, dp, pairs
+    torch.cuda.empty_cache()
+    # ---- (b) the sweep at the reference's shape on described rows
+    d = desc_chain_data(dev, 60_000, 2_000, compact=False)
+    VM, VS = d["VM"], d["VS"]
+    sw = SphereSweep(d["featM"][:VM], d["descM"][:VM], d["featS"][:VS], d["descS"][:VS], device=dev)
+    opt = dict(minPtNum=3, iterNum=10000, thDist=0.3, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    kw = dict(R_desc=9.0, d_spheres=5.0, min_pts=1400, putative_thresh=170, seed=0)
+    out = sw.run(MATCH_PAR, opt, **kw)
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); out = sw.run(MATCH_PAR, opt, **kw); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    check(L.pcreg_debug_set(b"match_stats", 1)); _match_stats()
+    sw.run(MATCH_PAR, opt, **kw)
+    st = _match_stats(); check(L.pcreg_debug_set(b"match_stats", 0))
+    ms = min(ts) * 1e3
+    S = len(out["centres"])
+    # a registration is right when its T carries the model keypoints onto their moved surface copies ([pts2, 1] * T = [pts1, 1],
+    # pts1 = surface, pts2 = model: estimateTransform.m's actual contract, SURVEY 8a row 5)
+    good = 0
+    for T in out["transforms"]:
+        if T is not None:
+            fwd = (np.c_[d["kpM"][d["near"][:50]], np.ones(50)] @ T)[:, :3]
+            good += bool(np.abs(fwd - d["kpS"][:50]).max() < 0.5)
+    union = int(len(np.unique(np.concatenate(out["model_rows"])))) if S else 0
+    flops = (3.0 * 981 - 1.0) * VS * union                       # each (surface row, model row IN SOME sphere) pair once
+    res["sweep"] = {"workload": f"describe 60000 + 2000 keypoints -> sweep: {S} spheres of {VM} described model keypoints, {VS} surface rows",
+                    "describe_model_ms": round(d["describe_model_ms"], 2), "ms": round(ms, 2), "spheres_per_s": round(S / ms * 1e3, 1) if ms > 0 else 0,
+                    "trial_spheres": int(len(out["trial"])), "registered": int(sum(t is not None for t in out["transforms"])), "registered_right": int(good),
+                    "stats": st,
+                    "roofline": {"bound": "valu", "achieved": round(flops / ms / 1e9, 1), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None, "dedup_model_rows": union}}
+    del sw, d
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_host_tier(dev, with_cpu: bool) -> dict:
+    """what a MATLAB caller gets -- the HOST tier of the C ABI (pageable host arrays in, host arrays out,
+    through ctypes exactly as through the MEX gateway), wall clock, beside the device-tier figures above."""
+    import pcreg_amd as pc
+    res = {}
+    wall = lambda fn, reps=3: min(_t(fn) for _ in range(reps)) * 1e3
+    def _t(fn):
+        t0 = time.perf_counter(); fn(); return time.perf_counter() - t0
+    # ransac, cfg 1's data
+    rng = np.random.default_rng(1)
+    n = 1000
+    pts = rng.uniform([-3, -2, 0], [3, 2, 3], (n, 3))
+    R = eul2rotm_zyx([1.5, -1.2, 0.8]); t = np.array([1.0, 2.0, 3.0])
+    loc1S = pts @ R + t; loc1M = pts + np.random.default_rng(2).normal(0, 0.1, pts.shape)
+    coef = dict(minPtNum=3, iterNum=20000, thInlrRatio=0.5, thDist=0.1, REFINE=True, VERBOSE=0)
+    pc.ransac(loc1M, loc1S, coef, pc.estimateTransform, pc.calcDists, seed=3)
+    res["ransac_n1000_ms"] = round(wall(lambda: pc.ransac(loc1M, loc1S, coef, pc.estimateTransform, pc.calcDists, seed=3), 5), 3)
+    # getMatches at the sweep's per-sphere shape and at cfg 2's
+    par = dict(MATCH_PAR)
+    dM = rng.poisson(3.0, (1500, 980)).astype(np.float64); dS = dM[rng.choice(1500, 1500)][:1500] + rng.poisson(0.15, (1500, 980))
+    dS = np.vstack([dS, rng.poisson(3.0, (500, 980))]).astype(np.float64)
+    pc.getMatches(dS, dM, par)
+    res["getMatches_2000x1500_ms"] = round(wall(lambda: pc.getMatches(dS, dM, par)), 2)
+    Q, M = 50_000, 200_000
+    dM = rng.poisson(3.0, (M, 980)).astype(np.float64)
+    dS = (dM[rng.choice(M, Q, replace=False)] + rng.poisson(0.15, (Q, 980))).astype(np.float64)
+    res["getMatches_50kx200k_ms"] = round(wall(lambda: pc.getMatches(dS, dM, par), 1), 1)
+    res["getMatches_50kx200k_upload_GB"] = round((Q + M) * 980 * 8 / 1e9, 2)
+    del dS, dM
+    # descriptors, 100 k keypoints: 784 MB of doubles come back
+    ptsc, kp = _ridge_cloud(1_000_000, 100_000)
+    pc.getSpacialHistogramDescriptors(ptsc[:50_000], kp[:500], DESC_OPT)
+    out = [None]
+    def run():
+        out[0] = pc.getSpacialHistogramDescriptors(ptsc, kp, DESC_OPT)
+    res["descriptors_100k_ms"] = round(wall(run, 2), 1)
+    res["descriptors_100k_rows_out"] = int(out[0][1].shape[0])
+    res["note"] = "pageable numpy in/out through ctypes (the MEX gateway's calls); compare extras.* device-tier ms"
+    return res
+
+
+
+def summary_of(out: dict) -> dict:
+    """Every config's headline number in < 600 characters, as the last object of the line."""
+    ex = out.get("extras", {})
+    g = lambda d, *ks: (lambda v: None if v is None else v)(_dig(d, ks))
+    sm = {"step_ms": out.get("ms_per_step"), "step_frac": g(out, "roofline", "frac"),
+          "step_ms_with_prepare": out.get("ms_per_step_with_model_prepare"),
+          "cfg2_ms": g(ex, "getMatches_cfg2", "ms"), "cfg2_frac": g(ex, "getMatches_cfg2", "roofline", "frac"),
+          "cfg3_ms": g(out, "cfg3_model_2M", "ms_per_step"),
+          "cfg4_ms": g(ex, "descriptors_cfg4", "ms"), "cfg4_frac": g(ex, "descriptors_cfg4", "roofline", "frac"),
+          "align_ms": g(ex, "align_points_knn_batched", "ms"), "align_frac": g(ex, "align_points_knn_batched", "roofline", "frac"),
+          "cfg1_ms": g(ex, "ransac_cfg1", "ms"), "cfg1b_ms": g(ex, "ransac_cfg1_batched", "ms"), "cfg1b_frac": g(ex, "ransac_cfg1_batched", "roofline", "frac"),
+          "sweep_ms": g(ex, "sweep", "ms"), "sweep_frac": g(ex, "sweep", "roofline", "frac"),
+          "cfg5_regs_per_s": g(out, "cfg5_batch", "registrations_per_s"),
+          "chain_match_ms": g(ex, "desc_chain", "get_matches", "ms"), "chain_match_unproven": g(ex, "desc_chain", "get_matches", "stats", "unproven"),
+          "chain_sweep_ms": g(ex, "desc_chain", "sweep", "ms"), "chain_sweep_right": g(ex, "desc_chain", "sweep", "registered_right"),
+          "host_ransac_ms": g(ex, "host_tier", "ransac_n1000_ms"), "host_cfg2_ms": g(ex, "host_tier", "getMatches_50kx200k_ms"),
+          "host_desc100k_ms": g(ex, "host_tier", "descriptors_100k_ms")}
+    return {k: v for k, v in sm.items() if v is not None}
+
+
+def _dig(d, ks):
+    for k in ks:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
 # ---- main ---------------------------------------------------------------------------------------------------------
 
 def main() -> None:
@@ -558,6 +760,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only")
     ap.add_argument("--crops", type=int, default=64, help="crops of the cfg 5 batch")
+    ap.add_argument("--skip", default="", help="comma-separated extras to leave out (e.g. host_tier,desc_chain)")
     args = ap.parse_args()
 
     import torch
@@ -635,7 +838,11 @@ def main() -> None:
         out = {
             "metric": "KNN Gpairs/s end-to-end (search + filters + RANSAC per step; registrations/s = 1000/ms_per_step)",
             "value": round(head["value"], 2), "unit": "Gpairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(head["ms_per_step"], 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(head["ms_per_step"], 4),
+            "ms_per_step_with_model_prepare": round(head["ms_per_step"] + head["model_prepare_ms"], 4),
+            "metric_definition": "step = search + filters + RANSAC on a PREPARED model (since round 3; rounds 1-2 prepared the model inside "
+                                 "every step: compare those with ms_per_step_with_model_prepare)",
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32 (search: f16-split matrix-core candidates, exact f32 re-rank) / f64 (RANSAC)", "data": "synthetic",
             "config": {"workload": f"{Q} surface pts vs a FIXED {M_total}-pt model ({rows} rows per GPU, row-sharded over {world} GPU(s)), "
                                    f"top-2 + threshold/ratio/Unique + RANSAC(3,1e4,0.3,0.08,REFINE)",
@@ -644,9 +851,7 @@ def main() -> None:
             "knn_kernel": {"name": "knn_candidates_f16_pipe_kernel", "ms": round(kernel_ms, 4), "search_call_ms": round(search_ms, 4),
                            "launches_timed": head["launches_timed"], "gpairs_per_s_per_gpu": round(Q * rows / (search_ms * 1e-3) / 1e9, 1),
                            "model_prepare_ms_once": round(head["model_prepare_ms"], 3),
-                           "note": "the model shard is prepared once per model (pcreg_dev_model_create: box, f16 operand tiles, seeding grid; "
-                                   "wall time incl. its hipMalloc) and searched by every step -- one model, many surfaces "
-                                   "(completeExperimentFast.m:131-149); a step = 4 search launches + 1 match launch + the RANSAC chain"},
+                           "note": "model prepared once per model; step = 4 search + 1 match launch + RANSAC chain"},
             "ransac": head["ransac"],
             "roofline": {"bound": "mfma", "achieved": round(alg_tflops, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(alg_tflops / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -655,14 +860,7 @@ def main() -> None:
                          "matrix_pipe": {"executed_flop_per_pair": FLOP_PER_PAIR_EXECUTED, "tflops": round(exe_tflops, 1),
                                          "occupancy_of_dense_f16_peak": round(exe_tflops / PEAK_F16_MFMA_TFLOPS, 4)},
                          "hbm_algorithmic_gbps": round(alg_bytes / (search_ms * 1e-3) / 1e9, 2),
-                         "note": "knn_candidates_f16_pipe_kernel, HIP events around each launch on its stream.  `achieved`/`frac`: SURVEY 8d's "
-                                 "algorithmic 8 flop/pair against the dense f16 matrix peak the products run on; `vs_fp32_vector_peak`: the same "
-                                 "flops against the fp32 vector roofline SURVEY 8d named (> 1: the dot products left that unit, every pair is "
-                                 "still scored); `matrix_pipe`: flops the MFMAs execute (one 32x32x16 per 1024 pairs).  The kernel is bound by "
-                                 "VALU issue, not by the matrix pipe: per 1024 pairs one MFMA (8 issue cycles) + 8 v_min3/v_min + 1 v_cmp (half "
-                                 "rate, 4 cycles each) = 44 cycles; scripts/ubench/mfma_f16_valu.hip (pipelined mode, 4 waves/SIMD) runs that "
-                                 "loop at 45 cycles = 23.4 ns per step at the 1.92 GHz the chip holds under this load, i.e. 1.12 ms for this shape.  "
-                                 f"HBM: {alg_bytes / 1e6:.1f} MB algorithmic = {alg_bytes / (search_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS:.5f} of peak: not HBM-bound"},
+                         "note": "HIP events per launch; VALU-issue-bound, not HBM: docs/BENCH_NOTES.md"},
         }
         out.update(more)
         if world == 1 and not args.no_cpu_baseline:
@@ -670,16 +868,21 @@ def main() -> None:
     del model, surf
     if world == 1 and not args.no_extras:
         ex = {}
+        skip = set(x for x in args.skip.split(",") if x)
         with_cpu = not args.no_cpu_baseline
         for name, fn in (("getMatches_cfg2", extra_get_matches), ("descriptors_cfg4", extra_descriptors),
                          ("align_points_knn_batched", extra_align), ("ransac_cfg1", extra_ransac_cfg1),
-                         ("ransac_cfg1_batched", extra_ransac_cfg1_batched), ("sweep", extra_sweep)):
+                         ("ransac_cfg1_batched", extra_ransac_cfg1_batched), ("sweep", extra_sweep),
+                         ("desc_chain", extra_desc_chain), ("host_tier", extra_host_tier)):
+            if name in skip:
+                continue
             try:
                 ex[name] = fn(dev, with_cpu)
             except Exception as e:          # an extra must never take the headline down with it
                 ex[name] = {"error": f"{type(e).__name__}: {e}"}
         out["extras"] = ex
     if rank == 0:
+        out["summary"] = summary_of(out)          # LAST key: the tail of stdout carries every config's number
         print(json.dumps(out), flush=True)
     if collective:
         dist.barrier()

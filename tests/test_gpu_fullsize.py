@@ -226,3 +226,62 @@ def test_sphere_sweep_at_the_reference_shape(oracle_c, oracle_py):
         idx = np.nonzero(oracle_py.getDescriptorMask(featM, out["centres"][i], kw["R_desc"], 0.0))[0]
         np.testing.assert_array_equal(idx, out["model_rows"][i])
         np.testing.assert_array_equal(oracle_c.getMatches(ds, dm[idx], par, nthreads=0), out["matches"][i])
+
+
+def test_chain_cfg4_to_cfg2_on_rows_the_descriptor_kernel_produces(oracle_c, oracle_py):
+    """getMatches at 20 k x 200 k and the sphere sweep at the reference's shape, on rows that the repo's own
+    descriptor kernel wrote for a synthetic scene (a model cloud and a moved, noisy crop of it: sparse, spatially correlated
+    histograms of overlapping supports -- not i.i.d. Poisson rows).  Oracle: 120 random surface rows against ALL model rows,
+    incl. the Unique rule over all surface rows; three spheres of the sweep through the oracle's getMatches."""
+    from bench import MATCH_PAR, desc_chain_data
+    from pcreg_amd.sweep import SphereSweep
+    dev = torch.device("cuda", 0)
+    d = desc_chain_data(dev, 200_000, 20_000)
+    dp, VM, VS = d["dp"], d["VM"], d["VS"]
+    assert VM > 100_000 and VS > 10_000
+    pairs_t, n_pairs = dp.match(d["descS"], VS, d["descM"], VM, MATCH_PAR)
+    P = int(n_pairs.item())
+    pairs = pairs_t[:P].cpu().numpy().astype(np.int64)
+    assert P > VS // 10 and np.all(np.diff(pairs[:, 0]) > 0) and len(np.unique(pairs[:, 1])) == P
+    iS = d["descS"].index[:VS].cpu().numpy(); iM = d["descM"].index[:VM].cpu().numpy()
+    right = np.sum(d["near"][iS[pairs[:, 0] - 1]] == iM[pairs[:, 1] - 1])
+    assert right > 0.5 * P                                        # the matches are the crop's own keypoints, mostly
+    dS = d["descS"].compact(VS).cpu().numpy().astype(np.float64); dM = d["descM"].compact(VM).cpu().numpy().astype(np.float64)
+    pS, pM = oracle_py.preprocess_descriptors(dS, dM, MATCH_PAR)
+    del dS, dM
+    nS, nM = oracle_py._normalize_rows(pS), oracle_py._normalize_rows(pM)
+    del pS, pM
+    rng = np.random.default_rng(12)
+    sel = np.sort(rng.choice(VS, 120, replace=False))
+    par_nu = dict(Metric="SAD", MatchThreshold=10, MaxRatio=0.99, Unique=False, Prenormalized=True)
+    cand, _ = oracle_c.matchFeatures(nS[sel], nM, par_nu, nthreads=CORES)
+    cand_of = {int(sel[i - 1]): int(j) - 1 for i, j in cand}
+    sel_set = set(sel.tolist())
+    got_of = {int(i) - 1: int(j) - 1 for i, j in pairs if (int(i) - 1) in sel_set}
+    for i in sel.tolist():
+        if i in got_of:
+            assert cand_of.get(i) == got_of[i], f"surface row {i}: GPU matched {got_of[i]}, oracle forward match {cand_of.get(i)}"
+        if i in cand_of:
+            col = np.abs(nS - nM[cand_of[i]]).sum(axis=1)
+            best = int(np.argmin(col))
+            assert (i in got_of) == (best == i), f"surface row {i}: Unique rule (best query of model row {cand_of[i]} is {best})"
+        else:
+            assert i not in got_of
+    assert len(cand_of) >= 30
+    del nS, nM, d, dp
+    torch.cuda.empty_cache()
+    # ---- the sweep on described rows
+    d = desc_chain_data(dev, 60_000, 2_000, compact=False)
+    VM, VS = d["VM"], d["VS"]
+    sw = SphereSweep(d["featM"][:VM], d["descM"][:VM], d["featS"][:VS], d["descS"][:VS], device=dev)
+    opt = dict(minPtNum=3, iterNum=2000, thDist=0.3, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    out = sw.run(MATCH_PAR, opt, R_desc=9.0, d_spheres=5.0, min_pts=1400, putative_thresh=170, seed=0)
+    S = len(out["centres"])
+    assert S > 20
+    fm, dm, ds = d["featM"][:VM].cpu().numpy(), d["descM"][:VM].cpu().numpy(), d["descS"][:VS].cpu().numpy()
+    best = int(np.argmax(out["num_putative"]))
+    for i in sorted({0, S // 2, best}):
+        idx = np.nonzero(oracle_py.getDescriptorMask(fm, out["centres"][i], 9.0, 0.0))[0]
+        np.testing.assert_array_equal(idx, out["model_rows"][i])
+        np.testing.assert_array_equal(oracle_c.getMatches(ds, dm[idx], MATCH_PAR, nthreads=CORES), out["matches"][i])
+    assert len(out["trial"]) >= 1 and any(t is not None for t in out["transforms"])
