@@ -2729,26 +2729,24 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         const int pb4 = hpw * kWavesPerBlock;
         hipLaunchKernelGGL(ransac_hyp_kernel, dim3((o.iterNum + pb4 - 1) / pb4, B), dim3(kBlock), lds, st, a);
     } else if (n_cap > 0 && n_cap <= (offsets ? kHyp32BatchCap : kHyp32Classes[kHyp32NClasses - 1])) {
-        // correspondences resident in LDS, scored through the fp32 screen (ransac_hyp32_kernel).  A workgroup reserves the LDS of
-        // its launch CLASS, not of the batch's capacity (the sweep passes the surface size, 2000; its trials hold ~250 pairs): one
-        // launch per class that the capacity reaches, a workgroup returns at once when its registration belongs to another class
-        // (n is read from the offsets on the device), and the last launch also takes what is above every class (fp64 from L2).
+        // correspondences resident in LDS, scored through the fp32 screen (ransac_hyp32_kernel); registrations of a batch above
+        // 2048 correspondences take the fp64 kernel on the raw coordinates from L2 (a second launch whose other workgroups return
+        // at once: n is read from the offsets on the device).  (Two launch classes by LDS size, <= 1024 and <= 2048, were measured
+        // on the sweep -- capacity 2000, most trials ~250 pairs, the right spheres ~2000: 1.13 + 0.61 ms one after the other.)
         // Hypotheses per wave: fill the chip first (>= ~2 waves per SIMD), then grow towards 64 so the lane-parallel fits run full.
         int hpw = 64;
         while (hpw > 8 && total / hpw < 256LL * 4 * 2) hpw >>= 1;
         a.hpw = hpw;
         a.msc = (double*)w; w += align_up(h * 16 * sizeof(double), 256);
-        int lo = -1;
-        for (int c = 0; c < kHyp32NClasses; ++c) {
-            const bool last = c == kHyp32NClasses - 1 || n_cap <= kHyp32Classes[c];
-            a.n_lo = lo; a.n_hi = last ? std::min(n_cap, kHyp32Classes[c]) : kHyp32Classes[c];
-            const int nw = kHyp32Waves[c], per_block = hpw * nw;
-            const dim3 grid((o.iterNum + per_block - 1) / per_block, B);
-            const int rc = nw == 8 ? launch_hyp32<8>(a, grid, hyp32_lds_bytes(a.n_hi, nw), st) : launch_hyp32<16>(a, grid, hyp32_lds_bytes(a.n_hi, nw), st);
-            if (rc != PCREG_OK) return rc;
-            lo = a.n_hi;
-            if (last) break;
-        }
+        // one launch: capacities up to 1024 as 8-wave workgroups with the LDS of the capacity (two to a CU), larger ones as 16-wave
+        // workgroups with the LDS of min(capacity, 2048) correspondences (one to a CU: the same sixteen waves)
+        const int c = n_cap <= kHyp32Classes[0] ? 0 : 1;
+        a.n_lo = -1; a.n_hi = std::min(n_cap, kHyp32Classes[c]);
+        const int nw = kHyp32Waves[c], per_block = hpw * nw;
+        const dim3 grid((o.iterNum + per_block - 1) / per_block, B);
+        const int rc = nw == 8 ? launch_hyp32<8>(a, grid, hyp32_lds_bytes(a.n_hi, nw), st) : launch_hyp32<16>(a, grid, hyp32_lds_bytes(a.n_hi, nw), st);
+        if (rc != PCREG_OK) return rc;
+        const int lo = a.n_hi;
         if (n_cap > lo) {     // registrations of a batch above every class: the fp64 kernel on the raw coordinates from L2
             a.n_lo = lo; a.n_hi = -1;
             const int pb4 = hpw * kWavesPerBlock;
