@@ -77,7 +77,7 @@ int  pcreg_device_name(char* buf, int cap);  /* e.g. "gfx950:..."               
 /* Test hook, not part of the reference's interface: selects the OTHER side of a certified fast path (process-wide), so that
  * the parity tests can run both sides inside one process.  Every setting returns the same indices and counts.  Keys:
  * "knn_exact", "match_exact", "match_force_fallback" (1, 2), "ransac_fused", "ransac_nolane", "ransac_f64score",
- * "ransac_resident_f64", "align_times", "align_shape", "seg_debug", "match_stats"; value 0 restores the default.  The library reads NO
+ * "ransac_resident_f64", "align_times", "align_shape", "seg_debug", "seg_batched", "match_stats"; value 0 restores the default.  The library reads NO
  * environment variable (tests/test_abi.py greps the binary).  PCREG_E_ARG for an unknown key. */
 int  pcreg_debug_set(const char* key, int value);
 /* With pcreg_debug_set("match_stats", 1): the counters of the certified SAD matcher summed over the calls since the last
@@ -415,7 +415,12 @@ int pcreg_dev_sphere_select_batched(const double* feat, int V, const double* cen
  * are known to the host from the counts.  pairs_all [S][Q][2]: segment s's pairs, 1-based, the model index counting WITHIN
  * the segment like the per-sphere call's; n_pairs [S]; metric_all [S][Q] or NULL.  The pairs are those of one
  * pcreg_dev_get_matches call per segment (same arithmetic on the same operands: the appended constant and the row norms
- * differ per segment, the powered columns do not and are computed once).  Metric SAD only; nothing synchronises. */
+ * differ per segment, the powered columns do not and are computed once).  Metric SAD only.
+ * Memory: the one-chain form takes  4 VM' Q'  (the shared score matrix, VM' / Q' = VM / Q rounded up to 128)  +  8 D (VM + Q)  (the
+ * powered rows)  +  ~S Q (32 splits + 150) bytes (the per-segment lists);  up to 4 GB of that it runs as ONE chain and nothing
+ * synchronises.  Above, the call runs in batches of consecutive segments on gathered sub-models (the union of the rows a batch
+ * names), inside a workspace of 4 GB + 12 VM + 4 total_rows + 4 S bytes: same pairs, one host synchronisation at entry and one or
+ * two per batch.  A single segment that does not fit the bound is refused with PCREG_E_WORKSPACE. */
 size_t pcreg_dev_get_matches_segmented_workspace(int Q, int VM, int D, int S, int total_rows, int max_rows);
 int pcreg_dev_get_matches_segmented(const double* descSurface, int Q, const double* descModel, int VM, int D, const int32_t* seg_rows,
                                     const int32_t* seg_off, int S, int total_rows, int max_rows, const pcreg_match_opts* par,

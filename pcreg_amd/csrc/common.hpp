@@ -67,6 +67,7 @@ enum DebugKey {
     kDbgAlignTimes,            // "align_times": per-phase timestamps of align_points_knn (host read-back)
     kDbgAlignShape,            // "align_shape": launch-shape override of align_points_knn
     kDbgSegDebug,              // "seg_debug": histogram dump of the segmented matcher
+    kDbgSegBatched,            // "seg_batched": the segmented matcher runs its bounded-workspace (batched) form whatever the size
     kDbgMatchStats,            // "match_stats": the certified matcher counts what it proves / re-scores / hands on (pcreg_debug_match_stats)
     kDbgCount
 };

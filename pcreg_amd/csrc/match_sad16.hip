@@ -1467,16 +1467,34 @@ SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
 }
 }  // namespace
 
+// ---- bounded workspace --------------------------------------------------------------------------------------------------
+// The one-chain layout grows with VM x Q (the shared score matrix) and with S x Q x splits (the per-segment lists): 0.6 GB at the
+// sweep's shape (60 k x 2 k, 329 spheres), tens of GB at 400 k x 6 k with 2000 spheres.  Above kSegBudget + kSegGatherBytes the
+// call runs in BATCHES of consecutive segments: the model rows a batch names are marked, numbered in ascending order (their
+// union) and gathered into a compact sub-model, the batch's lists are renumbered into it, and the one-chain form runs on
+// (surface, sub-model, batch).  Spheres that follow one another in the sweep's grid order overlap heavily, so a batch's union is
+// a small multiple of one sphere.  The pairs do not change: a pair's model index counts within its segment, and every exact
+// distance is computed from the same rows by the same arithmetic.  Price of the bound: one host synchronisation at entry (the
+// segment offsets) and one or two per batch (the size of its union); a model row is scored once per batch that names it.
+constexpr size_t kSegBudget = (size_t)3 << 30;          // the one-chain workspace of a batch
+constexpr size_t kSegGatherBytes = (size_t)1 << 30;     // the gathered sub-model of a batch
+static size_t seg_batched_fixed_bytes(int VM, int tot, int S) {
+    const size_t vm = (size_t)std::max(VM, 1);
+    return 3 * align_up(vm * 4, 256) + align_up((size_t)std::max(tot, 1) * 4, 256) + align_up(((size_t)std::max(S, 1) + 1) * 4, 256) +
+           align_up((vm + 1023) / 1024 * 4, 256) + 256;
+}
 size_t get_matches_segmented_workspace_bytes(int Q, int VM, int D, int S, int tot, int n_max) {
-    return seg_layout(Q, VM, D, D + 1, S, tot, n_max).total;
+    const size_t one = seg_layout(Q, VM, D, D + 1, S, tot, n_max).total;
+    if (one <= kSegBudget + kSegGatherBytes) return one;
+    return kSegBudget + kSegGatherBytes + seg_batched_fixed_bytes(VM, tot, S);
 }
 
 // descS [Q][D], descM [VM][D] row-major doubles; segment z = model rows seg_rows[seg_off[z] .. seg_off[z + 1]) (0-based, ascending;
 // seg_off [S + 1] on the device, tot = seg_off[S] and n_max = the longest segment known to the host).  pairs_all [S][Q][2]
 // (1-based; the model index counts within the segment), n_pairs [S], metric_all [S][Q] or null.  SAD only.
-int launch_get_matches_segmented(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
-                                 const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
-                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st) {
+static int launch_get_matches_segmented_one(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
+                                            const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
+                                            double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st) {
     if (S <= 0) return PCREG_OK;
     if (Q <= 0 || n_max <= 0 || VM <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, (size_t)S * sizeof(int32_t), st)); return PCREG_OK; }
     const int Dp = D + (o.unnormalize ? 1 : 0);
@@ -1572,6 +1590,159 @@ int launch_get_matches_segmented(const double* descS, int Q, const double* descM
         fprintf(stderr, "[pcreg] segmented: unproven queries forward %lld (in %d segments, at most %d in one)\n", ff, nz, mx); (void)f;
     }
 #endif
+    return PCREG_OK;
+}
+
+namespace {
+// flag[r] = 1 for every model row the batch's lists name
+__global__ void segb_mark_kernel(const int32_t* __restrict__ rows, int lo, int hi, int32_t* __restrict__ flag) {
+    const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hi) flag[rows[i]] = 1;
+}
+// the union's numbering = an exclusive scan of the flags in three deterministic steps (no atomics): counts per 1024 rows, their
+// scan by one workgroup, the numbers
+__global__ __launch_bounds__(256) void segb_count_kernel(const int32_t* __restrict__ flag, int VM, int32_t* __restrict__ bcnt) {
+    const int i = blockIdx.x * 1024 + threadIdx.x * 4;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c += (i + k < VM) ? flag[i + k] : 0;
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) c += __shfl_xor(c, o_);
+    __shared__ int sw[4];
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) bcnt[blockIdx.x] = sw[0] + sw[1] + sw[2] + sw[3];
+}
+__global__ __launch_bounds__(1024) void segb_scan_kernel(int32_t* __restrict__ bcnt, int nb, int32_t* __restrict__ n_union) {
+    __shared__ int sh[1024];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb ? bcnt[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o_ = 1; o_ < 1024; o_ <<= 1) {
+            const int t = (int)threadIdx.x >= o_ ? sh[threadIdx.x - o_] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) bcnt[i] = carry + sh[threadIdx.x] - v;
+        const int tot = sh[1023];
+        __syncthreads();
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *n_union = carry;
+}
+__global__ __launch_bounds__(256) void segb_number_kernel(const int32_t* __restrict__ flag, int VM, const int32_t* __restrict__ bcnt,
+                                                          int32_t* __restrict__ newidx, int32_t* __restrict__ urows) {
+    const int i = blockIdx.x * 1024 + threadIdx.x * 4;
+    int f[4], c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[k] = (i + k < VM) ? flag[i + k] : 0; c += f[k]; }
+    int incl = c;
+#pragma unroll
+    for (int o_ = 1; o_ < 64; o_ <<= 1) { const int t = __shfl_up(incl, o_); if ((int)(threadIdx.x & 63) >= o_) incl += t; }
+    __shared__ int sw[4];
+    if ((threadIdx.x & 63) == 63) sw[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int pos = bcnt[blockIdx.x] + incl - c;
+    for (int w_ = 0; w_ < (int)(threadIdx.x >> 6); ++w_) pos += sw[w_];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i + k < VM) { newidx[i + k] = f[k] ? pos : -1; if (f[k]) urows[pos] = i + k; }
+        pos += f[k];
+    }
+}
+__global__ void segb_renumber_kernel(const int32_t* __restrict__ rows, int lo, int hi, const int32_t* __restrict__ newidx, int32_t* __restrict__ out) {
+    const int i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hi) out[i - lo] = newidx[rows[i]];
+}
+__global__ void segb_offsets_kernel(const int32_t* __restrict__ seg_off, int z0, int Sb, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= Sb) out[i] = seg_off[z0 + i] - seg_off[z0];
+}
+// dst[u][:] = src[urows[u]][:], D doubles per row, one wave per row
+__global__ __launch_bounds__(256) void segb_gather_kernel(const double* __restrict__ src, int D, const int32_t* __restrict__ urows, int n,
+                                                          double* __restrict__ dst) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= n) return;
+    const double* a = src + (size_t)urows[u] * D; double* b = dst + (size_t)u * D;
+    for (int d = lane; d < D; d += 64) b[d] = a[d];
+}
+}  // namespace
+
+int launch_get_matches_segmented(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
+                                 const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
+                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (S <= 0) return PCREG_OK;
+    if (Q <= 0 || n_max <= 0 || VM <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, (size_t)S * sizeof(int32_t), st)); return PCREG_OK; }
+    const size_t one = seg_layout(Q, VM, D, D + 1, S, tot, n_max).total;
+    const size_t budget = PCREG_EXP_ENV("PCREG_SEG_BUDGET_MB", 0) > 0 ? (size_t)PCREG_EXP_ENV("PCREG_SEG_BUDGET_MB", 0) << 20 : kSegBudget;
+    if (one <= kSegBudget + kSegGatherBytes && !debug_flag(kDbgSegBatched))
+        return launch_get_matches_segmented_one(descS, Q, descM, VM, D, seg_rows, seg_off, S, tot, n_max, o, pairs_all, metric_all, n_pairs, ws, ws_bytes, st);
+    // ---- batches of consecutive segments on gathered sub-models
+    const size_t fixed = seg_batched_fixed_bytes(VM, tot, S);
+    if (ws_bytes < fixed + 4096) { set_error("segmented get_matches workspace too small: %zu bytes", ws_bytes); return PCREG_E_WORKSPACE; }
+    // whatever the caller's workspace holds beyond the fixed part is split 1 : 3 between the gathered rows and the one-chain form
+    // (the workspace query returns the fixed part + kSegGatherBytes + kSegBudget for a problem that needs batches)
+    const size_t room = ws_bytes - fixed;
+    const size_t gather_bytes = std::min(kSegGatherBytes, room / 4) / 256 * 256, one_bytes = std::min(budget, room - gather_bytes);
+    const size_t vm = (size_t)VM;
+    char* w = (char*)ws;
+    int32_t* flag = (int32_t*)w; w += align_up(vm * 4, 256);
+    int32_t* newidx = (int32_t*)w; w += align_up(vm * 4, 256);
+    int32_t* urows = (int32_t*)w; w += align_up(vm * 4, 256);
+    int32_t* rows_b = (int32_t*)w; w += align_up((size_t)std::max(tot, 1) * 4, 256);
+    int32_t* off_b = (int32_t*)w; w += align_up(((size_t)S + 1) * 4, 256);
+    int32_t* bcnt = (int32_t*)w; w += align_up((vm + 1023) / 1024 * 4, 256);
+    int32_t* n_union = (int32_t*)w; w += 256;
+    double* descMb = (double*)w; w += gather_bytes;
+    void* ws_one = w;
+    const int nb = (VM + 1023) / 1024;
+    const size_t cap_rows = gather_bytes / ((size_t)D * 8);
+    std::vector<int32_t> off((size_t)S + 1);
+    PCREG_HIP(hipMemcpyAsync(off.data(), seg_off, ((size_t)S + 1) * 4, hipMemcpyDeviceToHost, st));
+    PCREG_HIP(hipStreamSynchronize(st));
+    if (off[S] != tot) { set_error("segmented get_matches: seg_off[S] = %d, total_rows = %d", off[S], tot); return PCREG_E_ARG; }
+    int z0 = 0;
+    while (z0 < S) {
+        int Sb = S - z0;
+        for (;;) {                                   // the largest batch (halving) whose one-chain form fits
+            int nmax_b = 0;
+            for (int z = z0; z < z0 + Sb; ++z) nmax_b = std::max(nmax_b, off[z + 1] - off[z]);
+            const int tot_b = off[z0 + Sb] - off[z0];
+            if (tot_b == 0) { PCREG_HIP(hipMemsetAsync(n_pairs + z0, 0, (size_t)Sb * 4, st)); break; }
+            // first the terms that do not depend on the union (the per-segment lists), on the host alone
+            if (Sb > 1 && seg_layout(Q, 1, D, D + 1, Sb, tot_b, nmax_b).total > one_bytes / 2) { Sb = (Sb + 1) / 2; continue; }
+            int VMb = 0;
+            PCREG_HIP(hipMemsetAsync(flag, 0, vm * 4, st));
+            hipLaunchKernelGGL(segb_mark_kernel, dim3((tot_b + 255) / 256), dim3(256), 0, st, seg_rows, off[z0], off[z0 + Sb], flag);
+            hipLaunchKernelGGL(segb_count_kernel, dim3(nb), dim3(256), 0, st, flag, VM, bcnt);
+            hipLaunchKernelGGL(segb_scan_kernel, dim3(1), dim3(1024), 0, st, bcnt, nb, n_union);
+            PCREG_HIP(hipMemcpyAsync(&VMb, n_union, 4, hipMemcpyDeviceToHost, st));
+            PCREG_HIP(hipStreamSynchronize(st));
+            const size_t lay = seg_layout(Q, VMb, D, D + 1, Sb, tot_b, nmax_b).total;
+            if (lay > one_bytes || (size_t)VMb > cap_rows) {
+                if (Sb == 1) {
+                    set_error("segmented get_matches: one segment of %d rows against %d queries needs %zu bytes; the workspace leaves %zu", nmax_b, Q, lay, one_bytes);
+                    return PCREG_E_WORKSPACE;
+                }
+                Sb = (Sb + 1) / 2;
+                continue;
+            }
+            hipLaunchKernelGGL(segb_number_kernel, dim3(nb), dim3(256), 0, st, flag, VM, bcnt, newidx, urows);
+            hipLaunchKernelGGL(segb_renumber_kernel, dim3((tot_b + 255) / 256), dim3(256), 0, st, seg_rows, off[z0], off[z0 + Sb], newidx, rows_b);
+            hipLaunchKernelGGL(segb_offsets_kernel, dim3((Sb + 256) / 256), dim3(256), 0, st, seg_off, z0, Sb, off_b);
+            hipLaunchKernelGGL(segb_gather_kernel, dim3((VMb + 3) / 4), dim3(256), 0, st, descM, D, urows, VMb, descMb);
+            PCREG_HIP(hipGetLastError());
+            const int rc = launch_get_matches_segmented_one(descS, Q, descMb, VMb, D, rows_b, off_b, Sb, tot_b, nmax_b, o, pairs_all + (size_t)z0 * Q * 2,
+                                                            metric_all ? metric_all + (size_t)z0 * Q : nullptr, n_pairs + z0, ws_one, one_bytes, st);
+            if (rc) return rc;
+            break;
+        }
+        z0 += Sb;
+    }
     return PCREG_OK;
 }
 

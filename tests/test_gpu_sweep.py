@@ -196,6 +196,12 @@ def test_segmented_get_matches_equals_one_call_per_segment(oracle_c, par_over, d
         want = pc.getMatches(descS, descM[r], par)
         np.testing.assert_array_equal(got[z][0], want, err_msg=f"segment {z}")
         np.testing.assert_array_equal(want, oracle_c.getMatches(descS, descM[r], par))
+    debug_set("seg_batched")          # the bounded-workspace form: batches of consecutive segments on gathered sub-models (several
+    batched = _segments_direct(descS, descM, rows_list, par, metric=True)      # batches here: the workspace is the one-chain size)
+    debug_set("seg_batched", 0)
+    for (a, ma), (b, mb) in zip(got, batched):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ma, mb)
     for level in (1, 2):              # 1: every query through the score-filtered refinement; 2: and on to the exhaustive exact kernel
         debug_set("match_force_fallback", level)
         forced = _segments_direct(descS, descM, rows_list, par, metric=True)
@@ -234,3 +240,40 @@ def test_segmented_get_matches_other_shapes(oracle_c, case):
         want = pc.getMatches(descS, descM[r], par)
         np.testing.assert_array_equal(got[z][0], want, err_msg=f"{case}, segment {z}")
         np.testing.assert_array_equal(want, oracle_c.getMatches(descS, descM[r], par))
+
+
+def test_segmented_get_matches_with_a_bounded_workspace_at_400k_x_6k_x_2000_spheres():
+    """VERDICT r3 item 7 / ADVICE: the one-chain form would need tens of GB here (a 400 k x 6 k score matrix, 2000 x 6 k x 32 list
+    entries); pcreg_dev_get_matches_segmented runs it in batches of consecutive spheres on gathered sub-models inside a
+    workspace of <= 4 GB + O(VM + rows).  Sampled spheres must equal the per-sphere call (SphereSweep.match_sphere ->
+    pcreg_dev_get_matches on the gathered rows)."""
+    import torch
+    from pcreg_amd._lib import lib
+    from pcreg_amd.sweep import SphereSweep
+    dev = torch.device("cuda", 0)
+    VM, VS, D = 400_000, 6_000, 980
+    rng = np.random.default_rng(5)
+    box = np.array([120.0, 100.0, 66.0])
+    featM = rng.uniform(0, 1, (VM, 3)) * box
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    descM = torch.poisson(torch.full((VM, D), 3.0, device=dev), generator=g).to(torch.float64)
+    near = np.argsort(np.linalg.norm(featM - box / 2, axis=1))[:VS]
+    featS = featM[near] + rng.normal(0, 0.02, (VS, 3))
+    descS = (descM[torch.from_numpy(near).to(dev)] + torch.poisson(torch.full((VS, D), 0.15, device=dev), generator=g).to(torch.float64)).contiguous()
+    sw = SphereSweep(featM, descM, featS, descS, device=dev)
+    kw = dict(R_desc=9.0, d_spheres=7.0, min_pts=700)
+    centres = sw.sphere_centres(kw["d_spheres"])
+    valid, counts = sw.valid_spheres(centres, kw["R_desc"], kw["min_pts"])
+    S, tot, n_max = int(valid.sum()), int(counts[valid].sum()), int(counts[valid].max())
+    assert S > 1500
+    wsb = lib().pcreg_dev_get_matches_segmented_workspace(VS, VM, D, S, tot, n_max)
+    assert wsb < (4 << 30) + 16 * (VM + tot + S) + (1 << 20), wsb                  # the bound INTEGRATION.md states
+    opt = dict(minPtNum=3, iterNum=300, thDist=0.3, thInlrRatio=0.08, REFINE=True, VERBOSE=0)
+    out = sw.run(PAR, opt, putative_thresh=170, seed=0, **kw)
+    assert len(out["centres"]) == S
+    hit = np.argsort(-out["num_putative"])[:3].tolist()                            # the spheres that hold the surface's originals
+    for i in sorted(set(hit + [0, S // 3, S - 1])):
+        m = sw.match_sphere(out["centres"][i], kw["R_desc"], PAR)
+        np.testing.assert_array_equal(m["rows"].cpu().numpy().astype(np.int64), out["model_rows"][i])
+        np.testing.assert_array_equal(m["pairs"][:m["num_putative"]].cpu().numpy().astype(np.uint32), out["matches"][i])
+    assert out["num_putative"].max() > 170 and any(t is not None for t in out["transforms"])
