@@ -178,6 +178,19 @@ int pcreg_get_matches(const double* descSurface, int Q, int ldS, const double* d
                       int ldM, int D, const pcreg_match_opts* par, uint32_t* pairs, double* metric,
                       int* P);
 
+/* One surface set against MANY row subsets of one model set -- the loop of completeExperimentFast.m:101-150
+ *     descCur = descModel(mask, :);  matches = getMatches(descSurface, descCur, par);        (:121-149, hundreds of spheres)
+ * with both sets uploaded ONCE.  pcreg_desc_set_create copies an n x D column-major double matrix (ld >= n) to the device;
+ * pcreg_get_matches_on_sets(surface, model, rows, n_rows, ...) is pcreg_get_matches(descSurface, descModel(rows + 1, :), ...)
+ * -- the same kernels on the same values, the same pairs bit for bit -- with rows = the 0-based ascending row numbers of the
+ * subset (NULL: the whole model set).  A set belongs to the device that was current when it was created. */
+typedef struct pcreg_desc_set pcreg_desc_set;
+int pcreg_desc_set_create(const double* desc, int n, int ld, int D, pcreg_desc_set** set);
+int pcreg_desc_set_destroy(pcreg_desc_set* set);
+int pcreg_desc_set_size(const pcreg_desc_set* set, int* n, int* D);
+int pcreg_get_matches_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* model_rows, int n_rows,
+                              const pcreg_match_opts* par, uint32_t* pairs, double* metric, int* P);
+
 /* AlignPoints_KNN.m:1  [pts_aligned, coeff_unambig, c] = AlignPoints_KNN(pts, C1, C2).
  * aligned: n x 3 (ld n); coeff: column-major 3x3; c: 3. */
 int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2,

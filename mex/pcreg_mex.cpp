@@ -9,6 +9,8 @@
 //   'getSpacialHistogramDescriptors', pts, sample_pts, options -> feat (V x 3), desc (V x 980)
 //   'modelCreate', model (single M x 3) -> handle (uint64) | 'modelMatchPoints', handle, surface (single Q x 3), thrAbs, maxRatio, unique
 //                                          -> pairs (P x 2 uint32) | 'modelDestroy', handle      (one model, many surfaces)
+//   'descCreate', desc (double n x D) -> handle (uint64) | 'getMatchesOnSet', hSurface, hModel, int32 rows | [], par -> matches
+//                                          | 'descDestroy', handle        (one surface set, many row subsets of one model set)
 //   'setDevice', ordinal | 'commId' -> id | 'commInit', rank, world, id | 'commDestroy'     (one worker per GPU)
 //   'matchPointsSharded', surface, modelRows, m_lo, M_total, thrAbs, maxRatio, unique     -> pairs (P x 2 uint32, global model rows)
 //   'ransacSharded', pts1, pts2, coef, seed                -> T, inlierIdx, numSuccess, maxInliers, failed
@@ -249,6 +251,46 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             }
             mxDestroyArray(buf);
         }
+    } else if (!strcmp(cmd, "descCreate")) {                  // h = pcreg_mex('descCreate', desc): an n x D double descriptor set, uploaded ONCE
+        if (nrhs != 2 || !mxIsDouble(prhs[1])) usage = "descCreate: desc (double n x D)";
+        else {
+            const int n = (int)mxGetM(prhs[1]), D = (int)mxGetN(prhs[1]);
+            pcreg_desc_set* h = nullptr;
+            rc = pcreg_desc_set_create(mxGetPr(prhs[1]), n, n > 0 ? n : 1, D > 0 ? D : 1, &h);
+            if (rc == PCREG_OK) { plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h; }
+        }
+    } else if (!strcmp(cmd, "getMatchesOnSet")) {             // matches = pcreg_mex('getMatchesOnSet', hSurface, hModel, int32(rows) | [], par)
+        // = getMatches(descSurface, descModel(rows, :), par) on the resident sets (rows 1-based, ascending; []: the whole model set)
+        if (nrhs != 5 || !mxIsUint64(prhs[1]) || !mxIsUint64(prhs[2]) || !(mxIsInt32(prhs[3]) || mxGetM(prhs[3]) * mxGetN(prhs[3]) == 0))
+            usage = "getMatchesOnSet: hSurface (uint64), hModel (uint64), int32 rows or [], par";
+        else {
+            const mxArray* p = prhs[4];
+            pcreg_match_opts o;
+            o.metric = field_is(p, "Metric", "SAD") ? PCREG_METRIC_SAD : PCREG_METRIC_SSD;
+            o.matchThreshold = field(p, "MatchThreshold", 1.0); o.maxRatio = field(p, "MaxRatio", 0.6);
+            o.unique = (int)field(p, "Unique", 0); o.prenormalized = 0;
+            o.unnormalize = (int)field(p, "UNNORMALIZE", 0); o.norm_factor = field(p, "norm_factor", 0.0);
+            o.change_metric = (int)field(p, "CHANGE_METRIC", 0); o.metric_factor = field(p, "metric_factor", 1.0);
+            pcreg_desc_set* hS = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]);
+            pcreg_desc_set* hM = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[2]);
+            int Q = 0, D = 0;
+            rc = pcreg_desc_set_size(hS, &Q, &D);
+            const size_t nr = mxGetM(prhs[3]) * mxGetN(prhs[3]);
+            mxArray* r0 = mxCreateNumericMatrix(nr > 0 ? nr : 1, 1, mxINT32_CLASS, mxREAL);          // 0-based copy of the row list
+            if (nr > 0) { const int32_t* r1 = (const int32_t*)mxGetData(prhs[3]); int32_t* z = (int32_t*)mxGetData(r0); for (size_t k = 0; k < nr; ++k) z[k] = r1[k] - 1; }
+            mxArray* buf = mxCreateNumericMatrix(2, Q > 0 ? Q : 1, mxUINT32_CLASS, mxREAL);
+            int P = 0;
+            if (rc == PCREG_OK) rc = pcreg_get_matches_on_sets(hS, hM, nr > 0 ? (const int32_t*)mxGetData(r0) : nullptr, (int)nr, &o, (uint32_t*)mxGetData(buf), nullptr, &P);
+            if (rc == PCREG_OK) {
+                plhs[0] = mxCreateNumericMatrix(P, 2, mxUINT32_CLASS, mxREAL);
+                const uint32_t* src = (const uint32_t*)mxGetData(buf); uint32_t* dst = (uint32_t*)mxGetData(plhs[0]);
+                for (int k = 0; k < P; ++k) { dst[k] = src[2 * k]; dst[k + P] = src[2 * k + 1]; }
+            }
+            mxDestroyArray(buf); mxDestroyArray(r0);
+        }
+    } else if (!strcmp(cmd, "descDestroy")) {
+        if (nrhs != 2 || !mxIsUint64(prhs[1])) usage = "descDestroy: handle (uint64)";
+        else rc = pcreg_desc_set_destroy((pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]));
     } else if (!strcmp(cmd, "modelDestroy")) {
         if (nrhs != 2 || !mxIsUint64(prhs[1])) usage = "modelDestroy: handle (uint64)";
         else rc = pcreg_model_destroy((pcreg_model*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]));

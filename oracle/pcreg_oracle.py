@@ -752,3 +752,49 @@ def final_stage(ptsSurface, clusters, sample_pts, featModel_noLRF, descModel_noL
     T_refine = estimateTransform(b["pts1"][b["inliers"]], b["pts2"][b["inliers"]]) if len(b["inliers"]) >= 3 else None   # :391
     pts_final = quickTF(b["pts_tform"], invertTF(T_refine)) if T_refine is not None else b["pts_tform"]                 # :394
     return dict(per_cluster=per, precisions=precisions, best=best, T_refine=T_refine, pts_final=pts_final)
+
+
+def speedy_regions(pts, max_region_size: float):
+    """speedyDescriptors.m:17-27: the cloud's bounding box cut into ceil(range / max_region_size) equal cuboids per axis.
+    -> (bounds per axis: lo : step : hi as MATLAB's colon builds it, number of regions per axis)."""
+    pts = np.asarray(pts)
+    lo, hi = pts.min(axis=0).astype(np.float64), pts.max(axis=0).astype(np.float64)
+    rng_xyz = hi - lo                                                        # :19
+    n = np.ceil(rng_xyz / max_region_size).astype(np.int64)                  # :20
+    step = rng_xyz / n                                                       # :21
+    # :24-26  a : s : b  has floor((b - a) / s + tol) + 1 elements a + k s (MATLAB's colon tolerates rounding of (b - a) / s)
+    bounds = [lo[k] + step[k] * np.arange(int(np.floor((hi[k] - lo[k]) / step[k] + 1e-10)) + 1) for k in range(3)]
+    assert [len(b) - 1 for b in bounds] == n.tolist()                        # :27
+    return bounds, n
+
+
+def speedyDescriptors(pts, sample_opts: dict, options: dict, rng=None, get_descriptors=None):
+    """speedyDescriptors.m:10-82 as the reference runs it: region by region (x outermost, z innermost, :44-46), the crop with a
+    margin of R (open box, :48-52), round(volume of the crop's R-shrunk bounding box / d^3) uniform keypoints when the crop
+    holds more than 500 points (:55, :86-101), ONE getSpacialHistogramDescriptors call per region on the CROP (:58-59), results
+    stacked (:62-63).  MATLAB's rand stream is unknowable here: `rng` (numpy Generator; rand(n, 3) -> rng.random((n, 3))) stands
+    in.  -> (feat, desc, all sampled keypoints in region order)."""
+    get_descriptors = get_descriptors or getSpacialHistogramDescriptors
+    rng = rng or np.random.default_rng(0)
+    pts = np.asarray(pts)
+    d, R = float(sample_opts["d"]), float(options["R"])
+    bounds, n = speedy_regions(pts, float(options["max_region_size"]))
+    feats, descs, kps = [], [], []
+    for ix in range(n[0]):
+        for iy in range(n[1]):
+            for iz in range(n[2]):
+                b = (bounds[0][ix], bounds[0][ix + 1], bounds[1][iy], bounds[1][iy + 1], bounds[2][iz], bounds[2][iz + 1])
+                mask = ((pts[:, 0] > b[0] - R) & (pts[:, 0] < b[1] + R) & (pts[:, 1] > b[2] - R) & (pts[:, 1] < b[3] + R) &
+                        (pts[:, 2] > b[4] - R) & (pts[:, 2] < b[5] + R))                                          # :48-50
+                crop = pts[mask]
+                if crop.shape[0] <= 500:                                                                           # :87, else [] (:99)
+                    continue
+                spts = pcRandomUniformSamples(crop, d, -R, rng)                                                     # :55
+                kps.append(spts)
+                if spts.shape[0] == 0:
+                    continue
+                f, dsc = get_descriptors(crop, spts, options)                                                      # :58-59
+                feats.append(f); descs.append(dsc)
+    feat = np.vstack(feats) if feats else np.zeros((0, 3))
+    desc = np.vstack(descs) if descs else np.zeros((0, 980))
+    return feat, desc, (np.vstack(kps) if kps else np.zeros((0, 3)))

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import math
+
 import numpy as np
 
 from . import _lib
@@ -291,6 +293,52 @@ def getLocalPoints(pts, R, c, min_points, max_points):
     return res
 
 
+class DescSet:
+    """A descriptor set resident on the GPU (pcreg_desc_set_create): uploaded once, matched many times -- the surface set and
+    the model set of completeExperimentFast.m:101-150.  `with DescSet(desc) as h:` or call close()."""
+
+    def __init__(self, desc):
+        d = _fcol(desc)
+        self.n, self.D = d.shape
+        self._h = C.c_void_p()
+        check(lib().pcreg_desc_set_create(_ptr(d, C.c_double), self.n, max(self.n, 1), self.D, C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().pcreg_desc_set_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def getMatchesOnSet(hSurface: DescSet, hModel: DescSet, rows, par: dict) -> np.ndarray:
+    """getMatches(descSurface, descModel[rows], par) on resident sets (pcreg_get_matches_on_sets): the same pairs, bit for bit,
+    without uploading either matrix again.  rows: 0-based ascending row numbers of the model set, or None for all of it."""
+    o = _match_opts(par)
+    Q = hSurface.n
+    pairs = np.zeros((max(Q, 1), 2), dtype=np.uint32)
+    P = C.c_int(0)
+    if rows is None:
+        rp, nr = None, 0
+    else:
+        r = np.ascontiguousarray(np.asarray(rows, dtype=np.int32).ravel())
+        if r.size == 0:
+            return np.zeros((0, 2), dtype=np.uint32)
+        rp, nr = _ptr(r, C.c_int32), int(r.size)
+    check(lib().pcreg_get_matches_on_sets(hSurface._h, hModel._h, rp, nr, C.byref(o), _ptr(pairs, C.c_uint32), None, C.byref(P)))
+    return pairs[:P.value].copy()
+
+
 def getMatchesSegmented(descSurface, descModel, rows_list, par: dict) -> list:
     """[getMatches(descSurface, descModel[rows], par) for rows in rows_list] in ONE library call (pcreg_get_matches_segmented):
     the per-sphere calls of completeExperimentFast.m:131-149.  rows: 0-based ascending row numbers of descModel."""
@@ -465,6 +513,53 @@ def _desc_opts(options: dict) -> DescOpts:
     mx = 2**31 - 1 if (mx == float("inf") or mx > 2**31 - 1) else int(mx)
     return DescOpts(int(options["min_pts"]), mx, float(options["R"]), (C.c_double * 2)(*[float(v) for v in options["thVar"]]),
                     kf, int(bool(options["ALIGN_POINTS"])))
+
+
+def speedyDescriptors(pts, sample_opts: dict, options: dict, rng=None):
+    """[feat, desc] = speedyDescriptors(pts, sample_opts, options)  (speedyDescriptors.m:2-82).
+
+    The reference cuts the model into cuboid regions so that its brute-force getLocalPoints scans stay short, draws the
+    keypoints of every region on the host (:55, :86-101) and calls getSpacialHistogramDescriptors once per region on the
+    region's crop (+ a margin of R).  Every keypoint lies at least R inside its crop's bounding box, so its support is the same
+    in the crop and in the whole cloud: here the keypoints are drawn exactly as the reference draws them (same regions, same
+    order, same counts; `rng` -- a numpy Generator, default_rng(0) if None -- plays MATLAB's rand) and ALL of them go through
+    ONE device call on the whole cloud (the uniform grid replaces the tiling): the same rows in the same order.
+    -> (feat V x 3, desc V x 980, the sampled keypoints in region order)."""
+    for k in ("max_region_size", "R"):
+        if k not in options:
+            raise KeyError(f"options.{k} is required (speedyDescriptors.m:10,33)")
+    rng = rng or np.random.default_rng(0)
+    p = np.asarray(pts)
+    d, R = float(sample_opts["d"]), float(options["R"])
+    lo, hi = p.min(axis=0).astype(np.float64), p.max(axis=0).astype(np.float64)          # :18-19 (pointCloud limits)
+    ext = hi - lo
+    nreg = np.ceil(ext / float(options["max_region_size"])).astype(np.int64)              # :20
+    step = ext / nreg                                                                     # :21
+    edges = [lo[a] + step[a] * np.arange(int(np.floor(ext[a] / step[a] + 1e-10)) + 1) for a in range(3)]    # :24-26
+    if [len(e) - 1 for e in edges] != nreg.tolist():                                      # :27
+        raise AssertionError("region bounds do not tile the cloud")
+    if options.get("VERBOSE", 0):
+        print(f"Divided model into {int(nreg.prod())} regions")                           # :35-37
+    draws = []
+    for ix in range(nreg[0]):                                                             # :44-46
+        inx = (p[:, 0] > edges[0][ix] - R) & (p[:, 0] < edges[0][ix + 1] + R)
+        for iy in range(nreg[1]):
+            inxy = inx & (p[:, 1] > edges[1][iy] - R) & (p[:, 1] < edges[1][iy + 1] + R)
+            for iz in range(nreg[2]):
+                crop = p[inxy & (p[:, 2] > edges[2][iz] - R) & (p[:, 2] < edges[2][iz + 1] + R)]        # :48-52
+                if crop.shape[0] <= 500:                                                  # :87 / :99
+                    continue
+                clo, chi = crop.min(axis=0).astype(np.float64), crop.max(axis=0).astype(np.float64)
+                span = (chi - clo) - 2.0 * R                                              # :89-91, margin = -R
+                num = float(span[0] * span[1] * span[2]) / d ** 3
+                num = int(math.floor(num + 0.5)) if num >= 0 else -int(math.floor(-num + 0.5))          # :92 round
+                draws.append(rng.random((max(num, 0), 3)) * span + clo + R)              # :95-101
+    kp = np.vstack(draws) if draws else np.zeros((0, 3))
+    if kp.shape[0] == 0:
+        return np.zeros((0, 3)), np.zeros((0, 980)), kp
+    opt = dict(options); opt["VERBOSE"] = 0                                               # :12
+    feat, desc = getSpacialHistogramDescriptors(p, kp, opt)                               # ONE call instead of :58-59 per region
+    return feat, desc, kp
 
 
 def getSpacialHistogramDescriptors(pts, sample_pts, options: dict):

@@ -420,12 +420,13 @@ int pcreg_match_points_f32(const float* q, int Q, int ldq, const float* m, int M
     return match_points_on_view(v, q, Q, ldq, thr_abs, max_ratio, unique, pairs, P);
 }
 
-static int match_host(const double* f1, int Q, int ld1, const double* f2, int M, int ld2, int D,
-                      const pcreg_match_opts* o, bool preprocess, uint32_t* pairs, double* metric, int* P) {
+// raw descriptor matrices on the device (column-major, ld = rows) -> getMatches.m:22-56 -> pairs on the host.  rawS / rawM are not
+// modified: the preprocessing writes its own copies (scratch slots 0, 1).
+static int match_dev_raw(const double* rawS, int Q, const double* rawM, int M, int D, const pcreg_match_opts* o, uint32_t* pairs, double* metric, int* P) {
     *P = 0;
     if (Q == 0 || M == 0) return PCREG_OK;
-    const int Dp = D + ((preprocess && o->unnormalize) ? 1 : 0);
-    void *dS, *dM, *ws, *dpairs, *dmet, *dcnt, *rawS = nullptr, *rawM = nullptr, *pws = nullptr;
+    const int Dp = D + (o->unnormalize ? 1 : 0);
+    void *dS, *dM, *ws, *dpairs, *dmet, *dcnt, *pws = nullptr;
     size_t wsb = match_features_workspace_bytes(Q, M, Dp);
     TRY(scratch().get(0, sizeof(double) * (size_t)Q * Dp, &dS));
     TRY(scratch().get(1, sizeof(double) * (size_t)M * Dp, &dM));
@@ -433,18 +434,9 @@ static int match_host(const double* f1, int Q, int ld1, const double* f2, int M,
     TRY(scratch().get(3, sizeof(uint32_t) * 2 * (size_t)Q, &dpairs));
     TRY(scratch().get(4, sizeof(double) * (size_t)Q, &dmet));
     TRY(scratch().get(5, 256, &dcnt));
-    if (preprocess) {
-        TRY(scratch().get(6, sizeof(double) * (size_t)Q * D, &rawS));
-        TRY(scratch().get(7, sizeof(double) * (size_t)M * D, &rawM));
-        size_t pwb = sizeof(double) * ((size_t)Q + M + 1);
-        TRY(scratch().get(8, pwb, &pws));
-        TRY(upload_cols(f1, Q, ld1, D, (double*)rawS, g_stream));
-        TRY(upload_cols(f2, M, ld2, D, (double*)rawM, g_stream));
-        TRY(launch_preprocess((double*)rawS, Q, Q, (double*)rawM, M, M, D, *o, (double*)dS, (double*)dM, pws, pwb, g_stream));
-    } else {
-        TRY(upload_cols(f1, Q, ld1, D, (double*)dS, g_stream));
-        TRY(upload_cols(f2, M, ld2, D, (double*)dM, g_stream));
-    }
+    size_t pwb = sizeof(double) * ((size_t)Q + M + 1);
+    TRY(scratch().get(8, pwb, &pws));
+    TRY(launch_preprocess(rawS, Q, Q, rawM, M, M, D, *o, (double*)dS, (double*)dM, pws, pwb, g_stream));
     if (!o->prenormalized) {
         TRY(launch_normalize_rows2((double*)dS, Q, Q, (double*)dM, M, M, Dp, g_stream));
     }
@@ -459,6 +451,98 @@ static int match_host(const double* f1, int Q, int ld1, const double* f2, int M,
     }
     *P = np;
     return PCREG_OK;
+}
+
+static int match_host(const double* f1, int Q, int ld1, const double* f2, int M, int ld2, int D,
+                      const pcreg_match_opts* o, bool preprocess, uint32_t* pairs, double* metric, int* P) {
+    *P = 0;
+    if (Q == 0 || M == 0) return PCREG_OK;
+    if (preprocess) {
+        void *rawS = nullptr, *rawM = nullptr;
+        TRY(scratch().get(6, sizeof(double) * (size_t)Q * D, &rawS));
+        TRY(scratch().get(7, sizeof(double) * (size_t)M * D, &rawM));
+        TRY(upload_cols(f1, Q, ld1, D, (double*)rawS, g_stream));
+        TRY(upload_cols(f2, M, ld2, D, (double*)rawM, g_stream));
+        return match_dev_raw((const double*)rawS, Q, (const double*)rawM, M, D, o, pairs, metric, P);
+    }
+    const int Dp = D;
+    void *dS, *dM, *ws, *dpairs, *dmet, *dcnt;
+    size_t wsb = match_features_workspace_bytes(Q, M, Dp);
+    TRY(scratch().get(0, sizeof(double) * (size_t)Q * Dp, &dS));
+    TRY(scratch().get(1, sizeof(double) * (size_t)M * Dp, &dM));
+    TRY(scratch().get(2, wsb, &ws));
+    TRY(scratch().get(3, sizeof(uint32_t) * 2 * (size_t)Q, &dpairs));
+    TRY(scratch().get(4, sizeof(double) * (size_t)Q, &dmet));
+    TRY(scratch().get(5, 256, &dcnt));
+    TRY(upload_cols(f1, Q, ld1, D, (double*)dS, g_stream));
+    TRY(upload_cols(f2, M, ld2, D, (double*)dM, g_stream));
+    if (!o->prenormalized) {
+        TRY(launch_normalize_rows2((double*)dS, Q, Q, (double*)dM, M, M, Dp, g_stream));
+    }
+    TRY(launch_match_features((double*)dS, Q, Q, (double*)dM, M, M, Dp, *o, (uint32_t*)dpairs,
+                              metric ? (double*)dmet : nullptr, (int32_t*)dcnt, ws, wsb, g_stream));
+    int32_t np = 0;
+    PCREG_HIP(hipMemcpyAsync(&np, dcnt, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    if (np > 0) {
+        PCREG_HIP(hipMemcpy(pairs, dpairs, sizeof(uint32_t) * 2 * (size_t)np, hipMemcpyDeviceToHost));
+        if (metric) PCREG_HIP(hipMemcpy(metric, dmet, sizeof(double) * (size_t)np, hipMemcpyDeviceToHost));
+    }
+    *P = np;
+    return PCREG_OK;
+}
+
+// ---- resident descriptor sets (host tier): one surface set against hundreds of row subsets of one model set
+// (completeExperimentFast.m:101-150) without re-uploading ~28 MB of doubles per sphere
+struct pcreg_desc_set { double* d; int n, D; };       // n x D, column-major on the device (ld = n), as uploaded
+
+__global__ void gather_cols_kernel(const double* __restrict__ src, int n_src, int D, const int32_t* __restrict__ rows, int n, double* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, d = blockIdx.y;
+    if (i < n) dst[i + (size_t)d * n] = src[rows[i] + (size_t)d * n_src];
+}
+
+int pcreg_desc_set_create(const double* desc, int n, int ld, int D, pcreg_desc_set** set) {
+    PCREG_ARG(set != nullptr && n >= 0 && D >= 1 && ld >= n && (n == 0 || desc != nullptr));
+    GUARD();
+    *set = nullptr;
+    double* d = nullptr;
+    PCREG_HIP(hipMalloc((void**)&d, sizeof(double) * (size_t)(n > 0 ? n : 1) * D));
+    int rc = upload_cols(desc, n, ld, D, d, g_stream);
+    if (!rc && hipStreamSynchronize(g_stream) != hipSuccess) { set_error("descriptor upload failed"); rc = PCREG_E_HIP; }
+    if (rc) { (void)hipFree(d); return rc; }
+    *set = new pcreg_desc_set{d, n, D};
+    return PCREG_OK;
+}
+int pcreg_desc_set_destroy(pcreg_desc_set* set) {
+    if (!set) return PCREG_OK;
+    std::lock_guard<std::mutex> lock(g_mu);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(set->d);
+    delete set;
+    return PCREG_OK;
+}
+int pcreg_desc_set_size(const pcreg_desc_set* set, int* n, int* D) {
+    PCREG_ARG(set && n && D);
+    *n = set->n; *D = set->D;
+    return PCREG_OK;
+}
+int pcreg_get_matches_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* model_rows, int n_rows,
+                              const pcreg_match_opts* par, uint32_t* pairs, double* metric, int* P) {
+    PCREG_ARG(surface && model && par && pairs && P && surface->D == model->D && n_rows >= 0 && (model_rows || n_rows == 0));
+    PCREG_ARG(par->metric == PCREG_METRIC_SAD || par->metric == PCREG_METRIC_SSD);
+    GUARD();
+    *P = 0;
+    const int Q = surface->n, D = surface->D;
+    if (!model_rows) return match_dev_raw(surface->d, Q, model->d, model->n, D, par, pairs, metric, P);      // descModel(:, :)
+    for (int k = 0; k < n_rows; ++k) PCREG_ARG(model_rows[k] >= 0 && model_rows[k] < model->n);
+    if (Q == 0 || n_rows == 0) return PCREG_OK;
+    void *rawM, *drows;
+    TRY(scratch().get(7, sizeof(double) * (size_t)n_rows * D, &rawM));
+    TRY(scratch().get(9, sizeof(int32_t) * (size_t)n_rows, &drows));
+    PCREG_HIP(hipMemcpyAsync(drows, model_rows, sizeof(int32_t) * (size_t)n_rows, hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((n_rows + 255) / 256, D), dim3(256), 0, g_stream, model->d, model->n, D, (const int32_t*)drows, n_rows, (double*)rawM);   // descModel(rows, :)
+    PCREG_HIP(hipGetLastError());
+    return match_dev_raw(surface->d, Q, (const double*)rawM, n_rows, D, par, pairs, metric, P);
 }
 
 int pcreg_match_features(const double* f1, int Q, int ld1, const double* f2, int M, int ld2, int D,

@@ -197,6 +197,38 @@ int drv_model_round_trip(const float* model, int M, const float* surfaces /* n_s
     return rc;
 }
 
+// descCreate x 2, one getMatchesOnSet per row subset (rows1: 1-based, subsets back to back, off: n_sub + 1 offsets; an EMPTY subset
+// stands for "the whole model set", passed as []), descDestroy x 2
+int drv_desc_set_round_trip(const double* dS, int Q, const double* dM, int VM, int D, const double* par7, const int32_t* rows1, const int32_t* off,
+                            int n_sub, uint32_t* pairs_colmajor /* n_sub x (Q x 2) */, int* P /* n_sub */, char* err, int errlen) {
+    mxArray* lhs[1] = {nullptr};
+    { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dS, Q, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* hS = lhs[0]; lhs[0] = nullptr;
+    { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dM, VM, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* hM = lhs[0]; lhs[0] = nullptr;
+    if (!mxIsUint64(hS) || !mxIsUint64(hM)) { snprintf(err, errlen, "a handle is not uint64"); return 1; }
+    int rc = 0;
+    for (int k = 0; k < n_sub && !rc; ++k) {
+        mxArray* p = mxCreateStructMatrix(1, 1, 0, nullptr);
+        mxSetField(p, 0, "Metric", mxCreateString("SAD")); mxSetField(p, 0, "Method", mxCreateString("Approximate"));
+        put(p, "MatchThreshold", par7[0]); put(p, "MaxRatio", par7[1]); put(p, "Unique", par7[2]); put(p, "UNNORMALIZE", par7[3]);
+        put(p, "norm_factor", par7[4]); put(p, "CHANGE_METRIC", par7[5]); put(p, "metric_factor", par7[6]); put(p, "VERBOSE", 0);
+        const int n = off[k + 1] - off[k];
+        mxArray* r = n > 0 ? mxCreateNumericMatrix(n, 1, mxINT32_CLASS, mxREAL) : mxCreateDoubleMatrix(0, 0, mxREAL);
+        if (n > 0) memcpy(mxGetData(r), rows1 + off[k], (size_t)n * 4);
+        std::vector<mxArray*> rhs{mxCreateString("getMatchesOnSet"), mxDuplicateArray(hS), mxDuplicateArray(hM), r, p};
+        rc = call(1, lhs, rhs, err, errlen);
+        if (!rc) {
+            P[k] = (int)mxGetM(lhs[0]);
+            memcpy(pairs_colmajor + (size_t)k * Q * 2, mxGetData(lhs[0]), (size_t)P[k] * 2 * 4);
+            mxDestroyArray(lhs[0]); lhs[0] = nullptr;
+        }
+    }
+    { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hS}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hM}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    return rc;
+}
+
 // one-worker rehearsal of the spmd block of INTEGRATION.md section 3: setDevice, commId, commInit, matchPointsSharded,
 // ransacSharded, commDestroy -- all through the gateway
 int drv_comm_round_trip(const float* surf, int Q, const float* model, int M, float thr, float ratio, uint32_t* pairs_colmajor, int* P,

@@ -165,3 +165,26 @@ def test_more_candidate_chunks_than_the_kept_ballots(oracle_c):
     assert len(rfeat) >= 6 and rdesc.sum(axis=1).max() < 8000          # supports fit the list; the CANDIDATES are the 100 000
     np.testing.assert_array_equal(feat, rfeat)
     np.testing.assert_array_equal(desc, rdesc)
+
+
+def test_speedy_descriptors_one_call_equals_the_region_loop(oracle_c, oracle_py):
+    """pcreg_amd.speedyDescriptors (the reference's region walk and host-side sampling,
+    speedyDescriptors.m:17-101, then ONE device call for all regions on the whole cloud) returns the keypoints, locations and
+    rows of the oracle's restatement of the reference's loop (one getSpacialHistogramDescriptors call per region on the
+    region's CROP): same order, all 980 counts."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(17)
+    # an elongated, gently curved sheet bundle: several regions per axis at max_region_size 12, supports of R = 2 well filled
+    n = 120_000
+    x = rng.uniform(0, 40, n); y = rng.uniform(0, 25, n); s_ = rng.integers(0, 3, n)
+    pts = np.column_stack([x, y, 4.0 * s_ + 0.8 * np.sin(0.4 * x) + 0.5 * np.cos(0.5 * y) + rng.normal(0, 0.05, n)])
+    opt = dict(min_pts=60, max_pts=6000, R=2.0, thVar=[1.05, 1.05], k=0.85, ALIGN_POINTS=True, VERBOSE=0, max_region_size=12.0)
+    sopt = dict(d=1.6)
+    c_desc = lambda p, k, o: oracle_c.getSpacialHistogramDescriptors(p, k, o)
+    rfeat, rdesc, rkp = oracle_py.speedyDescriptors(pts, sopt, opt, rng=np.random.default_rng(5), get_descriptors=c_desc)
+    feat, desc, kp = pc.speedyDescriptors(pts, sopt, opt, rng=np.random.default_rng(5))
+    bounds, nreg = oracle_py.speedy_regions(pts, opt["max_region_size"])
+    assert int(np.prod(nreg)) >= 8 and len(rkp) > 500 and len(rfeat) > 100
+    np.testing.assert_array_equal(kp, rkp)                        # the same keypoints in the same (region) order
+    np.testing.assert_array_equal(feat, rfeat)
+    np.testing.assert_array_equal(desc, rdesc)

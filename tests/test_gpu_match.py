@@ -184,3 +184,31 @@ def test_getDescDist_known_answer_on_the_hip_path(oracle_py):
     for (i, j), d in zip(pairs.astype(int), met):
         assert abs(d - getDescDist_literal(dS[i - 1], dM[j - 1])) < 1e-13, (i, j)
     np.testing.assert_array_equal(pc.getMatches(dS, dM, par), pairs)
+
+
+@pytest.mark.parametrize("par_over", [dict(), dict(Unique=False, UNNORMALIZE=False), dict(Metric="SSD", MatchThreshold=1.0, MaxRatio=0.8)])
+def test_get_matches_on_resident_sets_equals_get_matches(par_over, oracle_c):
+    """pcreg_desc_set_create + pcreg_get_matches_on_sets == pcreg_get_matches on the same rows, bit for bit
+    (pairs AND the order), for row subsets, the whole set, an empty subset; the handles survive many calls."""
+    import pcreg_amd as pc
+    rng = np.random.default_rng(31)
+    Q, M, D = 300, 1200, 980
+    dM = rng.poisson(3.0, (M, D)).astype(np.float64)
+    dS = dM[rng.choice(M, Q, replace=False)] + rng.poisson(0.15, (Q, D))
+    par = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate", MatchThreshold=10, MaxRatio=0.99,
+               Metric="SAD", Unique=True, VERBOSE=0)
+    par.update(par_over)
+    with pc.DescSet(dS) as hS, pc.DescSet(dM) as hM:
+        assert (hS.n, hS.D, hM.n) == (Q, D, M)
+        for rows in (np.sort(rng.choice(M, 700, replace=False)), np.arange(0, M, 3), np.array([5]), None, np.zeros(0, np.int64)):
+            got = pc.getMatchesOnSet(hS, hM, rows, par)
+            if rows is not None and len(rows) == 0:
+                assert got.shape == (0, 2)
+                continue
+            sub = dM if rows is None else dM[rows]
+            want = pc.getMatches(dS, sub, par)
+            np.testing.assert_array_equal(got, want)
+            if par["Metric"] == "SAD":
+                np.testing.assert_array_equal(want, oracle_c.getMatches(dS, sub, par))
+        with pytest.raises(Exception):
+            pc.getMatchesOnSet(hS, hM, np.array([M]), par)                 # out of range: an argument error, not a fault

@@ -113,6 +113,17 @@ def test_shim_round_trips_equal_the_ctypes_path(drv):
     pairs3 = np.zeros(3 * 60 * 2, dtype=np.uint32); npairs = np.zeros(3, dtype=np.int32); Pt = C.c_int()
     assert drv.drv_get_matches_segmented(_p(_d(dS)), 60, _p(_d(dM)), 90, 980, _p(par7), _p(rows1, C.c_int32), len(rows1), _p(off, C.c_int32), 3,
                                          _p(pairs3, C.c_uint32), C.byref(Pt), _p(npairs, C.c_int32), e, 1024) == 0, e.value
+    # descCreate / getMatchesOnSet / descDestroy: the same three subsets + the whole set ([]) on RESIDENT sets, bit for bit getMatches'
+    subs = rows_list + [np.zeros(0, np.int64)]
+    offs = np.zeros(len(subs) + 1, dtype=np.int32); offs[1:] = np.cumsum([len(r) for r in subs])
+    rows1s = (np.concatenate(subs) + 1).astype(np.int32)
+    pairs4 = np.zeros(len(subs) * 60 * 2, dtype=np.uint32); P4 = (C.c_int * len(subs))()
+    assert drv.drv_desc_set_round_trip(_p(_d(dS)), 60, _p(_d(dM)), 90, 980, _p(par7), _p(rows1s, C.c_int32), _p(offs, C.c_int32), len(subs),
+                                       _p(pairs4, C.c_uint32), P4, e, 1024) == 0, e.value
+    for z, r in enumerate(subs):
+        wz = pc.getMatches(dS, dM[r] if len(r) else dM, par)
+        gz = pairs4[z * 120:z * 120 + 2 * P4[z]].reshape(P4[z], 2, order="F")
+        assert P4[z] == len(wz) and np.array_equal(gz, wz), z
     allp = pairs3[:2 * Pt.value].reshape(Pt.value, 2, order="F")
     seg = pc.getMatchesSegmented(dS, dM, rows_list, par)
     k = 0
