@@ -170,12 +170,17 @@ class Ctx:
         self.rank, self.world, self.dev, self.collective = rank, world, dev, collective
 
 
-def run_registration(ctx: Ctx, M_total: int, Q: int, steps: int, warmup: int, time_kernel: bool) -> dict:
-    """The step described in the module docstring on a model of M_total rows sharded over ctx.world ranks."""
+def run_registration(ctx: Ctx, M_total: int, Q: int, steps: int, warmup: int, time_kernel: bool, in_flight: int = 1,
+                     coef: dict | None = None) -> dict:
+    """The step described in the module docstring on a model of M_total rows sharded over ctx.world ranks.  in_flight > 1: that many
+    registrations in flight per rank (pcreg_amd/pipelined.py: one lane = one HIP stream + its own buffers, surfaces dealt round-robin;
+    every lane issues its collectives in host program order, the same on every rank)."""
     import torch
     import torch.distributed as dist
     from pcreg_amd.device import PreparedModel, RegistrationPipeline, soa
+    from pcreg_amd.pipelined import PipelinedRegistration
     from pcreg_amd._lib import lib
+    coef = coef or RANSAC_COEF
     model, surf, _ = synth(M_total, Q)
     per = (M_total + ctx.world - 1) // ctx.world
     m_lo = ctx.rank * per
@@ -189,19 +194,27 @@ def run_registration(ctx: Ctx, M_total: int, Q: int, steps: int, warmup: int, ti
     model_soa = PreparedModel(model_t)
     torch.cuda.synchronize()
     prepare_ms = (time.perf_counter() - t0) * 1e3
-    pipe = RegistrationPipeline(Q, shard.shape[0], m_lo=m_lo, M_total=M_total, device=ctx.dev)
+    piped = in_flight > 1
+    if piped:
+        pr = PipelinedRegistration(Q, shard.shape[0], lanes=in_flight, m_lo=m_lo, M_total=M_total, device=ctx.dev)
+        pipe = pr.lanes[0]
+    else:
+        pipe = RegistrationPipeline(Q, shard.shape[0], m_lo=m_lo, M_total=M_total, device=ctx.dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
     def step(k):
+        if piped:
+            pr.submit(q_soa, model_soa, MATCH_THR_ABS, MATCH_RATIO, coef, unique=True, seed=7)
+            return
         if k is not None:
             ev[k][0].record()
         pipe.search_local(q_soa, model_soa)
         if k is not None:
             ev[k][1].record()
         pipe.match_after_search(q_soa, model_soa, MATCH_THR_ABS, MATCH_RATIO, unique=True)
-        pipe.ransac_sharded(RANSAC_COEF, seed=7)        # one rank: plain ransac(); N ranks: hypotheses split N ways
+        pipe.ransac_sharded(coef, seed=7)               # one rank: plain ransac(); N ranks: hypotheses split N ways
 
-    for _ in range(warmup):
+    for _ in range(max(warmup, in_flight if piped else 0)):
         step(None)
     if time_kernel:
         lib().pcreg_dev_search_kernel_timing(1)       # HIP events around the dominant kernel, on its launch stream
@@ -219,7 +232,7 @@ def run_registration(ctx: Ctx, M_total: int, Q: int, steps: int, warmup: int, ti
         tt = torch.tensor([elapsed], device=ctx.dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    search_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))           # the whole search call
+    search_ms = None if piped else float(np.mean([a.elapsed_time(b) for a, b in ev]))           # the whole search call
     kernel_ms, launches = None, 0
     if time_kernel:
         kms, kn = C.c_float(0.0), C.c_int(0)
@@ -228,15 +241,38 @@ def run_registration(ctx: Ctx, M_total: int, Q: int, steps: int, warmup: int, ti
         if kn.value != steps:                                    # never price the roofline from another duration
             raise RuntimeError(f"the dominant kernel was timed {kn.value} times in {steps} steps: its HIP events are missing")
         kernel_ms, launches = float(kms.value), int(kn.value)
-    res = pipe.fetch_result()
+    if piped:
+        allres = pr.results()
+        res = allres[-1]
+        n_pairs = res["n_pairs"]
+    else:
+        res = pipe.fetch_result()
+        n_pairs = int(pipe.n_pairs.item())
     out = {"ms_per_step": elapsed / steps * 1e3, "value": float(Q) * float(M_total) * steps / elapsed / 1e9,
            "search_call_ms": search_ms, "kernel_ms": kernel_ms, "launches_timed": launches, "rows_per_gpu": int(shard.shape[0]),
-           "model_prepare_ms": prepare_ms,
-           "ransac": {"n_pairs": int(pipe.n_pairs.item()), "max_inliers": res["maxInliers"], "num_success": res["numSuccess"],
+           "model_prepare_ms": prepare_ms, "in_flight": in_flight,
+           "ransac": {"n_pairs": n_pairs, "max_inliers": res["maxInliers"], "num_success": res["numSuccess"],
                       "failed": res["failed"]}, "_model": model, "_surf": surf}
+    if piped:
+        del pr
     del pipe, model_soa, model_t, q_soa
     torch.cuda.empty_cache()
     return out
+
+
+def extra_two_in_flight(ctx: Ctx, Q: int, steps: int) -> dict:
+    """throughput with TWO registrations in flight per GPU (two HIP streams) against one, (a) at the headline's
+    shape and (b) at the shape one rank of an 8-GPU run sees: a 125 k-row shard and 1/8 of the hypotheses -- its collectives (three
+    latency-sized exchanges) excluded.  The launch-sized kernels of a step do not shrink with the shard; a second lane fills them."""
+    res = {}
+    for key, M, coef in (("model_1M", 1_000_000, RANSAC_COEF), ("rank_of_8_emulated_125k", 125_000, dict(RANSAC_COEF, iterNum=RANSAC_COEF["iterNum"] // 8))):
+        one = run_registration(ctx, M, Q, steps, 2, time_kernel=False, in_flight=1, coef=coef)
+        two = run_registration(ctx, M, Q, steps, 2, time_kernel=False, in_flight=2, coef=coef)
+        same = one["ransac"] == two["ransac"]
+        res[key] = {"one_in_flight_ms": round(one["ms_per_step"], 4), "two_in_flight_ms": round(two["ms_per_step"], 4),
+                    "speedup": round(one["ms_per_step"] / two["ms_per_step"], 3), "same_result": bool(same), "iterNum": coef["iterNum"]}
+    res["note"] = "125k: one rank of N = 8 (its shard, 1/8 of the hypotheses), collectives excluded"
+    return res
 
 
 def run_batch_cfg5(ctx: Ctx, n_crops: int, M: int, Q: int) -> dict:
@@ -733,6 +769,8 @@ def summary_of(out: dict) -> dict:
           "cfg1_ms": g(ex, "ransac_cfg1", "ms"), "cfg1b_ms": g(ex, "ransac_cfg1_batched", "ms"), "cfg1b_frac": g(ex, "ransac_cfg1_batched", "roofline", "frac"),
           "sweep_ms": g(ex, "sweep", "ms"), "sweep_frac": g(ex, "sweep", "roofline", "frac"),
           "cfg5_regs_per_s": g(out, "cfg5_batch", "registrations_per_s"),
+          "two_1M_x": g(out, "two_in_flight", "model_1M", "speedup"), "two_125k_x": g(out, "two_in_flight", "rank_of_8_emulated_125k", "speedup"),
+          "two_125k_ms": g(out, "two_in_flight", "rank_of_8_emulated_125k", "two_in_flight_ms"),
           "chain_match_ms": g(ex, "desc_chain", "get_matches", "ms"), "chain_match_unproven": g(ex, "desc_chain", "get_matches", "stats", "unproven"),
           "chain_sweep_ms": g(ex, "desc_chain", "sweep", "ms"), "chain_sweep_right": g(ex, "desc_chain", "sweep", "registered_right"),
           "host_ransac_ms": g(ex, "host_tier", "ransac_n1000_ms"), "host_cfg2_ms": g(ex, "host_tier", "getMatches_50kx200k_ms"),
@@ -760,6 +798,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only")
     ap.add_argument("--crops", type=int, default=64, help="crops of the cfg 5 batch")
+    ap.add_argument("--in-flight", type=int, default=1, help="registrations in flight per rank (HIP streams); the headline default is 1")
     ap.add_argument("--skip", default="", help="comma-separated extras to leave out (e.g. host_tier,desc_chain)")
     args = ap.parse_args()
 
@@ -792,7 +831,7 @@ def main() -> None:
     ctx = Ctx(rank, world, dev, collective)
 
     Q, M_total = args.surface_points, args.model_points
-    head = run_registration(ctx, M_total, Q, args.steps, args.warmup, time_kernel=True)
+    head = run_registration(ctx, M_total, Q, args.steps, args.warmup, time_kernel=True, in_flight=args.in_flight)
     model, surf = head.pop("_model"), head.pop("_surf")
     extra_steps, extra_warm = max(3, min(args.steps, 10)), min(args.warmup, 2)
     more = {}
@@ -811,6 +850,8 @@ def main() -> None:
                                      "scaling": "strong", "ms_per_step": round(r["ms_per_step"], 4), "value": round(r["value"], 2), "unit": "Gpairs/s",
                                      "search_call_ms": round(r["search_call_ms"], 4), "ransac": r["ransac"], "steps": extra_steps}
         more["cfg5_batch"] = run_batch_cfg5(ctx, args.crops, 1_000_000, Q)
+        if world == 1:
+            more["two_in_flight"] = extra_two_in_flight(ctx, Q, max(10, extra_steps))
 
     if rank == 0:
         rows = head["rows_per_gpu"]
@@ -847,9 +888,9 @@ def main() -> None:
             "config": {"workload": f"{Q} surface pts vs a FIXED {M_total}-pt model ({rows} rows per GPU, row-sharded over {world} GPU(s)), "
                                    f"top-2 + threshold/ratio/Unique + RANSAC(3,1e4,0.3,0.08,REFINE)",
                        "surface_points": Q, "model_points_total": M_total, "parallelism": f"model-shard x{world}"},
-            "registrations_per_s": round(1e3 / head["ms_per_step"], 2),
-            "knn_kernel": {"name": "knn_candidates_f16_pipe_kernel", "ms": round(kernel_ms, 4), "search_call_ms": round(search_ms, 4),
-                           "launches_timed": head["launches_timed"], "gpairs_per_s_per_gpu": round(Q * rows / (search_ms * 1e-3) / 1e9, 1),
+            "registrations_per_s": round(1e3 / head["ms_per_step"], 2), "in_flight": head["in_flight"],
+            "knn_kernel": {"name": "knn_candidates_f16_pipe_kernel", "ms": round(kernel_ms, 4), "search_call_ms": None if search_ms is None else round(search_ms, 4),
+                           "launches_timed": head["launches_timed"], "gpairs_per_s_per_gpu": round(Q * rows / ((search_ms or kernel_ms) * 1e-3) / 1e9, 1),
                            "model_prepare_ms_once": round(head["model_prepare_ms"], 3),
                            "note": "model prepared once per model; step = 4 search + 1 match launch + RANSAC chain"},
             "ransac": head["ransac"],
@@ -859,7 +900,7 @@ def main() -> None:
                          "vs_fp32_vector_peak": round(alg_tflops / PEAK_FP32_TFLOPS, 3),
                          "matrix_pipe": {"executed_flop_per_pair": FLOP_PER_PAIR_EXECUTED, "tflops": round(exe_tflops, 1),
                                          "occupancy_of_dense_f16_peak": round(exe_tflops / PEAK_F16_MFMA_TFLOPS, 4)},
-                         "hbm_algorithmic_gbps": round(alg_bytes / (search_ms * 1e-3) / 1e9, 2),
+                         "hbm_algorithmic_gbps": round(alg_bytes / ((search_ms or kernel_ms) * 1e-3) / 1e9, 2),
                          "note": "HIP events per launch; VALU-issue-bound, not HBM: docs/BENCH_NOTES.md"},
         }
         out.update(more)

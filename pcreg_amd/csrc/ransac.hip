@@ -1285,10 +1285,10 @@ __device__ __forceinline__ void make_t32(const double (&T)[12], const double (&o
 
 // stage 2: every workgroup folds the record workgroups' maxima (a few hundred doubles: cheaper than a launch of its own),
 // workgroup 0 leaves them in sa.bounds for the later stages, and each thread writes the fp32 row of its sample fit
-__global__ __launch_bounds__(256) void rs_stage2_kernel(StagedArgs sa, const double* __restrict__ TT, float* __restrict__ out) {
-    const RansacArgs& a = sa.a;
+__device__ __forceinline__ void rs_fold_maxima(const StagedArgs& sa, double (&mx)[4]) {
     __shared__ double s_mx[4][4];
-    double mx[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mx[k] = 0.0;
     for (int b = threadIdx.x; b < sa.n_rec_blocks; b += 256) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) mx[k] = fmax(mx[k], sa.bpart[(size_t)b * 4 + k]);
@@ -1305,6 +1305,16 @@ __global__ __launch_bounds__(256) void rs_stage2_kernel(StagedArgs sa, const dou
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) mx[k] = fmax(fmax(s_mx[0][k], s_mx[1][k]), fmax(s_mx[2][k], s_mx[3][k]));
+}
+__device__ __forceinline__ void rs_digits_body(const StagedArgs& sa, uint4* __restrict__ dig, int block, const double (&bounds)[4]);
+// workgroups [0, n_t32): the fp32 rows of the sample fits; the rest: the records' int8 digits (round 4: one launch for both -- the
+// digits only need the folded maxima, which every workgroup of this launch computes for itself)
+__global__ __launch_bounds__(256) void rs_stage2_kernel(StagedArgs sa, const double* __restrict__ TT, float* __restrict__ out, int n_t32,
+                                                        uint4* __restrict__ dig) {
+    const RansacArgs& a = sa.a;
+    double mx[4];
+    rs_fold_maxima(sa, mx);
+    if ((int)blockIdx.x >= n_t32) { rs_digits_body(sa, dig, blockIdx.x - n_t32, mx); return; }
     if (blockIdx.x == 0 && threadIdx.x < 4) sa.bounds[threadIdx.x] = mx[threadIdx.x];
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= a.iters || !sa.use_f32) return;
@@ -2070,15 +2080,15 @@ __device__ __forceinline__ int rs_rec_exp(const double* __restrict__ bounds, int
     return (b > 0.0 && b < INFINITY) ? ilogb(b) + 2 : 0;
 }
 // dig [(kstep * 4 + tile) * 64 + lane] (16 int8): lane = (half << 5) | col; byte b = correspondence kstep * 32 + half * 16 + b
-__global__ __launch_bounds__(256) void rs_digits_kernel(StagedArgs sa, uint4* __restrict__ dig) {
-    const int g = blockIdx.x * 256 + threadIdx.x;               // (kstep, tile, lane)
+__device__ __forceinline__ void rs_digits_body(const StagedArgs& sa, uint4* __restrict__ dig, int block, const double (&bounds)[4]) {
+    const int g = block * 256 + threadIdx.x;                    // (kstep, tile, lane)
     const int lane = g & 63, tile = (g >> 6) & 3, kstep = g >> 8;
     if (kstep >= sa.nslots_cap * 2) return;
     const int col = lane & 31, half = lane >> 5;
     const int c = col >> 1, pd = tile + 4 * (col & 1);
     unsigned w[4] = {0u, 0u, 0u, 0u};
     if (c < 15) {
-        const int E = rs_rec_exp(sa.bounds, c);
+        const int E = rs_rec_exp(bounds, c);
         const double* r = sa.rec + (size_t)(kstep * 32 + half * 16) * kRec + c;
 #pragma unroll
         for (int bb = 0; bb < 16; ++bb) {
@@ -2376,8 +2386,12 @@ __global__ __launch_bounds__(NTHR) void ransac_select_kernel(RansacArgs a, pcreg
 // them zero again.
 constexpr int kSelBlocks = 64, kSelThreads = 1024, kSelPerThread = 32;
 struct SelCtr { int32_t ticket, finished; int32_t status[kSelBlocks]; };
+// The staged chain's last epilogue (rs_finish: refined counts from the point blocks' partial rows, `has` flags) rides along:
+// every workgroup needs all counts for the maximum anyway, so each sums the partial rows itself (pb <= 64 coalesced rows of
+// `iters` words from L2) and the first one stores cnt2 / has for the callers that read them -- one launch fewer per step.
+struct SelFinish { const int32_t* part; const unsigned char* v2; int pb; };      // part == null: cnt2 / has are already final
 __global__ __launch_bounds__(kSelThreads) void ransac_select_multi_kernel(RansacArgs a, pcreg_dev_ransac_result* out, int32_t* inlier_idx,
-                                                                           SelCtr* __restrict__ ctr, int per_block) {
+                                                                           SelCtr* __restrict__ ctr, int per_block, SelFinish fin) {
     constexpr int NW = kSelThreads / 64;
     __shared__ unsigned long long s_key[NW];
     __shared__ int s_cnt[NW];
@@ -2393,9 +2407,18 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_multi_kernel(Ransac
     const int thInlr = matlab_round_i(a.ratio * (double)n);
     unsigned long long key = 0; int ns = 0;
     for (int p = threadIdx.x; p < a.iters; p += kSelThreads) {
-        unsigned long long k = ((unsigned long long)(unsigned)cc[p] << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(p + a.hyp0g));
+        int c;
+        if (fin.part) {                                                      // rs_finish_body, per workgroup
+            c = 0;
+            if (fin.v2[p]) {
+#pragma unroll 8
+                for (int pbk = 0; pbk < fin.pb; ++pbk) c += fin.part[(size_t)pbk * a.iters + p];
+            }
+            if (blockIdx.x == 0) { a.cnt2[p] = c; a.has[p] = fin.v2[p] && c >= thInlr; }
+        } else c = cc[p];
+        unsigned long long k = ((unsigned long long)(unsigned)c << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(p + a.hyp0g));
         key = k > key ? k : key;
-        ns += cc[p] >= thInlr;
+        ns += c >= thInlr;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -2411,7 +2434,8 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_multi_kernel(Ransac
     const int winner_g = a.iters > 0 ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0;
     const int winner = winner_g - a.hyp0g;
     const int maxInl = (int)(key >> 32);
-    const bool failed = !(a.iters > 0 && a.has[winner]);                 // ransac.m:75-89
+    // ransac.m:75-89.  (With the finish folded in, has[winner] = v2[winner] && its count >= thInlr: no read of another workgroup's store.)
+    const bool failed = !(a.iters > 0 && (fin.part ? (fin.v2[winner] != 0 && maxInl >= thInlr) : a.has[winner] != 0));
     if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : a.TF[(size_t)winner * 12 + threadIdx.x];
     __syncthreads();
     const int b = s_ticket;
@@ -2718,6 +2742,8 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
     a.has = (unsigned char*)w; w += align_up(h, 256);
     long long total = (long long)o.iterNum * B;
     void* sel_ctr = nullptr;              // set by the staged chain: its selection runs on several workgroups
+    SelFinish sel_fin{nullptr, nullptr, 0};
+    bool fold_finish = false;
     if (debug_flag(kDbgRansacResidentF64) && n_cap > 0 && (size_t)n_cap * 48 <= (offsets ? (size_t)152 * 1024 : (size_t)64 * 1024)) {
         // A/B and parity switch: the round-3 kernel, fp64 scoring on the raw coordinates in LDS (up to 32 KB per registration of a
         // batch of large capacity, the rest from L2)
@@ -2791,12 +2817,13 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         sa.a = a;
         const int it = o.iterNum;
         const dim3 sgrid(pb, (it + kSChunk - 1) / kSChunk);
-        // 11 launches (round 2: 11 + select): stage1 (sample fits + records), stage2 (maxima + fp32 rows), the records' digits,
-        // scoring pass 1, pass1, refit sums on the matrix cores, dense refit sums (normally idle), refits, scoring pass 2, finish; then select
+        // 9 launches (round 3: 11): stage1 (sample fits + records), stage2 (maxima + fp32 rows + the records' digits), scoring pass 1,
+        // pass1, refit sums on the matrix cores, dense refit sums (normally idle), refits, scoring pass 2; then select, which also
+        // does what rs_finish did
         const int n_fit = (it + 255) / 256;
         hipLaunchKernelGGL(rs_stage1_kernel, dim3((unsigned)(n_fit + sa.n_rec_blocks)), dim3(256), 0, st, sa, n_fit);
-        hipLaunchKernelGGL(rs_stage2_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a);
-        if (sa.use_lane) hipLaunchKernelGGL(rs_digits_kernel, dim3((unsigned)staged_slots_cap(n_cap) * 2), dim3(256), 0, st, sa, sa.dig);
+        const int n_t32 = (it + 255) / 256, n_dig = sa.use_lane ? (int)staged_slots_cap(n_cap) * 2 : 0;
+        hipLaunchKernelGGL(rs_stage2_kernel, dim3((unsigned)(n_t32 + n_dig)), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a, n_t32, sa.dig);
         if (sa.use_f32) {
             if (sa.use_lane)
                 hipLaunchKernelGGL(rs_score32_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1);
@@ -2818,7 +2845,9 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
                 hipLaunchKernelGGL(rs_score32_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const float*)sa.T32b, (const unsigned char*)sa.v2);
             else
                 hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const unsigned char*)sa.v2);
-            hipLaunchKernelGGL(rs_finish_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
+            fold_finish = !part && n_cap <= kSelBlocks * kSelPerThread * kSelThreads;        // ransac_select_multi_kernel does it
+            if (fold_finish) { sel_fin.part = sa.part; sel_fin.v2 = sa.v2; sel_fin.pb = sa.pb; }
+            else hipLaunchKernelGGL(rs_finish_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
         }
     } else {
         // several large sets: 8-wave workgroups share LDS tiles of the correspondences
@@ -2838,7 +2867,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         int per_block = 4 * kSelThreads;
         if ((n_cap + per_block - 1) / per_block > kSelBlocks) per_block = ((n_cap + kSelBlocks - 1) / kSelBlocks + kSelThreads - 1) / kSelThreads * kSelThreads;
         const int nb = std::max(1, (n_cap + per_block - 1) / per_block);
-        hipLaunchKernelGGL(ransac_select_multi_kernel, dim3(nb), dim3(kSelThreads), 0, st, a, out, inlier_idx, (SelCtr*)sel_ctr, per_block);
+        hipLaunchKernelGGL(ransac_select_multi_kernel, dim3(nb), dim3(kSelThreads), 0, st, a, out, inlier_idx, (SelCtr*)sel_ctr, per_block, sel_fin);
     }
     else if (n_cap >= 8192) hipLaunchKernelGGL(ransac_select_kernel<1024>, dim3(B), dim3(1024), 0, st, a, out, inlier_idx, part);   // long inlier lists
     else hipLaunchKernelGGL(ransac_select_kernel<kBlock>, dim3(B), dim3(kBlock), 0, st, a, out, inlier_idx, part);

@@ -38,6 +38,7 @@ class PreparedModel:
         if model_soa.dtype != torch.float32 or model_soa.dim() != 2 or model_soa.shape[0] != 3 or model_soa.stride(1) != 1:
             raise TypeError("a model is a [3, M] float32 tensor with contiguous rows (column-major M x 3)")
         self.tensor, self.version = model_soa, model_soa._version
+        self.key = _model_key(model_soa)
         self.M, self.ld = int(model_soa.shape[1]), int(model_soa.stride(0)) if model_soa.shape[1] > 0 else 1
         self.handle = C.c_void_p()
         with torch.cuda.device(model_soa.device):
@@ -55,13 +56,41 @@ class PreparedModel:
             pass
 
 
+_dropped: list = []            # handles replaced by as_prepared(): freed later, not in the middle of a hot loop
+_reprepared = 0
+
+
+def release_dropped() -> None:
+    """Free the prepared models that as_prepared() replaced (pcreg_dev_model_destroy synchronises the device: not something to
+    do between two launches of a hot loop, which is where a replaced cache entry used to die)."""
+    while _dropped:
+        _dropped.pop().close()
+
+
+def _model_key(t: torch.Tensor):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version, t.device.index)
+
+
 def as_prepared(model, cache: PreparedModel | None = None) -> PreparedModel:
-    """model: a PreparedModel (used as is) or a [3, M] tensor -- prepared now, unless `cache` was prepared from this very
-    tensor object and the tensor has not been written since."""
+    """model: a PreparedModel (used as is) or a [3, M] tensor -- prepared now, unless `cache` was prepared from the same memory
+    (data pointer, shape, strides) and torch has seen no write to it since (`_version`).  A fresh VIEW of the same storage
+    (`model[:, :M]`, `soa(x)` returning its input) therefore hits the cache.  Writes through raw pointers (this library's own
+    ctypes calls, another stream) are invisible to `_version`: after such a write build a new PreparedModel yourself.
+    A replaced entry is parked (release_dropped()) instead of being freed here; repeated re-preparation is reported once."""
+    global _reprepared
     if isinstance(model, PreparedModel):
         return model
-    if cache is not None and cache.tensor is model and cache.version == model._version and cache.handle.value:
+    if cache is not None and cache.handle.value and cache.key == _model_key(model):
         return cache
+    if cache is not None:
+        _dropped.append(cache)
+        _reprepared += 1
+        if _reprepared == 8:
+            import warnings
+            warnings.warn("pcreg_amd: a model tensor was re-prepared 8 times (box, operand tiles and seeding grid rebuilt per call); "
+                          "pass a PreparedModel, or keep the model tensor unmodified between calls", RuntimeWarning, stacklevel=3)
+        if len(_dropped) > 4:
+            _dropped.pop(0).close()
     return PreparedModel(model)
 
 

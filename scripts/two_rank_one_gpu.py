@@ -24,6 +24,24 @@ rp1 = surf[ref[:, 0] - 1].astype(np.float64); rp2 = model[ref[:, 1] - 1].astype(
 rr = c_oracle.ransac(rp1, rp2, dict(RANSAC_COEF, iterNum=1001), seed=7)
 ok2 = (np.array_equal(res["inlierIdx"].astype(np.int64), rr["inlierIdx"]) and res["numSuccess"] == rr["numSuccess"]
        and res["maxInliers"] == rr["maxInliers"] and res["winner"] == int(np.argmax(rr["inlrNum_refined"])) and np.linalg.norm(res["T"] - rr["T"]) < 1e-9)
-print(f"rank {rank}: pairs {n} match_ok={ok} ransac_ok={ok2}", flush=True)
+# two registrations in flight per rank (pcreg_amd/pipelined.py): four different surfaces dealt to two lanes, each lane issuing its
+# three collectives in host program order -- every result must be the serial pipeline's for that surface, bit for bit
+from pcreg_amd.pipelined import PipelinedRegistration
+coef = dict(RANSAC_COEF, iterNum=1001)
+surfs = [qs] + [soa(torch.from_numpy(surf + np.float32(0.01 * k) * np.array([1, -1, 0.5], np.float32)).to(dev)) for k in range(1, 4)]
+serial = []
+for q in surfs:
+    pipe.match(q, ms, MATCH_THR_ABS, MATCH_RATIO, True); pipe.ransac_sharded(coef, seed=7)
+    r = pipe.fetch_result(); r["n_pairs"] = int(pipe.n_pairs.item()); serial.append(r)
+pr = PipelinedRegistration(Q, M_local, lanes=2, m_lo=m_lo, M_total=M_local * world, device=dev)
+piped = []
+for k in (0, 2):                                   # two submissions, then their results (a lane keeps only its last result)
+    pr.submit(surfs[k], ms, MATCH_THR_ABS, MATCH_RATIO, coef, seed=7); pr.submit(surfs[k + 1], ms, MATCH_THR_ABS, MATCH_RATIO, coef, seed=7)
+    piped += pr.results()
+ok3 = len(piped) == 4
+for a, b in zip(serial, piped):
+    ok3 = ok3 and a["n_pairs"] == b["n_pairs"] and a["numSuccess"] == b["numSuccess"] and a["maxInliers"] == b["maxInliers"] and a["winner"] == b["winner"]
+    ok3 = ok3 and np.array_equal(a["inlierIdx"], b["inlierIdx"]) and np.array_equal(a["T"], b["T"])
+print(f"rank {rank}: pairs {n} match_ok={ok} ransac_ok={ok2} pipelined_ok={ok3}", flush=True)
 dist.barrier(); dist.destroy_process_group()
-sys.exit(0 if ok and ok2 else 1)
+sys.exit(0 if ok and ok2 and ok3 else 1)

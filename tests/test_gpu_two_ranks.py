@@ -17,7 +17,7 @@ def test_two_ranks_one_gpu():
                         os.path.join(ROOT, "scripts", "two_rank_one_gpu.py")], capture_output=True, text=True, env=env,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("match_ok=True ransac_ok=True") == 2
+    assert r.stdout.count("match_ok=True ransac_ok=True pipelined_ok=True") == 2     # incl. two registrations in flight per rank
 
 
 def test_one_rank_rccl_rehearsal_of_every_collective():
