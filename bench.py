@@ -204,7 +204,7 @@ def run_registration(ctx: Ctx, M_total: int, Q: int, steps: int, warmup: int, ti
 
     def step(k):
         if piped:
-            pr.submit(q_soa, model_soa, MATCH_THR_ABS, MATCH_RATIO, coef, unique=True, seed=7)
+            pr.submit(q_soa, model_soa, MATCH_THR_ABS, MATCH_RATIO, coef, unique=True, seed=7, inputs_ready=True)   # resident before the loop
             return
         if k is not None:
             ev[k][0].record()
@@ -851,7 +851,7 @@ def main() -> None:
                                      "search_call_ms": round(r["search_call_ms"], 4), "ransac": r["ransac"], "steps": extra_steps}
         more["cfg5_batch"] = run_batch_cfg5(ctx, args.crops, 1_000_000, Q)
         if world == 1:
-            more["two_in_flight"] = extra_two_in_flight(ctx, Q, max(10, extra_steps))
+            more["two_in_flight"] = extra_two_in_flight(ctx, Q, 40)
 
     if rank == 0:
         rows = head["rows_per_gpu"]

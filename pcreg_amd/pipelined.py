@@ -25,14 +25,16 @@ class PipelinedRegistration:
         self._next = 0
         self._pending = []          # (lane index) in submission order
 
-    def submit(self, q_soa, model, thr_abs: float, max_ratio: float, coef: dict, unique: bool = True, seed: int = 0) -> int:
+    def submit(self, q_soa, model, thr_abs: float, max_ratio: float, coef: dict, unique: bool = True, seed: int = 0,
+               inputs_ready: bool = False) -> int:
         """Enqueue one registration (search, filters, RANSAC with the hypotheses split over the group's ranks) on the next lane;
         returns the lane.  The lane's previous result must have been fetched (results()) before it is reused more than once:
         submit() reuses lane buffers in round-robin order, so at most `lanes` registrations are in flight."""
         k = self._next
         self._next = (k + 1) % len(self.lanes)
         lane, st = self.lanes[k], self.streams[k]
-        st.wait_stream(torch.cuda.current_stream(self.dev))          # inputs produced on the caller's stream
+        if not inputs_ready:
+            st.wait_stream(torch.cuda.current_stream(self.dev))      # inputs produced on the caller's stream
         with torch.cuda.stream(st):
             lane.search_local(q_soa, model)
             lane.match_after_search(q_soa, model, thr_abs, max_ratio, unique=unique)
