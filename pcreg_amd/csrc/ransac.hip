@@ -1343,7 +1343,8 @@ typedef int rs_i32x16 __attribute__((ext_vector_type(16)));
 template <bool EMIT>
 __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, const double* __restrict__ TT,
                                                               const float* __restrict__ T32,
-                                                              const unsigned char* __restrict__ valid) {
+                                                              const unsigned char* __restrict__ valid,
+                                                              int32_t* __restrict__ acc /* null: this block's row of partial counts; else counts are ADDED to acc[h] (integers: order-free) */) {
     const RansacArgs& a = sa.a;
     __shared__ int s_cnt[kSW][kSChunk];
     const int n = staged_n(a);
@@ -1444,7 +1445,7 @@ __global__ __launch_bounds__(kSW * 64) void rs_score32_kernel(StagedArgs sa, con
         int c = 0;
 #pragma unroll
         for (int w = 0; w < kSW; ++w) c += s_cnt[w][hl];
-        sa.part[(size_t)blockIdx.x * a.iters + h0 + hl] = c;
+        if (acc) { if (c) atomicAdd(&acc[h0 + hl], c); } else sa.part[(size_t)blockIdx.x * a.iters + h0 + hl] = c;
     }
 }
 
@@ -2389,7 +2390,7 @@ struct SelCtr { int32_t ticket, finished; int32_t status[kSelBlocks]; };
 // The staged chain's last epilogue (rs_finish: refined counts from the point blocks' partial rows, `has` flags) rides along:
 // every workgroup needs all counts for the maximum anyway, so each sums the partial rows itself (pb <= 64 coalesced rows of
 // `iters` words from L2) and the first one stores cnt2 / has for the callers that read them -- one launch fewer per step.
-struct SelFinish { const int32_t* part; const unsigned char* v2; int pb; };      // part == null: cnt2 / has are already final
+struct SelFinish { const int32_t* part; const unsigned char* v2; int pb; };      // v2 == null: cnt2 / has are already final; part == null: cnt2 holds the summed counts
 __global__ __launch_bounds__(kSelThreads) void ransac_select_multi_kernel(RansacArgs a, pcreg_dev_ransac_result* out, int32_t* inlier_idx,
                                                                            SelCtr* __restrict__ ctr, int per_block, SelFinish fin) {
     constexpr int NW = kSelThreads / 64;
@@ -2408,13 +2409,15 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_multi_kernel(Ransac
     unsigned long long key = 0; int ns = 0;
     for (int p = threadIdx.x; p < a.iters; p += kSelThreads) {
         int c;
-        if (fin.part) {                                                      // rs_finish_body, per workgroup
+        if (fin.v2) {                                                        // rs_finish_body, per workgroup
             c = 0;
             if (fin.v2[p]) {
+                if (fin.part) {
 #pragma unroll 8
-                for (int pbk = 0; pbk < fin.pb; ++pbk) c += fin.part[(size_t)pbk * a.iters + p];
+                    for (int pbk = 0; pbk < fin.pb; ++pbk) c += fin.part[(size_t)pbk * a.iters + p];
+                } else c = a.cnt2[p];
             }
-            if (blockIdx.x == 0) { a.cnt2[p] = c; a.has[p] = fin.v2[p] && c >= thInlr; }
+            if (blockIdx.x == 0) { if (fin.part) a.cnt2[p] = c; a.has[p] = fin.v2[p] && c >= thInlr; }
         } else c = cc[p];
         unsigned long long k = ((unsigned long long)(unsigned)c << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(p + a.hyp0g));
         key = k > key ? k : key;
@@ -2435,7 +2438,7 @@ __global__ __launch_bounds__(kSelThreads) void ransac_select_multi_kernel(Ransac
     const int winner = winner_g - a.hyp0g;
     const int maxInl = (int)(key >> 32);
     // ransac.m:75-89.  (With the finish folded in, has[winner] = v2[winner] && its count >= thInlr: no read of another workgroup's store.)
-    const bool failed = !(a.iters > 0 && (fin.part ? (fin.v2[winner] != 0 && maxInl >= thInlr) : a.has[winner] != 0));
+    const bool failed = !(a.iters > 0 && (fin.v2 ? (fin.v2[winner] != 0 && maxInl >= thInlr) : a.has[winner] != 0));
     if (threadIdx.x < 12) s_T[threadIdx.x] = failed ? 0.0 : a.TF[(size_t)winner * 12 + threadIdx.x];
     __syncthreads();
     const int b = s_ticket;
@@ -2826,9 +2829,9 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
         hipLaunchKernelGGL(rs_stage2_kernel, dim3((unsigned)(n_t32 + n_dig)), dim3(256), 0, st, sa, (const double*)sa.T1, sa.T32a, n_t32, sa.dig);
         if (sa.use_f32) {
             if (sa.use_lane)
-                hipLaunchKernelGGL(rs_score32_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1);
+                hipLaunchKernelGGL(rs_score32_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1, (int32_t*)nullptr);
             else
-                hipLaunchKernelGGL(rs_score32_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1);
+                hipLaunchKernelGGL(rs_score32_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const float*)sa.T32a, (const unsigned char*)sa.v1, (int32_t*)nullptr);
         } else if (sa.use_lane) {
             hipLaunchKernelGGL(rs_score_kernel<true>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)sa.T1, (const unsigned char*)sa.v1);
         } else {
@@ -2841,12 +2844,15 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
                                    (const uint4*)sa.dig, (const unsigned long long*)sa.masks);
             hipLaunchKernelGGL(rs_moments_kernel, dim3((it + hpw * kTW - 1) / (hpw * kTW)), dim3(kTBlock), 0, st, sa);
             hipLaunchKernelGGL(rs_fit2_kernel, dim3((it + 63) / 64), dim3(64), 0, st, sa);
+            fold_finish = !part && n_cap <= kSelBlocks * kSelPerThread * kSelThreads;        // ransac_select_multi_kernel does rs_finish's job
+            // with the finish folded into the selection the second pass ADDS its point blocks' counts into cnt2 (zeroed by rs_pass1;
+            // integer sums are order-free) instead of leaving pb partial rows that every selecting workgroup would have to sum
             if (sa.use_f32)
-                hipLaunchKernelGGL(rs_score32_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const float*)sa.T32b, (const unsigned char*)sa.v2);
+                hipLaunchKernelGGL(rs_score32_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const float*)sa.T32b, (const unsigned char*)sa.v2,
+                                   fold_finish ? a.cnt2 : (int32_t*)nullptr);
             else
                 hipLaunchKernelGGL(rs_score_kernel<false>, sgrid, dim3(kSW * 64), 0, st, sa, (const double*)a.TF, (const unsigned char*)sa.v2);
-            fold_finish = !part && n_cap <= kSelBlocks * kSelPerThread * kSelThreads;        // ransac_select_multi_kernel does it
-            if (fold_finish) { sel_fin.part = sa.part; sel_fin.v2 = sa.v2; sel_fin.pb = sa.pb; }
+            if (fold_finish) { sel_fin.part = sa.use_f32 ? nullptr : sa.part; sel_fin.v2 = sa.v2; sel_fin.pb = sa.pb; }
             else hipLaunchKernelGGL(rs_finish_kernel, dim3((it + 255) / 256), dim3(256), 0, st, sa);
         }
     } else {
