@@ -951,7 +951,7 @@ constexpr int kSMaxPB = 64;                     // point blocks with a partial-c
 #ifndef PCREG_MOM_SLOTS
 #define PCREG_MOM_SLOTS 44
 #endif
-constexpr int kStagedMinN = 4096;               // one registration of at least this many correspondences runs staged
+constexpr int kStagedMinN = 2049;               // one registration of at least this many correspondences MAY run staged (see staged_pays)
 constexpr int kMomSlots = PCREG_MOM_SLOTS;                   // lane-per-hypothesis refit: 64-correspondence slots per chunk
 constexpr int kRec = 16;                        // doubles per correspondence record (15 used)
 #ifndef PCREG_SCHUNK
@@ -2685,6 +2685,10 @@ __global__ void calc_dists_kernel(const double* T16, const double* p1, const dou
 }  // namespace
 
 // ---------------------------------------------------------------- launchers
+// The staged chain carries ~0.1 ms of launch-sized kernels; the tiled kernel (fp64 only) has none but scores at half the rate.
+// Measured (round 4, same box, REFINE): n = 2100 / 3000 / 4000 with 10^4 hypotheses 0.206 / 0.244 / 0.267 ms tiled against
+// 0.149 / 0.158 / 0.169 staged; (4000, 10^3) 0.099 against 0.119, (2500, 2 x 10^3) 0.079 against 0.114.
+static bool staged_pays(int n_cap, int iters) { return n_cap >= 4096 || (n_cap >= kStagedMinN && (long long)n_cap * iters >= 20000000LL); }
 static size_t staged_slots_cap(int n_cap) { return (size_t)((n_cap + kSPts - 1) / kSPts) * (kSPts / 64); }
 static size_t staged_chunks_cap(int n_cap) { return (staged_slots_cap(n_cap) + kMomSlots - 1) / kMomSlots; }
 static size_t staged_extra_bytes(size_t h, int n_cap) {    // T1 | mom | part | v1 | pass1 | v2 | cert | dense | lane-path buffers
@@ -2781,7 +2785,7 @@ static int launch_ransac_impl(const double* p1, const double* p2, int ld, const 
             const int pb4 = hpw * kWavesPerBlock;
             hipLaunchKernelGGL(ransac_hyp_kernel, dim3((o.iterNum + pb4 - 1) / pb4, B), dim3(kBlock), 0, st, a);
         }
-    } else if (B == 1 && !offsets && n_cap >= kStagedMinN && !debug_flag(kDbgRansacFused)) {
+    } else if (B == 1 && !offsets && staged_pays(n_cap, o.iterNum) && !debug_flag(kDbgRansacFused)) {
         // one large registration: the staged chain of lean kernels (see rs_* above)
         StagedArgs sa{};
         sa.T1 = (double*)w; w += align_up(h * 12 * sizeof(double), 256);

@@ -484,3 +484,16 @@ def test_ransac_batched_across_launch_classes(oracle_c):
         np.testing.assert_array_equal(inl.astype(np.int64), ref["inlierIdx"])
         assert ns == ref["numSuccess"] and mi == ref["maxInliers"]
         assert np.linalg.norm(T - ref["T"]) < T_TOL
+
+
+@pytest.mark.parametrize("n,iters", [(3000, 7000), (2049, 9800), (4095, 4900)])
+def test_staged_chain_between_2049_and_4095_when_the_work_pays(n, iters, oracle_c, debug_set):
+    """Round 4: one registration of 2049 <= n < 4096 correspondences runs the staged chain (fp32-screened scoring) when
+    n x iterNum >= 2 x 10^7, the fp64 tiled kernel otherwise (the chain's fixed cost); both give the oracle's bits."""
+    import pcreg_amd as pc
+    p1, p2, _ = rigid_case(n, 77 + n, outlier_frac=0.4)
+    coef = dict(minPtNum=3, iterNum=iters, thDist=0.05, thInlrRatio=0.1, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=9)
+    _cmp(pc.ransac(p1, p2, coef, seed=9, return_iter_counts=True), ref, n)
+    debug_set("ransac_fused")                                             # the tiled kernel on the same problem
+    _cmp(pc.ransac(p1, p2, coef, seed=9, return_iter_counts=True), ref, n)
