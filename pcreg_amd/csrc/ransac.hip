@@ -219,11 +219,89 @@ __device__ bool rank_gram_at_least(const double (&g)[6], int N, int need) {
     return ((s0 > tol) + (s1 > tol) + (s2 > tol)) >= need;
 }
 
+// R = V U' (estimateTransform.m:60-62) is the ORTHOGONAL POLAR FACTOR of H' = V S U' (SURVEY 8a row 5), reflections included
+// (its determinant has the sign of det H: the reference applies no fix either).  For a well-conditioned H it comes from the
+// scaled Newton iteration X <- (g X + e cof(X)) / 2, e ~ 1 / (g det X), which keeps the singular VECTORS and drives every
+// singular value to 1: seven 3 x 3 cofactor evaluations instead of ~6 one-sided Jacobi sweeps x 3 rotations, each of which is a
+// chain of fp64 divisions and square roots -- 3.6 x fewer dependent instructions per lane-parallel fit.  The scale factors of the
+// first five steps only steer the convergence (any g > 0, e det X > 0 preserves the singular vectors), so they are formed in
+// fp32 with single-instruction rcp / sqrt; the last two steps are the plain iteration with an fp64 division, which take an
+// X within 1e-4 of orthogonal to rounding (defect 4e-16; |R - V U'| <= 1e-14 over 3 x 10^4 sample fits incl. cond 10^6:
+// the conditioning of the problem, the same for the SVD).  H with sigma_3 / sigma_1 below ~2e-7 -- rank-2 H of a planar
+// set among them -- returns false and takes the SVD path below, which completes the missing singular vector.
+__device__ __forceinline__ bool polar_newton(const double (&H)[3][3], double (&X)[3][3]) {
+    double f2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f2 = fma(H[i][j], H[i][j], f2);
+    if (!(f2 > 1e-290) || !(f2 < 1e290)) return false;
+    const double inv = 1.0 / sqrt(f2);
+    {   // the decision from H itself (nothing else is live yet): det(H' / |H|_F) = det(H) / |H|_F^3
+        const double dh = fma(H[0][0], H[1][1] * H[2][2] - H[1][2] * H[2][1],
+                              fma(H[0][1], H[1][2] * H[2][0] - H[1][0] * H[2][2], H[0][2] * (H[1][0] * H[2][1] - H[1][1] * H[2][0])));
+        if (!(fabs(dh) * (inv * inv * inv) >= 1e-7)) return false;          // |X|_F = 1: sigma_3 >= 2 |det X|
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) X[i][j] = H[j][i] * inv;
+#define PCREG_COF(C, X)                                                                                   \
+    C[0][0] = X[1][1] * X[2][2] - X[1][2] * X[2][1]; C[0][1] = X[1][2] * X[2][0] - X[1][0] * X[2][2]; C[0][2] = X[1][0] * X[2][1] - X[1][1] * X[2][0]; \
+    C[1][0] = X[2][1] * X[0][2] - X[2][2] * X[0][1]; C[1][1] = X[2][2] * X[0][0] - X[2][0] * X[0][2]; C[1][2] = X[2][0] * X[0][1] - X[2][1] * X[0][0]; \
+    C[2][0] = X[0][1] * X[1][2] - X[0][2] * X[1][1]; C[2][1] = X[0][2] * X[1][0] - X[0][0] * X[1][2]; C[2][2] = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+    double C[3][3];
+    double det;
+#pragma unroll 1
+    for (int it = 0; it < 7; ++it) {
+        PCREG_COF(C, X)
+        det = fma(X[0][0], C[0][0], fma(X[0][1], C[0][1], X[0][2] * C[0][2]));
+        double g = 0.5, e;
+        if (it < 5) {
+            float sc = 0.0f, sx = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const float c = (float)C[i][j], x = (float)X[i][j]; sc = __builtin_fmaf(c, c, sc); sx = __builtin_fmaf(x, x, sx); }
+            const float d32 = (float)det;
+            const float q = sc * __builtin_amdgcn_rcpf(d32 * d32 * sx);                  // (|cof| / (|det| |X|))^2 = (|X^-1| / |X|)^2
+            const float gf = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(q));
+            const float ef = __builtin_amdgcn_rcpf(gf * d32);
+            // a non-finite or non-positive factor (overflow in fp32) would not be a scaling: take the plain step instead
+            const bool okf = gf > 0.0f && gf < 1e30f && ef * d32 > 0.0f && fabsf(ef) < 1e30f;
+            g = okf ? 0.5 * (double)gf : 0.5;
+            e = okf ? 0.5 * (double)ef : 0.5 / det;
+        } else {
+            e = 0.5 / det;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) X[i][j] = fma(g, X[i][j], e * C[i][j]);
+    }
+#undef PCREG_COF
+    return true;          // (a non-finite X -- impossible from a finite H past the determinant test -- is caught by the caller's finiteness test of T)
+}
+
 // R = V*U' of H = U*S*V' (estimateTransform.m:60-62; no reflection fix), then
 // t = cd - R*cm (:63).  T12[j*4+k] = R(j,k), T12[j*4+3] = t(j).  Returns false when the
 // rotation is undefined (rank(H) <= 1) or not finite.
 __device__ bool polar_to_T(const double (&H)[3][3], const double (&cd)[3], const double (&cm)[3],
                            double (&T)[12]) {
+    {
+        double Rn[3][3];
+        if (polar_newton(H, Rn)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double t = cd[i] - fma(Rn[i][2], cm[2], fma(Rn[i][1], cm[1], Rn[i][0] * cm[0]));
+                T[i * 4 + 0] = Rn[i][0]; T[i * 4 + 1] = Rn[i][1]; T[i * 4 + 2] = Rn[i][2]; T[i * 4 + 3] = t;
+            }
+            bool fin = true;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) fin = fin && isfinite(T[k]);
+            return fin;
+        }
+    }
     double W[3][3], V[3][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -1657,15 +1735,16 @@ __device__ __forceinline__ void score32_group(const RansacArgs& a, const Hyp32Ld
     }
 }
 
-// The old 27-sum refit pass of ONE hypothesis on the raw coordinates (uncertified rank, or exactly three inliers), then its
-// refit ON ONE LANE: rare by construction (a sample whose points are not inliers of their own fit seldom reaches thInlr), and
-// keeping these sums per lane for a lane-parallel refit would cost the whole kernel a wave of occupancy.
-__device__ __forceinline__ bool dense_refit(const RansacArgs& a, const Pts<false>& P, const int n, const int lane, const int h, const int ch,
-                                            const double (&T)[12], const double (&o)[6], double (&T2)[12]) {
-    double mom[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) mom[k] = 0.0;
-    if (ch == 3) {          // estimateTransform's N == 3 branch needs the points themselves (estimateTransform.m:18-37)
+// The refits the fifteen masked sums cannot serve -- the rank of the inlier set is not certified from the sample, or there are
+// exactly three inliers (estimateTransform's N == 3 branch needs the points themselves) -- one hypothesis at a time on the raw
+// coordinates (L2): rare by construction (a sample whose points are not inliers of their own fit seldom reaches thInlr).  Only
+// what is DIFFERENT runs here: the 27-sum pass and the two rank tests of estimateTransform.m:11-14 on lane h, or the search for
+// the three inliers.  The fits themselves stay lane-parallel in phase 3: a hypothesis whose rank test passes leaves its fifteen
+// sums in its scratch row like a certified one, a three-inlier hypothesis leaves the indices of its points (i3).
+// Returns (wave-uniform) 1: the row holds fifteen sums; 2: i3 holds three indices; 0: estimateTransform returns [].
+__device__ __forceinline__ int dense_refit_prepare(const RansacArgs& a, const Pts<false>& P, const int n, const int lane, const int h, const int ch,
+                                                   const double (&T)[12], const double (&o)[6], double* __restrict__ row, int (&i3)[3]) {
+    if (ch == 3) {
         int k = 0;
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
@@ -1675,37 +1754,37 @@ __device__ __forceinline__ bool dense_refit(const RansacArgs& a, const Pts<false
             while (bal) {
                 const int Ln = __builtin_ctzll(bal);
                 bal &= bal - 1;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const double v = rdlane(q[c], Ln);
-                    if (k == 0) mom[c] = v; else if (k == 1) mom[6 + c] = v; else if (k == 2) mom[12 + c] = v;
-                }
+                if (k < 3) i3[k] = i0 + Ln;
                 ++k;
             }
         }
-    } else {
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            const bool act = i < n;
-            double q[6]; P.load(act ? i : n - 1, q);
-            if (act && sqdist(q, T) < a.thDist) mom_accumulate(mom, q, o);
-        }
-        wave_sum27(mom);
+        return k == 3 ? 2 : 0;
     }
-    bool v2 = false;
+    if (ch < 4) return 0;                               // estimateTransform on fewer than three correspondences: []
+    double mom[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) mom[k] = 0.0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        const bool act = i < n;
+        double q[6]; P.load(act ? i : n - 1, q);
+        if (act && sqdist(q, T) < a.thDist) mom_accumulate(mom, q, o);
+    }
+    wave_sum27(mom);
+    int ok = 0;
     if (lane == h) {
-        if (ch == 3) {
-            double A1[3][3], A2[3][3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { A1[j][c] = mom[j * 6 + c]; A2[j][c] = mom[j * 6 + 3 + c]; }
-            v2 = fit_3pt(A1, A2, T2);
-        } else {
-            v2 = fit_moments(ch, mom, o, T2);
-        }
+        const double g1[6] = {mom[15], mom[16], mom[17], mom[18], mom[19], mom[20]};
+        const double g2[6] = {mom[21], mom[22], mom[23], mom[24], mom[25], mom[26]};
+        ok = rank_gram_at_least(g1, ch, 3) && rank_gram_at_least(g2, ch, 2);          // estimateTransform.m:11-14
     }
-    return v2;
+    ok = __builtin_amdgcn_readlane(ok, h);
+    if (ok) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) v = lane == k ? mom[k] : v;
+        if (lane < 15) row[lane] = v;
+    }
+    return ok;
 }
 
 template <int NW, bool REFINE>
@@ -1914,19 +1993,21 @@ __device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __r
 #else
         unsigned long long dense = __ballot(pass1 && !onlane);
 #endif
-        while (dense) {                   // rank not certified from the sample, or the N == 3 branch: the 27-sum pass on the raw coordinates,
-            const int h = __builtin_ctzll(dense);       // the refit on lane h alone, parked in its row at once (nothing of it stays live)
+        int i3[3] = {-1, -1, -1};         // this lane's three-inlier refit: the indices of its points
+        while (dense) {                   // rank not certified from the sample, or the N == 3 branch
+            const int h = __builtin_ctzll(dense);
             dense &= dense - 1;
             double T[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) T[k] = rdlane(ld_coherent(TFwave + (size_t)h * 12 + k), 0);
-            double Td[12];
-            if (dense_refit(a, P, n, lane, h, __builtin_amdgcn_readlane(c1, h), T, o, Td)) {      // true on lane h only
-                v2 = true;
-#pragma unroll
-                for (int k = 0; k < 12; ++k) TFwave[(size_t)lane * 12 + k] = Td[k];
+            int j3[3] = {-1, -1, -1};
+            const int kind = dense_refit_prepare(a, P, n, lane, h, __builtin_amdgcn_readlane(c1, h), T, o, MSwave + (size_t)h * 16, j3);
+            if (lane == h) {
+                if (kind == 1) onlane = true;
+                if (kind == 2) { i3[0] = j3[0]; i3[1] = j3[1]; i3[2] = j3[2]; }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         double T2[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) T2[k] = 0.0;
@@ -1935,13 +2016,19 @@ __device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __r
 #pragma unroll
             for (int k = 0; k < 15; ++k) mom[k] = ld_coherent(MSwave + (size_t)lane * 16 + k);
             v2 = fit_moments15(c1, mom, o, T2);
-            if (v2) {
+        } else if (i3[0] >= 0) {
+            double A1[3][3], A2[3][3];
 #pragma unroll
-                for (int k = 0; k < 12; ++k) TFwave[(size_t)lane * 12 + k] = T2[k];
+            for (int j = 0; j < 3; ++j) {
+                double q[6]; P.load(i3[j], q);
+                A1[j][0] = q[0]; A1[j][1] = q[1]; A1[j][2] = q[2];
+                A2[j][0] = q[3]; A2[j][1] = q[4]; A2[j][2] = q[5];
             }
-        } else if (v2) {
+            v2 = fit_3pt(A1, A2, T2);
+        }
+        if (v2) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) T2[k] = TFwave[(size_t)lane * 12 + k];     // this lane's own store
+            for (int k = 0; k < 12; ++k) TFwave[(size_t)lane * 12 + k] = T2[k];
         }
         float t16[16];
         make_t32(T2, o, bound(2), bound(3), a.thDist, t16, true);
