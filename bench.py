@@ -715,45 +715,57 @@ def extra_desc_chain(dev, with_cpu: bool) -> dict:
 
 
 def extra_host_tier(dev, with_cpu: bool) -> dict:
-    """what a MATLAB caller gets -- the HOST tier of the C ABI (pageable host arrays in, host arrays out,
-    through ctypes exactly as through the MEX gateway), wall clock, beside the device-tier figures above."""
+    """what a MATLAB caller gets -- the HOST tier of the C ABI (pageable host arrays in, host arrays out), wall
+    clock, beside the device-tier figures above.  The arrays are COLUMN-major like MATLAB's (what mxGetPr hands the gateway): a
+    row-major numpy array would first be transposed by numpy on the host, 0.55 s for cfg 2's 1.96 GB, which is not the library's
+    time.  Steady state = the second call (the library's scratch is grow-only); the first call's allocations are reported too."""
     import pcreg_amd as pc
+    from pcreg_amd._lib import check, lib
+    from pcreg_amd.api import _desc_opts
     res = {}
-    wall = lambda fn, reps=3: min(_t(fn) for _ in range(reps)) * 1e3
+    F = np.asfortranarray
     def _t(fn):
-        t0 = time.perf_counter(); fn(); return time.perf_counter() - t0
+        t0 = time.perf_counter(); fn(); return (time.perf_counter() - t0) * 1e3
+    wall = lambda fn, reps=3: min(_t(fn) for _ in range(reps))
     # ransac, cfg 1's data
     rng = np.random.default_rng(1)
     n = 1000
     pts = rng.uniform([-3, -2, 0], [3, 2, 3], (n, 3))
     R = eul2rotm_zyx([1.5, -1.2, 0.8]); t = np.array([1.0, 2.0, 3.0])
-    loc1S = pts @ R + t; loc1M = pts + np.random.default_rng(2).normal(0, 0.1, pts.shape)
+    loc1S = F(pts @ R + t); loc1M = F(pts + np.random.default_rng(2).normal(0, 0.1, pts.shape))
     coef = dict(minPtNum=3, iterNum=20000, thInlrRatio=0.5, thDist=0.1, REFINE=True, VERBOSE=0)
     pc.ransac(loc1M, loc1S, coef, pc.estimateTransform, pc.calcDists, seed=3)
     res["ransac_n1000_ms"] = round(wall(lambda: pc.ransac(loc1M, loc1S, coef, pc.estimateTransform, pc.calcDists, seed=3), 5), 3)
     # getMatches at the sweep's per-sphere shape and at cfg 2's
     par = dict(MATCH_PAR)
-    dM = rng.poisson(3.0, (1500, 980)).astype(np.float64); dS = dM[rng.choice(1500, 1500)][:1500] + rng.poisson(0.15, (1500, 980))
-    dS = np.vstack([dS, rng.poisson(3.0, (500, 980))]).astype(np.float64)
+    dM = rng.poisson(3.0, (1500, 980)).astype(np.float64)
+    dS = F(np.vstack([dM[rng.choice(1500, 1500)] + rng.poisson(0.15, (1500, 980)), rng.poisson(3.0, (500, 980))]).astype(np.float64)); dM = F(dM)
     pc.getMatches(dS, dM, par)
     res["getMatches_2000x1500_ms"] = round(wall(lambda: pc.getMatches(dS, dM, par)), 2)
+    with pc.DescSet(dS) as hS, pc.DescSet(dM) as hM:                     # both sets resident: the sphere loop's form
+        rows = np.arange(0, 1500, 1)
+        pc.getMatchesOnSet(hS, hM, rows, par)
+        res["getMatchesOnSet_2000x1500_ms"] = round(wall(lambda: pc.getMatchesOnSet(hS, hM, rows, par)), 2)
     Q, M = 50_000, 200_000
     dM = rng.poisson(3.0, (M, 980)).astype(np.float64)
-    dS = (dM[rng.choice(M, Q, replace=False)] + rng.poisson(0.15, (Q, 980))).astype(np.float64)
-    res["getMatches_50kx200k_ms"] = round(wall(lambda: pc.getMatches(dS, dM, par), 1), 1)
+    dS = F((dM[rng.choice(M, Q, replace=False)] + rng.poisson(0.15, (Q, 980))).astype(np.float64)); dM = F(dM)
+    res["getMatches_50kx200k_first_call_ms"] = round(_t(lambda: pc.getMatches(dS, dM, par)), 1)
+    res["getMatches_50kx200k_ms"] = round(wall(lambda: pc.getMatches(dS, dM, par), 2), 1)
     res["getMatches_50kx200k_upload_GB"] = round((Q + M) * 980 * 8 / 1e9, 2)
     del dS, dM
-    # descriptors, 100 k keypoints: 784 MB of doubles come back
+    # descriptors, 100 k keypoints: 784 MB of doubles come back (the C ABI call itself, outputs preallocated as a MEX gateway does)
     ptsc, kp = _ridge_cloud(1_000_000, 100_000)
-    pc.getSpacialHistogramDescriptors(ptsc[:50_000], kp[:500], DESC_OPT)
-    out = [None]
-    def run():
-        out[0] = pc.getSpacialHistogramDescriptors(ptsc, kp, DESC_OPT)
-    res["descriptors_100k_ms"] = round(wall(run, 2), 1)
-    res["descriptors_100k_rows_out"] = int(out[0][1].shape[0])
-    res["note"] = "pageable numpy in/out through ctypes (the MEX gateway's calls); compare extras.* device-tier ms"
+    ptsc, kp = F(ptsc), F(kp)
+    P_, S_ = ptsc.shape[0], kp.shape[0]
+    o = _desc_opts(DESC_OPT)
+    feat = np.empty((S_, 3)); desc = np.empty((S_, 980)); V = C.c_int(0)
+    pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    call = lambda: check(lib().pcreg_spatial_histogram_descriptors(pd(ptsc), P_, P_, pd(kp), S_, S_, C.byref(o), pd(feat), pd(desc), C.byref(V)))
+    res["descriptors_100k_first_call_ms"] = round(_t(call), 1)
+    res["descriptors_100k_ms"] = round(wall(call, 2), 1)
+    res["descriptors_100k_rows_out"] = int(V.value)
+    res["note"] = "column-major pageable arrays in/out (what the MEX gateway passes); steady state + first call"
     return res
-
 
 
 def summary_of(out: dict) -> dict:
@@ -774,6 +786,7 @@ def summary_of(out: dict) -> dict:
           "chain_match_ms": g(ex, "desc_chain", "get_matches", "ms"), "chain_match_unproven": g(ex, "desc_chain", "get_matches", "stats", "unproven"),
           "chain_sweep_ms": g(ex, "desc_chain", "sweep", "ms"), "chain_sweep_right": g(ex, "desc_chain", "sweep", "registered_right"),
           "host_ransac_ms": g(ex, "host_tier", "ransac_n1000_ms"), "host_cfg2_ms": g(ex, "host_tier", "getMatches_50kx200k_ms"),
+          "host_sphere_ms": g(ex, "host_tier", "getMatches_2000x1500_ms"), "host_sphere_on_sets_ms": g(ex, "host_tier", "getMatchesOnSet_2000x1500_ms"),
           "host_desc100k_ms": g(ex, "host_tier", "descriptors_100k_ms")}
     return {k: v for k, v in sm.items() if v is not None}
 
