@@ -864,7 +864,10 @@ def main() -> None:
                                      "search_call_ms": round(r["search_call_ms"], 4), "ransac": r["ransac"], "steps": extra_steps}
         more["cfg5_batch"] = run_batch_cfg5(ctx, args.crops, 1_000_000, Q)
         if world == 1:
-            more["two_in_flight"] = extra_two_in_flight(ctx, Q, 40)
+            try:
+                more["two_in_flight"] = extra_two_in_flight(ctx, Q, 40)
+            except Exception as e:          # an extra must never take the headline down with it
+                more["two_in_flight"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         rows = head["rows_per_gpu"]
