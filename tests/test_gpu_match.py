@@ -212,3 +212,35 @@ def test_get_matches_on_resident_sets_equals_get_matches(par_over, oracle_c):
                 np.testing.assert_array_equal(want, oracle_c.getMatches(dS, sub, par))
         with pytest.raises(Exception):
             pc.getMatchesOnSet(hS, hM, np.array([M]), par)                 # out of range: an argument error, not a fault
+
+
+def test_match_stats_hook_counts_what_the_certificate_did(debug_set):
+    """pcreg_debug_match_stats: with "match_stats" on, a getMatches call reports its queries (forward + the Unique back-search),
+    the candidates it re-scored exactly, what stayed unproven and what went to the exhaustive kernel; forcing the fallback makes
+    every query unproven; with the switch off the counters do not move."""
+    import ctypes as C
+    import pcreg_amd as pc
+    from pcreg_amd._lib import check, lib
+    rng = np.random.default_rng(3)
+    Q, M, D = 400, 3000, 980
+    dM = rng.poisson(3.0, (M, D)).astype(np.float64)
+    dS = dM[rng.choice(M, Q, replace=False)] + rng.poisson(0.15, (Q, D))
+    par = dict(UNNORMALIZE=True, norm_factor=2, CHANGE_METRIC=True, metric_factor=0.6, Method="Approximate", MatchThreshold=10, MaxRatio=0.99,
+               Metric="SAD", Unique=True, VERBOSE=0)
+    out = (C.c_longlong * 8)()
+    def stats(reset=1):
+        check(lib().pcreg_debug_match_stats(out, reset))
+        return [int(v) for v in out]
+    debug_set("match_stats")
+    stats()
+    want = pc.getMatches(dS, dM, par)
+    s = stats()
+    assert s[6] == 2 and s[0] >= Q and s[1] >= s[0] and s[2] <= s[0] // 10 and s[3] == s[2]        # forward + back call; few unproven
+    debug_set("match_force_fallback")
+    got = pc.getMatches(dS, dM, par)
+    s2 = stats()
+    np.testing.assert_array_equal(got, want)
+    assert s2[2] == s2[0] and s2[3] == s2[0]                                                          # every query handed on
+    debug_set("match_force_fallback", 0); debug_set("match_stats", 0)
+    pc.getMatches(dS, dM, par)
+    assert stats() == [0] * 8
