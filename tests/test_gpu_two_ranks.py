@@ -37,6 +37,13 @@ def test_one_rank_rccl_rehearsal_of_every_collective():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     plain = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert forced["ransac"] == plain["ransac"] and not plain["ransac"]["failed"] and plain["ransac"]["n_pairs"] > 1000
+    # the same protocol with TWO registrations in flight (two HIP streams issuing their RCCL collectives in host program order)
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                         "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py")] + common + ["--in-flight", "2"],
+                        capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    piped = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
+    assert piped["in_flight"] == 2 and piped["ransac"] == plain["ransac"]
 
 
 def test_bench_n2_control_flow_on_one_gpu():
