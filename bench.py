@@ -266,11 +266,12 @@ def extra_two_in_flight(ctx: Ctx, Q: int, steps: int) -> dict:
     latency-sized exchanges) excluded.  The launch-sized kernels of a step do not shrink with the shard; a second lane fills them."""
     res = {}
     for key, M, coef in (("model_1M", 1_000_000, RANSAC_COEF), ("rank_of_8_emulated_125k", 125_000, dict(RANSAC_COEF, iterNum=RANSAC_COEF["iterNum"] // 8))):
-        one = run_registration(ctx, M, Q, steps, 2, time_kernel=False, in_flight=1, coef=coef)
+        one = run_registration(ctx, M, Q, steps, 2, time_kernel=True, in_flight=1, coef=coef)
         two = run_registration(ctx, M, Q, steps, 2, time_kernel=False, in_flight=2, coef=coef)
         same = one["ransac"] == two["ransac"]
         res[key] = {"one_in_flight_ms": round(one["ms_per_step"], 4), "two_in_flight_ms": round(two["ms_per_step"], 4),
-                    "speedup": round(one["ms_per_step"] / two["ms_per_step"], 3), "same_result": bool(same), "iterNum": coef["iterNum"]}
+                    "speedup": round(one["ms_per_step"] / two["ms_per_step"], 3), "same_result": bool(same), "iterNum": coef["iterNum"],
+                    "knn_kernel_ms_one_in_flight": round(one["kernel_ms"], 4)}
     res["note"] = "125k: one rank of N = 8 (its shard, 1/8 of the hypotheses), collectives excluded"
     return res
 
@@ -772,7 +773,7 @@ def summary_of(out: dict) -> dict:
     """Every config's headline number in < 600 characters, as the last object of the line."""
     ex = out.get("extras", {})
     g = lambda d, *ks: (lambda v: None if v is None else v)(_dig(d, ks))
-    sm = {"step_ms": out.get("ms_per_step"), "step_frac": g(out, "roofline", "frac"),
+    sm = {"step_ms": out.get("ms_per_step"), "step_frac": g(out, "roofline", "frac"), "step_frac_alone": g(out, "roofline", "alone", "frac"),
           "step_ms_with_prepare": out.get("ms_per_step_with_model_prepare"),
           "cfg2_ms": g(ex, "getMatches_cfg2", "ms"), "cfg2_frac": g(ex, "getMatches_cfg2", "roofline", "frac"),
           "cfg3_ms": g(out, "cfg3_model_2M", "ms_per_step"),
@@ -781,6 +782,7 @@ def summary_of(out: dict) -> dict:
           "cfg1_ms": g(ex, "ransac_cfg1", "ms"), "cfg1b_ms": g(ex, "ransac_cfg1_batched", "ms"), "cfg1b_frac": g(ex, "ransac_cfg1_batched", "roofline", "frac"),
           "sweep_ms": g(ex, "sweep", "ms"), "sweep_frac": g(ex, "sweep", "roofline", "frac"),
           "cfg5_regs_per_s": g(out, "cfg5_batch", "registrations_per_s"),
+          "step_serial_ms": g(out, "two_in_flight", "model_1M", "one_in_flight_ms"),
           "two_1M_x": g(out, "two_in_flight", "model_1M", "speedup"), "two_125k_x": g(out, "two_in_flight", "rank_of_8_emulated_125k", "speedup"),
           "two_125k_ms": g(out, "two_in_flight", "rank_of_8_emulated_125k", "two_in_flight_ms"),
           "chain_match_ms": g(ex, "desc_chain", "get_matches", "ms"), "chain_match_unproven": g(ex, "desc_chain", "get_matches", "stats", "unproven"),
@@ -811,7 +813,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only")
     ap.add_argument("--crops", type=int, default=64, help="crops of the cfg 5 batch")
-    ap.add_argument("--in-flight", type=int, default=1, help="registrations in flight per rank (HIP streams); the headline default is 1")
+    ap.add_argument("--in-flight", type=int, default=2, help="registrations in flight per rank (one HIP stream + buffer set each); 1 = the serial step of rounds 1-3")
     ap.add_argument("--skip", default="", help="comma-separated extras to leave out (e.g. host_tier,desc_chain)")
     args = ap.parse_args()
 
@@ -851,17 +853,17 @@ def main() -> None:
     if not args.no_extras:
         if world > 1:
             for key, mt in (("cfg3_model_2M", 2_000_000), ("weak_1M_per_gpu", 1_000_000 * world)):
-                r = run_registration(ctx, mt, Q, extra_steps, extra_warm, time_kernel=False)
+                r = run_registration(ctx, mt, Q, extra_steps, extra_warm, time_kernel=False, in_flight=args.in_flight)
                 r.pop("_model"); r.pop("_surf")
                 more[key] = {"workload": f"{Q} surface pts vs {mt} model pts, {r['rows_per_gpu']} rows per GPU", "scaling": "strong" if key.startswith("cfg3") else "weak",
-                             "ms_per_step": round(r["ms_per_step"], 4), "value": round(r["value"], 2), "unit": "Gpairs/s",
-                             "search_call_ms": round(r["search_call_ms"], 4), "ransac": r["ransac"], "steps": extra_steps}
+                             "ms_per_step": round(r["ms_per_step"], 4), "value": round(r["value"], 2), "unit": "Gpairs/s", "in_flight": args.in_flight,
+                             "ransac": r["ransac"], "steps": extra_steps}
         else:
-            r = run_registration(ctx, 2_000_000, Q, extra_steps, extra_warm, time_kernel=False)
+            r = run_registration(ctx, 2_000_000, Q, extra_steps, extra_warm, time_kernel=False, in_flight=args.in_flight)
             r.pop("_model"); r.pop("_surf")
             more["cfg3_model_2M"] = {"workload": f"{Q} surface pts vs 2000000 model pts on one GPU (the 1-GPU point of cfg 3's strong-scaling curve)",
                                      "scaling": "strong", "ms_per_step": round(r["ms_per_step"], 4), "value": round(r["value"], 2), "unit": "Gpairs/s",
-                                     "search_call_ms": round(r["search_call_ms"], 4), "ransac": r["ransac"], "steps": extra_steps}
+                                     "in_flight": args.in_flight, "ransac": r["ransac"], "steps": extra_steps}
         more["cfg5_batch"] = run_batch_cfg5(ctx, args.crops, 1_000_000, Q)
         if world == 1:
             try:
@@ -897,8 +899,9 @@ def main() -> None:
             "value": round(head["value"], 2), "unit": "Gpairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(head["ms_per_step"], 4),
             "ms_per_step_with_model_prepare": round(head["ms_per_step"] + head["model_prepare_ms"], 4),
-            "metric_definition": "step = search + filters + RANSAC on a PREPARED model (since round 3; rounds 1-2 prepared the model inside "
-                                 "every step: compare those with ms_per_step_with_model_prepare)",
+            "metric_definition": "ms_per_step = wall time of `steps` registrations / steps, model PREPARED once (since round 3), `in_flight` "
+                                 "registrations in flight per rank (since round 4: 2; the serial step is two_in_flight.model_1M.one_in_flight_ms "
+                                 "or --in-flight 1); rounds 1-2 prepared the model inside every step (ms_per_step_with_model_prepare)",
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32 (search: f16-split matrix-core candidates, exact f32 re-rank) / f64 (RANSAC)", "data": "synthetic",
             "config": {"workload": f"{Q} surface pts vs a FIXED {M_total}-pt model ({rows} rows per GPU, row-sharded over {world} GPU(s)), "
@@ -920,6 +923,13 @@ def main() -> None:
                          "note": "HIP events per launch; VALU-issue-bound, not HBM: docs/BENCH_NOTES.md"},
         }
         out.update(more)
+        k1 = _dig(more, ("two_in_flight", "model_1M", "knn_kernel_ms_one_in_flight"))
+        if head["in_flight"] > 1:
+            out["roofline"]["in_flight"] = head["in_flight"]
+            out["roofline"]["contended"] = "the kernel shares the chip with the other lane's RANSAC chain inside the timed region"
+            if k1 and M_total == 1_000_000 and Q == 50_000:
+                t1 = FLOP_PER_PAIR * float(Q) * rows / (k1 * 1e-3) / 1e12
+                out["roofline"]["alone"] = {"ms": k1, "achieved": round(t1, 2), "frac": round(t1 / PEAK_F16_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, surf)
     del model, surf

@@ -25,7 +25,8 @@ def test_one_rank_rccl_rehearsal_of_every_collective():
     both all_gathers, the MAX / SUM all_reduces of the matcher and the three of the hypothesis-split RANSAC.
     The registration it finds must be the one the plain single-GPU step finds."""
     import json
-    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--model-points", "200000", "--surface-points", "20000"]
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--model-points", "200000", "--surface-points", "20000",
+              "--in-flight", "1"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCREG_FORCE_COLLECTIVES="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py")] + common,
@@ -39,7 +40,7 @@ def test_one_rank_rccl_rehearsal_of_every_collective():
     assert forced["ransac"] == plain["ransac"] and not plain["ransac"]["failed"] and plain["ransac"]["n_pairs"] > 1000
     # the same protocol with TWO registrations in flight (two HIP streams issuing their RCCL collectives in host program order)
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
-                         "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py")] + common + ["--in-flight", "2"],
+                         "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py")] + common[:-2] + ["--in-flight", "2", "--steps", "4"],
                         capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
     piped = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
@@ -54,7 +55,7 @@ def test_bench_n2_control_flow_on_one_gpu():
     small = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--model-points", "200000", "--surface-points", "20000", "--crops", "4"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PCREG_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small,
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--in-flight", "1"] + small,
                        capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     two = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
@@ -73,3 +74,10 @@ def test_bench_n2_control_flow_on_one_gpu():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     one = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert two["ransac"] == one["ransac"] and not one["ransac"]["failed"]          # the sharded run finds the single-GPU registration
+    # the DEFAULT form of the line (two registrations in flight per rank), two ranks: same registration, headline fields in place
+    d = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-extras", "--steps", "4"] + small[2:],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert d.returncode == 0, d.stdout[-2000:] + d.stderr[-3000:]
+    dd = json.loads([l for l in d.stdout.splitlines() if l.startswith("{")][-1])
+    assert dd["in_flight"] == 2 and dd["n_gpus"] == 2 and dd["ransac"] == one["ransac"] and dd["knn_kernel"]["launches_timed"] == 4
