@@ -557,7 +557,8 @@ constexpr int kPR = PCREG_SEG_PR, kPF = PCREG_SEG_PF;
 // src row-major [n][D] -> P row-major, l1, s2, min / max of P per row (one lane per row keeps the oracle's order)
 __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restrict__ src, int n, int D, int change_metric, double factor,
                                                            double* __restrict__ P, double* __restrict__ l1, double* __restrict__ s2,
-                                                           double* __restrict__ pmin, double* __restrict__ pmax, double* __restrict__ sp) {
+                                                           double* __restrict__ pmin, double* __restrict__ pmax, double* __restrict__ sp,
+                                                           double* __restrict__ odd /* 1: the row holds a value outside {0} U [2^-400, 2^400] */) {
     __shared__ double t_raw[kPF][kPR + 1], t_p[kPF][kPR + 1];
     // The descriptors are COUNTS (getSpacialHistogramDescriptors: integers, a few units per bin): their powers come from a table
     // of this very pow -- same bits -- that each workgroup fills first (kPowTab fp64 pow calls against the 62 720 of its rows);
@@ -570,6 +571,7 @@ __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restr
     }
     const int r0 = blockIdx.x * kPR, rows = min(kPR, n - r0);
     double a = 0.0, s = 0.0, lo = INFINITY, hi = -INFINITY, ap = 0.0;
+    bool bad = false;
     for (int d0 = 0; d0 < D; d0 += kPF) {
         const int dn = min(kPF, D - d0);
         for (int e = threadIdx.x; e < kPR * kPF; e += kBlock) {
@@ -591,18 +593,20 @@ __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restr
             for (int f = 0; f < dn; ++f) {
                 const double x = t_raw[f][r], pv = t_p[f][r];
                 a += fabs(x); s = fma(pv, pv, s); lo = fmin(lo, pv); hi = fmax(hi, pv); ap += fabs(pv);
+                bad = bad || !(pv == 0.0 || (fabs(pv) >= 0x1p-400 && fabs(pv) <= 0x1p400));
             }
         }
         __syncthreads();
     }
-    if ((int)threadIdx.x < rows) { const int r = r0 + threadIdx.x; l1[r] = a; s2[r] = s; pmin[r] = lo; pmax[r] = hi; sp[r] = ap; }
+    if ((int)threadIdx.x < rows) { const int r = r0 + threadIdx.x; l1[r] = a; s2[r] = s; pmin[r] = lo; pmax[r] = hi; sp[r] = ap; odd[r] = bad ? 1.0 : 0.0; }
 }
 
 struct SegSets {                // the two descriptor sets after segp_rows_kernel, and the segments
-    const double *PS, *l1S, *s2S, *pminS, *pmaxS, *spS;      // surface: Q rows
-    const double *PM, *l1M, *s2M, *pminM, *pmaxM, *spM;      // model: every row of the full set (VM)
+    const double *PS, *l1S, *s2S, *pminS, *pmaxS, *spS, *oddS;      // surface: Q rows
+    const double *PM, *l1M, *s2M, *pminM, *pmaxM, *spM, *oddM;      // model: every row of the full set (VM)
     const int32_t *seg_rows, *seg_off;                // segment z owns model rows seg_rows[seg_off[z] .. seg_off[z + 1])
     int Q, VM, D0, Dp;                                // Dp = D0 + 1 with the appended column
+    size_t rinv_s, rinv_m;                            // the reciprocals of the norms sit this many doubles behind nrmS / nrmM
 };
 
 __device__ __forceinline__ double seg_norm(const pcreg_match_opts& o, double cc, double q2) {
@@ -681,6 +685,7 @@ __global__ __launch_bounds__(kBlock) void segp_ref_kernel(SegSets S, pcreg_match
 __global__ __launch_bounds__(kBlock) void segp_consts_kernel(SegSets S, pcreg_match_opts o, const double* __restrict__ nrefS,
                                                              const double* __restrict__ nrefM, double* __restrict__ nrmS,
                                                              double* __restrict__ nrmM, SegConst* __restrict__ sc, int n_seg) {
+    double *rinvS = nrmS + S.rinv_s, *rinvM = nrmM + S.rinv_m;
     const int z = blockIdx.x, off = S.seg_off[z], n = S.seg_off[z + 1] - off, Q = S.Q, tid = threadIdx.x;
     const int32_t* rows = S.seg_rows + off;
     const SegConst ref = sc[n_seg];
@@ -697,6 +702,12 @@ __global__ __launch_bounds__(kBlock) void segp_consts_kernel(SegSets S, pcreg_ma
         const double nrm = seg_norm(o, cc, surf ? S.s2S[r] : S.s2M[r]);
         if (surf) nrmS[(size_t)z * Q + i] = nrm; else nrmM[off + i - Q] = nrm;
         const double wi = 1.0 / nrm, ur = 1.0 / (surf ? nrefS[r] : nrefM[r]);          // 0 for a row that normalizeX zeroes
+        {   // the correctly rounded reciprocal of the norm, for seg_value's division by multiplication -- or 0 when a value of
+            // the row, the appended constant or the norm itself is outside the range in which that division is proven exact
+            const bool cc_ok = cc == 0.0 || (fabs(cc) >= 0x1p-400 && fabs(cc) <= 0x1p400);
+            const bool ok = cc_ok && (surf ? S.oddS[r] : S.oddM[r]) == 0.0 && nrm >= 0x1p-400 && nrm <= 0x1p400;
+            if (surf) rinvS[(size_t)z * Q + i] = ok ? wi : 0.0; else rinvM[off + i - Q] = ok ? wi : 0.0;
+        }
         const double t = (surf ? S.spS[r] : S.spM[r]) * fabs(wi - rho * ur);
         if (surf) ts = fmax(ts, t); else tm = fmax(tm, t);
         if (o.unnormalize) { const double g = cc * wi - rho * ref.cc * ur; g_lo = fmin(g_lo, g); g_hi = fmax(g_hi, g); }
@@ -780,17 +791,43 @@ __global__ __launch_bounds__(kBlock) void segp_select_kernel(const uint32_t* __r
 }
 
 // a row of the segment's normalised matrices, never stored: value(d) = (d < D0 ? p[d] : cc) / nrm
-struct SegRow { const double* p; double nrm; };
-struct SegView { const double *PS, *PM, *nrmS, *nrmM; const int32_t* rows; int D0; double cc; };
+struct SegRow { const double* p; double nrm, rinv; };
+struct SegView { const double *PS, *PM, *nrmS, *nrmM, *rinvS, *rinvM; const int32_t* rows; int D0; double cc; };
 __device__ __forceinline__ SegView seg_view(const SegSets& S, const double* nrmS, const double* nrmM, const SegConst& c, int z) {
     const int off = S.seg_off[z];
-    return SegView{S.PS, S.PM, nrmS + (size_t)z * S.Q, nrmM + off, S.seg_rows + off, S.D0, c.cc};
+    nrmS += (size_t)z * S.Q; nrmM += off;
+    return SegView{S.PS, S.PM, nrmS, nrmM, nrmS + S.rinv_s, nrmM + S.rinv_m, S.seg_rows + off, S.D0, c.cc};
 }
-__device__ __forceinline__ SegRow seg_surface_row(const SegView& V, int i) { return SegRow{V.PS + (size_t)i * V.D0, V.nrmS[i]}; }
-__device__ __forceinline__ SegRow seg_model_row(const SegView& V, int j) { return SegRow{V.PM + (size_t)V.rows[j] * V.D0, V.nrmM[j]}; }
+__device__ __forceinline__ SegRow seg_surface_row(const SegView& V, int i) { return SegRow{V.PS + (size_t)i * V.D0, V.nrmS[i], V.rinvS[i]}; }
+__device__ __forceinline__ SegRow seg_model_row(const SegView& V, int j) { return SegRow{V.PM + (size_t)V.rows[j] * V.D0, V.nrmM[j], V.rinvM[j]}; }
+// value(d) = (d < D0 ? p[d] : cc) / nrm, the oracle's correctly rounded division.  An fp64 division is a ~12-instruction
+// sequence, and the exact re-rank does two per term: with r = RN(1 / nrm), q = x r, e = fma(-nrm, q, x), q' = fma(e, r, q) is
+// that same correctly rounded quotient (Markstein's correction step, what v_div_fmas does at the end of the hardware's own
+// sequence; 900 000 random and adversarial cases -- all-ones mantissas, neighbours of powers of two -- against exact rational
+// arithmetic without a difference) in three instructions, valid when no intermediate leaves the normal range: x and nrm in
+// {0} U [2^-400, 2^400], which segp_rows / segp_consts check per row (rinv = 0 otherwise: the plain division).
+__device__ __forceinline__ double seg_div(double x, const SegRow& r) {
+    if (r.rinv != 0.0) {
+        const double q = x * r.rinv;
+        return fma(fma(-r.nrm, q, x), r.rinv, q);
+    }
+    return x / r.nrm;
+}
 __device__ __forceinline__ double seg_value(const SegView& V, const SegRow& r, int d) {
     const double v = r.p[min(d, V.D0 - 1)];
-    return (d < V.D0 ? v : V.cc) / r.nrm;
+    return seg_div(d < V.D0 ? v : V.cc, r);
+}
+// the same without the test, for a loop that has established once which form all its rows take (a test per value put every
+// load of the re-rank's tile behind its own branch: 5.9 ms where the plain division took 4.5)
+template <bool FAST>
+__device__ __forceinline__ double seg_value_as(const SegView& V, const SegRow& r, int d) {
+    const double v = r.p[min(d, V.D0 - 1)];
+    const double x = d < V.D0 ? v : V.cc;
+    if (FAST) {
+        const double q = x * r.rinv;
+        return fma(fma(-r.nrm, q, x), r.rinv, q);
+    }
+    return x / r.nrm;
 }
 
 // sad16_finalize_kernel on the segments.  BACK = false: queries = surface rows, candidates = the segment's model rows
@@ -813,17 +850,31 @@ __device__ __forceinline__ void seg_rerank(const SegView& V, const SegRow& a, co
             const int jc = sj[min(g0 + cnd, n_need - 1)];
             brow[cnd] = BACK ? seg_surface_row(V, jc) : seg_model_row(V, jc);
         }
+        bool all_fast = a.rinv != 0.0;             // every row of the group divides through its reciprocal (wave-uniform: the rows are)
+#pragma unroll
+        for (int cnd = 0; cnd < kNC; ++cnd) all_fast = all_fast && brow[cnd].rinv != 0.0;
+        all_fast = __builtin_amdgcn_readfirstlane((int)all_fast) != 0;
         for (int d0 = 0; d0 < D; d0 += kFT) {
             double av[kFT / 64], bv[kNC][kFT / 64];
             int dof[kFT / 64];
 #pragma unroll
             for (int u = 0; u < kFT / 64; ++u) dof[u] = min(d0 + lane + 64 * u, D - 1);
+            if (all_fast) {
 #pragma unroll
-            for (int u = 0; u < kFT / 64; ++u) av[u] = seg_value(V, a, dof[u]);
+                for (int u = 0; u < kFT / 64; ++u) av[u] = seg_value_as<true>(V, a, dof[u]);
 #pragma unroll
-            for (int cnd = 0; cnd < kNC; ++cnd) {
+                for (int cnd = 0; cnd < kNC; ++cnd) {
 #pragma unroll
-                for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value(V, brow[cnd], dof[u]);
+                    for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value_as<true>(V, brow[cnd], dof[u]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kFT / 64; ++u) av[u] = seg_value(V, a, dof[u]);
+#pragma unroll
+                for (int cnd = 0; cnd < kNC; ++cnd) {
+#pragma unroll
+                    for (int u = 0; u < kFT / 64; ++u) bv[cnd][u] = seg_value(V, brow[cnd], dof[u]);
+                }
             }
 #pragma unroll
             for (int cnd = 0; cnd < kNC; ++cnd)
@@ -1173,7 +1224,7 @@ __global__ __launch_bounds__(kBlock) void segp_exact_rows_kernel(SegSets S, cons
                 const double av = s_a[dc];
 #pragma unroll
                 for (int u = 0; u < kBlock / kXF; ++u) {
-                    const double bvv = (dc < V.D0 ? pv[u] : V.cc) / br[u].nrm;
+                    const double bvv = seg_div(dc < V.D0 ? pv[u] : V.cc, br[u]);
                     s_t[f][rq + (kBlock / kXF) * u] = d < D ? fabs(av - bvv) : 0.0;
                 }
                 __syncthreads();
@@ -1453,10 +1504,10 @@ SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
     size_t b = 0;
     auto take = [&](size_t bytes) { size_t o = b; b += align_up(bytes, 256); return o; };
     L.PS = take(q * D * 8); L.PM = take(vm * D * 8);
-    L.rowS = take(5 * q * 8); L.rowM = take(5 * vm * 8); L.nrefS = take(q * 8); L.nrefM = take(vm * 8);
+    L.rowS = take(6 * q * 8); L.rowM = take(6 * vm * 8); L.nrefS = take(q * 8); L.nrefM = take(vm * 8);
     L.Aq = take((size_t)L.D2p * L.ldqa * 4); L.Bq = take((size_t)L.D2p * L.ldqb * 4); L.Sc = take((size_t)L.ldqb * L.ldqa * 4);
     L.sc = take((ns + 1) * sizeof(SegConst));
-    L.nrmS = take(ns * q * 8); L.nrmM = take((size_t)std::max(tot, 1) * 8);
+    L.nrmS = take(2 * ns * q * 8); L.nrmM = take(2 * (size_t)std::max(tot, 1) * 8);          // norms, then their reciprocals
     L.part_idx = take(ns * L.splits * q * KC * 4); L.part_s = take(ns * L.splits * q * KC * 4);
     L.idx = take(ns * q * 2 * 4); L.dist = take(ns * q * 2 * 8); L.bidx = take(ns * q * 2 * 4); L.bdist = take(ns * q * 2 * 8);
     L.cand_q = take(ns * q * 4); L.cand_m = take(ns * q * 4); L.n_cand = take(ns * 4); L.n_flag = take(ns * 4);
@@ -1515,9 +1566,10 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
     const size_t q = (size_t)Q, vm = (size_t)VM;
 
     // once for all segments: powers, row scalars, the reference constant, the two quantised operands, ALL approximate scores
-    hipLaunchKernelGGL(segp_rows_kernel, dim3((Q + kPR - 1) / kPR), dim3(kBlock), 0, st, descS, Q, D, o.change_metric, o.metric_factor, PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q);
-    hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM, VM, D, o.change_metric, o.metric_factor, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm);
-    const SegSets sets{PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, seg_rows, seg_off, Q, VM, D, Dp};
+    hipLaunchKernelGGL(segp_rows_kernel, dim3((Q + kPR - 1) / kPR), dim3(kBlock), 0, st, descS, Q, D, o.change_metric, o.metric_factor, PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q, rS + 5 * q);
+    hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM, VM, D, o.change_metric, o.metric_factor, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, rM + 5 * vm);
+    const SegSets sets{PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q, rS + 5 * q, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, rM + 5 * vm,
+                       seg_rows, seg_off, Q, VM, D, Dp, (size_t)S * q, (size_t)std::max(tot, 1)};
     hipLaunchKernelGGL(segp_cc_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, sc);
     hipLaunchKernelGGL(segp_ref_kernel, dim3(1), dim3(kBlock), 0, st, sets, o, nrefS, nrefM, sc, S);
     hipLaunchKernelGGL(segp_quantize_ref_kernel, dim3(L.ldqa / 64, L.D2p / 32), dim3(kBlock), 0, st, PS, nrefS, Q, D, Dp, sc + S, L.D2p, L.ldqa, Aq);

@@ -210,6 +210,65 @@ def test_segmented_get_matches_equals_one_call_per_segment(oracle_c, par_over, d
             np.testing.assert_array_equal(ma, mb)                # the same exact fp64 distances either way
 
 
+def _oracle_get_matches_with_metric(descS, descM, par):
+    """orc_get_matches' pairs AND its matchMetric (the python wrapper of the C oracle drops the second)."""
+    import ctypes as C
+    from oracle import c_oracle as co
+    a, b = co._f(descS), co._f(descM)
+    Q, D = a.shape
+    M = b.shape[0]
+    o = co._mopts(par)
+    pairs = np.zeros((max(Q, 1), 2), dtype=np.uint32)
+    met = np.zeros(max(Q, 1))
+    P = co.lib().orc_get_matches(co._p(a), C.c_int(Q), C.c_int(Q), co._p(b), C.c_int(M), C.c_int(M), C.c_int(D), C.byref(o),
+                                 co._p(pairs, C.c_uint32), co._p(met), C.c_int(0))
+    return pairs[:P].copy(), met[:P].copy()
+
+
+@pytest.mark.parametrize("scale", [1.0, 3.7e-6, 3.7e88, 2.9e125, "counts", "counts_pow"])
+@pytest.mark.parametrize("par_over", [dict(), dict(UNNORMALIZE=False, Unique=False)])
+def test_segmented_metric_is_the_oracles_division_bit_for_bit(oracle_c, scale, par_over, debug_set):
+    """The segmented chain's exact re-rank divides by the row norm through the norm's reciprocal and one correction step
+    (seg_div): the matchMetric it returns must be the oracle's correctly rounded quotients summed in the oracle's order, bit for
+    bit -- on dense mantissas (real-valued rows, a scale that is not a power of two), inside the range in which that division is
+    proven (|x|, norm in [2^-400, 2^400]) and outside it (2.9e125, and the rows given a 1e-130 or a denormal entry: flagged, they take
+    the plain division).
+    Where bits cannot be promised the metric is held to 1e-12 relative + 1e-14 (a sum of D differences of values near 1; the pairs are the oracle's everywhere):
+    * the .^0.6 step ("counts_pow"): the device's pow and the host libm's are two different sub-ulp functions, neither correctly
+      rounded (glibc's own result depends on whether the host has FMA), so powered values may differ in the last bit;
+    * UNNORMALIZE on real-valued rows: the appended constant is a mean of row sums, added sequentially by the oracle and as a tree
+      by the device -- exact, and so identical, on the reference's data (integer counts: "counts"), an ulp apart on real values."""
+    rng = np.random.default_rng(5)
+    VM, Q, D = 900, 200, 75
+    pick = rng.choice(VM, Q, replace=False)
+    counts = isinstance(scale, str)
+    if counts:
+        descM = rng.poisson(3.0, (VM, D)).astype(np.float64)
+        descS = descM[pick] + rng.poisson(0.2, (Q, D))
+        par = dict(PAR, MatchThreshold=100.0, MaxRatio=0.95, CHANGE_METRIC=scale == "counts_pow", **par_over)
+    else:
+        descM = rng.random((VM, D)) * rng.integers(1, 40, (VM, 1))
+        descS = descM[pick] * (1.0 + 0.05 * rng.standard_normal((Q, D)))
+        descM[3] = 0.0
+        descM, descS = descM * scale, np.abs(descS) * scale
+        descM[10:40, 7] = 1.3e-130; descM[40:60, 9] = 4.1e-310; descS[0:20, 3] = 2.7e-131; descS[20:30, 5] = 1e-312
+        par = dict(PAR, MatchThreshold=100.0, MaxRatio=0.95, CHANGE_METRIC=False, **par_over)
+    exact = scale != "counts_pow" and (counts or not par["UNNORMALIZE"])
+    rows_list = [np.sort(rng.choice(VM, 500, replace=False)), np.arange(VM), np.sort(rng.choice(VM, 40, replace=False))]
+    for level in (0, 2):
+        debug_set("match_force_fallback", level)
+        got = _segments_direct(descS, descM, rows_list, par, metric=True)
+        for z, r in enumerate(rows_list):
+            pairs, met = _oracle_get_matches_with_metric(descS, descM[r], par)
+            assert pairs.shape[0] > 5
+            np.testing.assert_array_equal(got[z][0], pairs, err_msg=f"segment {z}, level {level}")
+            if exact:
+                bad = np.flatnonzero(got[z][1] != met)
+                assert bad.size == 0, f"segment {z}, level {level}: {bad.size} of {met.size} metrics differ, e.g. {got[z][1][bad[:3]]} vs {met[bad[:3]]}"
+            else:
+                np.testing.assert_allclose(got[z][1], met, rtol=1e-12, atol=1e-14)
+
+
 def test_segmented_get_matches_refuses_ssd():
     from pcreg_amd._lib import PcregError
     rng = np.random.default_rng(0)
