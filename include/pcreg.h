@@ -77,7 +77,7 @@ int  pcreg_device_name(char* buf, int cap);  /* e.g. "gfx950:..."               
 /* Test hook, not part of the reference's interface: selects the OTHER side of a certified fast path (process-wide), so that
  * the parity tests can run both sides inside one process.  Every setting returns the same indices and counts.  Keys:
  * "knn_exact", "match_exact", "match_force_fallback" (1, 2), "ransac_fused", "ransac_nolane", "ransac_f64score",
- * "ransac_resident_f64", "align_times", "align_shape", "seg_debug", "seg_batched", "match_stats"; value 0 restores the default.  The library reads NO
+ * "ransac_resident_f64", "align_times", "align_shape", "seg_debug", "seg_batched", "seg_wave_finalize", "match_stats"; value 0 restores the default.  The library reads NO
  * environment variable (tests/test_abi.py greps the binary).  PCREG_E_ARG for an unknown key. */
 int  pcreg_debug_set(const char* key, int value);
 /* With pcreg_debug_set("match_stats", 1): the counters of the certified SAD matcher summed over the calls since the last

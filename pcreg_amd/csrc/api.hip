@@ -106,7 +106,7 @@ extern "C" {
 int pcreg_debug_set(const char* key, int value) {
     static const char* const names[pcreg::kDbgCount] = {"knn_exact", "match_exact", "match_force_fallback", "ransac_fused", "ransac_nolane",
                                                         "ransac_f64score", "ransac_resident_f64", "align_times", "align_shape", "seg_debug",
-                                                        "seg_batched", "match_stats"};
+                                                        "seg_batched", "seg_wave_finalize", "match_stats"};
     PCREG_ARG(key != nullptr);
     for (int k = 0; k < pcreg::kDbgCount; ++k)
         if (!strcmp(key, names[k])) { pcreg::g_debug[k].store(value, std::memory_order_relaxed); return PCREG_OK; }

@@ -68,6 +68,7 @@ enum DebugKey {
     kDbgAlignShape,            // "align_shape": launch-shape override of align_points_knn
     kDbgSegDebug,              // "seg_debug": histogram dump of the segmented matcher
     kDbgSegBatched,            // "seg_batched": the segmented matcher runs its bounded-workspace (batched) form whatever the size
+    kDbgSegWaveFinalize,       // "seg_wave_finalize": the segmented matcher's forward re-rank as one wave per query (rounds 2-3) instead of pick / pairs / decide
     kDbgMatchStats,            // "match_stats": the certified matcher counts what it proves / re-scores / hands on (pcreg_debug_match_stats)
     kDbgCount
 };

@@ -1051,6 +1051,387 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
     }
 }
 
+// ---- the forward re-rank as a dense chain (round 4) -----------------------------------------------------------------------
+// segp_finalize_kernel gives a WAVE to each query, and in its summing phase kNC = 4 lanes of the 64 add (the oracle's order is one
+// chain of D adds per candidate): 4.2 of the sweep's 11.7 ms, half of the vector cycles spent with 60 lanes masked off.  Here
+//   segp_pick_kernel    (a wave per query) reads the query's lists, drops it if no pair can pass the filter, and writes up to
+//                       TWO groups of kNC candidates (the 8 smallest reference scores inside the slack): rows, norms, numbers;
+//   segp_scan_kernel    (a workgroup per segment) numbers the groups that exist: slot -> group;
+//   segp_rerank_pairs_kernel (a wave per kRQ groups = 4 kRQ (query, candidate) pairs) forms the a - b terms of a 64-feature tile
+//                       pair by pair -- lane = feature, the norms in scalar registers -- into LDS [pair][feature], then lane p adds
+//                       pair p's 64 |terms| in order: every lane sums;
+//   segp_decide_kernel  (a THREAD per query) takes the exact distances, applies the certificate, writes idx / dist / the unproven
+//                       list -- or, for the few queries with more than 8 candidates inside the slack, lists them for
+//   segp_decide_more_kernel (a wave per such query): the remaining candidates that the exact second distance does not exclude
+//                       are summed by seg_rerank as before.
+// The sums are the same chains of the same terms; the top two of ALL candidates inside the slack equal the top two of
+// segp_finalize_kernel's "first four, then whoever the bound leaves" because that bound only drops rows that are strictly
+// farther than the second distance.  segp_finalize_kernel<false> stays as the reference ("seg_wave_finalize").
+constexpr int kNG = 2;                                                            // groups per query
+struct alignas(32) SegGroupRows { int32_t arow, fast, row[kNC], pad[2]; };          // the a-side row, the kNC b-side rows (row 0 where there is no candidate); fast: all six divide through rinv
+struct alignas(16) SegGroupNorms { double nrm_a, rinv_a, nrm[kNC], rinv[kNC]; };  // of the surface row and the kNC rows (1, 1 where none)
+struct alignas(16) SegQueryInfo { int32_t j[kNG * kNC]; uint32_t g; int32_t ng, n_need, fast; };   // j < 0: none; g: seg_front's; ng groups
+
+struct SegFront { int j[kEPL]; unsigned sq[kEPL]; unsigned a1, a2, g; };
+// a query's candidate lists (entry lane + 64 u), the two smallest reference scores and the smallest KC-th score of a chunk
+__device__ __forceinline__ SegFront seg_front(const int32_t* __restrict__ part_idx, const uint32_t* __restrict__ part_s, int splits, int nA, int qi, int lane) {
+    SegFront F;
+    const int total = splits * KC;
+    F.a1 = 0xFFFFFFFFu; F.a2 = 0xFFFFFFFFu; F.g = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < kEPL; ++u) {
+        const int e = lane + 64 * u;
+        F.j[u] = -1; F.sq[u] = 0xFFFFFFFFu;
+        if (e < total) { size_t o = ((size_t)(e / KC) * nA + qi) * KC + (e % KC); F.j[u] = part_idx[o]; F.sq[u] = part_s[o]; }
+        if (F.j[u] >= 0) {
+            if (F.sq[u] < F.a1) { F.a2 = F.a1; F.a1 = F.sq[u]; } else if (F.sq[u] < F.a2) F.a2 = F.sq[u];
+            if ((e % KC) == KC - 1) F.g = min(F.g, F.sq[u]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned b1 = __shfl_xor(F.a1, o), b2 = __shfl_xor(F.a2, o);
+        unsigned n1 = min(F.a1, b1), n2 = min(max(F.a1, b1), min(F.a2, b2));
+        F.a1 = n1; F.a2 = n2;
+        F.g = min(F.g, (unsigned)__shfl_xor((int)F.g, o));
+    }
+    return F;
+}
+__device__ __forceinline__ bool seg_front_need(const SegFront& F, int u, unsigned slack) {
+    return F.j[u] >= 0 && (F.a2 == 0xFFFFFFFFu || F.a2 > 0xFFFFFFFFu - slack || F.sq[u] <= F.a2 + slack);
+}
+// kNG kNC rounds of a wave-wide (score, entry) minimum over the entries still in jk: the winners leave jk (-> -1) and, if out is
+// given, are written to out[0 .. kNG kNC) in the order found.  Deterministic: the same lists give the same picks in every kernel.
+__device__ __forceinline__ void seg_pick_first(int (&jk)[kEPL], const unsigned (&sk)[kEPL], int lane, int* out) {
+#pragma unroll
+    for (int r = 0; r < kNG * kNC; ++r) {
+        unsigned long long key = 0xFFFFFFFFFFFFFFFFull;
+#pragma unroll
+        for (int u = 0; u < kEPL; ++u) if (jk[u] >= 0) { const unsigned long long k2 = ((unsigned long long)sk[u] << 32) | (unsigned)(lane + 64 * u); key = k2 < key ? k2 : key; }
+        unsigned long long m = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(m, o); m = x < m ? x : m; }
+        if (m == 0xFFFFFFFFFFFFFFFFull) break;                  // nobody left (wave-uniform)
+        const int e = (int)(unsigned)(m & 0xFFFFFFFFull);          // the winning entry (lane + 64 u): unique
+#pragma unroll
+        for (int u = 0; u < kEPL; ++u) if (lane + 64 * u == e && jk[u] >= 0) { if (out) out[r] = jk[u]; jk[u] = -1; }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void segp_pick_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
+                                                           const SegConst* __restrict__ sc, const int32_t* __restrict__ part_idx,
+                                                           const uint32_t* __restrict__ part_s, int splits, int32_t* __restrict__ idx,
+                                                           double* __restrict__ dist, int force_unproven, double match_thr, double max_ratio,
+                                                           SegGroupRows* __restrict__ grows, SegGroupNorms* __restrict__ gnorms,
+                                                           SegQueryInfo* __restrict__ qinfo) {
+    __shared__ int s_j[kBlock / 64][kNG * kNC];
+    __shared__ unsigned long long s_key[kBlock / 64][64 * kEPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.z, nA = S.Q, D = S.Dp;
+    const int qi = blockIdx.x * (kBlock / 64) + wave;
+    if (qi >= nA) return;                                      // wave-uniform; no block barrier below
+    const SegConst c = sc[z];
+    const SegView V = seg_view(S, nrmS, nrmM, c, z);
+    part_idx += (size_t)z * splits * nA * KC; part_s += (size_t)z * splits * nA * KC;
+    idx += (size_t)z * nA * 2; dist += (size_t)z * nA * 2;
+    const size_t o = (size_t)z * nA + qi;
+    const SegFront F = seg_front(part_idx, part_s, splits, nA, qi, lane);
+    // (segp_finalize_kernel's comment) a query that cannot pass filter_keep needs no exact sums; neither does one without candidates
+    bool none = F.a1 == 0xFFFFFFFFu;
+    if (!force_unproven && !none) {
+        const double lower1 = (c.rho * ((double)F.a1 - (double)(D + 1)) - (double)c.eunits) * c.inv_scale * (1.0 - 1e-12);
+        none = lower1 > match_thr;
+        if (!none && F.a2 != 0xFFFFFFFFu && S.seg_off[z + 1] - S.seg_off[z] > 1) {
+            const double upper2 = (c.rho * ((double)F.a2 + (double)(D + 1)) + (double)c.eunits) * c.inv_scale * (1.0 + 1e-12);
+            none = upper2 >= 1e-6 && lower1 > max_ratio * upper2 * (1.0 + 1e-12);
+        }
+    }
+    if (none) {                                                                 // wave-uniform
+        if (lane == 0) {
+            idx[(size_t)qi * 2] = -1; idx[(size_t)qi * 2 + 1] = -1; dist[(size_t)qi * 2] = INFINITY; dist[(size_t)qi * 2 + 1] = INFINITY;
+            qinfo[o].ng = 0;
+        }
+        return;
+    }
+    const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
+    int jk[kEPL]; unsigned sk[kEPL];
+    int n_need = 0;
+#pragma unroll
+    for (int u = 0; u < kEPL; ++u) {
+        const bool need = seg_front_need(F, u, slack);
+        jk[u] = need ? F.j[u] : -1; sk[u] = need ? F.sq[u] : 0xFFFFFFFFu;
+        n_need += __popcll(__ballot(need));
+    }
+    // The kNG kNC smallest (score, entry) keys in ascending order = seg_pick_first's picks, without its rounds of wave-wide minima
+    // (8 x 6 cross-lane steps of 64 bits: two thirds of this kernel's instructions): the needed entries are compacted into LDS
+    // (5 of them on average) and each looks up its rank among them.
+    if (lane < kNG * kNC) s_j[wave][lane] = -1;
+    int pos[kEPL];
+    {
+        int n0 = 0;
+#pragma unroll
+        for (int u = 0; u < kEPL; ++u) {
+            const unsigned long long m = __ballot(jk[u] >= 0);
+            pos[u] = n0 + __popcll(m & ((1ull << lane) - 1ull));
+            if (jk[u] >= 0) s_key[wave][pos[u]] = ((unsigned long long)sk[u] << 32) | (unsigned)(lane + 64 * u);
+            n0 += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < kEPL; ++u) {
+        if (jk[u] >= 0) {
+            const unsigned long long mine = ((unsigned long long)sk[u] << 32) | (unsigned)(lane + 64 * u);
+            int rank = 0;
+            for (int k = 0; k < n_need; ++k) rank += s_key[wave][k] < mine ? 1 : 0;
+            if (rank < kNG * kNC) s_j[wave][rank] = jk[u];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const int ng = n_need > kNC ? 2 : 1;
+    const SegRow a = seg_surface_row(V, qi);
+    bool fast = a.rinv != 0.0;
+    if (lane < kNG * kNC) {
+        const int jc = s_j[wave][lane], gq = lane / kNC, cq = lane % kNC;
+        int row = 0; double nrm = 1.0, rinv = 1.0;              // no candidate: row 0 (readable), nobody looks at its sum
+        if (jc >= 0) { row = V.rows[jc]; nrm = V.nrmM[jc]; rinv = V.rinvM[jc]; fast = fast && rinv != 0.0; }
+        qinfo[o].j[lane] = jc;
+        if (gq < ng) {
+            grows[o * kNG + gq].row[cq] = row; gnorms[o * kNG + gq].nrm[cq] = nrm; gnorms[o * kNG + gq].rinv[cq] = rinv;
+            if (cq == 0) { gnorms[o * kNG + gq].nrm_a = a.nrm; gnorms[o * kNG + gq].rinv_a = a.rinv; }
+        }
+    }
+    fast = __ballot(fast) == ~0ull;                            // lanes >= 8 carry the surface row's flag
+    if (lane < ng) { grows[o * kNG + lane].arow = qi; grows[o * kNG + lane].fast = fast ? 1 : 0; }
+    if (lane == 0) { qinfo[o].g = F.g; qinfo[o].ng = ng; qinfo[o].n_need = n_need; qinfo[o].fast = fast ? 1 : 0; }
+}
+
+// slot -> group (2 qi + g) for the groups that exist, in ascending order; n_slots[z] = their number.  One workgroup per segment.
+__global__ __launch_bounds__(kBlock) void segp_scan_kernel(const SegQueryInfo* __restrict__ qinfo, int Q, const int32_t* __restrict__ n_items,
+                                                           int32_t* __restrict__ map, int32_t* __restrict__ n_slots) {
+    __shared__ int s_w[kBlock / 64], s_base;
+    const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    qinfo += (size_t)z * Q; map += (size_t)z * Q * kNG;
+    const int n = n_items ? min(n_items[z], Q) : Q;            // items 0 .. n of the segment carry an ng
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < n; q0 += kBlock) {
+        const int qi = q0 + tid;
+        const int ng = qi < n ? qinfo[qi].ng : 0;
+        int incl = ng;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int base = s_base;
+        for (int w = 0; w < wave; ++w) base += s_w[w];
+        const int first = base + incl - ng;
+        for (int g = 0; g < ng; ++g) map[first + g] = qi * kNG + g;
+        __syncthreads();
+        if (tid == kBlock - 1) s_base = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) n_slots[z] = s_base;
+}
+
+constexpr int kRT = 64;          // features per tile of the pairs kernel
+#ifndef PCREG_SEG_RQ
+#define PCREG_SEG_RQ 8
+#endif
+#ifndef PCREG_SEG_RW
+#define PCREG_SEG_RW 4
+#endif
+constexpr int kRQ = PCREG_SEG_RQ, kRP = kRQ * kNC, kRW = PCREG_SEG_RW;          // groups, pairs per wave; waves per workgroup
+// One wave = kRQ groups of a segment = kRP pairs.  The grid is one-dimensional and XCD-aware: the hardware deals consecutive
+// workgroups to the 8 XCDs in turn, so workgroup L works for segment 8 (L / 8 / nb) + L % 8 -- all batches of a segment run on ONE
+// XCD, whose L2 then holds that sphere's rows (each is a candidate of ~6 queries) instead of an eighth of eight spheres'.
+template <bool FAST>
+__device__ __forceinline__ double seg_quot(double x, double nrm, double rinv) {
+    if (FAST) { const double q = x * rinv; return fma(fma(-nrm, q, x), rinv, q); }
+    return x / nrm;
+}
+typedef const double __attribute__((address_space(1)))* SegGlobalPtr;          // global, not flat: a flat load counts on both wait counters and
+                                                                               // makes the tile wait for ALL its loads before the first is used
+// One tile: ALL the tile's loads first (5 per group: the latency of one round trip per tile, not per group -- the LDS tile leaves
+// two waves per SIMD, so the loads in flight have to come from the wave itself), then the differences a - b into LDS
+// [pair][feature]; the summing lane takes the absolute value (a free operand modifier there).  Every lane keeps the running
+// address of its feature in each of the 5 kRQ rows (wave-uniform row, + 512 bytes per tile): one vector add per load and no scalar
+// load in front of any of them.
+template <bool FAST, bool TAIL>
+__device__ __forceinline__ void seg_pairs_tile(SegGlobalPtr (&pa)[kRQ], SegGlobalPtr (&pb)[kRQ][kNC], const SegGroupNorms* __restrict__ gn, const int (&code)[kRQ],
+                                               int D0, int Dp, double cc, int d0, int lane, double (*st)[kRT + 2]) {
+    static_assert(kNC == 4, "the pair tile is written for four candidates per group");
+    const int d = d0 + lane;
+    const int back = TAIL ? max(d - (D0 - 1), 0) : 0;                               // past the row's end: re-read its last value (unused)
+    const bool is_cc = TAIL && d >= D0, valid = !TAIL || d < Dp;
+    double xa[kRQ], xb[kRQ][kNC];
+#pragma unroll
+    for (int q = 0; q < kRQ; ++q) {
+        xa[q] = *(pa[q] - back); pa[q] += kRT;
+#pragma unroll
+        for (int c = 0; c < kNC; ++c) { xb[q][c] = *(pb[q][c] - back); pb[q][c] += kRT; }
+    }
+    SegGroupNorms N = gn[code[0]];
+#pragma unroll
+    for (int q = 0; q < kRQ; ++q) {
+        const SegGroupNorms Nn = gn[code[min(q + 1, kRQ - 1)]];                     // the next group's norms are on their way while this one computes
+        // (a short batch repeats its last group into LDS rows nobody sums -- straight-line code)
+        if (is_cc) { xa[q] = cc; xb[q][0] = cc; xb[q][1] = cc; xb[q][2] = cc; xb[q][3] = cc; }
+        const double av = seg_quot<FAST>(xa[q], N.nrm_a, N.rinv_a);
+#pragma unroll
+        for (int c = 0; c < kNC; ++c) {
+            const double t = av - seg_quot<FAST>(xb[q][c], N.nrm[c], N.rinv[c]);
+            st[q * kNC + c][lane] = valid ? t : 0.0;
+        }
+        N = Nn;
+    }
+}
+__global__ __launch_bounds__(64 * kRW) void segp_rerank_pairs_kernel(const double* __restrict__ A, const double* __restrict__ B, int nA, int D0, int Dp,
+                                                                     const SegConst* __restrict__ sc, const SegGroupRows* __restrict__ grows,
+                                                                     const SegGroupNorms* __restrict__ gnorms,
+                                                                     const int32_t* __restrict__ map, const int32_t* __restrict__ n_slots,
+                                                                     int nb, int n_seg, double* __restrict__ psum) {
+    __shared__ __attribute__((aligned(16))) double s_t[kRW][kRP][kRT + 2];            // rows of 528 bytes: b128 reads of 16 lanes cover the 64 banks once
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int L = blockIdx.x, xcd = L & 7, r = L >> 3;
+    const int z = (r / nb) * 8 + xcd, bx = r % nb;
+    if (z >= n_seg) return;
+    const int ns = min(n_slots[z], nA * kNG);                  // nA: items per segment (the arrays hold kNG groups for each)
+    const int s0 = (bx * kRW + wave) * kRQ;
+    if (s0 >= ns) return;                                      // wave-uniform; no block barrier below
+    const int nsb = min(kRQ, ns - s0);
+    map += (size_t)z * nA * kNG + s0;
+    grows += (size_t)z * nA * kNG; const SegGroupNorms* gn = gnorms + (size_t)z * nA * kNG;
+    psum += (size_t)z * nA * kNG * kNC;
+    const double cc = sc[z].cc;
+    double (*st)[kRT + 2] = s_t[wave];
+    bool fast = true;
+    int code[kRQ];
+    SegGlobalPtr pa[kRQ], pb[kRQ][kNC];
+#pragma unroll
+    for (int q = 0; q < kRQ; ++q) {
+        code[q] = map[min(q, nsb - 1)];                        // a short batch repeats its last group (loads only: nothing is stored for it)
+        const SegGroupRows R = grows[code[q]];
+        fast = fast && R.fast != 0;
+        pa[q] = (SegGlobalPtr)(A + (unsigned long long)(unsigned)R.arow * (unsigned)D0 + lane);
+#pragma unroll
+        for (int c = 0; c < kNC; ++c) pb[q][c] = (SegGlobalPtr)(B + (unsigned long long)(unsigned)R.row[c] * (unsigned)D0 + lane);
+    }
+    double sum = 0.0;                                          // lane p: pair p = (group p / kNC, candidate p % kNC)
+    for (int d0 = 0; d0 < Dp; d0 += kRT) {
+        const bool tail = d0 + kRT > D0;
+        if (fast) { if (tail) seg_pairs_tile<true, true>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); else seg_pairs_tile<true, false>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); }
+        else { if (tail) seg_pairs_tile<false, true>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); else seg_pairs_tile<false, false>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (lane < nsb * kNC) {
+            // the oracle's order; terms past D are +0.0, which leaves a non-negative sum unchanged
+            const double* t = st[lane];
+#pragma unroll 2
+            for (int k = 0; k < kRT; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = t[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += fabs(v[u]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    if (lane < nsb * kNC) {
+        const int cd = map[lane / kNC];                        // (per-lane: the group this pair belongs to)
+        psum[(size_t)cd * kNC + lane % kNC] = sum;
+    }
+}
+
+// the certificate of a query whose candidates inside the slack have all been summed (seg_front's g: the smallest KC-th score of a chunk)
+__device__ __forceinline__ bool seg_certified(const SegConst& c, unsigned g, int D, const Top2T<double>& t2) {
+    if (g == 0xFFFFFFFFu) return true;
+    const double lower = (c.rho * ((double)g - (double)(D + 1)) - (double)c.eunits) * c.inv_scale;
+    return t2.i2 >= 0 && lower * (1.0 - 1e-12) > t2.d2;
+}
+__global__ __launch_bounds__(kBlock) void segp_decide_kernel(const SegConst* __restrict__ sc, const SegQueryInfo* __restrict__ qinfo, const double* __restrict__ psum,
+                                                             int Q, int D, int32_t* __restrict__ idx, double* __restrict__ dist,
+                                                             int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag,
+                                                             int32_t* __restrict__ more_list, int32_t* __restrict__ n_more, int force_unproven,
+                                                             unsigned long long* __restrict__ stats) {
+    const int z = blockIdx.z, qi = blockIdx.x * kBlock + threadIdx.x;
+    if (qi >= Q) return;
+    const size_t o = (size_t)z * Q + qi;
+    const SegQueryInfo I = qinfo[o];
+    if (I.ng == 0) return;                                     // segp_pick_kernel wrote "no pair"
+    if (I.n_need > kNG * kNC) { more_list[(size_t)z * Q + atomicAdd(&n_more[z], 1)] = qi; return; }
+    Top2T<double> t2{INFINITY, INFINITY, -1, -1};
+#pragma unroll
+    for (int r = 0; r < kNG * kNC; ++r) if (r < I.ng * kNC) top2_insert_lex_t(t2, psum[o * kNG * kNC + r], I.j[r]);          // j < 0: no candidate
+    const bool ok = !force_unproven && seg_certified(sc[z], I.g, D, t2);
+    idx[o * 2] = t2.i1; idx[o * 2 + 1] = t2.i2; dist[o * 2] = t2.d1; dist[o * 2 + 1] = t2.d2;          // unproven: the provisional pair segp_refine_kernel starts from
+    if (!ok) flag_list[(size_t)z * Q + atomicAdd(&n_flag[z], 1)] = qi;
+    if (stats) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)I.n_need); if (!ok) atomicAdd(&stats[2], 1ull); }
+}
+// a query with more candidates inside the slack than the two groups hold: the exact second distance of the 8 summed bounds the
+// true one from above, and a remaining candidate matters only if its own lower bound does not exceed it
+__global__ __launch_bounds__(kBlock) void segp_decide_more_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
+                                                                  const SegConst* __restrict__ sc, const int32_t* __restrict__ part_idx,
+                                                                  const uint32_t* __restrict__ part_s, int splits, const SegQueryInfo* __restrict__ qinfo,
+                                                                  const double* __restrict__ psum, const int32_t* __restrict__ more_list,
+                                                                  const int32_t* __restrict__ n_more, int32_t* __restrict__ idx, double* __restrict__ dist,
+                                                                  int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag, int force_unproven,
+                                                                  unsigned long long* __restrict__ stats) {
+    __shared__ double s_t[kBlock / 64][kNC][kFT];
+    __shared__ int s_j[kBlock / 64][64 * kEPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.z, nA = S.Q, D = S.Dp;
+    const int nm = min(n_more[z], nA);
+    if (nm == 0) return;
+    const SegConst c = sc[z];
+    const SegView V = seg_view(S, nrmS, nrmM, c, z);
+    part_idx += (size_t)z * splits * nA * KC; part_s += (size_t)z * splits * nA * KC;
+    idx += (size_t)z * nA * 2; dist += (size_t)z * nA * 2; flag_list += (size_t)z * nA; more_list += (size_t)z * nA;
+    for (int k = blockIdx.x * (kBlock / 64) + wave; k < nm; k += gridDim.x * (kBlock / 64)) {       // wave-uniform
+        const int qi = more_list[k];
+        const size_t o = (size_t)z * nA + qi;
+        const SegQueryInfo I = qinfo[o];
+        Top2T<double> t2{INFINITY, INFINITY, -1, -1};
+#pragma unroll
+        for (int r = 0; r < kNG * kNC; ++r) top2_insert_lex_t(t2, psum[o * kNG * kNC + r], I.j[r]);
+        const SegFront F = seg_front(part_idx, part_s, splits, nA, qi, lane);
+        const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
+        int jk[kEPL]; unsigned sk[kEPL];
+#pragma unroll
+        for (int u = 0; u < kEPL; ++u) {
+            const bool need = seg_front_need(F, u, slack);
+            jk[u] = need ? F.j[u] : -1; sk[u] = need ? F.sq[u] : 0xFFFFFFFFu;
+        }
+        seg_pick_first(jk, sk, lane, nullptr);                 // the 8 that were summed leave jk
+        unsigned smax = 0xFFFFFFFFu;
+        if (t2.i2 >= 0 && t2.d2 < INFINITY) {
+            const double t = (t2.d2 * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0;
+            if (t < 4.0e9) smax = (unsigned)t;
+        }
+        int n_left = 0;
+#pragma unroll
+        for (int u = 0; u < kEPL; ++u) {
+            const bool more = jk[u] >= 0 && sk[u] <= smax;
+            const unsigned long long m = __ballot(more);
+            if (more) s_j[wave][n_left + __popcll(m & ((1ull << lane) - 1ull))] = jk[u];
+            n_left += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (n_left > 0) {
+            double e1, e2; int k1, k2;
+            seg_rerank<false>(V, seg_surface_row(V, qi), s_j[wave], n_left, D, s_t[wave], e1, k1, e2, k2);
+            top2_insert_lex_t(t2, e1, k1); top2_insert_lex_t(t2, e2, k2);
+        }
+        const bool ok = !force_unproven && seg_certified(c, F.g, D, t2);
+        if (lane == 0) {
+            idx[(size_t)qi * 2] = t2.i1; idx[(size_t)qi * 2 + 1] = t2.i2; dist[(size_t)qi * 2] = t2.d1; dist[(size_t)qi * 2 + 1] = t2.d2;
+            if (!ok) { int sl = atomicAdd(&n_flag[z], 1); flag_list[sl] = qi; }
+            if (stats) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)I.n_need); if (!ok) atomicAdd(&stats[2], 1ull); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // An unproven query does not need every row: a row whose reference score s has rho (s - (D + 1)) - E > scale * d2 for the
 // provisional (exact) second distance d2 cannot enter the pair.  One wave per unproven query reads the query's scores of all
 // candidate rows from the score matrix, keeps the rows below that threshold (a few dozen where the exhaustive scan read 1533 rows of
@@ -1172,6 +1553,100 @@ __global__ __launch_bounds__(kBlock) void segp_back_direct_kernel(SegSets S, con
         if (lane == 0) { bidx[(size_t)k * 2] = i1; bidx[(size_t)k * 2 + 1] = i2; bdist[(size_t)k * 2] = d1; bdist[(size_t)k * 2 + 1] = d2; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
+}
+
+// segp_back_direct_kernel with its exact sums handed to the dense chain: an item whose rows to sum (q among them) fit two groups
+// writes them as groups 2 k, 2 k + 1 of item k -- a-side = the model row, b-side = surface rows -- for segp_scan_kernel /
+// segp_rerank_pairs_kernel (A = PM, B = PS) / segp_back_decide_kernel; the few with more rows are summed here as before.
+__global__ __launch_bounds__(kBlock) void segp_back_pick_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
+                                                                const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_q,
+                                                                const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
+                                                                const uint32_t* __restrict__ Sc, int ldsc, const double* __restrict__ fdist,
+                                                                int32_t* __restrict__ bidx, double* __restrict__ bdist,
+                                                                int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip,
+                                                                SegGroupRows* __restrict__ grows, SegGroupNorms* __restrict__ gnorms,
+                                                                SegQueryInfo* __restrict__ qinfo, unsigned long long* __restrict__ stats) {
+    __shared__ double s_t[kBlock / 64][kNC][kFT];
+    __shared__ int s_j[kBlock / 64][64 * kEPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.z, nA = S.Q, D = S.Dp;
+    const int nc = min(n_cand[z], nA);
+    const SegConst c = sc[z];
+    const SegView V = seg_view(S, nrmS, nrmM, c, z);
+    cand_q += (size_t)z * nA; cand_m += (size_t)z * nA; fdist += (size_t)z * nA * 2;
+    bidx += (size_t)z * nA * 2; bdist += (size_t)z * nA * 2; flag2 += (size_t)z * nA;
+    for (int k = blockIdx.x * (kBlock / 64) + wave; k < nc; k += gridDim.x * (kBlock / 64)) {       // wave-uniform
+        const size_t o = (size_t)z * nA + k;
+        const int qi = cand_q[k], jm = cand_m[k];
+        const double dq = fdist[(size_t)qi * 2];
+        unsigned smax = 0xFFFFFFFFu;
+        { const double t = (dq * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0; if (t < 4.0e9) smax = (unsigned)t; }
+        const uint32_t* row = Sc + (size_t)V.rows[jm] * ldsc;
+        // (segp_back_direct_kernel's comments)
+        unsigned best = 0xFFFFFFFFu;
+        for (int a = lane; a < nA; a += 64) best = min(best, row[a]);
+#pragma unroll
+        for (int o_ = 32; o_ > 0; o_ >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o_));
+        const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
+        const unsigned bmax = best > 0xFFFFFFFFu - slack ? 0xFFFFFFFFu : best + slack;
+        if (row[qi] > bmax && !skip) {
+            if (lane == 0) { bidx[(size_t)k * 2] = -1; bidx[(size_t)k * 2 + 1] = -1; bdist[(size_t)k * 2] = INFINITY; bdist[(size_t)k * 2 + 1] = INFINITY; qinfo[o].ng = 0; }
+            continue;
+        }
+        smax = min(smax, bmax);
+        int n_need = 0; bool over = skip != 0;
+        for (int a0 = 0; a0 < nA && !over; a0 += 64) {
+            const int a = a0 + lane;
+            const bool take = a < nA && row[a] <= smax;
+            const unsigned long long m = __ballot(take);
+            const int cnt = __popcll(m);
+            if (n_need + cnt > 64 * kEPL) { over = true; break; }
+            if (take) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = a;
+            n_need += cnt;
+        }
+        if (stats && lane == 0) atomicAdd(&stats[4], 1ull);
+        if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = k; qinfo[o].ng = 0; if (stats) atomicAdd(&stats[5], 1ull); } continue; }
+        if (n_need == 1) {
+            if (lane == 0) { bidx[(size_t)k * 2] = qi; bidx[(size_t)k * 2 + 1] = -1; bdist[(size_t)k * 2] = dq; bdist[(size_t)k * 2 + 1] = INFINITY; qinfo[o].ng = 0; }
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        const SegRow am = seg_model_row(V, jm);
+        if (n_need <= kNG * kNC) {
+            const int ng = (n_need + kNC - 1) / kNC;
+            bool fast = am.rinv != 0.0;
+            if (lane < kNG * kNC) {
+                const int a = lane < n_need ? s_j[wave][lane] : -1, gq = lane / kNC, cq = lane % kNC;
+                int rw = 0; double nrm = 1.0, rinv = 1.0;
+                if (a >= 0) { rw = a; nrm = V.nrmS[a]; rinv = V.rinvS[a]; fast = fast && rinv != 0.0; }
+                qinfo[o].j[lane] = a;
+                if (gq < ng) {
+                    grows[o * kNG + gq].row[cq] = rw; gnorms[o * kNG + gq].nrm[cq] = nrm; gnorms[o * kNG + gq].rinv[cq] = rinv;
+                    if (cq == 0) { gnorms[o * kNG + gq].nrm_a = am.nrm; gnorms[o * kNG + gq].rinv_a = am.rinv; }
+                }
+            }
+            fast = __ballot(fast) == ~0ull;
+            if (lane < ng) { grows[o * kNG + lane].arow = V.rows[jm]; grows[o * kNG + lane].fast = fast ? 1 : 0; }
+            if (lane == 0) qinfo[o].ng = ng;
+        } else {
+            double d1, d2; int i1, i2;
+            seg_rerank<true>(V, am, s_j[wave], n_need, D, s_t[wave], d1, i1, d2, i2);
+            if (lane == 0) { bidx[(size_t)k * 2] = i1; bidx[(size_t)k * 2 + 1] = i2; bdist[(size_t)k * 2] = d1; bdist[(size_t)k * 2 + 1] = d2; qinfo[o].ng = 0; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ __launch_bounds__(kBlock) void segp_back_decide_kernel(const SegQueryInfo* __restrict__ qinfo, const double* __restrict__ psum, const int32_t* __restrict__ n_cand,
+                                                                  int Q, int32_t* __restrict__ bidx, double* __restrict__ bdist) {
+    const int z = blockIdx.z, k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= min(n_cand[z], Q)) return;
+    const size_t o = (size_t)z * Q + k;
+    const SegQueryInfo I = qinfo[o];
+    if (I.ng == 0) return;                                     // answered by segp_back_pick_kernel
+    Top2T<double> t2{INFINITY, INFINITY, -1, -1};
+#pragma unroll
+    for (int r = 0; r < kNG * kNC; ++r) if (r < I.ng * kNC) top2_insert_lex_t(t2, psum[o * kNG * kNC + r], I.j[r]);
+    bidx[o * 2] = t2.i1; bidx[o * 2 + 1] = t2.i2; bdist[o * 2] = t2.d1; bdist[o * 2 + 1] = t2.d2;
 }
 
 // unproven queries of every segment, exhaustively and exactly (sad_exact_rows_kernel's order); grid (queries, slices, segments).
@@ -1486,7 +1961,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
 namespace {
 struct SegLayout {
     size_t PS, PM, rowS, rowM, nrefS, nrefM, Aq, Bq, Sc, sc, nrmS, nrmM, part_idx, part_s, idx, dist, bidx, bdist, cand_q, cand_m, n_cand, n_flag,
-           flag_list, flag2, n_flag2, fpi, fpd, total;
+           flag_list, flag2, n_flag2, fpi, fpd, grows, gnorms, qinfo, psum, map, n_slots, more_list, n_more, total;
     int D2p, ldqa, ldqb, splits, chunk;
 };
 SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
@@ -1513,6 +1988,8 @@ SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
     L.cand_q = take(ns * q * 4); L.cand_m = take(ns * q * 4); L.n_cand = take(ns * 4); L.n_flag = take(ns * 4);
     L.flag_list = take(ns * q * 4); L.flag2 = take(ns * q * 4); L.n_flag2 = take(ns * 4);
     L.fpi = take(ns * kSegFbSlices * q * 2 * 4); L.fpd = take(ns * kSegFbSlices * q * 2 * 8);
+    L.grows = take(ns * q * kNG * sizeof(SegGroupRows)); L.gnorms = take(ns * q * kNG * sizeof(SegGroupNorms)); L.qinfo = take(ns * q * sizeof(SegQueryInfo));
+    L.psum = take(ns * q * kNG * kNC * 8); L.map = take(ns * q * kNG * 4); L.n_slots = take(ns * 4); L.more_list = take(ns * q * 4); L.n_more = take(ns * 4);
     L.total = b;
     return L;
 }
@@ -1595,8 +2072,25 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
 #ifdef PCREG_EXPERIMENTS
     if (debug_flag(kDbgSegDebug)) { PCREG_HIP(hipMalloc((void**)&dbg_hist, 2 * 130 * sizeof(int32_t))); PCREG_HIP(hipMemsetAsync(dbg_hist, 0, 2 * 130 * sizeof(int32_t), st)); }
 #endif
-    hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                       part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, dbg_hist, stats);
+    if (debug_flag(kDbgSegWaveFinalize) || dbg_hist) {
+        hipLaunchKernelGGL(segp_finalize_kernel<false>, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                           part_idx, part_s, L.splits, idx, dist, flag_list, n_flag, force, (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, dbg_hist, stats);
+    } else {
+        SegGroupRows* grows = (SegGroupRows*)(w + L.grows); SegGroupNorms* gnorms = (SegGroupNorms*)(w + L.gnorms); SegQueryInfo* qinfo = (SegQueryInfo*)(w + L.qinfo);
+        double* psum = (double*)(w + L.psum); int32_t *map = (int32_t*)(w + L.map), *n_slots = (int32_t*)(w + L.n_slots);
+        int32_t *more_list = (int32_t*)(w + L.more_list), *n_more = (int32_t*)(w + L.n_more);
+        PCREG_HIP(hipMemsetAsync(n_more, 0, (size_t)S * sizeof(int32_t), st));
+        hipLaunchKernelGGL(segp_pick_kernel, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, part_idx, part_s, L.splits, idx, dist, force,
+                           (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, grows, gnorms, qinfo);
+        hipLaunchKernelGGL(segp_scan_kernel, dim3(S), dim3(kBlock), 0, st, qinfo, Q, (const int32_t*)nullptr, map, n_slots);
+        const int nb = (Q * kNG + kRQ * kRW - 1) / (kRQ * kRW);          // workgroups per segment; segments in groups of 8 (one per XCD)
+        hipLaunchKernelGGL(segp_rerank_pairs_kernel, dim3((unsigned)(((S + 7) / 8) * 8 * nb)), dim3(64 * kRW), 0, st, (const double*)PS, (const double*)PM, Q, D, Dp, sc,
+                           grows, gnorms, map, n_slots, nb, S, psum);
+        hipLaunchKernelGGL(segp_decide_kernel, dim3((Q + kBlock - 1) / kBlock, 1, S), dim3(kBlock), 0, st, sc, qinfo, psum, Q, Dp, idx, dist, flag_list, n_flag, more_list, n_more,
+                           force, stats);
+        hipLaunchKernelGGL(segp_decide_more_kernel, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, part_idx, part_s, L.splits, qinfo, psum, more_list, n_more,
+                           idx, dist, flag_list, n_flag, force, stats);
+    }
     const int slice_f = (n_max + kSegFbSlices - 1) / kSegFbSlices;
     PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
     hipLaunchKernelGGL(segp_refine_kernel<false>, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, (const int32_t*)nullptr, (const uint32_t*)Sc, L.ldqa,
@@ -1615,9 +2109,22 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
     if (o.unique) {
         // back: every candidate's model row against the surface rows that can still beat its own query -- a row of the same matrix
         PCREG_HIP(hipMemsetAsync(n_flag2, 0, (size_t)S * sizeof(int32_t), st));
-        hipLaunchKernelGGL(segp_back_direct_kernel, dim3(std::max(1, std::min((Q + 3) / 4, 128)), 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc,
-                           (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const double*)dist, bidx, bdist,
-                           flag2, n_flag2, skip_refine, stats);
+        if (debug_flag(kDbgSegWaveFinalize)) {
+            hipLaunchKernelGGL(segp_back_direct_kernel, dim3(std::max(1, std::min((Q + 3) / 4, 128)), 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc,
+                               (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const double*)dist, bidx, bdist,
+                               flag2, n_flag2, skip_refine, stats);
+        } else {
+            SegGroupRows* grows = (SegGroupRows*)(w + L.grows); SegGroupNorms* gnorms = (SegGroupNorms*)(w + L.gnorms); SegQueryInfo* qinfo = (SegQueryInfo*)(w + L.qinfo);
+            double* psum = (double*)(w + L.psum); int32_t *map = (int32_t*)(w + L.map), *n_slots = (int32_t*)(w + L.n_slots);
+            hipLaunchKernelGGL(segp_back_pick_kernel, dim3(std::max(1, std::min((Q + 3) / 4, 128)), 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc,
+                               (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const double*)dist, bidx, bdist,
+                               flag2, n_flag2, skip_refine, grows, gnorms, qinfo, stats);
+            hipLaunchKernelGGL(segp_scan_kernel, dim3(S), dim3(kBlock), 0, st, qinfo, Q, (const int32_t*)n_cand, map, n_slots);
+            const int nb = (Q * kNG + kRQ * kRW - 1) / (kRQ * kRW);
+            hipLaunchKernelGGL(segp_rerank_pairs_kernel, dim3((unsigned)(((S + 7) / 8) * 8 * nb)), dim3(64 * kRW), 0, st, (const double*)PM, (const double*)PS, Q, D, Dp, sc,
+                               grows, gnorms, map, n_slots, nb, S, psum);
+            hipLaunchKernelGGL(segp_back_decide_kernel, dim3((Q + kBlock - 1) / kBlock, 1, S), dim3(kBlock), 0, st, qinfo, psum, (const int32_t*)n_cand, Q, bidx, bdist);
+        }
         hipLaunchKernelGGL(segp_exact_rows_kernel<true>, dim3(std::min(Q, 16), kSegFbSlices, S), dim3(kBlock), (size_t)Dp * sizeof(double), st, sets, nrmS, nrmM, sc,
                            cand_m, flag2, n_flag2, 0, fpi, fpd);
         hipLaunchKernelGGL(segp_fallback_finish_kernel, dim3(std::min((Q + 255) / 256, 8), 1, S), dim3(256), 0, st, flag2, n_flag2, Q, fpi, fpd, bidx, bdist);

@@ -202,6 +202,12 @@ def test_segmented_get_matches_equals_one_call_per_segment(oracle_c, par_over, d
     for (a, ma), (b, mb) in zip(got, batched):
         np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(ma, mb)
+    debug_set("seg_wave_finalize")    # the forward re-rank as one wave per query (the form of rounds 2-3) instead of pick / pairs / decide
+    waves = _segments_direct(descS, descM, rows_list, par, metric=True)
+    debug_set("seg_wave_finalize", 0)
+    for (a, ma), (b, mb) in zip(got, waves):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(ma, mb)
     for level in (1, 2):              # 1: every query through the score-filtered refinement; 2: and on to the exhaustive exact kernel
         debug_set("match_force_fallback", level)
         forced = _segments_direct(descS, descM, rows_list, par, metric=True)
