@@ -547,19 +547,18 @@ __global__ void sad_fallback_finish_kernel(const int32_t* __restrict__ list, con
 // the rounding already costs, so the certificate is as strong as the one-segment path's.
 struct SegConst { double cc, fmin, scale, inv_scale, rho; unsigned eunits, slack2; };
 
-#ifndef PCREG_SEG_PR
-#define PCREG_SEG_PR 64
-#endif
-#ifndef PCREG_SEG_PF
-#define PCREG_SEG_PF 48
-#endif
-constexpr int kPR = PCREG_SEG_PR, kPF = PCREG_SEG_PF;
-// src row-major [n][D] -> P row-major, l1, s2, min / max of P per row (one lane per row keeps the oracle's order)
+constexpr int kPR = 64, kPW = 16, kPT = 64;          // rows per workgroup, per wave; features per tile
+// src row-major [n][D] -> P row-major, l1, s2, min / max of P per row.  One LANE per row keeps the oracle's order (980 dependent
+// adds per row), so the kernel has only n / 64 waves' worth of arithmetic and lives on latency: each WAVE takes 16 rows (four
+// times the waves of one wave per 64 rows, no workgroup barrier anywhere), reads a 16 x 64 tile with 16 coalesced loads that are
+// issued before the previous tile's chains run, and hands the tile to its 16 summing lanes through LDS.  (Round 3's form -- a
+// workgroup per 64 rows, one of its four waves summing between two barriers per 48 features -- took 0.62 ms for the sweep's
+// 60 000 x 980 model, 1 GB of traffic.)
 __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restrict__ src, int n, int D, int change_metric, double factor,
                                                            double* __restrict__ P, double* __restrict__ l1, double* __restrict__ s2,
                                                            double* __restrict__ pmin, double* __restrict__ pmax, double* __restrict__ sp,
                                                            double* __restrict__ odd /* 1: the row holds a value outside {0} U [2^-400, 2^400] */) {
-    __shared__ double t_raw[kPF][kPR + 1], t_p[kPF][kPR + 1];
+    __shared__ double t_raw[kBlock / 64][kPT][kPW + 1], t_p[kBlock / 64][kPT][kPW + 1];
     // The descriptors are COUNTS (getSpacialHistogramDescriptors: integers, a few units per bin): their powers come from a table
     // of this very pow -- same bits -- that each workgroup fills first (kPowTab fp64 pow calls against the 62 720 of its rows);
     // anything that is not a small integer takes pow itself.
@@ -569,36 +568,45 @@ __global__ __launch_bounds__(kBlock) void segp_rows_kernel(const double* __restr
         for (int e = threadIdx.x; e < kPowTab; e += kBlock) s_pow[e] = pow((double)e, factor);
         __syncthreads();
     }
-    const int r0 = blockIdx.x * kPR, rows = min(kPR, n - r0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = blockIdx.x * kPR + wave * kPW, rows = min(kPW, n - r0);
+    if (rows <= 0) return;                                     // wave-uniform; no workgroup barrier below
+    double (*traw)[kPW + 1] = t_raw[wave], (*tp)[kPW + 1] = t_p[wave];
     double a = 0.0, s = 0.0, lo = INFINITY, hi = -INFINITY, ap = 0.0;
     bool bad = false;
-    for (int d0 = 0; d0 < D; d0 += kPF) {
-        const int dn = min(kPF, D - d0);
-        for (int e = threadIdx.x; e < kPR * kPF; e += kBlock) {
-            const int r = e / kPF, f = e % kPF;
-            double x = 0.0, pv = 0.0;
-            if (r < rows && f < dn) {
-                x = src[(size_t)(r0 + r) * D + d0 + f];
-                if (change_metric) {
-                    const int xi = (x >= 0.0 && x < (double)kPowTab) ? (int)x : -1;
-                    pv = (xi >= 0 && (double)xi == x) ? s_pow[xi] : pow(x, factor);
-                } else pv = x;
-                P[(size_t)(r0 + r) * D + d0 + f] = pv;
-            }
-            t_raw[f][r] = x; t_p[f][r] = pv;
+    double x[kPW];
+    auto load_tile = [&](int d0) {
+#pragma unroll
+        for (int i = 0; i < kPW; ++i) {
+            const int r = min(i, rows - 1), d = min(d0 + lane, D - 1);          // clamped: the loads are unconditional, the surplus unused
+            x[i] = src[(size_t)(r0 + r) * D + d];
         }
-        __syncthreads();
-        if ((int)threadIdx.x < rows) {
-            const int r = threadIdx.x;
+    };
+    load_tile(0);
+    for (int d0 = 0; d0 < D; d0 += kPT) {
+        const int dn = min(kPT, D - d0);
+#pragma unroll
+        for (int i = 0; i < kPW; ++i) {
+            double pv = x[i];
+            if (change_metric) {
+                const int xi = (x[i] >= 0.0 && x[i] < (double)kPowTab) ? (int)x[i] : -1;
+                pv = (xi >= 0 && (double)xi == x[i]) ? s_pow[xi] : pow(x[i], factor);
+            }
+            if (i < rows && lane < dn) P[(size_t)(r0 + i) * D + d0 + lane] = pv;
+            traw[lane][i] = x[i]; tp[lane][i] = pv;
+        }
+        if (d0 + kPT < D) load_tile(d0 + kPT);                 // in flight while the chains below run
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        if (lane < rows) {
             for (int f = 0; f < dn; ++f) {
-                const double x = t_raw[f][r], pv = t_p[f][r];
-                a += fabs(x); s = fma(pv, pv, s); lo = fmin(lo, pv); hi = fmax(hi, pv); ap += fabs(pv);
+                const double xr = traw[f][lane], pv = tp[f][lane];
+                a += fabs(xr); s = fma(pv, pv, s); lo = fmin(lo, pv); hi = fmax(hi, pv); ap += fabs(pv);
                 bad = bad || !(pv == 0.0 || (fabs(pv) >= 0x1p-400 && fabs(pv) <= 0x1p400));
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
-    if ((int)threadIdx.x < rows) { const int r = r0 + threadIdx.x; l1[r] = a; s2[r] = s; pmin[r] = lo; pmax[r] = hi; sp[r] = ap; odd[r] = bad ? 1.0 : 0.0; }
+    if (lane < rows) { const int r = r0 + lane; l1[r] = a; s2[r] = s; pmin[r] = lo; pmax[r] = hi; sp[r] = ap; odd[r] = bad ? 1.0 : 0.0; }
 }
 
 struct SegSets {                // the two descriptor sets after segp_rows_kernel, and the segments
@@ -1582,9 +1590,19 @@ __global__ __launch_bounds__(kBlock) void segp_back_pick_kernel(SegSets S, const
         unsigned smax = 0xFFFFFFFFu;
         { const double t = (dq * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0; if (t < 4.0e9) smax = (unsigned)t; }
         const uint32_t* row = Sc + (size_t)V.rows[jm] * ldsc;
-        // (segp_back_direct_kernel's comments)
+        // (segp_back_direct_kernel's comments)  The row of the matrix is read 16 bytes per lane, four loads in flight (one 4-byte
+        // load per trip left the wave waiting out a memory latency for every 64 surface rows: 0.8 ms per sweep).
         unsigned best = 0xFFFFFFFFu;
-        for (int a = lane; a < nA; a += 64) best = min(best, row[a]);
+        const int n4 = (nA + 3) / 4;                              // ldsc is a multiple of 4 and >= nA: the 16-byte loads stay inside the row
+#pragma unroll 4
+        for (int a4 = lane; a4 < n4; a4 += 64) {
+            const uint4 v = *(const uint4*)(row + (size_t)a4 * 4);
+            const int a = a4 * 4;
+            best = min(best, v.x);
+            if (a + 1 < nA) best = min(best, v.y);
+            if (a + 2 < nA) best = min(best, v.z);
+            if (a + 3 < nA) best = min(best, v.w);
+        }
 #pragma unroll
         for (int o_ = 32; o_ > 0; o_ >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o_));
         const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
@@ -1595,14 +1613,23 @@ __global__ __launch_bounds__(kBlock) void segp_back_pick_kernel(SegSets S, const
         }
         smax = min(smax, bmax);
         int n_need = 0; bool over = skip != 0;
-        for (int a0 = 0; a0 < nA && !over; a0 += 64) {
-            const int a = a0 + lane;
-            const bool take = a < nA && row[a] <= smax;
-            const unsigned long long m = __ballot(take);
-            const int cnt = __popcll(m);
-            if (n_need + cnt > 64 * kEPL) { over = true; break; }
-            if (take) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = a;
-            n_need += cnt;
+        // (the list's order is not ascending: no consumer depends on it -- the top two are taken by (distance, row))
+        for (int a0 = 0; a0 < n4 && !over; a0 += 64) {
+            const int a4 = a0 + lane;
+            uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (a4 < n4) v = *(const uint4*)(row + (size_t)a4 * 4);
+            const unsigned ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = a4 * 4 + e;
+                const bool take = a4 < n4 && a < nA && ve[e] <= smax;
+                const unsigned long long m = __ballot(take);
+                const int cnt = __popcll(m);
+                if (cnt && !over) {
+                    if (n_need + cnt > 64 * kEPL) over = true;
+                    else { if (take) s_j[wave][n_need + __popcll(m & ((1ull << lane) - 1ull))] = a; n_need += cnt; }
+                }
+            }
         }
         if (stats && lane == 0) atomicAdd(&stats[4], 1ull);
         if (over) { if (lane == 0) { const int slot = atomicAdd(&n_flag2[z], 1); flag2[slot] = k; qinfo[o].ng = 0; if (stats) atomicAdd(&stats[5], 1ull); } continue; }
