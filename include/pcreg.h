@@ -430,7 +430,7 @@ int pcreg_dev_sphere_select_batched(const double* feat, int V, const double* cen
  * pcreg_dev_get_matches call per segment (same arithmetic on the same operands: the appended constant and the row norms
  * differ per segment, the powered columns do not and are computed once).  Metric SAD only.
  * Memory: the one-chain form takes  4 VM' Q'  (the shared score matrix, VM' / Q' = VM / Q rounded up to 128)  +  8 D (VM + Q)  (the
- * powered rows)  +  ~S Q (32 splits + 150) bytes (the per-segment lists);  up to 4 GB of that it runs as ONE chain and nothing
+ * powered rows)  +  ~S Q (32 splits + 500) bytes (the per-segment lists and re-rank work items);  up to 4 GB of that it runs as ONE chain and nothing
  * synchronises.  Above, the call runs in batches of consecutive segments on gathered sub-models (the union of the rows a batch
  * names), inside a workspace of 4 GB + 12 VM + 4 total_rows + 4 S bytes: same pairs, one host synchronisation at entry and one or
  * two per batch.  A single segment that does not fit the bound is refused with PCREG_E_WORKSPACE. */

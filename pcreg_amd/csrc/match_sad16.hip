@@ -2023,7 +2023,7 @@ SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
 }  // namespace
 
 // ---- bounded workspace --------------------------------------------------------------------------------------------------
-// The one-chain layout grows with VM x Q (the shared score matrix) and with S x Q x splits (the per-segment lists): 0.6 GB at the
+// The one-chain layout grows with VM x Q (the shared score matrix) and with S x Q x splits (the per-segment lists): 0.85 GB at the
 // sweep's shape (60 k x 2 k, 329 spheres), tens of GB at 400 k x 6 k with 2000 spheres.  Above kSegBudget + kSegGatherBytes the
 // call runs in BATCHES of consecutive segments: the model rows a batch names are marked, numbered in ascending order (their
 // union) and gathered into a compact sub-model, the batch's lists are renumbered into it, and the one-chain form runs on
