@@ -903,10 +903,12 @@ __device__ __forceinline__ void seg_rerank(const SegView& V, const SegRow& a, co
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
-        if (lane < nc) {
-            const int jc = sj[g0 + lane];
-            if (lexd_lt(sum, jc, d1, i1)) { d2 = d1; i2 = i1; d1 = sum; i1 = jc; }
-            else if (lexd_lt(sum, jc, d2, i2)) { d2 = sum; i2 = jc; }
+        {   // selects, not branches: as two conditional blocks the compiler stored through a SELECTED ADDRESS, which put the four
+            // results in scratch memory for every kernel that calls this (1.7 GB of scratch writes per sweep in round 3's finalize)
+            const int jc = sj[min(g0 + lane, n_need - 1)];
+            const bool in = lane < nc, b1 = in && lexd_lt(sum, jc, d1, i1), b2 = in && !b1 && lexd_lt(sum, jc, d2, i2);
+            const double nd2 = b1 ? d1 : (b2 ? sum : d2); const int ni2 = b1 ? i1 : (b2 ? jc : i2);
+            d1 = b1 ? sum : d1; i1 = b1 ? jc : i1; d2 = nd2; i2 = ni2;
         }
     }
 #pragma unroll
