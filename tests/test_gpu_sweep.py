@@ -275,6 +275,35 @@ def test_segmented_metric_is_the_oracles_division_bit_for_bit(oracle_c, scale, p
                 np.testing.assert_allclose(got[z][1], met, rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("copies", [(3, 2), (20, 12)])
+def test_segmented_get_matches_with_many_tied_candidates(oracle_c, copies, debug_set):
+    """Model rows in identical copies and surface rows in identical copies: every query has `copies[0]` candidates at the same
+    reference score and the same exact distance (with 20, more than the two groups of the dense re-rank hold: the remaining ones
+    are summed by the wave path of segp_decide_more_kernel), every back-check item `copies[1]` surface rows tied with its own
+    (with 12, more than two groups: summed inside segp_back_pick_kernel).  Ties go by index, as in the oracle."""
+    import pcreg_amd as pc
+    cm, cs = copies
+    rng = np.random.default_rng(33)
+    D = 90
+    base = rng.poisson(3.0, (40, D)).astype(np.float64)
+    descM = np.repeat(base, cm, axis=0)[rng.permutation(40 * cm)]
+    descS = np.repeat(base[:25] + rng.poisson(0.1, (25, D)), cs, axis=0)[rng.permutation(25 * cs)]
+    VM = descM.shape[0]
+    par = dict(PAR, MatchThreshold=50.0, MaxRatio=1.0)
+    rows_list = [np.arange(VM), np.sort(rng.choice(VM, VM // 2, replace=False)), np.sort(rng.choice(VM, 5, replace=False))]
+    got = _segments_direct(descS, descM, rows_list, par, metric=True)
+    debug_set("seg_wave_finalize")
+    waves = _segments_direct(descS, descM, rows_list, par, metric=True)
+    debug_set("seg_wave_finalize", 0)
+    for z, r in enumerate(rows_list):
+        pairs, met = _oracle_get_matches_with_metric(descS, descM[r], par)
+        np.testing.assert_array_equal(got[z][0], pairs, err_msg=f"segment {z}")
+        np.testing.assert_array_equal(got[z][0], waves[z][0])
+        np.testing.assert_array_equal(got[z][1], waves[z][1])
+        np.testing.assert_allclose(got[z][1], met, rtol=1e-12, atol=1e-14)
+    assert sum(g[0].shape[0] for g in got) > 0
+
+
 def test_segmented_get_matches_refuses_ssd():
     from pcreg_amd._lib import PcregError
     rng = np.random.default_rng(0)
