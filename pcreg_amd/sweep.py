@@ -184,6 +184,15 @@ class SphereSweep:
                                                 C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws), C.c_size_t(self._seg_ws.numel()), sp))   # :131-149
         return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev)
 
+    def _pinned(self, key: str, n: int, dtype) -> "torch.Tensor":
+        """A page-locked host buffer of at least n elements, kept across sweeps (the first n elements are returned)."""
+        cache = self.__dict__.setdefault("_pin", {})
+        t = cache.get(key)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+            cache[key] = t
+        return t[:n]
+
     def _finish_sweep(self, centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev=None) -> dict:
         """:166-224 on the current stream + the sweep's second (last) host synchronisation."""
         from ._lib import DevRansacResult
@@ -211,15 +220,26 @@ class SphereSweep:
             self._rs_ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
         check(L.pcreg_dev_ransac_batched(_p(p1), _p(p2), ld, _p(offsets), S, self.VS, C.byref(o), _p(results), _p(inliers), _p(self._rs_ws),
                                          C.c_size_t(self._rs_ws.numel()), sp))
-        # ---- sync 2: everything comes back together
-        npr = n_pairs.cpu().numpy().astype(np.int64)
-        nt = int(n_trials.item())
-        trial = trial_idx[:nt].cpu().numpy().astype(np.int64)
-        raw = results[:max(nt, 1)].cpu().numpy()
+        # ---- sync 2: everything comes back together -- the small results in ONE pinned transfer (seven separate .cpu() calls were
+        # seven synchronisations, ~0.4 ms of the sweep), then the pair and row lists, which need the pair counts for their size
+        small = torch.cat([n_pairs, n_trials, trial_idx, n_sel, results.view(torch.int32).view(-1)])
+        hs = self._pinned("small", small.numel(), torch.int32)
+        hs.copy_(small, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        h = hs.numpy()
+        npr = h[:S].astype(np.int64)
+        nt = int(h[S])
+        trial = h[S + 1:S + 1 + nt].astype(np.int64)
+        nsel = h[2 * S + 1:3 * S + 1].copy()
+        raw = h[3 * S + 1:].view(np.uint8).reshape(S, rs)[:max(nt, 1)].copy()
         m_pairs = max(int(npr.max()) if S else 0, 1)                # only the columns that hold pairs cross the bus
-        pairs_host = pairs_all[:, :m_pairs].contiguous().cpu().numpy().astype(np.uint32)     # one conversion; the per-sphere lists are views of it
-        rows_host = rows_all.cpu().numpy().astype(np.int64)
-        nsel = n_sel.cpu().numpy()
+        hp = self._pinned("pairs", S * m_pairs * 2, torch.int32).view(S, m_pairs, 2)
+        hp.copy_(pairs_all[:, :m_pairs], non_blocking=True)
+        hr = self._pinned("rows", max(rows_all.numel(), 1), torch.int32)[:rows_all.numel()]
+        hr.copy_(rows_all, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        pairs_host = hp.numpy().astype(np.uint32)                   # one conversion (a copy: the pinned buffer is reused); the per-sphere lists are views of it
+        rows_host = hr.numpy().astype(np.int64)
         assert np.array_equal(nsel, num_desc), "sphere_select disagrees with sphere_counts"
         sp_, ss, si, sr, tf = [], [], [], [], []
         for t in range(nt):
