@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
 //   segp_pick_kernel    (a wave per query) reads the query's lists, drops it if no pair can pass the filter, and writes up to
 //                       TWO groups of kNC candidates (the 8 smallest reference scores inside the slack): rows, norms, numbers;
 //   segp_scan_kernel    (a workgroup per segment) numbers the groups that exist: slot -> group;
-//   segp_rerank_pairs_kernel (a wave per kRQ groups = 4 kRQ (query, candidate) pairs) forms the a - b terms of a 64-feature tile
+//   segp_rerank_pairs_kernel (a wave per kRQ = 4 groups = 16 (query, candidate) pairs) forms the a - b terms of a 64-feature tile
 //                       pair by pair -- lane = feature, the norms in scalar registers -- into LDS [pair][feature], then lane p adds
 //                       pair p's 64 |terms| in order: every lane sums;
 //   segp_decide_kernel  (a THREAD per query) takes the exact distances, applies the certificate, writes idx / dist / the unproven
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(kBlock) void segp_scan_kernel(const SegQueryInfo* _
 
 constexpr int kRT = 64;          // features per tile of the pairs kernel
 #ifndef PCREG_SEG_RQ
-#define PCREG_SEG_RQ 8
+#define PCREG_SEG_RQ 4          // same-box A/B of the forward launch: 8 groups per wave 2.11 ms (2 waves per SIMD), 6: 2.12, 4: 1.98 (3 waves per SIMD)
 #endif
 #ifndef PCREG_SEG_RW
 #define PCREG_SEG_RW 4
@@ -1266,21 +1266,28 @@ typedef const double __attribute__((address_space(1)))* SegGlobalPtr;          /
 // two waves per SIMD, so the loads in flight have to come from the wave itself), then the differences a - b into LDS
 // [pair][feature]; the summing lane takes the absolute value (a free operand modifier there).  Every lane keeps the running
 // address of its feature in each of the 5 kRQ rows (wave-uniform row, + 512 bytes per tile): one vector add per load and no scalar
-// load in front of any of them.
-template <bool FAST, bool TAIL>
-__device__ __forceinline__ void seg_pairs_tile(SegGlobalPtr (&pa)[kRQ], SegGlobalPtr (&pb)[kRQ][kNC], const SegGroupNorms* __restrict__ gn, const int (&code)[kRQ],
-                                               int D0, int Dp, double cc, int d0, int lane, double (*st)[kRT + 2]) {
-    static_assert(kNC == 4, "the pair tile is written for four candidates per group");
-    const int d = d0 + lane;
-    const int back = TAIL ? max(d - (D0 - 1), 0) : 0;                               // past the row's end: re-read its last value (unused)
-    const bool is_cc = TAIL && d >= D0, valid = !TAIL || d < Dp;
-    double xa[kRQ], xb[kRQ][kNC];
+// load in front of any of them.  The loads of tile t + 1 are issued as soon as tile t's differences are in LDS -- the registers are
+// free then -- so their latency runs under the summing phase's chain of 64 dependent adds.
+template <bool TAIL>
+__device__ __forceinline__ void seg_pairs_load(SegGlobalPtr (&pa)[kRQ], SegGlobalPtr (&pb)[kRQ][kNC], double (&xa)[kRQ], double (&xb)[kRQ][kNC], int D0, int d0, int lane) {
+    const int back = TAIL ? max(d0 + lane - (D0 - 1), 0) : 0;                       // past the row's end: re-read its last value (unused)
 #pragma unroll
     for (int q = 0; q < kRQ; ++q) {
         xa[q] = *(pa[q] - back); pa[q] += kRT;
 #pragma unroll
         for (int c = 0; c < kNC; ++c) { xb[q][c] = *(pb[q][c] - back); pb[q][c] += kRT; }
     }
+}
+// the terms of tile d0 from the values in (xa, xb); NEXT = 1 / 2: group by group, as soon as a group's values are used, its
+// loads for the tile behind (2: that tile reaches past the row's end) go out into the same registers
+template <bool FAST, bool TAIL, int NEXT>
+__device__ __forceinline__ void seg_pairs_terms(SegGlobalPtr (&pa)[kRQ], SegGlobalPtr (&pb)[kRQ][kNC], double (&xa)[kRQ], double (&xb)[kRQ][kNC],
+                                                const SegGroupNorms* __restrict__ gn, const int (&code)[kRQ],
+                                                int D0, int Dp, double cc, int d0, int lane, double (*st)[kRT + 2]) {
+    static_assert(kNC == 4, "the pair tile is written for four candidates per group");
+    const int d = d0 + lane;
+    const bool is_cc = TAIL && d >= D0, valid = !TAIL || d < Dp;
+    const int back = NEXT == 2 ? max(d + kRT - (D0 - 1), 0) : 0;
     SegGroupNorms N = gn[code[0]];
 #pragma unroll
     for (int q = 0; q < kRQ; ++q) {
@@ -1288,15 +1295,21 @@ __device__ __forceinline__ void seg_pairs_tile(SegGlobalPtr (&pa)[kRQ], SegGloba
         // (a short batch repeats its last group into LDS rows nobody sums -- straight-line code)
         if (is_cc) { xa[q] = cc; xb[q][0] = cc; xb[q][1] = cc; xb[q][2] = cc; xb[q][3] = cc; }
         const double av = seg_quot<FAST>(xa[q], N.nrm_a, N.rinv_a);
+        double t[kNC];
 #pragma unroll
-        for (int c = 0; c < kNC; ++c) {
-            const double t = av - seg_quot<FAST>(xb[q][c], N.nrm[c], N.rinv[c]);
-            st[q * kNC + c][lane] = valid ? t : 0.0;
+        for (int c = 0; c < kNC; ++c) t[c] = av - seg_quot<FAST>(xb[q][c], N.nrm[c], N.rinv[c]);
+        if (NEXT) {
+            xa[q] = *(pa[q] - back); pa[q] += kRT;
+#pragma unroll
+            for (int c = 0; c < kNC; ++c) { xb[q][c] = *(pb[q][c] - back); pb[q][c] += kRT; }
         }
+#pragma unroll
+        for (int c = 0; c < kNC; ++c) st[q * kNC + c][lane] = valid ? t[c] : 0.0;
         N = Nn;
+        __builtin_amdgcn_sched_barrier(0);          // the scheduler would hoist all 40 loads to the top of the tile: twice the registers, spills
     }
 }
-__global__ __launch_bounds__(64 * kRW) void segp_rerank_pairs_kernel(const double* __restrict__ A, const double* __restrict__ B, int nA, int D0, int Dp,
+__global__ __launch_bounds__(64 * kRW, kRQ <= 4 ? 3 : 2) void segp_rerank_pairs_kernel(const double* __restrict__ A, const double* __restrict__ B, int nA, int D0, int Dp,
                                                                      const SegConst* __restrict__ sc, const SegGroupRows* __restrict__ grows,
                                                                      const SegGroupNorms* __restrict__ gnorms,
                                                                      const int32_t* __restrict__ map, const int32_t* __restrict__ n_slots,
@@ -1328,10 +1341,8 @@ __global__ __launch_bounds__(64 * kRW) void segp_rerank_pairs_kernel(const doubl
         for (int c = 0; c < kNC; ++c) pb[q][c] = (SegGlobalPtr)(B + (unsigned long long)(unsigned)R.row[c] * (unsigned)D0 + lane);
     }
     double sum = 0.0;                                          // lane p: pair p = (group p / kNC, candidate p % kNC)
-    for (int d0 = 0; d0 < Dp; d0 += kRT) {
-        const bool tail = d0 + kRT > D0;
-        if (fast) { if (tail) seg_pairs_tile<true, true>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); else seg_pairs_tile<true, false>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); }
-        else { if (tail) seg_pairs_tile<false, true>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); else seg_pairs_tile<false, false>(pa, pb, gn, code, D0, Dp, cc, d0, lane, st); }
+    double xa[kRQ], xb[kRQ][kNC];
+    auto add_tile = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
         if (lane < nsb * kNC) {
             // the oracle's order; terms past D are +0.0, which leaves a non-negative sum unchanged
@@ -1346,7 +1357,21 @@ __global__ __launch_bounds__(64 * kRW) void segp_rerank_pairs_kernel(const doubl
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    }
+    };
+    // tiles 0 .. n_full - 1 lie inside the rows (no clamps, no selects), one more holds the rows' end and the appended constant
+    const int n_full = D0 / kRT, has_tail = Dp > n_full * kRT;
+    auto run = [&](auto fastc) {
+        constexpr bool F = decltype(fastc)::value;
+        if (n_full == 0) seg_pairs_load<true>(pa, pb, xa, xb, D0, 0, lane); else seg_pairs_load<false>(pa, pb, xa, xb, D0, 0, lane);
+        for (int t = 0; t + 1 < n_full; ++t) { seg_pairs_terms<F, false, 1>(pa, pb, xa, xb, gn, code, D0, Dp, cc, t * kRT, lane, st); add_tile(); }
+        if (n_full > 0) {
+            if (has_tail) seg_pairs_terms<F, false, 2>(pa, pb, xa, xb, gn, code, D0, Dp, cc, (n_full - 1) * kRT, lane, st);
+            else seg_pairs_terms<F, false, 0>(pa, pb, xa, xb, gn, code, D0, Dp, cc, (n_full - 1) * kRT, lane, st);
+            add_tile();
+        }
+        if (has_tail) { seg_pairs_terms<F, true, 0>(pa, pb, xa, xb, gn, code, D0, Dp, cc, n_full * kRT, lane, st); add_tile(); }
+    };
+    if (fast) run(std::true_type{}); else run(std::false_type{});
     if (lane < nsb * kNC) {
         const int cd = map[lane / kNC];                        // (per-lane: the group this pair belongs to)
         psum[(size_t)cd * kNC + lane % kNC] = sum;
