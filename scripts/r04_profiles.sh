@@ -12,6 +12,8 @@ echo "== kernel stats of the batched cfg 1 RANSAC (ransac_hyp32_kernel)"
 bash scripts/prof_stats.sh r04_cfg1b 4 -m ransac_hyp32 -- scripts/ransac_extras.py ransac_cfg1_batched > gpurun_out/r04_cfg1b_stats.txt 2>&1 || exit 1
 echo "== sweep kernel stats (Poisson rows)"
 bash scripts/prof_stats.sh r04_sweep 2 -- scripts/sweep_prof.py 2 > gpurun_out/r04_sweep_stats.txt 2>&1 || exit 1
+echo "== counters of the sweep's exact re-rank (segp_rerank_pairs_kernel)"
+bash scripts/pmc_counters.sh r04_segpairs segp_rerank_pairs gpurun_out/r04_pmc_segp_rerank_pairs.json -- scripts/sweep_prof.py 2 > gpurun_out/r04_pmc_segpairs.txt 2>&1 || exit 1
 echo "== traffic of the headline step"
 bash scripts/pmc_traffic.sh r04_step gpurun_out/r04_pmc_step_traffic.json "knn_candidates_f16,prep_model_f16" -- bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --in-flight 1 > gpurun_out/r04_step_traffic.txt 2>&1 || exit 1
 echo "== descriptors at cfg 4: kernel stats"
