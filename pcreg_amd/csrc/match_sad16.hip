@@ -640,52 +640,63 @@ __global__ __launch_bounds__(kBlock) void segp_cc_kernel(SegSets S, pcreg_match_
     if (tid == 0) sc[z].cc = cc;
 }
 // The reference constant = the middle of the segments' constants (any value works: it only sets how much slack the segments
-// need), every row's norm under it, and the common quantisation range.  One workgroup; ref = sc[n_seg].
+// need), every row's norm under it, and the common quantisation range; ref = sc[n_seg].  Minima and maxima only, so the rows are
+// spread over kRefParts workgroups whose partial ranges a second, one-workgroup launch folds (as ONE workgroup over all 62 000
+// rows of the sweep -- 242 square roots and divisions in a row per thread -- it was 0.14 ms of every sweep).
+constexpr int kRefParts = 1024;
+__device__ __forceinline__ void seg_ref_fold(double (&v)[4], double (*s_w)[kBlock / 64]) {      // v = {lo, hi, q_lo, q_hi} -> thread 0 holds the workgroup's
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) {
+        v[0] = fmin(v[0], __shfl_xor(v[0], w)); v[1] = fmax(v[1], __shfl_xor(v[1], w));
+        v[2] = fmin(v[2], __shfl_xor(v[2], w)); v[3] = fmax(v[3], __shfl_xor(v[3], w));
+    }
+    if ((tid & 63) == 0) { for (int k = 0; k < 4; ++k) s_w[k][tid >> 6] = v[k]; }
+    __syncthreads();
+    if (tid == 0)
+        for (int w = 1; w < kBlock / 64; ++w) { v[0] = fmin(v[0], s_w[0][w]); v[1] = fmax(v[1], s_w[1][w]); v[2] = fmin(v[2], s_w[2][w]); v[3] = fmax(v[3], s_w[3][w]); }
+}
 __global__ __launch_bounds__(kBlock) void segp_ref_kernel(SegSets S, pcreg_match_opts o, double* __restrict__ nrefS, double* __restrict__ nrefM,
-                                                          SegConst* __restrict__ sc, int n_seg) {
-    __shared__ double s_lo[kBlock / 64], s_hi[kBlock / 64];
+                                                          const SegConst* __restrict__ sc, int n_seg, double* __restrict__ part /*[gridDim.x][4]*/) {
+    __shared__ double s_w[4][kBlock / 64];
     __shared__ double s_cc;
     const int tid = threadIdx.x, n = S.Q + S.VM;
-    {
-        double lo = INFINITY, hi = -INFINITY;
-        for (int z = tid; z < n_seg; z += kBlock) { lo = fmin(lo, sc[z].cc); hi = fmax(hi, sc[z].cc); }
-#pragma unroll
-        for (int w = 32; w > 0; w >>= 1) { lo = fmin(lo, __shfl_xor(lo, w)); hi = fmax(hi, __shfl_xor(hi, w)); }
-        if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < kBlock / 64; ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); }
-            s_cc = 0.5 * (lo + hi);
-        }
+    {   // every workgroup derives the same constant from the segments' (a few hundred values)
+        double v[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+        for (int z = tid; z < n_seg; z += kBlock) { v[0] = fmin(v[0], sc[z].cc); v[1] = fmax(v[1], sc[z].cc); }
+        seg_ref_fold(v, s_w);
+        if (tid == 0) s_cc = 0.5 * (v[0] + v[1]);
         __syncthreads();
     }
     const double cc = o.unnormalize ? s_cc : 0.0;
-    SegConst* ref = sc + n_seg;
-    double lo = INFINITY, hi = -INFINITY, q_lo = INFINITY, q_hi = -INFINITY;
-    for (int i = tid; i < n; i += kBlock) {
+    double v[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
         const bool surf = i < S.Q;
         const int r = surf ? i : i - S.Q;
         const double q2 = surf ? S.s2S[r] : S.s2M[r];
-        q_lo = fmin(q_lo, q2); q_hi = fmax(q_hi, q2);
+        v[2] = fmin(v[2], q2); v[3] = fmax(v[3], q2);
         const double nrm = seg_norm(o, cc, q2);
         if (surf) nrefS[r] = nrm; else nrefM[r] = nrm;
         const double a = (surf ? S.pminS[r] : S.pminM[r]) / nrm, b = (surf ? S.pmaxS[r] : S.pmaxM[r]) / nrm;
-        lo = fmin(lo, fmin(a, b)); hi = fmax(hi, fmax(a, b));
-        if (o.unnormalize) { const double c = cc / nrm; lo = fmin(lo, c); hi = fmax(hi, c); }
+        v[0] = fmin(v[0], fmin(a, b)); v[1] = fmax(v[1], fmax(a, b));
+        if (o.unnormalize) { const double c = cc / nrm; v[0] = fmin(v[0], c); v[1] = fmax(v[1], c); }
     }
-    __shared__ double s_q[2][kBlock / 64];
-#pragma unroll
-    for (int w = 32; w > 0; w >>= 1) {
-        lo = fmin(lo, __shfl_xor(lo, w)); hi = fmax(hi, __shfl_xor(hi, w));
-        q_lo = fmin(q_lo, __shfl_xor(q_lo, w)); q_hi = fmax(q_hi, __shfl_xor(q_hi, w));
+    seg_ref_fold(v, s_w);
+    if (tid == 0) { for (int k = 0; k < 4; ++k) part[(size_t)blockIdx.x * 4 + k] = v[k]; if (blockIdx.x == 0) part[(size_t)gridDim.x * 4] = cc; }
+}
+__global__ __launch_bounds__(kBlock) void segp_ref_final_kernel(const double* __restrict__ part, int n_parts, SegConst* __restrict__ ref) {
+    __shared__ double s_w[4][kBlock / 64];
+    double v[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int p = threadIdx.x; p < n_parts; p += kBlock) {
+        v[0] = fmin(v[0], part[(size_t)p * 4]); v[1] = fmax(v[1], part[(size_t)p * 4 + 1]);
+        v[2] = fmin(v[2], part[(size_t)p * 4 + 2]); v[3] = fmax(v[3], part[(size_t)p * 4 + 3]);
     }
-    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; s_q[0][tid >> 6] = q_lo; s_q[1][tid >> 6] = q_hi; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < kBlock / 64; ++w) { lo = fmin(lo, s_lo[w]); hi = fmax(hi, s_hi[w]); q_lo = fmin(q_lo, s_q[0][w]); q_hi = fmax(q_hi, s_q[1][w]); }
+    seg_ref_fold(v, s_w);
+    if (threadIdx.x == 0) {
+        double lo = v[0], hi = v[1];
         if (!(hi > lo)) hi = lo + 1.0;
         // .rho of the reference slot carries the typical row's sum of squares (the segments derive their factor from it)
-        *ref = SegConst{cc, lo, 65535.0 / (hi - lo), (hi - lo) / 65535.0, 0.5 * (q_lo + q_hi), 0u, 0u};
+        *ref = SegConst{part[(size_t)n_parts * 4], lo, 65535.0 / (hi - lo), (hi - lo) / 65535.0, 0.5 * (v[2] + v[3]), 0u, 0u};
     }
 }
 
@@ -2015,7 +2026,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
 namespace {
 struct SegLayout {
     size_t PS, PM, rowS, rowM, nrefS, nrefM, Aq, Bq, Sc, sc, nrmS, nrmM, part_idx, part_s, idx, dist, bidx, bdist, cand_q, cand_m, n_cand, n_flag,
-           flag_list, flag2, n_flag2, fpi, fpd, grows, gnorms, qinfo, psum, map, n_slots, more_list, n_more, total;
+           flag_list, flag2, n_flag2, fpi, fpd, grows, gnorms, qinfo, psum, map, n_slots, more_list, n_more, refpart, total;
     int D2p, ldqa, ldqb, splits, chunk;
 };
 SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
@@ -2043,6 +2054,7 @@ SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
     L.flag_list = take(ns * q * 4); L.flag2 = take(ns * q * 4); L.n_flag2 = take(ns * 4);
     L.fpi = take(ns * kSegFbSlices * q * 2 * 4); L.fpd = take(ns * kSegFbSlices * q * 2 * 8);
     L.grows = take(ns * q * kNG * sizeof(SegGroupRows)); L.gnorms = take(ns * q * kNG * sizeof(SegGroupNorms)); L.qinfo = take(ns * q * sizeof(SegQueryInfo));
+    L.refpart = take((kRefParts * 4 + 1) * 8);
     L.psum = take(ns * q * kNG * kNC * 8); L.map = take(ns * q * kNG * 4); L.n_slots = take(ns * 4); L.more_list = take(ns * q * 4); L.n_more = take(ns * 4);
     L.total = b;
     return L;
@@ -2102,7 +2114,12 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
     const SegSets sets{PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q, rS + 5 * q, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, rM + 5 * vm,
                        seg_rows, seg_off, Q, VM, D, Dp, (size_t)S * q, (size_t)std::max(tot, 1)};
     hipLaunchKernelGGL(segp_cc_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, sc);
-    hipLaunchKernelGGL(segp_ref_kernel, dim3(1), dim3(kBlock), 0, st, sets, o, nrefS, nrefM, sc, S);
+    {
+        const int n_parts = std::max(1, std::min(kRefParts, (Q + VM + kBlock - 1) / kBlock));
+        double* refpart = (double*)(w + L.refpart);
+        hipLaunchKernelGGL(segp_ref_kernel, dim3(n_parts), dim3(kBlock), 0, st, sets, o, nrefS, nrefM, (const SegConst*)sc, S, refpart);
+        hipLaunchKernelGGL(segp_ref_final_kernel, dim3(1), dim3(kBlock), 0, st, (const double*)refpart, n_parts, sc + S);
+    }
     hipLaunchKernelGGL(segp_quantize_ref_kernel, dim3(L.ldqa / 64, L.D2p / 32), dim3(kBlock), 0, st, PS, nrefS, Q, D, Dp, sc + S, L.D2p, L.ldqa, Aq);
     hipLaunchKernelGGL(segp_quantize_ref_kernel, dim3(L.ldqb / 64, L.D2p / 32), dim3(kBlock), 0, st, PM, nrefM, VM, D, Dp, sc + S, L.D2p, L.ldqb, Bq);
     {
