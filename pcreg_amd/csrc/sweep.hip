@@ -11,28 +11,40 @@
 namespace pcreg {
 namespace {
 
-// dists = vecnorm(feat - c, 2, 2): sqrt((dx^2 + dy^2) + dz^2), compared with strict '<'
-__device__ __forceinline__ bool in_sphere(const double* __restrict__ feat, int i, double cx, double cy, double cz, double R) {
+// the smallest double t with sqrt(t) >= r under IEEE round-to-nearest (r > 0 finite): sqrt(d2) < r <=> d2 < t  (descriptors.hip has
+// the same function for getLocalPoints)
+__host__ __device__ inline double sphere_sqrt_threshold(double r) {
+    if (!(r > 0.0) || !(r < INFINITY)) return r > 0.0 ? r : 0.0;       // r <= 0 or NaN: nothing is inside; +inf: everything finite
+    double t = r * r;
+    for (int it = 0; it < 64 && t > 0.0 && sqrt(t) >= r; ++it) t = nextafter(t, 0.0);
+    for (int it = 0; it < 64 && sqrt(t) < r; ++it) t = nextafter(t, INFINITY);
+    return t;
+}
+// dists = vecnorm(feat - c, 2, 2): sqrt((dx^2 + dy^2) + dz^2), compared with strict '<' -- as a comparison of the square root's
+// ARGUMENT with R2T = sphere_sqrt_threshold(R): the same decision for every input (the rounded square root is monotone), without
+// an fp64 square root per (sphere, keypoint)
+__device__ __forceinline__ bool in_sphere(const double* __restrict__ feat, int i, double cx, double cy, double cz, double R2T) {
     const double dx = feat[(size_t)i * 3] - cx, dy = feat[(size_t)i * 3 + 1] - cy, dz = feat[(size_t)i * 3 + 2] - cz;
-    return sqrt((dx * dx + dy * dy) + dz * dz) < R;
+    return (dx * dx + dy * dy) + dz * dz < R2T;
 }
 
 // one workgroup per centre
-__global__ __launch_bounds__(256) void sphere_counts_kernel(const double* __restrict__ feat, int V, const double* __restrict__ centres,
-                                                            int S, double R, int32_t* __restrict__ counts) {
+__global__ __launch_bounds__(1024) void sphere_counts_kernel(const double* __restrict__ feat, int V, const double* __restrict__ centres,
+                                                             int S, double R2T, int32_t* __restrict__ counts) {
     const int s = blockIdx.x;
     const double cx = centres[(size_t)s * 3], cy = centres[(size_t)s * 3 + 1], cz = centres[(size_t)s * 3 + 2];
     int c = 0;
-    for (int i = threadIdx.x; i < V; i += 256) c += in_sphere(feat, i, cx, cy, cz, R);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < V; i += 1024) c += in_sphere(feat, i, cx, cy, cz, R2T);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    __shared__ int sc[4];
+    __shared__ int sc[16];
     if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[s] = sc[0] + sc[1] + sc[2] + sc[3];
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += sc[w]; counts[s] = t; }
 }
 
-__global__ __launch_bounds__(256) void sphere_flag_kernel(const double* __restrict__ feat, int V, double cx, double cy, double cz, double R,
+__global__ __launch_bounds__(256) void sphere_flag_kernel(const double* __restrict__ feat, int V, double cx, double cy, double cz, double R /* the threshold R2T */,
                                                           int32_t* __restrict__ flag, int32_t* __restrict__ block_cnt) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool in = i < V && in_sphere(feat, i, cx, cy, cz, R);
@@ -61,7 +73,7 @@ __global__ __launch_bounds__(256) void sphere_scatter_kernel(const int32_t* __re
 // ascending 0-based row list of sphere s at idx[seg_off[s] ..] (seg_off from sphere_counts: the same predicate, so the
 // lengths agree; a longer list would be cut) and, optionally, featCur = feat(mask, :) beside it.
 __global__ __launch_bounds__(1024) void sphere_select_batched_kernel(const double* __restrict__ feat, int V, const double* __restrict__ centres,
-                                                                     double R, const int32_t* __restrict__ seg_off, int32_t* __restrict__ idx,
+                                                                     double R /* the threshold R2T */, const int32_t* __restrict__ seg_off, int32_t* __restrict__ idx,
                                                                      double* __restrict__ feat_out, int32_t* __restrict__ n_out) {
     __shared__ int sc[16];
     __shared__ int s_base;
@@ -244,7 +256,7 @@ __global__ void quick_tf_kernel(const double* __restrict__ pts, int n, int ld, T
 
 int launch_sphere_counts(const double* feat, int V, const double* centres, int S, double R, int32_t* counts, hipStream_t st) {
     if (S <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(sphere_counts_kernel, dim3(S), dim3(256), 0, st, feat, V, centres, S, R, counts);
+    hipLaunchKernelGGL(sphere_counts_kernel, dim3(S), dim3(1024), 0, st, feat, V, centres, S, sphere_sqrt_threshold(R), counts);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
@@ -260,7 +272,7 @@ int launch_sphere_select(const double* feat, int V, const double c[3], double R,
     int32_t* flag = (int32_t*)ws;
     int32_t* bc = (int32_t*)((char*)ws + align_up((size_t)V * 4, 256));
     const int nb = (V + 255) / 256;
-    hipLaunchKernelGGL(sphere_flag_kernel, dim3(nb), dim3(256), 0, st, feat, V, c[0], c[1], c[2], R, flag, bc);
+    hipLaunchKernelGGL(sphere_flag_kernel, dim3(nb), dim3(256), 0, st, feat, V, c[0], c[1], c[2], sphere_sqrt_threshold(R), flag, bc);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, bc, nb, n_out);
     hipLaunchKernelGGL(sphere_scatter_kernel, dim3(nb), dim3(256), 0, st, flag, V, bc, idx);
     PCREG_HIP(hipGetLastError());
@@ -270,7 +282,7 @@ int launch_sphere_select(const double* feat, int V, const double c[3], double R,
 int launch_sphere_select_batched(const double* feat, int V, const double* centres, int S, double R, const int32_t* seg_off, int32_t* idx,
                                  double* feat_out, int32_t* n_out, hipStream_t st) {
     if (S <= 0) return PCREG_OK;
-    hipLaunchKernelGGL(sphere_select_batched_kernel, dim3(S), dim3(1024), 0, st, feat, V, centres, R, seg_off, idx, feat_out, n_out);
+    hipLaunchKernelGGL(sphere_select_batched_kernel, dim3(S), dim3(1024), 0, st, feat, V, centres, sphere_sqrt_threshold(R), seg_off, idx, feat_out, n_out);
     PCREG_HIP(hipGetLastError());
     return PCREG_OK;
 }
