@@ -83,6 +83,31 @@ def test_sphere_counts_select_and_gather(oracle_py):
     assert e["num_desc"] == 0 and e["num_putative"] == 0
 
 
+def test_sphere_masks_decide_like_the_square_root_at_the_boundary(oracle_py):
+    """The sphere kernels compare the square root's ARGUMENT with the smallest double whose rounded root reaches R
+    (sphere_sqrt_threshold) instead of taking an fp64 square root per (sphere, keypoint).  Keypoints parked within a few ulps of
+    the sphere's surface -- for radii whose square is not a double, and whose square root is not either -- must get the
+    decision of `vecnorm(feat - c, 2, 2) < R` (getDescriptorMask, completeExperimentFast.m:435-439), counts and row lists."""
+    import torch
+    from pcreg_amd.sweep import SphereSweep
+    rng = np.random.default_rng(8)
+    for R in (9.0, 9.1, 0.3, float(np.sqrt(7.0)), 1e-3, 123.456):
+        c = rng.uniform(-5, 5, 3)
+        u = rng.standard_normal((4000, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+        k = rng.integers(-4, 5, (4000, 1))
+        feat = c + u * (R * (1.0 + k * 2.220446049250313e-16))                  # distances within a few ulps of R, either side
+        feat = np.vstack([feat, c + u[:500] * R * rng.uniform(0.2, 1.8, (500, 1))])
+        d = feat - c
+        want = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]) < R
+        assert 100 < want[:4000].sum() < 3900                                       # the boundary really splits the parked points
+        np.testing.assert_array_equal(want, oracle_py.getDescriptorMask(feat, c, R))
+        sw = SphereSweep(feat, np.zeros((feat.shape[0], 4)), feat[:8], np.zeros((8, 4)))
+        _, n = sw.valid_spheres(np.array([c]), R, min_pts=1)
+        assert int(n[0]) == int(want.sum()), R
+        m = sw.match_sphere(c, R, PAR)
+        np.testing.assert_array_equal(m["rows"].cpu().numpy(), np.nonzero(want)[0])
+
+
 def test_quicktf_inverttf_and_distance_refine(oracle_py):
     import torch
     import pcreg_amd as pc
