@@ -747,6 +747,18 @@ def extra_host_tier(dev, with_cpu: bool) -> dict:
         rows = np.arange(0, 1500, 1)
         pc.getMatchesOnSet(hS, hM, rows, par)
         res["getMatchesOnSet_2000x1500_ms"] = round(wall(lambda: pc.getMatchesOnSet(hS, hM, rows, par)), 2)
+    # all spheres of the sweep in one call: 329 row subsets (~1533 rows each) of a 60 000 x 980 model set, 2000 surface rows --
+    # with the 470 MB model set uploaded by every call, and with both sets resident
+    VMs, Ss = 60_000, 329
+    dMs = rng.poisson(3.0, (VMs, 980)).astype(np.float64)
+    dSs = F((dMs[rng.choice(VMs, 2000, replace=False)] + rng.poisson(0.15, (2000, 980))).astype(np.float64)); dMs = F(dMs)
+    rows_list = [np.sort(rng.choice(VMs, 1533, replace=False)) for _ in range(Ss)]
+    pc.getMatchesSegmented(dSs, dMs, rows_list, par)
+    res["getMatchesSegmented_329x1533_ms"] = round(wall(lambda: pc.getMatchesSegmented(dSs, dMs, rows_list, par), 2), 1)
+    with pc.DescSet(dSs) as hS, pc.DescSet(dMs) as hM:
+        pc.getMatchesSegmentedOnSet(hS, hM, rows_list, par)
+        res["getMatchesSegmentedOnSet_329x1533_ms"] = round(wall(lambda: pc.getMatchesSegmentedOnSet(hS, hM, rows_list, par), 2), 1)
+    del dSs, dMs
     Q, M = 50_000, 200_000
     dM = rng.poisson(3.0, (M, 980)).astype(np.float64)
     dS = F((dM[rng.choice(M, Q, replace=False)] + rng.poisson(0.15, (Q, 980))).astype(np.float64)); dM = F(dM)
@@ -789,6 +801,7 @@ def summary_of(out: dict) -> dict:
           "chain_sweep_ms": g(ex, "desc_chain", "sweep", "ms"), "chain_sweep_right": g(ex, "desc_chain", "sweep", "registered_right"),
           "host_ransac_ms": g(ex, "host_tier", "ransac_n1000_ms"), "host_cfg2_ms": g(ex, "host_tier", "getMatches_50kx200k_ms"),
           "host_sphere_ms": g(ex, "host_tier", "getMatches_2000x1500_ms"), "host_sphere_on_sets_ms": g(ex, "host_tier", "getMatchesOnSet_2000x1500_ms"),
+          "host_sweep_ms": g(ex, "host_tier", "getMatchesSegmented_329x1533_ms"), "host_sweep_on_sets_ms": g(ex, "host_tier", "getMatchesSegmentedOnSet_329x1533_ms"),
           "host_desc100k_ms": g(ex, "host_tier", "descriptors_100k_ms")}
     return {k: v for k, v in sm.items() if v is not None}
 

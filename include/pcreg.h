@@ -190,6 +190,11 @@ int pcreg_desc_set_destroy(pcreg_desc_set* set);
 int pcreg_desc_set_size(const pcreg_desc_set* set, int* n, int* D);
 int pcreg_get_matches_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* model_rows, int n_rows,
                               const pcreg_match_opts* par, uint32_t* pairs, double* metric, int* P);
+/* pcreg_get_matches_segmented on uploaded sets: ALL spheres of the loop above in one call, nothing but the row lists going up and
+ * the pairs coming down (the 470 MB of a 60 000 x 980 model set take longer to upload than the whole sweep takes to match).
+ * Arguments and results as pcreg_get_matches_segmented; the sets keep a row-major copy from their first segmented call on. */
+int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* seg_rows,
+                                        const int32_t* seg_off, int S, const pcreg_match_opts* par, uint32_t* pairs_all, int32_t* n_pairs);
 
 /* AlignPoints_KNN.m:1  [pts_aligned, coeff_unambig, c] = AlignPoints_KNN(pts, C1, C2).
  * aligned: n x 3 (ld n); coeff: column-major 3x3; c: 3. */

@@ -288,6 +288,46 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             }
             mxDestroyArray(buf); mxDestroyArray(r0);
         }
+    } else if (!strcmp(cmd, "getMatchesSegmentedOnSet")) {    // [pairs, nPairs] = pcreg_mex('getMatchesSegmentedOnSet', hSurface, hModel, int32(rows), int32(segOff), par)
+        // getMatchesSegmented on the resident sets: rows / segOff / outputs as there.  matlab/getMatchesSegmentedOnSet.m
+        if (nrhs != 6 || !mxIsUint64(prhs[1]) || !mxIsUint64(prhs[2]) || !mxIsInt32(prhs[3]) || !mxIsInt32(prhs[4]))
+            usage = "getMatchesSegmentedOnSet: hSurface (uint64), hModel (uint64), int32 rows, int32 segOff, par";
+        else {
+            const mxArray* p = prhs[5];
+            pcreg_match_opts o;
+            o.metric = field_is(p, "Metric", "SAD") ? PCREG_METRIC_SAD : PCREG_METRIC_SSD;
+            o.matchThreshold = field(p, "MatchThreshold", 1.0); o.maxRatio = field(p, "MaxRatio", 0.6);
+            o.unique = (int)field(p, "Unique", 0); o.prenormalized = 0;
+            o.unnormalize = (int)field(p, "UNNORMALIZE", 0); o.norm_factor = field(p, "norm_factor", 0.0);
+            o.change_metric = (int)field(p, "CHANGE_METRIC", 0); o.metric_factor = field(p, "metric_factor", 1.0);
+            pcreg_desc_set* hS = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]);
+            pcreg_desc_set* hM = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[2]);
+            int Q = 0, D = 0;
+            rc = pcreg_desc_set_size(hS, &Q, &D);
+            const int S = (int)(mxGetM(prhs[4]) * mxGetN(prhs[4])) - 1;
+            const size_t tot = mxGetM(prhs[3]) * mxGetN(prhs[3]);
+            const int32_t* off = (const int32_t*)mxGetData(prhs[4]);
+            if (S < 0 || off[0] != 0 || (size_t)off[S] != tot) usage = "getMatchesSegmentedOnSet: segOff must run from 0 to numel(rows)";
+            else if (rc == PCREG_OK) {
+                mxArray* r0 = mxCreateNumericMatrix(tot > 0 ? tot : 1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* buf = mxCreateNumericMatrix(2, (size_t)(S > 0 ? S : 1) * (Q > 0 ? Q : 1), mxUINT32_CLASS, mxREAL);
+                mxArray* np = mxCreateNumericMatrix(S > 0 ? S : 1, 1, mxINT32_CLASS, mxREAL);
+                int32_t* rz = (int32_t*)mxGetData(r0); const int32_t* r1 = (const int32_t*)mxGetData(prhs[3]);
+                for (size_t k = 0; k < tot; ++k) rz[k] = r1[k] - 1;
+                rc = pcreg_get_matches_segmented_on_sets(hS, hM, rz, off, S, &o, (uint32_t*)mxGetData(buf), (int32_t*)mxGetData(np));
+                if (rc == PCREG_OK) {
+                    const int32_t* n = (const int32_t*)mxGetData(np);
+                    size_t P = 0; for (int z = 0; z < S; ++z) P += (size_t)n[z];
+                    plhs[0] = mxCreateNumericMatrix(P, 2, mxUINT32_CLASS, mxREAL);
+                    const uint32_t* src = (const uint32_t*)mxGetData(buf); uint32_t* dst = (uint32_t*)mxGetData(plhs[0]);
+                    size_t k = 0;
+                    for (int z = 0; z < S; ++z)
+                        for (int e = 0; e < n[z]; ++e, ++k) { dst[k] = src[((size_t)z * Q + e) * 2]; dst[k + P] = src[((size_t)z * Q + e) * 2 + 1]; }
+                    if (nlhs > 1) { plhs[1] = mxCreateNumericMatrix(S, 1, mxINT32_CLASS, mxREAL); memcpy(mxGetData(plhs[1]), n, (size_t)S * 4); }
+                }
+                mxDestroyArray(r0); mxDestroyArray(buf); mxDestroyArray(np);
+            }
+        }
     } else if (!strcmp(cmd, "descDestroy")) {
         if (nrhs != 2 || !mxIsUint64(prhs[1])) usage = "descDestroy: handle (uint64)";
         else rc = pcreg_desc_set_destroy((pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]));

@@ -360,6 +360,23 @@ def getMatchesSegmented(descSurface, descModel, rows_list, par: dict) -> list:
     return [pairs[z, :n_pairs[z]].copy() for z in range(S)]
 
 
+def getMatchesSegmentedOnSet(hSurface: DescSet, hModel: DescSet, rows_list, par: dict) -> list:
+    """getMatchesSegmented on resident sets (pcreg_get_matches_segmented_on_sets): every sphere of completeExperimentFast.m:131-149
+    in one call with only the row lists going up and the pairs coming down."""
+    if hSurface.D != hModel.D:
+        raise ValueError("descriptor lengths differ")
+    Q, S = hSurface.n, len(rows_list)
+    off = np.zeros(S + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(r) for r in rows_list])
+    rows = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.int32).ravel() for r in rows_list] + [np.zeros(0, np.int32)]))
+    o = _match_opts(par)
+    pairs = np.zeros((max(S, 1), max(Q, 1), 2), dtype=np.uint32)
+    n_pairs = np.zeros(max(S, 1), dtype=np.int32)
+    check(lib().pcreg_get_matches_segmented_on_sets(hSurface._h, hModel._h, _ptr(rows, C.c_int32) if rows.size else None, _ptr(off, C.c_int32), S,
+                                                    C.byref(o), _ptr(pairs, C.c_uint32), _ptr(n_pairs, C.c_int32)))
+    return [pairs[z, :n_pairs[z]].copy() for z in range(S)]
+
+
 def getMatches(descSurface, descModel, par: dict) -> np.ndarray:
     """matches = getMatches(descSurface, descModel, par)  (getMatches.m:1-59):
     P x 2 uint32, 1-based [surfaceIdx, modelIdx], ascending in the first column."""

@@ -494,7 +494,8 @@ static int match_host(const double* f1, int Q, int ld1, const double* f2, int M,
 
 // ---- resident descriptor sets (host tier): one surface set against hundreds of row subsets of one model set
 // (completeExperimentFast.m:101-150) without re-uploading ~28 MB of doubles per sphere
-struct pcreg_desc_set { double* d; int n, D; };       // n x D, column-major on the device (ld = n), as uploaded
+struct pcreg_desc_set { double* d; int n, D; double* rows; };       // d: n x D column-major on the device (ld = n), as uploaded; rows: the dense
+                                                                     // row-major copy the segmented matcher reads, made at its first use
 
 __global__ void gather_cols_kernel(const double* __restrict__ src, int n_src, int D, const int32_t* __restrict__ rows, int n, double* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, d = blockIdx.y;
@@ -510,7 +511,7 @@ int pcreg_desc_set_create(const double* desc, int n, int ld, int D, pcreg_desc_s
     int rc = upload_cols(desc, n, ld, D, d, g_stream);
     if (!rc && hipStreamSynchronize(g_stream) != hipSuccess) { set_error("descriptor upload failed"); rc = PCREG_E_HIP; }
     if (rc) { (void)hipFree(d); return rc; }
-    *set = new pcreg_desc_set{d, n, D};
+    *set = new pcreg_desc_set{d, n, D, nullptr};
     return PCREG_OK;
 }
 int pcreg_desc_set_destroy(pcreg_desc_set* set) {
@@ -518,6 +519,7 @@ int pcreg_desc_set_destroy(pcreg_desc_set* set) {
     std::lock_guard<std::mutex> lock(g_mu);
     (void)hipDeviceSynchronize();
     (void)hipFree(set->d);
+    if (set->rows) (void)hipFree(set->rows);
     delete set;
     return PCREG_OK;
 }
@@ -625,6 +627,55 @@ int pcreg_get_matches_segmented(const double* descSurface, int Q, int ldS, const
     PCREG_HIP(hipMemcpyAsync(dr, seg_rows, sizeof(int32_t) * (size_t)tot, hipMemcpyHostToDevice, g_stream));
     PCREG_HIP(hipMemcpyAsync(doff, seg_off, sizeof(int32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, g_stream));
     TRY(launch_get_matches_segmented((const double*)rS, Q, (const double*)rM, VM, D, (const int32_t*)dr, (const int32_t*)doff, S, tot, n_max, *par,
+                                     (uint32_t*)dp, nullptr, (int32_t*)dn, ws, wsb, g_stream));
+    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * q * 2, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    return PCREG_OK;
+}
+
+// the set's rows as the segmented matcher wants them (dense row-major), transposed once per set (caller holds the library lock)
+static int desc_set_rows(const pcreg_desc_set* cs, const double** out) {
+    pcreg_desc_set* s = const_cast<pcreg_desc_set*>(cs);
+    if (!s->rows) {
+        double* r = nullptr;
+        PCREG_HIP(hipMalloc((void**)&r, sizeof(double) * (size_t)(s->n > 0 ? s->n : 1) * s->D));
+        const int rc = s->n > 0 ? launch_transpose_rows(s->d, s->n, s->n, s->D, r, g_stream) : PCREG_OK;
+        if (rc) { (void)hipFree(r); return rc; }
+        s->rows = r;
+    }
+    *out = s->rows;
+    return PCREG_OK;
+}
+int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* seg_rows,
+                                        const int32_t* seg_off, int S, const pcreg_match_opts* par, uint32_t* pairs_all, int32_t* n_pairs) {
+    PCREG_ARG(surface && model && seg_off && par && pairs_all && n_pairs && S >= 0 && surface->D == model->D);
+    PCREG_ARG(S <= 65535);
+    if (par->metric != PCREG_METRIC_SAD) { set_error("pcreg_get_matches_segmented_on_sets: Metric must be SAD (call pcreg_get_matches_on_sets per segment for SSD)"); return PCREG_E_ARG; }
+    GUARD();
+    if (S == 0) return PCREG_OK;
+    const int Q = surface->n, VM = model->n, D = surface->D;
+    PCREG_ARG(seg_off[0] == 0);
+    int n_max = 0;
+    for (int z = 0; z < S; ++z) { const int n = seg_off[z + 1] - seg_off[z]; PCREG_ARG(n >= 0); if (n > n_max) n_max = n; }
+    const int tot = seg_off[S];
+    PCREG_ARG(tot == 0 || seg_rows);
+    for (int k = 0; k < tot; ++k) PCREG_ARG(seg_rows[k] >= 0 && seg_rows[k] < VM);
+    if (Q == 0 || VM == 0 || tot == 0) { for (int z = 0; z < S; ++z) n_pairs[z] = 0; return PCREG_OK; }
+    const double *rS, *rM;
+    TRY(desc_set_rows(surface, &rS));
+    TRY(desc_set_rows(model, &rM));
+    const size_t q = (size_t)Q;
+    void *dr, *doff, *dp, *dn, *ws;
+    TRY(scratch().get(4, sizeof(int32_t) * (size_t)tot, &dr));
+    TRY(scratch().get(5, sizeof(int32_t) * ((size_t)S + 1), &doff));
+    TRY(scratch().get(6, sizeof(uint32_t) * (size_t)S * q * 2, &dp));
+    TRY(scratch().get(7, sizeof(int32_t) * (size_t)S, &dn));
+    const size_t wsb = get_matches_segmented_workspace_bytes(Q, VM, D, S, tot, n_max);
+    TRY(scratch().get(8, wsb, &ws));
+    PCREG_HIP(hipMemcpyAsync(dr, seg_rows, sizeof(int32_t) * (size_t)tot, hipMemcpyHostToDevice, g_stream));
+    PCREG_HIP(hipMemcpyAsync(doff, seg_off, sizeof(int32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, g_stream));
+    TRY(launch_get_matches_segmented(rS, Q, rM, VM, D, (const int32_t*)dr, (const int32_t*)doff, S, tot, n_max, *par,
                                      (uint32_t*)dp, nullptr, (int32_t*)dn, ws, wsb, g_stream));
     PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * q * 2, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));

@@ -229,6 +229,39 @@ int drv_desc_set_round_trip(const double* dS, int Q, const double* dM, int VM, i
     return rc;
 }
 
+// descCreate x 2, ONE getMatchesSegmentedOnSet for all row subsets (rows1: 1-based, subsets back to back, off: n_sub + 1 offsets),
+// descDestroy x 2.  pairs_colmajor: sum(P) x 2 as the gateway returns it; P: the S counts
+int drv_desc_set_segmented(const double* dS, int Q, const double* dM, int VM, int D, const double* par7, const int32_t* rows1, int n_rows,
+                           const int32_t* off, int n_sub, uint32_t* pairs_colmajor, int* P, int* P_total, char* err, int errlen) {
+    mxArray* lhs[2] = {nullptr, nullptr};
+    { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dS, Q, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* hS = lhs[0]; lhs[0] = nullptr;
+    { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dM, VM, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* hM = lhs[0]; lhs[0] = nullptr;
+    mxArray* p = mxCreateStructMatrix(1, 1, 0, nullptr);
+    mxSetField(p, 0, "Metric", mxCreateString("SAD")); mxSetField(p, 0, "Method", mxCreateString("Approximate"));
+    put(p, "MatchThreshold", par7[0]); put(p, "MaxRatio", par7[1]); put(p, "Unique", par7[2]); put(p, "UNNORMALIZE", par7[3]);
+    put(p, "norm_factor", par7[4]); put(p, "CHANGE_METRIC", par7[5]); put(p, "metric_factor", par7[6]); put(p, "VERBOSE", 0);
+    mxArray* r = mxCreateNumericMatrix(n_rows > 0 ? n_rows : 0, 1, mxINT32_CLASS, mxREAL);
+    if (n_rows > 0) memcpy(mxGetData(r), rows1, (size_t)n_rows * 4);
+    mxArray* o = mxCreateNumericMatrix(n_sub + 1, 1, mxINT32_CLASS, mxREAL);
+    memcpy(mxGetData(o), off, (size_t)(n_sub + 1) * 4);
+    int rc = 0;
+    {
+        std::vector<mxArray*> rhs{mxCreateString("getMatchesSegmentedOnSet"), mxDuplicateArray(hS), mxDuplicateArray(hM), r, o, p};
+        rc = call(2, lhs, rhs, err, errlen);
+    }
+    if (!rc) {
+        *P_total = (int)mxGetM(lhs[0]);
+        memcpy(pairs_colmajor, mxGetData(lhs[0]), (size_t)*P_total * 2 * 4);
+        memcpy(P, mxGetData(lhs[1]), (size_t)n_sub * 4);
+        mxDestroyArray(lhs[0]); mxDestroyArray(lhs[1]); lhs[0] = lhs[1] = nullptr;
+    }
+    { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hS}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hM}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    return rc;
+}
+
 // one-worker rehearsal of the spmd block of INTEGRATION.md section 3: setDevice, commId, commInit, matchPointsSharded,
 // ransacSharded, commDestroy -- all through the gateway
 int drv_comm_round_trip(const float* surf, int Q, const float* model, int M, float thr, float ratio, uint32_t* pairs_colmajor, int* P,

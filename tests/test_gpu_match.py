@@ -212,6 +212,21 @@ def test_get_matches_on_resident_sets_equals_get_matches(par_over, oracle_c):
                 np.testing.assert_array_equal(want, oracle_c.getMatches(dS, sub, par))
         with pytest.raises(Exception):
             pc.getMatchesOnSet(hS, hM, np.array([M]), par)                 # out of range: an argument error, not a fault
+        if par["Metric"] == "SAD":
+            # all subsets in ONE call on the resident sets (pcreg_get_matches_segmented_on_sets) == the per-subset calls == the host form
+            rows_list = [np.sort(rng.choice(M, 700, replace=False)), np.arange(0, M, 3), np.array([5]), np.zeros(0, np.int64), np.arange(M)]
+            on = pc.getMatchesSegmentedOnSet(hS, hM, rows_list, par)
+            host = pc.getMatchesSegmented(dS, dM, rows_list, par)
+            for z, r in enumerate(rows_list):
+                want = pc.getMatchesOnSet(hS, hM, r, par) if len(r) else np.zeros((0, 2), np.uint32)
+                np.testing.assert_array_equal(on[z], want, err_msg=f"segment {z}")
+                np.testing.assert_array_equal(host[z], want, err_msg=f"segment {z}")
+            assert pc.getMatchesSegmentedOnSet(hS, hM, [], par) == []
+            with pytest.raises(Exception):
+                pc.getMatchesSegmentedOnSet(hS, hM, [np.array([M])], par)
+        else:
+            with pytest.raises(Exception):
+                pc.getMatchesSegmentedOnSet(hS, hM, [np.arange(10)], par)  # SSD: refused, as by the host form
 
 
 def test_match_stats_hook_counts_what_the_certificate_did(debug_set):

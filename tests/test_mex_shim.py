@@ -132,6 +132,21 @@ def test_shim_round_trips_equal_the_ctypes_path(drv):
         assert npairs[z] == len(wz) and np.array_equal(allp[k:k + npairs[z]], wz) and np.array_equal(seg[z], wz)
         k += npairs[z]
     assert k == Pt.value
+    # getMatchesSegmentedOnSet: the three subsets in ONE gateway call on resident sets == getMatchesSegmented, and the Python mirror
+    off3 = np.zeros(len(rows_list) + 1, dtype=np.int32); off3[1:] = np.cumsum([len(r) for r in rows_list])
+    rows13 = (np.concatenate(rows_list) + 1).astype(np.int32)
+    pairs5 = np.zeros(len(rows_list) * 60 * 2, dtype=np.uint32); P5 = (C.c_int * len(rows_list))(); Pt5 = C.c_int()
+    assert drv.drv_desc_set_segmented(_p(_d(dS)), 60, _p(_d(dM)), 90, 980, _p(par7), _p(rows13, C.c_int32), len(rows13), _p(off3, C.c_int32),
+                                      len(rows_list), _p(pairs5, C.c_uint32), P5, C.byref(Pt5), e, 1024) == 0, e.value
+    assert Pt5.value == Pt.value and list(P5) == [int(x) for x in npairs[:len(rows_list)]]
+    assert np.array_equal(pairs5[:2 * Pt5.value].reshape(Pt5.value, 2, order="F"), allp)
+    with pc.DescSet(dS) as hS, pc.DescSet(dM) as hM:
+        on = pc.getMatchesSegmentedOnSet(hS, hM, rows_list, par)
+        on2 = pc.getMatchesSegmentedOnSet(hS, hM, rows_list[::-1], par)          # the sets' row-major copies are reused
+        one = pc.getMatchesOnSet(hS, hM, rows_list[0], par)                        # and the column-major ones still serve the per-sphere call
+    for z in range(len(rows_list)):
+        assert np.array_equal(on[z], seg[z]) and np.array_equal(on2[len(rows_list) - 1 - z], seg[z])
+    assert np.array_equal(one, seg[0])
     # AlignPoints_KNN
     X = rng.normal(size=(500, 3)) * [3.0, 1.5, 0.4] + 20
     al = np.zeros((500, 3), order="F"); co = np.zeros(9); c3 = np.zeros(3)
