@@ -94,6 +94,62 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
             }
             mxDestroyArray(inl);
         }
+    } else if (!strcmp(cmd, "ransacBatched")) {                // [T, inlierIdx, nInliers, numSuccess, maxInliers, failed] =
+        // pcreg_mex('ransacBatched', pts1, pts2, int32(offsets), coef[, sampleIdx, seed]): B registrations in one launch (the parfor of
+        // completeExperimentFast.m:201-216).  pts1 / pts2: the registrations' rows back to back (total x 3); offsets: B + 1 running row
+        // offsets (0-based); sampleIdx: int32 minPtNum x (iterNum B), registration after registration, or []; seed: registration b
+        // samples with seed + b.  T: 4 x 4 x B (zeros where failed); inlierIdx: the lists back to back (1-based inside a registration),
+        // nInliers / numSuccess / maxInliers / failed: B x 1.  matlab/ransacBatched.m
+        if (nrhs < 5 || !mxIsInt32(prhs[3])) usage = "ransacBatched: pts1, pts2, int32 offsets, coef[, sample_idx, seed]";
+        else {
+            const mxArray* c = prhs[4];
+            pcreg_ransac_opts o;
+            o.minPtNum = (int)field(c, "minPtNum", 3); o.iterNum = (int)field(c, "iterNum", 1000);
+            o.thDist = field(c, "thDist", 0.5); o.thInlrRatio = field(c, "thInlrRatio", 0.1);
+            o.REFINE = (int)field(c, "REFINE", 1); o.VERBOSE = (int)field(c, "VERBOSE", 1);
+            o.seed = nrhs > 6 ? (uint64_t)mxGetScalar(prhs[6]) : 0;
+            const int total = (int)mxGetM(prhs[1]);
+            const int B = (int)(mxGetM(prhs[3]) * mxGetN(prhs[3])) - 1;
+            const int32_t* off = (const int32_t*)mxGetData(prhs[3]);
+            const int32_t* si = (nrhs > 5 && !mxIsEmpty(prhs[5]) && mxIsInt32(prhs[5])) ? (const int32_t*)mxGetData(prhs[5]) : nullptr;
+            if (B < 0 || off[0] != 0 || off[B] != total || (int)mxGetM(prhs[2]) != total) usage = "ransacBatched: offsets must run from 0 to size(pts1, 1) = size(pts2, 1)";
+            else if (si && mxGetM(prhs[5]) * mxGetN(prhs[5]) != (size_t)o.minPtNum * (size_t)o.iterNum * (size_t)B) usage = "ransacBatched: sampleIdx must be minPtNum x (iterNum * B)";
+            else {
+                const size_t b1 = (size_t)(B > 0 ? B : 1);
+                mxArray* inl = mxCreateNumericMatrix(total > 0 ? total : 1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* ni = mxCreateNumericMatrix(b1, 1, mxINT32_CLASS, mxREAL); mxArray* ns = mxCreateNumericMatrix(b1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* mi = mxCreateNumericMatrix(b1, 1, mxINT32_CLASS, mxREAL); mxArray* fl = mxCreateNumericMatrix(b1, 1, mxINT32_CLASS, mxREAL);
+                mwSize dims[3] = {4, 4, (mwSize)B};
+                plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+                rc = B == 0 ? PCREG_OK : pcreg_ransac_batched(mxGetPr(prhs[1]), mxGetPr(prhs[2]), total, total > 0 ? total : 1, off, B, &o, si, mxGetPr(plhs[0]),
+                                                               (int32_t*)mxGetData(inl), (int32_t*)mxGetData(ni), (int32_t*)mxGetData(ns), (int32_t*)mxGetData(mi),
+                                                               (int32_t*)mxGetData(fl));
+                if (rc == PCREG_OK) {
+                    const int32_t *n_ = (const int32_t*)mxGetData(ni), *f_ = (const int32_t*)mxGetData(fl), *src = (const int32_t*)mxGetData(inl);
+                    size_t tot_inl = 0;
+                    for (int b = 0; b < B; ++b) {
+                        if (f_[b]) memset(mxGetPr(plhs[0]) + (size_t)b * 16, 0, 128);
+                        else tot_inl += (size_t)n_[b];
+                    }
+                    if (nlhs > 1) {                     // the inlier lists back to back, as a double column like find()
+                        plhs[1] = mxCreateDoubleMatrix(tot_inl, tot_inl ? 1 : 0, mxREAL);
+                        size_t k = 0;
+                        for (int b = 0; b < B; ++b) if (!f_[b]) for (int e = 0; e < n_[b]; ++e) mxGetPr(plhs[1])[k++] = (double)src[off[b] + e];
+                    }
+                    auto col = [&](const mxArray* a, bool zero_failed) {
+                        mxArray* out = mxCreateDoubleMatrix(B, B ? 1 : 0, mxREAL);
+                        const int32_t* v = (const int32_t*)mxGetData(a);
+                        for (int b = 0; b < B; ++b) mxGetPr(out)[b] = (zero_failed && f_[b]) ? 0.0 : (double)v[b];
+                        return out;
+                    };
+                    if (nlhs > 2) plhs[2] = col(ni, true);
+                    if (nlhs > 3) plhs[3] = col(ns, false);
+                    if (nlhs > 4) plhs[4] = col(mi, false);
+                    if (nlhs > 5) plhs[5] = col(fl, false);
+                }
+                mxDestroyArray(inl); mxDestroyArray(ni); mxDestroyArray(ns); mxDestroyArray(mi); mxDestroyArray(fl);
+            }
+        }
     } else if (!strcmp(cmd, "getMatches")) {
         if (nrhs != 4) usage = "getMatches: descSurface, descModel, par";
         else {

@@ -40,6 +40,12 @@ inline mxArray* mxCreateNumericMatrix(size_t m, size_t n, mxClassID c, mxComplex
     mxArray* a = new mxArray; a->cls = c; a->m = m; a->n = n; a->data.assign(m * n * mx_elem_size(c), 0); ++g_mex_live_arrays; return a;
 }
 inline mxArray* mxCreateDoubleMatrix(size_t m, size_t n, mxComplexity k) { return mxCreateNumericMatrix(m, n, mxDOUBLE_CLASS, k); }
+/* N-d arrays: stored as dims[0] x prod(dims[1..]) -- mxGetN of an N-d array is that product in MATLAB too */
+inline mxArray* mxCreateNumericArray(size_t ndim, const mwSize* dims, mxClassID c, mxComplexity k) {
+    size_t m = ndim > 0 ? dims[0] : 0, n = ndim > 1 ? 1 : (ndim == 1 ? 1 : 0);
+    for (size_t d = 1; d < ndim; ++d) n *= dims[d];
+    return mxCreateNumericMatrix(m, n, c, k);
+}
 inline mxArray* mxCreateDoubleScalar(double v) { mxArray* a = mxCreateDoubleMatrix(1, 1, mxREAL); memcpy(a->data.data(), &v, 8); return a; }
 inline mxArray* mxCreateString(const char* s) { mxArray* a = new mxArray; a->cls = mxCHAR_CLASS; a->m = 1; a->n = strlen(s); a->str = s; ++g_mex_live_arrays; return a; }
 inline mxArray* mxCreateStructMatrix(size_t, size_t, int, const char**) { mxArray* a = new mxArray; a->cls = mxSTRUCT_CLASS; a->m = a->n = 1; ++g_mex_live_arrays; return a; }

@@ -62,6 +62,31 @@ int drv_ransac(const double* p1, const double* p2, int n, const double* coef5, c
     return 0;
 }
 
+// B registrations through ONE 'ransacBatched' call: p1 / p2 total x 3 column-major, off B + 1 offsets, sample (or null): 3 x (iterNum B)
+int drv_ransac_batched(const double* p1, const double* p2, int total, const int32_t* off, int B, const double* coef5, const int32_t* sample, double seed,
+                       double* T16 /* B x 16 */, double* inlier_idx /* cap total */, int* n_inl_total, double* n_inl, double* num_success, double* max_inl,
+                       double* failed, char* err, int errlen) {
+    mxArray* c = mxCreateStructMatrix(1, 1, 0, nullptr);
+    put(c, "minPtNum", coef5[0]); put(c, "iterNum", coef5[1]); put(c, "thDist", coef5[2]); put(c, "thInlrRatio", coef5[3]);
+    put(c, "REFINE", coef5[4]); put(c, "VERBOSE", 0);
+    mxArray* o = mxCreateNumericMatrix(B + 1, 1, mxINT32_CLASS, mxREAL);
+    memcpy(mxGetData(o), off, (size_t)(B + 1) * 4);
+    mxArray* si;
+    if (sample) { const size_t ne = (size_t)coef5[0] * (size_t)coef5[1] * (size_t)B; si = mxCreateNumericMatrix((size_t)coef5[0], ne / (size_t)coef5[0], mxINT32_CLASS, mxREAL); memcpy(mxGetData(si), sample, ne * 4); }
+    else si = mxCreateDoubleMatrix(0, 0, mxREAL);
+    std::vector<mxArray*> rhs{mxCreateString("ransacBatched"), dmat(p1, total, 3), dmat(p2, total, 3), o, c, si, mxCreateDoubleScalar(seed)};
+    mxArray* lhs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (call(6, lhs, rhs, err, errlen)) return 1;
+    if (mxGetM(lhs[0]) != 4 || mxGetN(lhs[0]) != (size_t)4 * B) { snprintf(err, errlen, "T is not 4 x 4 x B"); return 1; }
+    memcpy(T16, mxGetPr(lhs[0]), (size_t)B * 128);
+    *n_inl_total = (int)(mxGetM(lhs[1]) * mxGetN(lhs[1]));
+    if (*n_inl_total) memcpy(inlier_idx, mxGetPr(lhs[1]), (size_t)*n_inl_total * 8);
+    memcpy(n_inl, mxGetPr(lhs[2]), (size_t)B * 8); memcpy(num_success, mxGetPr(lhs[3]), (size_t)B * 8);
+    memcpy(max_inl, mxGetPr(lhs[4]), (size_t)B * 8); memcpy(failed, mxGetPr(lhs[5]), (size_t)B * 8);
+    for (mxArray* a : lhs) mxDestroyArray(a);
+    return 0;
+}
+
 // par = {MatchThreshold, MaxRatio, Unique, UNNORMALIZE, norm_factor, CHANGE_METRIC, metric_factor}; metric "SAD" | "SSD"
 int drv_get_matches(const double* dS, int Q, const double* dM, int M, int D, const char* metric, const double* par7,
                     uint32_t* pairs_colmajor /* cap Q x 2 */, int* P, char* err, int errlen) {

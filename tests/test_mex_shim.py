@@ -95,6 +95,32 @@ def test_shim_round_trips_equal_the_ctypes_path(drv):
                           C.byref(ni), C.byref(ns), C.byref(mi), C.byref(fl), e, 1024) == 0, e.value
     assert fl.value == 0 and np.array_equal(T.reshape(4, 4, order="F"), ref[0])
     assert np.array_equal(inl[:ni.value], np.asarray(ref[1], dtype=np.float64).ravel()) and (ns.value, mi.value) == (ref[2], ref[3])
+    # ransacBatched: three registrations of different sizes (one of them hopeless: pure noise) in ONE gateway call, sample tables
+    # registration after registration -- every field equals the per-registration ransac calls
+    sizes = [300, 120, 40]
+    cases = [rigid_case(sizes[0], 5), rigid_case(sizes[1], 6), (rng.normal(size=(40, 3)), rng.normal(size=(40, 3)) * 7 + 3, None)]
+    tabs = [np.stack([rng.permutation(nn)[:3] + 1 for _ in range(iters)]).astype(np.int32) for nn in sizes]
+    refs = [pc.ransac(c[0], c[1], coef, pc.estimateTransform, pc.calcDists, sample_idx=tb) for c, tb in zip(cases, tabs)]
+    P1 = np.vstack([c[0] for c in cases]); P2 = np.vstack([c[1] for c in cases])
+    offb = np.zeros(4, dtype=np.int32); offb[1:] = np.cumsum(sizes)
+    tabB = np.asfortranarray(np.vstack(tabs).T)                                               # 3 x (iterNum B) column-major
+    TB = np.zeros(3 * 16); inlB = np.zeros(sum(sizes)); nit = C.c_int()
+    nB, nsB, miB, flB = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+    assert drv.drv_ransac_batched(_p(_d(P1)), _p(_d(P2)), sum(sizes), _p(offb, C.c_int32), 3, _p(coef5), _p(tabB, C.c_int32), C.c_double(0), _p(TB), _p(inlB),
+                                  C.byref(nit), _p(nB), _p(nsB), _p(miB), _p(flB), e, 1024) == 0, e.value
+    k = 0
+    for b, ref_b in enumerate(refs):
+        failed_b = ref_b[0] is None or np.size(ref_b[0]) == 0
+        assert bool(flB[b]) == failed_b, b
+        if failed_b:
+            assert nB[b] == 0 and not TB[16 * b:16 * b + 16].any()
+            continue
+        assert np.array_equal(TB[16 * b:16 * b + 16].reshape(4, 4, order="F"), ref_b[0]), b
+        want_inl = np.asarray(ref_b[1], dtype=np.float64).ravel()
+        assert nB[b] == len(want_inl) and np.array_equal(inlB[k:k + len(want_inl)], want_inl), b
+        assert (nsB[b], miB[b]) == (ref_b[2], ref_b[3]), b
+        k += len(want_inl)
+    assert k == nit.value and flB[2] == 1 and flB[0] == 0
     # getMatches (par struct with strings; P x 2 uint32 column-major out)
     dS = rng.poisson(3.0, (60, 980)).astype(np.float64); dM = rng.poisson(3.0, (90, 980)).astype(np.float64)
     dM[:40] = dS[:40] + (rng.random((40, 980)) < 0.02)
