@@ -565,6 +565,28 @@ def extra_sweep(dev, with_cpu: bool) -> dict:
                         "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None, "dedup_model_rows": union,
                         "sphere_overlap": round(pairs_per_sphere_calls / max(pairs_dedup, 1.0), 2),
                         "note": "(3D-1) flop per de-duplicated pair; kernel split: docs/BENCH_NOTES.md"}}
+    try:
+        # the same sweep through the HOST tier (pcreg_sphere_counts + pcreg_sphere_sweep: what matlab/sphereSweep.m calls), keypoints
+        # as pageable host arrays, the two descriptor sets resident (pcreg_desc_set_create, not timed: once per model / surface)
+        import pcreg_amd as pc
+        centres_all = sw.sphere_centres(kw["d_spheres"])
+        with pc.DescSet(np.asfortranarray(descS.cpu().numpy())) as hS, pc.DescSet(np.asfortranarray(descM.cpu().numpy())) as hM:
+            fMf, fSf = np.asfortranarray(featM), np.asfortranarray(featS)
+            def host_sweep():
+                cnt = pc.sphereCounts(fMf, centres_all, kw["R_desc"])
+                keep = cnt >= kw["min_pts"]
+                return pc.sphereSweep(hS, hM, fSf, fMf, centres_all[keep], cnt[keep], kw["R_desc"], par, kw["putative_thresh"], opt, seed=kw["seed"])
+            h = host_sweep()
+            th = []
+            for _ in range(3):
+                t0 = time.perf_counter(); h = host_sweep(); th.append(time.perf_counter() - t0)
+        same = (np.array_equal(h["trial"], out["trial"]) and np.array_equal(h["num_putative"], out["num_putative"]) and
+                all(np.array_equal(a, b) for a, b in zip(h["matches"], out["matches"])) and
+                all((a is None) == (b is None) and (a is None or np.array_equal(a, b)) for a, b in zip(h["transforms"], out["transforms"])))
+        res["host_tier"] = {"ms": round(min(th) * 1e3, 2), "same_as_device_driver": bool(same),
+                            "note": "pcreg_sphere_counts + pcreg_sphere_sweep, descriptor sets resident, keypoints + results over PCIe"}
+    except Exception as e:
+        res["host_tier"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:
         from oracle import c_oracle
         import oracle.pcreg_oracle as opy
@@ -792,7 +814,7 @@ def summary_of(out: dict) -> dict:
           "cfg4_ms": g(ex, "descriptors_cfg4", "ms"), "cfg4_frac": g(ex, "descriptors_cfg4", "roofline", "frac"),
           "align_ms": g(ex, "align_points_knn_batched", "ms"), "align_frac": g(ex, "align_points_knn_batched", "roofline", "frac"),
           "cfg1_ms": g(ex, "ransac_cfg1", "ms"), "cfg1b_ms": g(ex, "ransac_cfg1_batched", "ms"), "cfg1b_frac": g(ex, "ransac_cfg1_batched", "roofline", "frac"),
-          "sweep_ms": g(ex, "sweep", "ms"), "sweep_frac": g(ex, "sweep", "roofline", "frac"),
+          "sweep_ms": g(ex, "sweep", "ms"), "sweep_host_ms": g(ex, "sweep", "host_tier", "ms"), "sweep_frac": g(ex, "sweep", "roofline", "frac"),
           "cfg5_regs_per_s": g(out, "cfg5_batch", "registrations_per_s"),
           "step_serial_ms": g(out, "two_in_flight", "model_1M", "one_in_flight_ms"),
           "two_1M_x": g(out, "two_in_flight", "model_1M", "speedup"), "two_125k_x": g(out, "two_in_flight", "rank_of_8_emulated_125k", "speedup"),

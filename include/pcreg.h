@@ -196,6 +196,26 @@ int pcreg_get_matches_on_sets(const pcreg_desc_set* surface, const pcreg_desc_se
 int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* seg_rows,
                                         const int32_t* seg_off, int S, const pcreg_match_opts* par, uint32_t* pairs_all, int32_t* n_pairs);
 
+/* The sphere sweep of completeExperimentFast.m:46-224 at the host tier, in two calls (the first fixes the sizes of the second).
+ *
+ * pcreg_sphere_counts: counts[i] = #{ rows of featModel with norm(row - centres(i, :)) < R }  (:52-64; featModel VM x 3, centres
+ * S x 3, both column-major doubles).  The caller keeps the spheres with min_pts <= counts <= max_pts (:61-64).
+ *
+ * pcreg_sphere_sweep, for the S spheres kept (centres S x 3, num_desc[i] = their counts): per sphere
+ *     mask = getDescriptorMask(featModel, c_i, R_desc);  matches = getMatches(descSurface, descModel(mask, :), par)      (:109-149)
+ * on resident descriptor sets (pcreg_desc_set_create), then for every sphere with more than putative_thresh matches (:166-184)
+ *     [T, ~, numSuccess, maxInliers] = ransac(featSurface(matches(:,1), :), featCur(matches(:,2), :), coef, ...)          (:201-216)
+ * with the built-in sampler seeded coef->seed + t for the t-th such sphere -- one launch chain, two synchronisations.
+ * Outputs: model_rows: the spheres' 0-based ascending row lists back to back (sum of num_desc entries); pairs_all [S][Q][2]
+ * (Q = rows of the surface set) and n_pairs[S] as pcreg_get_matches_segmented; trial[t], t < *n_trials: the 0-based spheres
+ * that were registered, in ascending order; T (16 per trial, column-major 4 x 4, zeros where failed[t]), num_success, max_inliers,
+ * failed: capacity S each.  Metric SAD; coef->minPtNum = 3. */
+int pcreg_sphere_counts(const double* featModel, int VM, int ldM, const double* centres, int S, int ldC, double R, int32_t* counts);
+int pcreg_sphere_sweep(const pcreg_desc_set* surface, const pcreg_desc_set* model, const double* featSurface, int ldS, const double* featModel, int ldM,
+                       const double* centres, int S, int ldC, const int32_t* num_desc, double R_desc, const pcreg_match_opts* par, int putative_thresh,
+                       const pcreg_ransac_opts* coef, int32_t* model_rows, uint32_t* pairs_all, int32_t* n_pairs, int32_t* trial, int* n_trials,
+                       double* T, int32_t* num_success, int32_t* max_inliers, int32_t* failed);
+
 /* AlignPoints_KNN.m:1  [pts_aligned, coeff_unambig, c] = AlignPoints_KNN(pts, C1, C2).
  * aligned: n x 3 (ld n); coeff: column-major 3x3; c: 3. */
 int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2,

@@ -384,6 +384,88 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                 mxDestroyArray(r0); mxDestroyArray(buf); mxDestroyArray(np);
             }
         }
+    } else if (!strcmp(cmd, "sphereCounts")) {                // counts = pcreg_mex('sphereCounts', featModel, centres, R): completeExperimentFast.m:52-64
+        if (nrhs != 4 || !mxIsDouble(prhs[1]) || !mxIsDouble(prhs[2]) || mxGetN(prhs[1]) != 3 || mxGetN(prhs[2]) != 3) usage = "sphereCounts: featModel (n x 3 double), centres (S x 3 double), R";
+        else {
+            const int VM = (int)mxGetM(prhs[1]), S = (int)mxGetM(prhs[2]);
+            mxArray* cnt = mxCreateNumericMatrix(S > 0 ? S : 1, 1, mxINT32_CLASS, mxREAL);
+            rc = pcreg_sphere_counts(mxGetPr(prhs[1]), VM, VM > 0 ? VM : 1, mxGetPr(prhs[2]), S, S > 0 ? S : 1, mxGetScalar(prhs[3]), (int32_t*)mxGetData(cnt));
+            if (rc == PCREG_OK) {
+                plhs[0] = mxCreateDoubleMatrix(S, S ? 1 : 0, mxREAL);
+                const int32_t* c = (const int32_t*)mxGetData(cnt);
+                for (int i = 0; i < S; ++i) mxGetPr(plhs[0])[i] = (double)c[i];
+            }
+            mxDestroyArray(cnt);
+        }
+    } else if (!strcmp(cmd, "sphereSweep")) {
+        // [modelRows, pairs, nPairs, trial, T, numSuccess, maxInliers, failed] = pcreg_mex('sphereSweep', hSurface, hModel, featSurface, featModel,
+        //     centres, int32(numDesc), R_desc, par, putativeThresh, ransacCoef, seed)
+        // completeExperimentFast.m:101-224 for the spheres kept after sphereCounts.  modelRows: the spheres' row lists back to back (1-based);
+        // pairs: sum(nPairs) x 2 uint32, sphere after sphere; trial: the registered spheres (1-based); T: 4 x 4 x numel(trial).  matlab/sphereSweep.m
+        if (nrhs != 12 || !mxIsUint64(prhs[1]) || !mxIsUint64(prhs[2]) || !mxIsDouble(prhs[3]) || !mxIsDouble(prhs[4]) || !mxIsDouble(prhs[5]) || !mxIsInt32(prhs[6]))
+            usage = "sphereSweep: hSurface, hModel (uint64), featSurface, featModel, centres (double n x 3), int32 numDesc, R_desc, par, putativeThresh, ransacCoef, seed";
+        else {
+            const mxArray* p = prhs[8];
+            pcreg_match_opts o;
+            o.metric = field_is(p, "Metric", "SAD") ? PCREG_METRIC_SAD : PCREG_METRIC_SSD;
+            o.matchThreshold = field(p, "MatchThreshold", 1.0); o.maxRatio = field(p, "MaxRatio", 0.6);
+            o.unique = (int)field(p, "Unique", 0); o.prenormalized = 0;
+            o.unnormalize = (int)field(p, "UNNORMALIZE", 0); o.norm_factor = field(p, "norm_factor", 0.0);
+            o.change_metric = (int)field(p, "CHANGE_METRIC", 0); o.metric_factor = field(p, "metric_factor", 1.0);
+            const mxArray* c = prhs[10];
+            pcreg_ransac_opts ro;
+            ro.minPtNum = (int)field(c, "minPtNum", 3); ro.iterNum = (int)field(c, "iterNum", 1000);
+            ro.thDist = field(c, "thDist", 0.5); ro.thInlrRatio = field(c, "thInlrRatio", 0.1);
+            ro.REFINE = (int)field(c, "REFINE", 1); ro.VERBOSE = 0;
+            ro.seed = (uint64_t)mxGetScalar(prhs[11]);
+            pcreg_desc_set* hS = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]);
+            pcreg_desc_set* hM = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[2]);
+            int Q = 0, VM = 0, D = 0, D2 = 0;
+            rc = pcreg_desc_set_size(hS, &Q, &D);
+            if (rc == PCREG_OK) rc = pcreg_desc_set_size(hM, &VM, &D2);
+            const int S = (int)mxGetM(prhs[5]);
+            const int32_t* nd = (const int32_t*)mxGetData(prhs[6]);
+            if (rc == PCREG_OK && ((int)mxGetM(prhs[3]) != Q || (int)mxGetM(prhs[4]) != VM || mxGetN(prhs[3]) != 3 || mxGetN(prhs[4]) != 3 || (S > 0 && mxGetN(prhs[5]) != 3) ||
+                                   (int)(mxGetM(prhs[6]) * mxGetN(prhs[6])) != S))
+                usage = "sphereSweep: featSurface / featModel must have the rows of their descriptor sets, centres S x 3, numDesc S entries";
+            else if (rc == PCREG_OK) {
+                size_t tot = 0; for (int i = 0; i < S; ++i) tot += (size_t)(nd[i] > 0 ? nd[i] : 0);
+                const size_t s1 = (size_t)(S > 0 ? S : 1);
+                mxArray* rows = mxCreateNumericMatrix(tot > 0 ? tot : 1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* buf = mxCreateNumericMatrix(2, s1 * (Q > 0 ? Q : 1), mxUINT32_CLASS, mxREAL);
+                mxArray* np = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL); mxArray* tr = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* Tb = mxCreateDoubleMatrix(16, s1, mxREAL);
+                mxArray* ns = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL); mxArray* mi = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* fl = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL);
+                int nt = 0;
+                rc = pcreg_sphere_sweep(hS, hM, mxGetPr(prhs[3]), Q > 0 ? Q : 1, mxGetPr(prhs[4]), VM > 0 ? VM : 1, mxGetPr(prhs[5]), S, S > 0 ? S : 1, nd, mxGetScalar(prhs[7]),
+                                        &o, (int)mxGetScalar(prhs[9]), &ro, (int32_t*)mxGetData(rows), (uint32_t*)mxGetData(buf), (int32_t*)mxGetData(np), (int32_t*)mxGetData(tr),
+                                        &nt, mxGetPr(Tb), (int32_t*)mxGetData(ns), (int32_t*)mxGetData(mi), (int32_t*)mxGetData(fl));
+                if (rc == PCREG_OK) {
+                    const int32_t* n = (const int32_t*)mxGetData(np);
+                    size_t P = 0; for (int z = 0; z < S; ++z) P += (size_t)n[z];
+                    plhs[0] = mxCreateDoubleMatrix(tot, tot ? 1 : 0, mxREAL);
+                    { const int32_t* r = (const int32_t*)mxGetData(rows); for (size_t k = 0; k < tot; ++k) mxGetPr(plhs[0])[k] = (double)r[k] + 1.0; }
+                    auto out = [&](int k, mxArray* a) { if (nlhs > k) plhs[k] = a; else mxDestroyArray(a); };
+                    {
+                        mxArray* pr = mxCreateNumericMatrix(P, 2, mxUINT32_CLASS, mxREAL);
+                        const uint32_t* src = (const uint32_t*)mxGetData(buf); uint32_t* dst = (uint32_t*)mxGetData(pr);
+                        size_t k = 0;
+                        for (int z = 0; z < S; ++z)
+                            for (int e = 0; e < n[z]; ++e, ++k) { dst[k] = src[((size_t)z * Q + e) * 2]; dst[k + P] = src[((size_t)z * Q + e) * 2 + 1]; }
+                        out(1, pr);
+                    }
+                    auto col = [&](const int32_t* v, int len, double add) { mxArray* a = mxCreateDoubleMatrix(len, len ? 1 : 0, mxREAL); for (int i = 0; i < len; ++i) mxGetPr(a)[i] = (double)v[i] + add; return a; };
+                    out(2, col(n, S, 0.0));
+                    out(3, col((const int32_t*)mxGetData(tr), nt, 1.0));
+                    { mwSize dims[3] = {4, 4, (mwSize)nt}; mxArray* T3 = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); if (nt) memcpy(mxGetPr(T3), mxGetPr(Tb), (size_t)nt * 128); out(4, T3); }
+                    out(5, col((const int32_t*)mxGetData(ns), nt, 0.0));
+                    out(6, col((const int32_t*)mxGetData(mi), nt, 0.0));
+                    out(7, col((const int32_t*)mxGetData(fl), nt, 0.0));
+                }
+                mxDestroyArray(rows); mxDestroyArray(buf); mxDestroyArray(np); mxDestroyArray(tr); mxDestroyArray(Tb); mxDestroyArray(ns); mxDestroyArray(mi); mxDestroyArray(fl);
+            }
+        }
     } else if (!strcmp(cmd, "descDestroy")) {
         if (nrhs != 2 || !mxIsUint64(prhs[1])) usage = "descDestroy: handle (uint64)";
         else rc = pcreg_desc_set_destroy((pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]));

@@ -377,6 +377,47 @@ def getMatchesSegmentedOnSet(hSurface: DescSet, hModel: DescSet, rows_list, par:
     return [pairs[z, :n_pairs[z]].copy() for z in range(S)]
 
 
+def sphereCounts(featModel, centres, R: float) -> np.ndarray:
+    """counts(i) = nnz(vecnorm(featModel - centres(i, :), 2, 2) < R)  (completeExperimentFast.m:52-64, pcreg_sphere_counts)."""
+    f, c = _fcol(featModel), _fcol(centres)
+    VM, S = f.shape[0], c.shape[0]
+    counts = np.zeros(max(S, 1), dtype=np.int32)
+    check(lib().pcreg_sphere_counts(_ptr(f, C.c_double), VM, max(VM, 1), _ptr(c, C.c_double), S, max(S, 1), C.c_double(R), _ptr(counts, C.c_int32)))
+    return counts[:S].astype(np.int64)
+
+
+def sphereSweep(hSurface: DescSet, hModel: DescSet, featSurface, featModel, centres, num_desc, R_desc: float, par: dict, putative_thresh: int,
+                ransacCoef: dict, seed: int = 0) -> dict:
+    """completeExperimentFast.m:101-224 for the spheres `centres` (already filtered by their counts `num_desc` = sphereCounts) in one
+    library call on resident descriptor sets (pcreg_sphere_sweep): per-sphere row lists and matches, the spheres above the putative
+    threshold and their ransac results.  Keys as pcreg_amd.sweep.SphereSweep.run's."""
+    fS, fM, c = _fcol(featSurface), _fcol(featModel), _fcol(centres)
+    S = c.shape[0]
+    nd = np.ascontiguousarray(num_desc, dtype=np.int32)
+    Q = hSurface.n
+    tot = int(nd.sum())
+    rows = np.zeros(max(tot, 1), dtype=np.int32)
+    pairs = np.zeros((max(S, 1), max(Q, 1), 2), dtype=np.uint32)
+    n_pairs = np.zeros(max(S, 1), dtype=np.int32)
+    trial = np.zeros(max(S, 1), dtype=np.int32)
+    nt = C.c_int(0)
+    T = np.zeros((max(S, 1), 16)); ns = np.zeros(max(S, 1), dtype=np.int32); mi = np.zeros(max(S, 1), dtype=np.int32); fl = np.zeros(max(S, 1), dtype=np.int32)
+    o, rc = _match_opts(par), _ransac_opts(ransacCoef, seed)
+    check(lib().pcreg_sphere_sweep(hSurface._h, hModel._h, _ptr(fS, C.c_double), max(fS.shape[0], 1), _ptr(fM, C.c_double), max(fM.shape[0], 1),
+                                   _ptr(c, C.c_double), S, max(S, 1), _ptr(nd, C.c_int32), C.c_double(R_desc), C.byref(o), int(putative_thresh), C.byref(rc),
+                                   _ptr(rows, C.c_int32), _ptr(pairs, C.c_uint32), _ptr(n_pairs, C.c_int32), _ptr(trial, C.c_int32), C.byref(nt),
+                                   _ptr(T, C.c_double), _ptr(ns, C.c_int32), _ptr(mi, C.c_int32), _ptr(fl, C.c_int32)))
+    n = nt.value
+    off = np.zeros(S + 1, dtype=np.int64); off[1:] = np.cumsum(nd)
+    npr = n_pairs[:S].astype(np.int64)
+    tr = trial[:n].astype(np.int64)
+    return dict(centres=np.asarray(centres, dtype=np.float64), num_desc=nd.astype(np.int64), num_putative=npr,
+                matches=[pairs[i, :npr[i]].copy() for i in range(S)], model_rows=[rows[off[i]:off[i + 1]].astype(np.int64) for i in range(S)], trial=tr,
+                statsPutative=npr[tr], statsSuccess=ns[:n].astype(np.int64), statsInliers=mi[:n].astype(np.int64),
+                statsRatio=np.array([100.0 * mi[t] / npr[tr[t]] if not fl[t] else 0.0 for t in range(n)], dtype=np.float64),
+                transforms=[None if fl[t] else T[t].reshape(4, 4, order="F").copy() for t in range(n)])
+
+
 def getMatches(descSurface, descModel, par: dict) -> np.ndarray:
     """matches = getMatches(descSurface, descModel, par)  (getMatches.m:1-59):
     P x 2 uint32, 1-based [surfaceIdx, modelIdx], ascending in the first column."""

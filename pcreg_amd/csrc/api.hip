@@ -683,6 +683,119 @@ int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcr
     return PCREG_OK;
 }
 
+// n x 3 column-major host doubles -> [n][3] on the device (what the sphere kernels and the gather read)
+static int upload_points_aos(const double* host, int n, int ld, double* cols_tmp, double* aos, hipStream_t st) {
+    if (n <= 0) return PCREG_OK;
+    TRY(upload_cols(host, n, ld, 3, cols_tmp, st));
+    return launch_transpose_rows(cols_tmp, n, n, 3, aos, st);
+}
+int pcreg_sphere_counts(const double* featModel, int VM, int ldM, const double* centres, int S, int ldC, double R, int32_t* counts) {
+    PCREG_ARG(VM >= 0 && S >= 0 && ldM >= VM && ldC >= S && (VM == 0 || featModel) && (S == 0 || (centres && counts)));
+    GUARD();
+    if (S == 0) return PCREG_OK;
+    if (VM == 0) { for (int i = 0; i < S; ++i) counts[i] = 0; return PCREG_OK; }
+    void *tmp, *fm, *tc, *cen, *cnt;
+    TRY(scratch().get(0, sizeof(double) * 3 * (size_t)VM, &tmp));
+    TRY(scratch().get(1, sizeof(double) * 3 * (size_t)VM, &fm));
+    TRY(scratch().get(2, sizeof(double) * 3 * (size_t)S, &tc));
+    TRY(scratch().get(3, sizeof(double) * 3 * (size_t)S, &cen));
+    TRY(scratch().get(4, sizeof(int32_t) * (size_t)S, &cnt));
+    TRY(upload_points_aos(featModel, VM, ldM, (double*)tmp, (double*)fm, g_stream));
+    TRY(upload_points_aos(centres, S, ldC, (double*)tc, (double*)cen, g_stream));
+    TRY(launch_sphere_counts((const double*)fm, VM, (const double*)cen, S, R, (int32_t*)cnt, g_stream));
+    PCREG_HIP(hipMemcpyAsync(counts, cnt, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    return PCREG_OK;
+}
+int pcreg_sphere_sweep(const pcreg_desc_set* surface, const pcreg_desc_set* model, const double* featSurface, int ldS, const double* featModel, int ldM,
+                       const double* centres, int S, int ldC, const int32_t* num_desc, double R_desc, const pcreg_match_opts* par, int putative_thresh,
+                       const pcreg_ransac_opts* coef, int32_t* model_rows, uint32_t* pairs_all, int32_t* n_pairs, int32_t* trial, int* n_trials,
+                       double* T, int32_t* num_success, int32_t* max_inliers, int32_t* failed) {
+    PCREG_ARG(surface && model && featSurface && featModel && par && coef && n_trials && S >= 0 && surface->D == model->D);
+    PCREG_ARG(S == 0 || (centres && num_desc && model_rows && pairs_all && n_pairs && trial && T && num_success && max_inliers && failed));
+    PCREG_ARG(S <= 65535 && ldC >= S && ldS >= surface->n && ldM >= model->n && coef->minPtNum == 3 && coef->iterNum >= 1);
+    if (par->metric != PCREG_METRIC_SAD) { set_error("pcreg_sphere_sweep: Metric must be SAD (every driver of the reference uses it)"); return PCREG_E_ARG; }
+    GUARD();
+    *n_trials = 0;
+    if (S == 0) return PCREG_OK;
+    const int VS = surface->n, VM = model->n, D = surface->D;
+    std::vector<int32_t> off((size_t)S + 1, 0); std::vector<int64_t> roff((size_t)S, 0);
+    int n_max = 0;
+    for (int i = 0; i < S; ++i) {
+        PCREG_ARG(num_desc[i] >= 0 && num_desc[i] <= VM && (long long)off[i] + num_desc[i] < 2147483647LL);
+        off[i + 1] = off[i] + num_desc[i]; roff[i] = off[i]; n_max = std::max(n_max, num_desc[i]);
+    }
+    const int tot = off[S];
+    if (VS == 0 || VM == 0 || tot == 0) { for (int i = 0; i < S; ++i) n_pairs[i] = 0; return PCREG_OK; }
+    const size_t vs = (size_t)VS, ld = (size_t)S * vs;
+    void *tmp, *fm, *fs, *tc, *cen, *doff, *droff, *rows, *fall, *nsel, *dp, *dn, *ws, *tidx, *toff, *nt, *p12, *res, *inl, *rws;
+    TRY(scratch().get(0, sizeof(double) * 3 * (size_t)std::max(VM, VS), &tmp));
+    TRY(scratch().get(1, sizeof(double) * 3 * (size_t)VM, &fm));
+    TRY(scratch().get(2, sizeof(double) * 3 * vs, &fs));
+    TRY(scratch().get(3, sizeof(double) * 3 * (size_t)S, &tc));
+    TRY(scratch().get(9, sizeof(double) * 3 * (size_t)S, &cen));
+    TRY(scratch().get(4, sizeof(int32_t) * (size_t)tot, &rows));
+    TRY(scratch().get(5, sizeof(int32_t) * ((size_t)S + 1), &doff));
+    TRY(scratch().get(6, sizeof(uint32_t) * (size_t)S * vs * 2, &dp));
+    TRY(scratch().get(7, sizeof(int32_t) * (size_t)S, &dn));
+    const size_t wsb = get_matches_segmented_workspace_bytes(VS, VM, D, S, tot, n_max);
+    TRY(scratch().get(8, wsb, &ws));
+    TRY(scratch().get(10, sizeof(int64_t) * (size_t)S, &droff));
+    TRY(scratch().get(11, sizeof(double) * 3 * (size_t)tot, &fall));
+    TRY(scratch().get(12, sizeof(int32_t) * (size_t)S, &nsel));
+    TRY(scratch().get(13, sizeof(int32_t) * (3 * (size_t)S + 2), &tidx));          // trial_idx [S] | offsets [S + 1] | n_trials
+    toff = (int32_t*)tidx + S; nt = (int32_t*)tidx + 2 * (size_t)S + 1;
+    TRY(scratch().get(14, sizeof(double) * 6 * ld, &p12));
+    TRY(scratch().get(15, sizeof(pcreg_dev_ransac_result) * (size_t)S, &res));
+    TRY(scratch().get(16, sizeof(int32_t) * ld, &inl));
+    const size_t rwsb = ransac_workspace_bytes(coef->iterNum, S, VS);
+    TRY(scratch().get(17, rwsb, &rws));
+    const double *rS, *rM;
+    TRY(desc_set_rows(surface, &rS));
+    TRY(desc_set_rows(model, &rM));
+    // :52-125: the keypoints, the spheres' row lists and their keypoints back to back
+    TRY(upload_points_aos(featModel, VM, ldM, (double*)tmp, (double*)fm, g_stream));
+    TRY(upload_points_aos(featSurface, VS, ldS, (double*)tmp, (double*)fs, g_stream));
+    TRY(upload_points_aos(centres, S, ldC, (double*)tc, (double*)cen, g_stream));
+    PCREG_HIP(hipMemcpyAsync(doff, off.data(), sizeof(int32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, g_stream));
+    PCREG_HIP(hipMemcpyAsync(droff, roff.data(), sizeof(int64_t) * (size_t)S, hipMemcpyHostToDevice, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));                   // off / roff are locals: the copies must have read them before anything can fail and return
+    TRY(launch_sphere_select_batched((const double*)fm, VM, (const double*)cen, S, R_desc, (const int32_t*)doff, (int32_t*)rows, (double*)fall, (int32_t*)nsel, g_stream));
+    // :131-149: getMatches of the surface against every sphere's rows
+    TRY(launch_get_matches_segmented(rS, VS, rM, VM, D, (const int32_t*)rows, (const int32_t*)doff, S, tot, n_max, *par, (uint32_t*)dp, nullptr, (int32_t*)dn,
+                                     ws, wsb, g_stream));
+    // :166-216: the putative threshold, the trial spheres' correspondences, one batched ransac (registration t: seed + t)
+    TRY(launch_sweep_plan((const int32_t*)dn, S, putative_thresh, (int32_t*)tidx, (int32_t*)toff, (int32_t*)nt, g_stream));
+    double *p1 = (double*)p12, *p2 = (double*)p12 + 3 * ld;
+    PCREG_HIP(hipMemsetAsync(p12, 0, sizeof(double) * 6 * ld, g_stream));
+    TRY(launch_sweep_gather((const uint32_t*)dp, VS, (const int32_t*)dn, (const int32_t*)tidx, (const int32_t*)toff, (const int32_t*)nt, S, (const double*)fs,
+                            (const double*)fall, (const int64_t*)droff, p1, p2, (int)ld, g_stream));
+    PCREG_HIP(hipMemsetAsync(res, 0, sizeof(pcreg_dev_ransac_result) * (size_t)S, g_stream));
+    TRY(launch_ransac(p1, p2, (int)ld, (const int32_t*)toff, nullptr, VS, S, *coef, nullptr, (pcreg_dev_ransac_result*)res, (int32_t*)inl, nullptr, nullptr,
+                      rws, rwsb, g_stream));
+    std::vector<int32_t> h_nsel((size_t)S), h_tr((size_t)S);
+    std::vector<pcreg_dev_ransac_result> h_res((size_t)S);
+    int32_t h_nt = 0;
+    PCREG_HIP(hipMemcpyAsync(h_nsel.data(), nsel, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(model_rows, rows, sizeof(int32_t) * (size_t)tot, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * vs * 2, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(h_tr.data(), tidx, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(&h_nt, nt, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(h_res.data(), res, sizeof(pcreg_dev_ransac_result) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
+    for (int i = 0; i < S; ++i)
+        if (h_nsel[i] != num_desc[i]) { set_error("pcreg_sphere_sweep: num_desc[%d] = %d, but the sphere holds %d keypoints (pass pcreg_sphere_counts' values)", i, num_desc[i], h_nsel[i]); return PCREG_E_ARG; }
+    *n_trials = h_nt;
+    for (int t = 0; t < h_nt; ++t) {
+        trial[t] = h_tr[t];
+        const pcreg_dev_ransac_result& r = h_res[t];
+        for (int k = 0; k < 16; ++k) T[(size_t)t * 16 + k] = r.failed ? 0.0 : r.T[k];
+        num_success[t] = r.num_success; max_inliers[t] = r.max_inliers; failed[t] = r.failed;
+    }
+    return PCREG_OK;
+}
+
 int pcreg_align_points_knn_batched(const double* pts, int total, int ld, const int32_t* offsets, int B, int C1, int C2,
                                    double* aligned, double* coeff, double* c, int32_t* status) {
     PCREG_ARG(pts && offsets && aligned && coeff && c && status && total >= 0 && ld >= total && B >= 0);

@@ -287,6 +287,58 @@ int drv_desc_set_segmented(const double* dS, int Q, const double* dM, int VM, in
     return rc;
 }
 
+// sphereCounts, descCreate x 2, sphereSweep, descDestroy x 2 through the gateway.  Every output flattened as the gateway returns it
+// (rows1 / trial1 are 1-based); capacities: rows1 >= sum(num_desc of the kept spheres), pairs_colmajor >= S x Q x 2, the per-trial arrays >= S.
+int drv_sphere_sweep(const double* dS, int Q, const double* dM, int VM, int D, const double* fS, const double* fM, const double* centres, int n_c, double R,
+                     double min_pts, const double* par7, double thresh, const double* coef5, double seed, double* counts, double* rows1, int* n_rows,
+                     uint32_t* pairs_colmajor, int* P_total, double* n_pairs, int* S_out, double* trial1, int* n_trials, double* T16, double* num_success,
+                     double* max_inl, double* failed, char* err, int errlen) {
+    mxArray* lhs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    { std::vector<mxArray*> rhs{mxCreateString("sphereCounts"), dmat(fM, VM, 3), dmat(centres, n_c, 3), mxCreateDoubleScalar(R)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    memcpy(counts, mxGetPr(lhs[0]), (size_t)n_c * 8);
+    mxDestroyArray(lhs[0]); lhs[0] = nullptr;
+    std::vector<double> kept; std::vector<int32_t> nd;
+    for (int i = 0; i < n_c; ++i) if (counts[i] >= min_pts) nd.push_back((int32_t)counts[i]);
+    const int S = (int)nd.size();
+    kept.resize((size_t)S * 3);
+    for (int i = 0, k = 0; i < n_c; ++i) if (counts[i] >= min_pts) { for (int c = 0; c < 3; ++c) kept[k + (size_t)c * S] = centres[i + (size_t)c * n_c]; ++k; }
+    *S_out = S;
+    { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dS, Q, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* hS = lhs[0]; lhs[0] = nullptr;
+    { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dM, VM, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* hM = lhs[0]; lhs[0] = nullptr;
+    mxArray* p = mxCreateStructMatrix(1, 1, 0, nullptr);
+    mxSetField(p, 0, "Metric", mxCreateString("SAD")); mxSetField(p, 0, "Method", mxCreateString("Approximate"));
+    put(p, "MatchThreshold", par7[0]); put(p, "MaxRatio", par7[1]); put(p, "Unique", par7[2]); put(p, "UNNORMALIZE", par7[3]);
+    put(p, "norm_factor", par7[4]); put(p, "CHANGE_METRIC", par7[5]); put(p, "metric_factor", par7[6]); put(p, "VERBOSE", 0);
+    mxArray* c = mxCreateStructMatrix(1, 1, 0, nullptr);
+    put(c, "minPtNum", coef5[0]); put(c, "iterNum", coef5[1]); put(c, "thDist", coef5[2]); put(c, "thInlrRatio", coef5[3]);
+    put(c, "REFINE", coef5[4]); put(c, "VERBOSE", 0);
+    mxArray* ndm = mxCreateNumericMatrix(S, 1, mxINT32_CLASS, mxREAL);
+    if (S) memcpy(mxGetData(ndm), nd.data(), (size_t)S * 4);
+    int rc = 0;
+    {
+        std::vector<mxArray*> rhs{mxCreateString("sphereSweep"), mxDuplicateArray(hS), mxDuplicateArray(hM), dmat(fS, Q, 3), dmat(fM, VM, 3), dmat(kept.data(), S, 3), ndm,
+                                  mxCreateDoubleScalar(R), p, mxCreateDoubleScalar(thresh), c, mxCreateDoubleScalar(seed)};
+        rc = call(8, lhs, rhs, err, errlen);
+    }
+    if (!rc) {
+        *n_rows = (int)(mxGetM(lhs[0]) * mxGetN(lhs[0])); if (*n_rows) memcpy(rows1, mxGetPr(lhs[0]), (size_t)*n_rows * 8);
+        *P_total = (int)mxGetM(lhs[1]); if (*P_total) memcpy(pairs_colmajor, mxGetData(lhs[1]), (size_t)*P_total * 2 * 4);
+        if (S) memcpy(n_pairs, mxGetPr(lhs[2]), (size_t)S * 8);
+        *n_trials = (int)(mxGetM(lhs[3]) * mxGetN(lhs[3]));
+        if (*n_trials) {
+            memcpy(trial1, mxGetPr(lhs[3]), (size_t)*n_trials * 8); memcpy(T16, mxGetPr(lhs[4]), (size_t)*n_trials * 128);
+            memcpy(num_success, mxGetPr(lhs[5]), (size_t)*n_trials * 8); memcpy(max_inl, mxGetPr(lhs[6]), (size_t)*n_trials * 8);
+            memcpy(failed, mxGetPr(lhs[7]), (size_t)*n_trials * 8);
+        }
+        for (mxArray*& a : lhs) { mxDestroyArray(a); a = nullptr; }
+    }
+    { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hS}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hM}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    return rc;
+}
+
 // one-worker rehearsal of the spmd block of INTEGRATION.md section 3: setDevice, commId, commInit, matchPointsSharded,
 // ransacSharded, commDestroy -- all through the gateway
 int drv_comm_round_trip(const float* surf, int Q, const float* model, int M, float thr, float ratio, uint32_t* pairs_colmajor, int* P,

@@ -60,6 +60,38 @@ def test_sphere_sweep_equals_oracle_driver(oracle_c, oracle_py):
             assert np.linalg.norm(a - b) < 1e-9
 
 
+def test_host_tier_sphere_sweep_equals_the_device_driver(oracle_py):
+    """pcreg_sphere_counts + pcreg_sphere_sweep (what MATLAB reaches through pcreg_mex: host arrays, descriptor sets resident) ==
+    SphereSweep.run field for field -- counts, row lists, matches, trial spheres, transforms (the same kernels, the same seeds)."""
+    import pcreg_amd as pc
+    from pcreg_amd.sweep import SphereSweep
+    featM, descM, featS, descS = _scene()
+    kw = dict(R_desc=9.0, d_spheres=6.0, min_pts=500, putative_thresh=60, seed=3)
+    sw = SphereSweep(featM, descM, featS, descS)
+    want = sw.run(PAR, OPT, **kw)
+    assert len(want["centres"]) >= 4 and len(want["trial"]) >= 1
+    centres = oracle_py.pcUniformSamples(featM, kw["d_spheres"])
+    counts = pc.sphereCounts(featM, centres, kw["R_desc"])
+    np.testing.assert_array_equal(counts, [oracle_py.getDescriptorMask(featM, c, kw["R_desc"]).sum() for c in centres])
+    keep = counts >= kw["min_pts"]
+    with pc.DescSet(descS) as hS, pc.DescSet(descM) as hM:
+        got = pc.sphereSweep(hS, hM, featS, featM, centres[keep], counts[keep], kw["R_desc"], PAR, kw["putative_thresh"], OPT, seed=kw["seed"])
+        again = pc.sphereSweep(hS, hM, featS, featM, centres[keep], counts[keep], kw["R_desc"], PAR, kw["putative_thresh"], OPT, seed=kw["seed"])
+        with pytest.raises(Exception):                                       # counts that are not the spheres' counts: refused, not a fault
+            pc.sphereSweep(hS, hM, featS, featM, centres[keep], counts[keep] - 1, kw["R_desc"], PAR, kw["putative_thresh"], OPT)
+        empty = pc.sphereSweep(hS, hM, featS, featM, centres[:0], counts[:0], kw["R_desc"], PAR, kw["putative_thresh"], OPT)
+    assert len(empty["trial"]) == 0 and empty["matches"] == []
+    for g in (got, again):
+        for k in ("centres", "num_desc", "num_putative", "trial", "statsPutative", "statsSuccess", "statsInliers", "statsRatio"):
+            np.testing.assert_array_equal(g[k], want[k], err_msg=k)
+        for k in ("matches", "model_rows"):
+            assert len(g[k]) == len(want[k])
+            for a, b in zip(g[k], want[k]):
+                np.testing.assert_array_equal(a, b)
+        for a, b in zip(g["transforms"], want["transforms"]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+
+
 def test_sphere_counts_select_and_gather(oracle_py):
     import torch
     from pcreg_amd.sweep import SphereSweep

@@ -255,6 +255,46 @@ def test_shim_multi_gpu_commands_one_worker(drv):
 
 
 @pytest.mark.gpu
+def test_shim_sphere_sweep(drv, oracle_py):
+    """sphereCounts + descCreate + sphereSweep + descDestroy through the gateway (what matlab/sphereSweep.m calls) == the Python mirror
+    of the same C entry points, output for output (row lists and trial numbers 1-based at the MATLAB boundary)."""
+    import pcreg_amd as pc
+    from test_gpu_sweep import _scene, PAR, OPT
+    featM, descM, featS, descS = _scene()
+    R, d_sph, min_pts, thresh, seed = 9.0, 6.0, 500, 60, 3
+    centres = oracle_py.pcUniformSamples(featM, d_sph)
+    counts = pc.sphereCounts(featM, centres, R)
+    keep = counts >= min_pts
+    with pc.DescSet(descS) as hS, pc.DescSet(descM) as hM:
+        want = pc.sphereSweep(hS, hM, featS, featM, centres[keep], counts[keep], R, PAR, thresh, OPT, seed=seed)
+    S, Q, VM, D, n_c = int(keep.sum()), featS.shape[0], featM.shape[0], descM.shape[1], len(centres)
+    assert S >= 4 and len(want["trial"]) >= 1
+    par7 = np.array([PAR["MatchThreshold"], PAR["MaxRatio"], PAR["Unique"], PAR["UNNORMALIZE"], PAR["norm_factor"], PAR["CHANGE_METRIC"], PAR["metric_factor"]], dtype=np.float64)
+    coef5 = np.array([OPT["minPtNum"], OPT["iterNum"], OPT["thDist"], OPT["thInlrRatio"], OPT["REFINE"]], dtype=np.float64)
+    cnt = np.zeros(n_c); rows1 = np.zeros(int(counts[keep].sum())); nrows = C.c_int()
+    pairs = np.zeros(S * Q * 2, dtype=np.uint32); Pt = C.c_int(); npairs = np.zeros(S); S_out = C.c_int()
+    trial1 = np.zeros(S); nt = C.c_int(); T = np.zeros(S * 16); ns = np.zeros(S); mi = np.zeros(S); fl = np.zeros(S)
+    e = _err()
+    rc = drv.drv_sphere_sweep(_p(_d(descS)), Q, _p(_d(descM)), VM, D, _p(_d(featS)), _p(_d(featM)), _p(_d(centres)), n_c, C.c_double(R), C.c_double(min_pts),
+                              _p(par7), C.c_double(thresh), _p(coef5), C.c_double(seed), _p(cnt), _p(rows1), C.byref(nrows), _p(pairs, C.c_uint32), C.byref(Pt),
+                              _p(npairs), C.byref(S_out), _p(trial1), C.byref(nt), _p(T), _p(ns), _p(mi), _p(fl), e, 1024)
+    assert rc == 0, e.value
+    assert np.array_equal(cnt, counts) and S_out.value == S
+    assert np.array_equal(npairs, want["num_putative"]) and nrows.value == len(rows1)
+    assert np.array_equal(rows1, np.concatenate(want["model_rows"]) + 1)
+    allp = pairs[:2 * Pt.value].reshape(Pt.value, 2, order="F")
+    assert np.array_equal(allp, np.vstack([m for m in want["matches"]]))
+    n = nt.value
+    assert np.array_equal(trial1[:n], want["trial"] + 1) and np.array_equal(ns[:n], want["statsSuccess"]) and np.array_equal(mi[:n], want["statsInliers"])
+    for t in range(n):
+        Tt = want["transforms"][t]
+        assert bool(fl[t]) == (Tt is None)
+        if Tt is not None:
+            assert np.array_equal(T[16 * t:16 * t + 16].reshape(4, 4, order="F"), Tt)
+    assert drv.drv_live_arrays() == 0
+
+
+@pytest.mark.gpu
 def test_shim_get_local_points_keeps_matlabs_classes(drv, oracle_py):
     """getLocalPoints through the gateway: a single cloud with a double centre is evaluated in single arithmetic and comes back
     single (getLocalPoints.m:8-25); [] when a gate fails."""
