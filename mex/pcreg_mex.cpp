@@ -11,6 +11,12 @@
 //                                          -> pairs (P x 2 uint32) | 'modelDestroy', handle      (one model, many surfaces)
 //   'descCreate', desc (double n x D) -> handle (uint64) | 'getMatchesOnSet', hSurface, hModel, int32 rows | [], par -> matches
 //                                          | 'descDestroy', handle        (one surface set, many row subsets of one model set)
+//   'getMatchesSegmented', descSurface, descModel, int32 rows, int32 segOff, par | 'getMatchesSegmentedOnSet', hSurface, hModel, ...
+//                                          -> pairs, nPairs                (every sphere of the sweep in one call)
+//   'ransacBatched', pts1, pts2, int32 offsets, coef, sample_idx|[], seed -> T (4x4xB), inlierIdx, nInliers, numSuccess, maxInliers, failed
+//   'sphereCounts', featModel, centres, R -> counts | 'sphereSweep', hSurface, hModel, featSurface, featModel, centres, int32 numDesc,
+//       R_desc, par, putativeThresh, coef, seed -> modelRows, pairs, nPairs, trial, T, numSuccess, maxInliers, failed   (completeExperimentFast.m:52-224)
+//   'getLocalPoints', pts, R, c, min_points, max_points   -> pts_sphere, dists
 //   'setDevice', ordinal | 'commId' -> id | 'commInit', rank, world, id | 'commDestroy'     (one worker per GPU)
 //   'matchPointsSharded', surface, modelRows, m_lo, M_total, thrAbs, maxRatio, unique     -> pairs (P x 2 uint32, global model rows)
 //   'ransacSharded', pts1, pts2, coef, seed                -> T, inlierIdx, numSuccess, maxInliers, failed
