@@ -192,7 +192,8 @@ int pcreg_get_matches_on_sets(const pcreg_desc_set* surface, const pcreg_desc_se
                               const pcreg_match_opts* par, uint32_t* pairs, double* metric, int* P);
 /* pcreg_get_matches_segmented on uploaded sets: ALL spheres of the loop above in one call, nothing but the row lists going up and
  * the pairs coming down (the 470 MB of a 60 000 x 980 model set take longer to upload than the whole sweep takes to match).
- * Arguments and results as pcreg_get_matches_segmented; the sets keep a row-major copy from their first segmented call on. */
+ * Arguments and results as pcreg_get_matches_segmented.  From their first segmented call on the sets keep a row-major copy, and
+ * the model set its powered rows for the options of the last call (so a set then holds up to three times its n x D doubles). */
 int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* seg_rows,
                                         const int32_t* seg_off, int S, const pcreg_match_opts* par, uint32_t* pairs_all, int32_t* n_pairs);
 

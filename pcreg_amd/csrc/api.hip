@@ -494,8 +494,12 @@ static int match_host(const double* f1, int Q, int ld1, const double* f2, int M,
 
 // ---- resident descriptor sets (host tier): one surface set against hundreds of row subsets of one model set
 // (completeExperimentFast.m:101-150) without re-uploading ~28 MB of doubles per sphere
-struct pcreg_desc_set { double* d; int n, D; double* rows; };       // d: n x D column-major on the device (ld = n), as uploaded; rows: the dense
-                                                                     // row-major copy the segmented matcher reads, made at its first use
+struct pcreg_desc_set {
+    double* d; int n, D;            // n x D column-major on the device (ld = n), as uploaded
+    double* rows;                   // the dense row-major copy the segmented matcher reads, made at its first use
+    double* prep;                   // as a MODEL of the segmented matcher: powered rows + row scalars (SegPreparedModel), for ...
+    int prep_cm; double prep_factor;   // ... these getMatches options (made at the first use, remade when they change)
+};
 
 __global__ void gather_cols_kernel(const double* __restrict__ src, int n_src, int D, const int32_t* __restrict__ rows, int n, double* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, d = blockIdx.y;
@@ -511,7 +515,7 @@ int pcreg_desc_set_create(const double* desc, int n, int ld, int D, pcreg_desc_s
     int rc = upload_cols(desc, n, ld, D, d, g_stream);
     if (!rc && hipStreamSynchronize(g_stream) != hipSuccess) { set_error("descriptor upload failed"); rc = PCREG_E_HIP; }
     if (rc) { (void)hipFree(d); return rc; }
-    *set = new pcreg_desc_set{d, n, D, nullptr};
+    *set = new pcreg_desc_set{d, n, D, nullptr, nullptr, 0, 0.0};
     return PCREG_OK;
 }
 int pcreg_desc_set_destroy(pcreg_desc_set* set) {
@@ -520,6 +524,7 @@ int pcreg_desc_set_destroy(pcreg_desc_set* set) {
     (void)hipDeviceSynchronize();
     (void)hipFree(set->d);
     if (set->rows) (void)hipFree(set->rows);
+    if (set->prep) (void)hipFree(set->prep);
     delete set;
     return PCREG_OK;
 }
@@ -647,6 +652,21 @@ static int desc_set_rows(const pcreg_desc_set* cs, const double** out) {
     *out = s->rows;
     return PCREG_OK;
 }
+// the set as the segmented matcher's prepared model for these options (caller holds the library lock)
+static int desc_set_prepared(const pcreg_desc_set* cs, const pcreg_match_opts& o, SegPreparedModel* out) {
+    pcreg_desc_set* s = const_cast<pcreg_desc_set*>(cs);
+    const double* rows;
+    TRY(desc_set_rows(cs, &rows));
+    const bool have = s->prep && s->prep_cm == o.change_metric && (!o.change_metric || s->prep_factor == o.metric_factor);
+    if (!have) {
+        if (!s->prep) PCREG_HIP(hipMalloc((void**)&s->prep, segmented_prepared_model_bytes(s->n, s->D)));
+        s->prep_cm = -1;                                         // not valid until the launch below has been enqueued
+        TRY(launch_segmented_prepare_model(rows, s->n, s->D, o, s->prep, s->prep + (size_t)(s->n > 0 ? s->n : 1) * s->D, g_stream));
+        s->prep_cm = o.change_metric; s->prep_factor = o.metric_factor;
+    }
+    *out = SegPreparedModel{s->prep, s->prep + (size_t)(s->n > 0 ? s->n : 1) * s->D, s->n, s->D, s->prep_cm, s->prep_factor};
+    return PCREG_OK;
+}
 int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcreg_desc_set* model, const int32_t* seg_rows,
                                         const int32_t* seg_off, int S, const pcreg_match_opts* par, uint32_t* pairs_all, int32_t* n_pairs) {
     PCREG_ARG(surface && model && seg_off && par && pairs_all && n_pairs && S >= 0 && surface->D == model->D);
@@ -675,8 +695,10 @@ int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcr
     TRY(scratch().get(8, wsb, &ws));
     PCREG_HIP(hipMemcpyAsync(dr, seg_rows, sizeof(int32_t) * (size_t)tot, hipMemcpyHostToDevice, g_stream));
     PCREG_HIP(hipMemcpyAsync(doff, seg_off, sizeof(int32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, g_stream));
+    SegPreparedModel prep;
+    TRY(desc_set_prepared(model, *par, &prep));
     TRY(launch_get_matches_segmented(rS, Q, rM, VM, D, (const int32_t*)dr, (const int32_t*)doff, S, tot, n_max, *par,
-                                     (uint32_t*)dp, nullptr, (int32_t*)dn, ws, wsb, g_stream));
+                                     (uint32_t*)dp, nullptr, (int32_t*)dn, ws, wsb, g_stream, &prep));
     PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * q * 2, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipStreamSynchronize(g_stream));
@@ -762,8 +784,10 @@ int pcreg_sphere_sweep(const pcreg_desc_set* surface, const pcreg_desc_set* mode
     PCREG_HIP(hipStreamSynchronize(g_stream));                   // off / roff are locals: the copies must have read them before anything can fail and return
     TRY(launch_sphere_select_batched((const double*)fm, VM, (const double*)cen, S, R_desc, (const int32_t*)doff, (int32_t*)rows, (double*)fall, (int32_t*)nsel, g_stream));
     // :131-149: getMatches of the surface against every sphere's rows
+    SegPreparedModel prep;
+    TRY(desc_set_prepared(model, *par, &prep));
     TRY(launch_get_matches_segmented(rS, VS, rM, VM, D, (const int32_t*)rows, (const int32_t*)doff, S, tot, n_max, *par, (uint32_t*)dp, nullptr, (int32_t*)dn,
-                                     ws, wsb, g_stream));
+                                     ws, wsb, g_stream, &prep));
     // :166-216: the putative threshold, the trial spheres' correspondences, one batched ransac (registration t: seed + t)
     TRY(launch_sweep_plan((const int32_t*)dn, S, putative_thresh, (int32_t*)tidx, (int32_t*)toff, (int32_t*)nt, g_stream));
     double *p1 = (double*)p12, *p2 = (double*)p12 + 3 * ld;

@@ -177,9 +177,16 @@ int launch_local_points(const double* pts, int N, int ld, double R, const double
 int launch_sphere_select_batched(const double* feat, int V, const double* centres, int S, double R, const int32_t* seg_off, int32_t* idx,
                                  double* feat_out, int32_t* n_out, hipStream_t st);
 size_t get_matches_segmented_workspace_bytes(int Q, int VM, int D, int S, int tot, int n_max);
+// The model side of the segmented matcher that does not depend on the surface or the segments: the powered rows and the six
+// scalars per row (segp_rows_kernel).  A caller that matches MANY surfaces against one immutable model set (the host tier's
+// descriptor sets) prepares them once: P [VM][D], r [6][VM]; valid for the (change_metric, metric_factor) they were made with.
+struct SegPreparedModel { const double* P; const double* r; int VM, D, change_metric; double metric_factor; };
+size_t segmented_prepared_model_bytes(int VM, int D);          // doubles of P and r together, in bytes
+int launch_segmented_prepare_model(const double* descM_rows, int VM, int D, const pcreg_match_opts& o, double* P, double* r, hipStream_t st);
 int launch_get_matches_segmented(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
                                  const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
-                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st);
+                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st,
+                                 const SegPreparedModel* prepared = nullptr);
 int launch_sweep_plan(const int32_t* n_pairs, int S, int thresh, int32_t* trial_idx, int32_t* offsets, int32_t* n_trials, hipStream_t st);
 int launch_sweep_gather(const uint32_t* pairs_all, int VS, const int32_t* n_pairs, const int32_t* trial_idx, const int32_t* offsets,
                         const int32_t* n_trials, int S, const double* featS, const double* featCur_all, const int64_t* row_off,

@@ -2088,7 +2088,8 @@ size_t get_matches_segmented_workspace_bytes(int Q, int VM, int D, int S, int to
 // (1-based; the model index counts within the segment), n_pairs [S], metric_all [S][Q] or null.  SAD only.
 static int launch_get_matches_segmented_one(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
                                             const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
-                                            double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st) {
+                                            double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st,
+                                            const SegPreparedModel* prepared = nullptr) {
     if (S <= 0) return PCREG_OK;
     if (Q <= 0 || n_max <= 0 || VM <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, (size_t)S * sizeof(int32_t), st)); return PCREG_OK; }
     const int Dp = D + (o.unnormalize ? 1 : 0);
@@ -2110,7 +2111,12 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
 
     // once for all segments: powers, row scalars, the reference constant, the two quantised operands, ALL approximate scores
     hipLaunchKernelGGL(segp_rows_kernel, dim3((Q + kPR - 1) / kPR), dim3(kBlock), 0, st, descS, Q, D, o.change_metric, o.metric_factor, PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q, rS + 5 * q);
-    hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM, VM, D, o.change_metric, o.metric_factor, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, rM + 5 * vm);
+    if (prepared && prepared->VM == VM && prepared->D == D && prepared->change_metric == o.change_metric &&
+        (!o.change_metric || prepared->metric_factor == o.metric_factor)) {
+        PM = const_cast<double*>(prepared->P); rM = const_cast<double*>(prepared->r);          // read-only from here on
+    } else {
+        hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM, VM, D, o.change_metric, o.metric_factor, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, rM + 5 * vm);
+    }
     const SegSets sets{PS, rS, rS + q, rS + 2 * q, rS + 3 * q, rS + 4 * q, rS + 5 * q, PM, rM, rM + vm, rM + 2 * vm, rM + 3 * vm, rM + 4 * vm, rM + 5 * vm,
                        seg_rows, seg_off, Q, VM, D, Dp, (size_t)S * q, (size_t)std::max(tot, 1)};
     hipLaunchKernelGGL(segp_cc_kernel, dim3(S), dim3(kBlock), 0, st, sets, o, sc);
@@ -2302,16 +2308,25 @@ __global__ __launch_bounds__(256) void segb_gather_kernel(const double* __restri
 }
 }  // namespace
 
+size_t segmented_prepared_model_bytes(int VM, int D) { const size_t vm = (size_t)std::max(VM, 1); return (vm * (size_t)D + 6 * vm) * sizeof(double); }
+int launch_segmented_prepare_model(const double* descM_rows, int VM, int D, const pcreg_match_opts& o, double* P, double* r, hipStream_t st) {
+    if (VM <= 0) return PCREG_OK;
+    const size_t vm = (size_t)VM;
+    hipLaunchKernelGGL(segp_rows_kernel, dim3((VM + kPR - 1) / kPR), dim3(kBlock), 0, st, descM_rows, VM, D, o.change_metric, o.metric_factor, P, r, r + vm, r + 2 * vm,
+                       r + 3 * vm, r + 4 * vm, r + 5 * vm);
+    PCREG_HIP(hipGetLastError());
+    return PCREG_OK;
+}
 int launch_get_matches_segmented(const double* descS, int Q, const double* descM, int VM, int D, const int32_t* seg_rows,
                                  const int32_t* seg_off, int S, int tot, int n_max, const pcreg_match_opts& o, uint32_t* pairs_all,
-                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st) {
+                                 double* metric_all, int32_t* n_pairs, void* ws, size_t ws_bytes, hipStream_t st, const SegPreparedModel* prepared) {
     if (S <= 0) return PCREG_OK;
     if (Q <= 0 || n_max <= 0 || VM <= 0) { PCREG_HIP(hipMemsetAsync(n_pairs, 0, (size_t)S * sizeof(int32_t), st)); return PCREG_OK; }
     const size_t one = seg_layout(Q, VM, D, D + 1, S, tot, n_max).total;
     const size_t budget = PCREG_EXP_ENV("PCREG_SEG_BUDGET_MB", 0) > 0 ? (size_t)PCREG_EXP_ENV("PCREG_SEG_BUDGET_MB", 0) << 20 : kSegBudget;
     if (one <= kSegBudget + kSegGatherBytes && !debug_flag(kDbgSegBatched))
-        return launch_get_matches_segmented_one(descS, Q, descM, VM, D, seg_rows, seg_off, S, tot, n_max, o, pairs_all, metric_all, n_pairs, ws, ws_bytes, st);
-    // ---- batches of consecutive segments on gathered sub-models
+        return launch_get_matches_segmented_one(descS, Q, descM, VM, D, seg_rows, seg_off, S, tot, n_max, o, pairs_all, metric_all, n_pairs, ws, ws_bytes, st, prepared);
+    // ---- batches of consecutive segments on gathered sub-models (they gather the RAW rows: a prepared model is not used)
     const size_t fixed = seg_batched_fixed_bytes(VM, tot, S);
     if (ws_bytes < fixed + 4096) { set_error("segmented get_matches workspace too small: %zu bytes", ws_bytes); return PCREG_E_WORKSPACE; }
     // whatever the caller's workspace holds beyond the fixed part is split 1 : 3 between the gathered rows and the one-chain form

@@ -221,6 +221,12 @@ def test_get_matches_on_resident_sets_equals_get_matches(par_over, oracle_c):
                 want = pc.getMatchesOnSet(hS, hM, r, par) if len(r) else np.zeros((0, 2), np.uint32)
                 np.testing.assert_array_equal(on[z], want, err_msg=f"segment {z}")
                 np.testing.assert_array_equal(host[z], want, err_msg=f"segment {z}")
+            # the model set caches its powered rows for the options of the last call: other options must not see them
+            for other in (dict(par, metric_factor=0.8, CHANGE_METRIC=True), dict(par, CHANGE_METRIC=False), par):
+                on2 = pc.getMatchesSegmentedOnSet(hS, hM, rows_list[:2], other)
+                host2 = pc.getMatchesSegmented(dS, dM, rows_list[:2], other)
+                for a, b in zip(on2, host2):
+                    np.testing.assert_array_equal(a, b)
             assert pc.getMatchesSegmentedOnSet(hS, hM, [], par) == []
             with pytest.raises(Exception):
                 pc.getMatchesSegmentedOnSet(hS, hM, [np.array([M])], par)
