@@ -465,6 +465,18 @@ int pcreg_dev_get_matches_segmented(const double* descSurface, int Q, const doub
                                     const int32_t* seg_off, int S, int total_rows, int max_rows, const pcreg_match_opts* par,
                                     uint32_t* pairs_all, double* metric_all, int32_t* n_pairs, void* workspace, size_t workspace_bytes,
                                     void* stream);
+/* One model, many surfaces: the part of the call above that depends on the model set and the options only -- its powered rows and
+ * six scalars per row -- prepared once into a caller-owned buffer of pcreg_dev_segmented_model_bytes(VM, D) bytes, and the call that
+ * uses it (prepared_change_metric / prepared_metric_factor: the options it was made with; a call whose par differs recomputes them
+ * itself).  The caller must not change descModel while the preparation is in use.  Same pairs as pcreg_dev_get_matches_segmented. */
+size_t pcreg_dev_segmented_model_bytes(int VM, int D);
+int pcreg_dev_segmented_model_prepare(const double* descModel, int VM, int D, const pcreg_match_opts* par, void* prepared, size_t prepared_bytes,
+                                      void* stream);
+int pcreg_dev_get_matches_segmented_prepared(const double* descSurface, int Q, const double* descModel, int VM, int D, const void* prepared,
+                                             int prepared_change_metric, double prepared_metric_factor, const int32_t* seg_rows,
+                                             const int32_t* seg_off, int S, int total_rows, int max_rows, const pcreg_match_opts* par,
+                                             uint32_t* pairs_all, double* metric_all, int32_t* n_pairs, void* workspace, size_t workspace_bytes,
+                                             void* stream);
 
 /* dst(k,:) = src(idx(k),:), k < min(*n, cap): featCur / descCur of completeExperimentFast.m:122-125
  * (row-major, D doubles per row). */

@@ -66,7 +66,7 @@ SYMBOLS = [
     "pcreg_dev_spatial_histogram_descriptors_rows_u16", "pcreg_dev_get_matches_rows_u16",
     "pcreg_dev_get_matches_workspace", "pcreg_dev_get_matches", "pcreg_dev_gather_matched_rows",
     "pcreg_dev_sphere_counts", "pcreg_dev_sphere_select_workspace", "pcreg_dev_sphere_select", "pcreg_dev_sphere_select_batched",
-    "pcreg_dev_get_matches_segmented_workspace", "pcreg_dev_get_matches_segmented",
+    "pcreg_dev_get_matches_segmented_workspace", "pcreg_dev_get_matches_segmented", "pcreg_dev_segmented_model_bytes", "pcreg_dev_segmented_model_prepare", "pcreg_dev_get_matches_segmented_prepared",
     "pcreg_dev_gather_rows_f64", "pcreg_dev_sweep_plan", "pcreg_dev_sweep_gather", "pcreg_dev_ransac_batched_workspace",
     "pcreg_dev_ransac_batched", "pcreg_dev_align_points_knn_batched", "pcreg_dev_quick_tf", "pcreg_dev_refine_by_distance",
     "pcreg_comm_get_unique_id", "pcreg_comm_init", "pcreg_comm_init_host_staged", "pcreg_comm_rank", "pcreg_comm_destroy",
@@ -98,7 +98,7 @@ def lib() -> C.CDLL:
         for name in ("pcreg_dev_model_search_workspace", "pcreg_dev_knn2_points_f32_workspace",
                      "pcreg_dev_ransac_workspace", "pcreg_dev_spatial_histogram_descriptors_workspace",
                      "pcreg_dev_get_matches_workspace", "pcreg_dev_sphere_select_workspace", "pcreg_dev_ransac_batched_workspace",
-                     "pcreg_dev_get_matches_segmented_workspace"):
+                     "pcreg_dev_get_matches_segmented_workspace", "pcreg_dev_segmented_model_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib

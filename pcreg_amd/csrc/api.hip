@@ -1154,6 +1154,27 @@ int pcreg_dev_get_matches_segmented(const double* descSurface, int Q, const doub
     return launch_get_matches_segmented(descSurface, Q, descModel, VM, D, seg_rows, seg_off, S, total_rows, max_rows, *par, pairs_all,
                                         metric_all, n_pairs, workspace, workspace_bytes, (hipStream_t)stream);
 }
+size_t pcreg_dev_segmented_model_bytes(int VM, int D) { return segmented_prepared_model_bytes(VM, D); }
+int pcreg_dev_segmented_model_prepare(const double* descModel, int VM, int D, const pcreg_match_opts* par, void* prepared, size_t prepared_bytes, void* stream) {
+    PCREG_ARG(descModel && par && prepared && VM >= 0 && D >= 1 && prepared_bytes >= segmented_prepared_model_bytes(VM, D));
+    GUARD();
+    double* P = (double*)prepared;
+    return launch_segmented_prepare_model(descModel, VM, D, *par, P, P + (size_t)(VM > 0 ? VM : 1) * D, (hipStream_t)stream);
+}
+int pcreg_dev_get_matches_segmented_prepared(const double* descSurface, int Q, const double* descModel, int VM, int D, const void* prepared,
+                                             int prepared_change_metric, double prepared_metric_factor, const int32_t* seg_rows,
+                                             const int32_t* seg_off, int S, int total_rows, int max_rows, const pcreg_match_opts* par,
+                                             uint32_t* pairs_all, double* metric_all, int32_t* n_pairs, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+    PCREG_ARG(descSurface && descModel && prepared && seg_rows && seg_off && par && pairs_all && n_pairs && workspace);
+    PCREG_ARG(Q >= 0 && VM >= 0 && D >= 1 && S >= 0 && S <= 65535 && total_rows >= 0 && max_rows >= 0 && max_rows <= total_rows);
+    if (par->metric != PCREG_METRIC_SAD) { set_error("pcreg_dev_get_matches_segmented_prepared: Metric must be SAD"); return PCREG_E_ARG; }
+    GUARD();
+    const double* P = (const double*)prepared;
+    const SegPreparedModel prep{P, P + (size_t)(VM > 0 ? VM : 1) * D, VM, D, prepared_change_metric, prepared_metric_factor};
+    return launch_get_matches_segmented(descSurface, Q, descModel, VM, D, seg_rows, seg_off, S, total_rows, max_rows, *par, pairs_all,
+                                        metric_all, n_pairs, workspace, workspace_bytes, (hipStream_t)stream, &prep);
+}
 size_t pcreg_dev_sphere_select_workspace(int V) { return sphere_select_workspace_bytes(V); }
 int pcreg_dev_sphere_select(const double* feat, int V, const double centre[3], double R, int32_t* idx, int32_t* n_out,
                             void* workspace, size_t workspace_bytes, void* stream) {

@@ -180,8 +180,18 @@ class SphereSweep:
         wsb = L.pcreg_dev_get_matches_segmented_workspace(VS, self.VM, self.D, S, tot, n_max)
         if getattr(self, "_seg_ws", None) is None or self._seg_ws.numel() < wsb:
             self._seg_ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
-        check(L.pcreg_dev_get_matches_segmented(_p(self.descS), VS, _p(self.descM), self.VM, self.D, _p(rows_all), _p(seg_off), S, tot, n_max,
-                                                C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws), C.c_size_t(self._seg_ws.numel()), sp))   # :131-149
+        # the model is fixed for the life of this object (one model, many surfaces): its powered rows and row scalars -- what the
+        # segmented matcher makes of the model set alone -- are prepared once per set of options, not once per sweep
+        key = (int(o.change_metric), float(o.metric_factor) if o.change_metric else 0.0)
+        if getattr(self, "_seg_prep_key", None) != key:
+            nb = L.pcreg_dev_segmented_model_bytes(self.VM, self.D)
+            if getattr(self, "_seg_prep", None) is None or self._seg_prep.numel() < nb:
+                self._seg_prep = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
+            check(L.pcreg_dev_segmented_model_prepare(_p(self.descM), self.VM, self.D, C.byref(o), _p(self._seg_prep), C.c_size_t(self._seg_prep.numel()), sp))
+            self._seg_prep_key = key
+        check(L.pcreg_dev_get_matches_segmented_prepared(_p(self.descS), VS, _p(self.descM), self.VM, self.D, _p(self._seg_prep), key[0], C.c_double(o.metric_factor),
+                                                         _p(rows_all), _p(seg_off), S, tot, n_max, C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws),
+                                                         C.c_size_t(self._seg_ws.numel()), sp))                                  # :131-149
         return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev)
 
     def _pinned(self, key: str, n: int, dtype) -> "torch.Tensor":
