@@ -361,6 +361,46 @@ def test_segmented_get_matches_with_many_tied_candidates(oracle_c, copies, debug
     assert sum(g[0].shape[0] for g in got) > 0
 
 
+def test_segmented_get_matches_on_a_prepared_model():
+    """pcreg_dev_segmented_model_prepare + pcreg_dev_get_matches_segmented_prepared == pcreg_dev_get_matches_segmented, also when the
+    call's options are not the ones the model was prepared with (the call then makes its own powered rows)."""
+    import ctypes as C
+    import torch
+    from pcreg_amd._lib import check, lib
+    from pcreg_amd.api import _match_opts
+    rng = np.random.default_rng(17)
+    VM, Q, D = 1100, 240, 96
+    descM = rng.poisson(3.0, (VM, D)).astype(np.float64)
+    descS = descM[rng.choice(VM, Q, replace=False)] + rng.poisson(0.2, (Q, D))
+    rows_list = [np.sort(rng.choice(VM, 500, replace=False)), np.arange(VM), np.sort(rng.choice(VM, 33, replace=False))]
+    dev = torch.device("cuda", 0)
+    L = lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    dS, dM = torch.from_numpy(descS).to(dev), torch.from_numpy(descM).to(dev)
+    S = len(rows_list)
+    off = np.zeros(S + 1, dtype=np.int32); off[1:] = np.cumsum([len(r) for r in rows_list])
+    tot, n_max = int(off[-1]), max(len(r) for r in rows_list)
+    rows = torch.from_numpy(np.concatenate(rows_list).astype(np.int32)).to(dev); seg_off = torch.from_numpy(off).to(dev)
+    prep_par = dict(PAR)
+    o_prep = _match_opts(prep_par)
+    nb = L.pcreg_dev_segmented_model_bytes(VM, D)
+    prep = torch.empty(nb, dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(L.pcreg_dev_segmented_model_prepare(p(dM), VM, D, C.byref(o_prep), p(prep), C.c_size_t(nb), st))
+    ws = torch.empty(max(L.pcreg_dev_get_matches_segmented_workspace(Q, VM, D, S, tot, n_max), 256), dtype=torch.uint8, device=dev)
+    for par in (prep_par, dict(PAR, metric_factor=0.8), dict(PAR, CHANGE_METRIC=False)):
+        want = _segments_direct(descS, descM, rows_list, par, metric=True)
+        o = _match_opts(par)
+        pairs = torch.zeros((S, Q, 2), dtype=torch.int32, device=dev); met = torch.zeros((S, Q), dtype=torch.float64, device=dev)
+        n_pairs = torch.full((S,), -1, dtype=torch.int32, device=dev)
+        check(L.pcreg_dev_get_matches_segmented_prepared(p(dS), Q, p(dM), VM, D, p(prep), int(o_prep.change_metric), C.c_double(o_prep.metric_factor), p(rows),
+                                                         p(seg_off), S, tot, n_max, C.byref(o), p(pairs), p(met), p(n_pairs), p(ws), C.c_size_t(ws.numel()), st))
+        n = n_pairs.cpu().numpy(); ph = pairs.cpu().numpy().astype(np.uint32); mh = met.cpu().numpy()
+        for z in range(S):
+            np.testing.assert_array_equal(ph[z, :n[z]], want[z][0])
+            np.testing.assert_array_equal(mh[z, :n[z]], want[z][1])
+
+
 def test_segmented_get_matches_refuses_ssd():
     from pcreg_amd._lib import PcregError
     rng = np.random.default_rng(0)
