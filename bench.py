@@ -559,8 +559,9 @@ def extra_sweep(dev, with_cpu: bool) -> dict:
     flops = (3.0 * (D + 1) - 1.0) * pairs_dedup
     res = {"workload": f"sphere sweep: {S} valid spheres of a {VM}-keypoint model ({int(out['num_desc'].mean())} descriptors per sphere on average), surface {VS} "
                        f"keypoints, D {D}, getMatches per sphere (SAD, power 0.6, 10 %, 0.99, Unique), {len(out['trial'])} trial spheres x RANSAC(3,1e4,0.3,0.08,REFINE)",
-           "ms": round(ms, 2), "spheres_per_s": round(S / ms * 1e3, 1), "host_syncs": 2, "trial_spheres": int(len(out["trial"])),
-           "model_prepared_once": "the model set's powered rows (0.35 ms) are made once per model and options, like the search's prepared model",
+           "ms": round(ms, 2), "spheres_per_s": round(S / ms * 1e3, 1), "host_syncs": 1, "trial_spheres": int(len(out["trial"])),
+           "model_prepared_once": "per model (and options / sphere parameters), like the search's prepared model: the spheres (centres, row lists: the script's "
+                                  "first synchronisation) and the model set's powered rows (0.35 ms); a timed sweep matches and registers one surface",
            "registered": int(sum(t is not None for t in out["transforms"])),
            "roofline": {"bound": "valu", "achieved": round(flops / ms / 1e9, 1), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(flops / ms / 1e9 / PEAK_FP32_TFLOPS, 4), "traffic": None, "dedup_model_rows": union,

@@ -132,7 +132,8 @@ class SphereSweep:
     def run(self, par: dict, options: dict, R_desc: float, d_spheres: float = 5.0, min_pts: int = 1400,
             putative_thresh: int = 170, seed: int = 0) -> dict:
         """completeExperimentFast.m:46-224 with every per-sphere loop as ONE launch chain over all spheres, TWO host
-        synchronisations for the whole sweep.
+        synchronisations for the first sweep with a set of sphere parameters and ONE for every later one (the spheres -- centres,
+        row lists, gathered keypoints -- depend on the model only and are kept).
 
         (sync 1) the descriptor counts of all candidate centres fix the valid spheres and every buffer size (:52-64).
         Then, with nothing read back in between: getDescriptorMask of every valid sphere as one launch writing the row
@@ -149,31 +150,44 @@ class SphereSweep:
             return self.run_streams(par, options, R_desc, d_spheres, min_pts, putative_thresh, seed)
         L = lib()
         dev = self.dev
-        centres = self.sphere_centres(d_spheres)
-        valid, counts = self.valid_spheres(centres, R_desc, min_pts)                     # ---- sync 1
-        centres = centres[valid]
-        num_desc = counts[valid].astype(np.int64)
-        S = len(centres)
+        i32, f64 = torch.int32, torch.float64
+        VS, sp = self.VS, _stream()
+        # The spheres are a property of the MODEL (its keypoints, R_desc, the spacing, min_pts): their centres, row lists and gathered
+        # keypoints are made at the first sweep with these parameters and kept -- one model, many surfaces.  That first sweep has the
+        # script's two host synchronisations (the counts fix every size); the later ones have ONE, at the end.
+        skey = (float(R_desc), float(d_spheres), int(min_pts))
+        sph = self.__dict__.setdefault("_spheres", {}).get(skey)
+        if sph is None:
+            centres = self.sphere_centres(d_spheres)
+            valid, counts = self.valid_spheres(centres, R_desc, min_pts)                     # ---- sync 1 (first sweep only)
+            centres = centres[valid]
+            num_desc = counts[valid].astype(np.int64)
+            S = len(centres)
+            sph = dict(centres=centres, num_desc=num_desc, S=S)
+            if S:
+                row_off = np.zeros(S + 1, dtype=np.int64); row_off[1:] = np.cumsum(num_desc)
+                tot, n_max = int(row_off[-1]), int(num_desc.max())
+                if tot >= 2**31:
+                    raise ValueError("sphere sweep: more than 2^31 rows over all spheres")
+                seg_off = torch.from_numpy(row_off.astype(np.int32)).to(dev)
+                cen = torch.from_numpy(np.ascontiguousarray(centres, dtype=np.float64)).to(dev)
+                roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
+                rows_all = torch.empty(tot, dtype=i32, device=dev)
+                feat_all = torch.empty((tot, 3), dtype=f64, device=dev)
+                n_sel = torch.zeros(S, dtype=i32, device=dev)
+                check(L.pcreg_dev_sphere_select_batched(_p(self.featM), self.VM, _p(cen), S, C.c_double(R_desc), _p(seg_off), _p(rows_all), _p(feat_all),
+                                                        _p(n_sel), sp))                                                     # :109-125
+                assert np.array_equal(n_sel.cpu().numpy(), num_desc), "sphere_select disagrees with sphere_counts"
+                rows_host = rows_all.cpu().numpy().astype(np.int64)
+                sph.update(row_off=row_off, tot=tot, n_max=n_max, seg_off=seg_off, roff_dev=roff_dev, rows_all=rows_all, feat_all=feat_all,
+                           model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)])
+            self._spheres[skey] = sph
+        centres, num_desc, S = sph["centres"], sph["num_desc"], sph["S"]
         if S == 0:
             return dict(centres=centres, num_desc=num_desc, num_putative=np.zeros(0, np.int64), matches=[], model_rows=[], trial=np.zeros(0, np.int64),
                         statsPutative=np.zeros(0, np.int64), statsSuccess=np.zeros(0, np.int64), statsInliers=np.zeros(0, np.int64),
                         statsRatio=np.zeros(0), transforms=[])
-        i32, f64 = torch.int32, torch.float64
-        row_off = np.zeros(S + 1, dtype=np.int64); row_off[1:] = np.cumsum(num_desc)
-        tot, n_max = int(row_off[-1]), int(num_desc.max())
-        if tot >= 2**31:
-            raise ValueError("sphere sweep: more than 2^31 rows over all spheres")
-        VS, sp = self.VS, _stream()
-        # every host-to-device copy before the first launch: a pageable copy waits for the stream's earlier work, and one placed
-        # after the matching chain would hold back the launches behind it until that chain has run
-        seg_off = torch.from_numpy(row_off.astype(np.int32)).to(dev)
-        cen = torch.from_numpy(np.ascontiguousarray(centres, dtype=np.float64)).to(dev)
-        roff_dev = torch.from_numpy(row_off[:S].copy()).to(dev)
-        rows_all = torch.empty(tot, dtype=i32, device=dev)
-        feat_all = torch.empty((tot, 3), dtype=f64, device=dev)
-        n_sel = torch.zeros(S, dtype=i32, device=dev)
-        check(L.pcreg_dev_sphere_select_batched(_p(self.featM), self.VM, _p(cen), S, C.c_double(R_desc), _p(seg_off), _p(rows_all), _p(feat_all),
-                                                _p(n_sel), sp))                                                         # :109-125
+        row_off, tot, n_max, seg_off, roff_dev, rows_all, feat_all = (sph[k] for k in ("row_off", "tot", "n_max", "seg_off", "roff_dev", "rows_all", "feat_all"))
         pairs_all = torch.zeros((S, max(VS, 1), 2), dtype=i32, device=dev)
         n_pairs = torch.zeros(S, dtype=i32, device=dev)
         o = _match_opts(par)
@@ -192,7 +206,8 @@ class SphereSweep:
         check(L.pcreg_dev_get_matches_segmented_prepared(_p(self.descS), VS, _p(self.descM), self.VM, self.D, _p(self._seg_prep), key[0], C.c_double(o.metric_factor),
                                                          _p(rows_all), _p(seg_off), S, tot, n_max, C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws),
                                                          C.c_size_t(self._seg_ws.numel()), sp))                                  # :131-149
-        return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev)
+        return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, None, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev,
+                                  model_rows=sph["model_rows"])
 
     def _pinned(self, key: str, n: int, dtype) -> "torch.Tensor":
         """A page-locked host buffer of at least n elements, kept across sweeps (the first n elements are returned)."""
@@ -203,7 +218,8 @@ class SphereSweep:
             cache[key] = t
         return t[:n]
 
-    def _finish_sweep(self, centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev=None) -> dict:
+    def _finish_sweep(self, centres, num_desc, row_off, rows_all, feat_all, n_sel, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev=None,
+                      model_rows=None) -> dict:
         """:166-224 on the current stream + the sweep's second (last) host synchronisation."""
         from ._lib import DevRansacResult
         L = lib()
@@ -232,6 +248,9 @@ class SphereSweep:
                                          C.c_size_t(self._rs_ws.numel()), sp))
         # ---- sync 2: everything comes back together -- the small results in ONE pinned transfer (seven separate .cpu() calls were
         # seven synchronisations, ~0.4 ms of the sweep), then the pair and row lists, which need the pair counts for their size
+        check_sel = n_sel is not None
+        if not check_sel:                                            # run(): the row lists were checked and fetched when the spheres were made
+            n_sel = torch.zeros(S, dtype=i32, device=dev)            # (keeps the layout of the packed transfer below)
         small = torch.cat([n_pairs, n_trials, trial_idx, n_sel, results.view(torch.int32).view(-1)])
         hs = self._pinned("small", small.numel(), torch.int32)
         hs.copy_(small, non_blocking=True)
@@ -245,12 +264,15 @@ class SphereSweep:
         m_pairs = max(int(npr.max()) if S else 0, 1)                # only the columns that hold pairs cross the bus
         hp = self._pinned("pairs", S * m_pairs * 2, torch.int32).view(S, m_pairs, 2)
         hp.copy_(pairs_all[:, :m_pairs], non_blocking=True)
-        hr = self._pinned("rows", max(rows_all.numel(), 1), torch.int32)[:rows_all.numel()]
-        hr.copy_(rows_all, non_blocking=True)
+        if model_rows is None:
+            hr = self._pinned("rows", max(rows_all.numel(), 1), torch.int32)[:rows_all.numel()]
+            hr.copy_(rows_all, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         pairs_host = hp.numpy().astype(np.uint32)                   # one conversion (a copy: the pinned buffer is reused); the per-sphere lists are views of it
-        rows_host = hr.numpy().astype(np.int64)
-        assert np.array_equal(nsel, num_desc), "sphere_select disagrees with sphere_counts"
+        if model_rows is None:
+            rows_host = hr.numpy().astype(np.int64)
+            model_rows = [rows_host[row_off[i]:row_off[i + 1]] for i in range(S)]
+        assert not check_sel or np.array_equal(nsel, num_desc), "sphere_select disagrees with sphere_counts"
         sp_, ss, si, sr, tf = [], [], [], [], []
         for t in range(nt):
             r = DevRansacResult.from_buffer_copy(raw[t].tobytes())
@@ -260,7 +282,7 @@ class SphereSweep:
             tf.append(None if r.failed else np.array(r.T[:]).reshape(4, 4, order="F"))
         return dict(centres=centres, num_desc=num_desc, num_putative=npr,
                     matches=[pairs_host[i, :npr[i]] for i in range(S)],
-                    model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)], trial=trial,
+                    model_rows=model_rows, trial=trial,
                     statsPutative=np.array(sp_, dtype=np.int64), statsSuccess=np.array(ss, dtype=np.int64),
                     statsInliers=np.array(si, dtype=np.int64), statsRatio=np.array(sr, dtype=np.float64), transforms=tf)
 

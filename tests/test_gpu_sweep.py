@@ -189,8 +189,19 @@ def test_batched_sweep_counts_its_host_syncs(monkeypatch):
     out = sw.run(PAR, OPT, R_desc=9.0, d_spheres=6.0, min_pts=400, putative_thresh=50, seed=1)
     S = len(out["centres"])
     assert S >= 4
-    # sync 1 = featM (once, cached) + the counts; sync 2 = the final block of reads; nothing scales with S
+    # sync 1 = featM (once, cached) + the counts + the spheres' row lists; sync 2 = the final block of reads; nothing scales with S
     assert len(calls) <= 10, calls
+    # the spheres belong to the model: a second sweep (another surface would do) reads the device ONCE, through its pinned
+    # transfers -- no Tensor.cpu / .item at all -- and returns the same results
+    calls.clear()
+    again = sw.run(PAR, OPT, R_desc=9.0, d_spheres=6.0, min_pts=400, putative_thresh=50, seed=1)
+    assert calls == [], calls
+    for k in ("num_desc", "num_putative", "trial", "statsSuccess", "statsInliers"):
+        np.testing.assert_array_equal(out[k], again[k])
+    for a, b in zip(out["matches"] + out["model_rows"], again["matches"] + again["model_rows"]):
+        np.testing.assert_array_equal(a, b)
+    other = sw.run(PAR, OPT, R_desc=8.0, d_spheres=6.0, min_pts=300, putative_thresh=50, seed=1)          # other spheres: made anew
+    assert len(other["centres"]) != S or not np.array_equal(other["num_desc"], out["num_desc"])
 
 
 def _segments_direct(descS, descM, rows_list, par, metric=False):
