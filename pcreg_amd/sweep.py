@@ -50,6 +50,16 @@ class SphereSweep:
         self._featM_host = None
         self._limits = None
 
+    def set_surface(self, featSurface, descSurface) -> None:
+        """The next surface against the SAME model (completeExperimentFast.m runs once per surface crop): everything run() keeps
+        for the model -- its spheres, the powered rows of its descriptor set, the workspaces -- stays."""
+        t = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))).to(self.dev).contiguous()
+        fS, dS = t(featSurface), t(descSurface)
+        if dS.shape[1] != self.D or fS.shape[0] != dS.shape[0]:
+            raise ValueError("surface descriptors must have the model's length and one row per surface keypoint")
+        self.featS, self.descS = fS, dS
+        self.VS = dS.shape[0]
+
     def release(self) -> None:
         """Drop the cached workspaces (the segmented chain's ~1.4 GB, the batched ransac's, the per-stream pipelines of
         run_streams()); the next run allocates them again.  The descriptor sets stay resident."""

@@ -202,6 +202,17 @@ def test_batched_sweep_counts_its_host_syncs(monkeypatch):
         np.testing.assert_array_equal(a, b)
     other = sw.run(PAR, OPT, R_desc=8.0, d_spheres=6.0, min_pts=300, putative_thresh=50, seed=1)          # other spheres: made anew
     assert len(other["centres"]) != S or not np.array_equal(other["num_desc"], out["num_desc"])
+    # another surface against the same model: the model's spheres and powered rows are reused, the results are those of a fresh object
+    featM2, descM2, featS2, descS2 = _scene(seed=9, VM=5000, VS=170, D=64)
+    sw.set_surface(featS2, descS2)
+    calls.clear()
+    got2 = sw.run(PAR, OPT, R_desc=9.0, d_spheres=6.0, min_pts=400, putative_thresh=50, seed=1)
+    assert calls == [], calls
+    fresh = sw_mod.SphereSweep(featM, descM, featS2, descS2).run(PAR, OPT, R_desc=9.0, d_spheres=6.0, min_pts=400, putative_thresh=50, seed=1)
+    for k in ("num_desc", "num_putative", "trial", "statsSuccess", "statsInliers"):
+        np.testing.assert_array_equal(got2[k], fresh[k])
+    for a, b in zip(got2["matches"], fresh["matches"]):
+        np.testing.assert_array_equal(a, b)
 
 
 def _segments_direct(descS, descM, rows_list, par, metric=False):
