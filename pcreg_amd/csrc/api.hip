@@ -750,6 +750,7 @@ int pcreg_sphere_sweep(const pcreg_desc_set* surface, const pcreg_desc_set* mode
     const int tot = off[S];
     if (VS == 0 || VM == 0 || tot == 0) { for (int i = 0; i < S; ++i) n_pairs[i] = 0; return PCREG_OK; }
     const size_t vs = (size_t)VS, ld = (size_t)S * vs;
+    PCREG_ARG(ld <= 0x7FFFFFFFull);                              // the packed correspondences are indexed with int
     void *tmp, *fm, *fs, *tc, *cen, *doff, *droff, *rows, *fall, *nsel, *dp, *dn, *ws, *tidx, *toff, *nt, *p12, *res, *inl, *rws;
     TRY(scratch().get(0, sizeof(double) * 3 * (size_t)std::max(VM, VS), &tmp));
     TRY(scratch().get(1, sizeof(double) * 3 * (size_t)VM, &fm));
