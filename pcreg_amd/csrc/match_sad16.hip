@@ -1601,13 +1601,38 @@ __global__ __launch_bounds__(kBlock) void segp_back_direct_kernel(SegSets S, con
     }
 }
 
+// min over the surface rows of every model row's reference scores: the back-check of EVERY sphere compares a candidate's own score
+// with it first (most weak matches end there), so it is taken once per call from the shared matrix -- a wave per model row, 0.1 ms --
+// instead of once per back-check item (a full pass over the 8 KB row of the matrix per item: 1.5 ms of the sweep on described rows,
+// where half the queries reach the back-check).
+__global__ __launch_bounds__(kBlock) void segp_rowmin_kernel(const uint32_t* __restrict__ Sc, int ldsc, int nA, int VM, uint32_t* __restrict__ rowmin) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (r >= VM) return;
+    const uint32_t* row = Sc + (size_t)r * ldsc;
+    unsigned best = 0xFFFFFFFFu;
+    const int n4 = (nA + 3) / 4;
+#pragma unroll 4
+    for (int a4 = lane; a4 < n4; a4 += 64) {
+        const uint4 v = *(const uint4*)(row + (size_t)a4 * 4);
+        const int a = a4 * 4;
+        best = min(best, v.x);
+        if (a + 1 < nA) best = min(best, v.y);
+        if (a + 2 < nA) best = min(best, v.z);
+        if (a + 3 < nA) best = min(best, v.w);
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o_));
+    if (lane == 0) rowmin[r] = best;
+}
+
 // segp_back_direct_kernel with its exact sums handed to the dense chain: an item whose rows to sum (q among them) fit two groups
 // writes them as groups 2 k, 2 k + 1 of item k -- a-side = the model row, b-side = surface rows -- for segp_scan_kernel /
 // segp_rerank_pairs_kernel (A = PM, B = PS) / segp_back_decide_kernel; the few with more rows are summed here as before.
 __global__ __launch_bounds__(kBlock) void segp_back_pick_kernel(SegSets S, const double* __restrict__ nrmS, const double* __restrict__ nrmM,
                                                                 const SegConst* __restrict__ sc, const int32_t* __restrict__ cand_q,
                                                                 const int32_t* __restrict__ cand_m, const int32_t* __restrict__ n_cand,
-                                                                const uint32_t* __restrict__ Sc, int ldsc, const double* __restrict__ fdist,
+                                                                const uint32_t* __restrict__ Sc, int ldsc, const uint32_t* __restrict__ rowmin,
+                                                                const double* __restrict__ fdist,
                                                                 int32_t* __restrict__ bidx, double* __restrict__ bdist,
                                                                 int32_t* __restrict__ flag2, int32_t* __restrict__ n_flag2, int skip,
                                                                 SegGroupRows* __restrict__ grows, SegGroupNorms* __restrict__ gnorms,
@@ -1628,21 +1653,10 @@ __global__ __launch_bounds__(kBlock) void segp_back_pick_kernel(SegSets S, const
         unsigned smax = 0xFFFFFFFFu;
         { const double t = (dq * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0; if (t < 4.0e9) smax = (unsigned)t; }
         const uint32_t* row = Sc + (size_t)V.rows[jm] * ldsc;
-        // (segp_back_direct_kernel's comments)  The row of the matrix is read 16 bytes per lane, four loads in flight (one 4-byte
-        // load per trip left the wave waiting out a memory latency for every 64 surface rows: 0.8 ms per sweep).
-        unsigned best = 0xFFFFFFFFu;
+        // (segp_back_direct_kernel's comments)  The row's minimum comes from segp_rowmin_kernel; the row itself is read -- 16 bytes per lane,
+        // four loads in flight -- only by the items that survive the test against it.
+        const unsigned best = rowmin[V.rows[jm]];
         const int n4 = (nA + 3) / 4;                              // ldsc is a multiple of 4 and >= nA: the 16-byte loads stay inside the row
-#pragma unroll 4
-        for (int a4 = lane; a4 < n4; a4 += 64) {
-            const uint4 v = *(const uint4*)(row + (size_t)a4 * 4);
-            const int a = a4 * 4;
-            best = min(best, v.x);
-            if (a + 1 < nA) best = min(best, v.y);
-            if (a + 2 < nA) best = min(best, v.z);
-            if (a + 3 < nA) best = min(best, v.w);
-        }
-#pragma unroll
-        for (int o_ = 32; o_ > 0; o_ >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o_));
         const unsigned slack = 2u * (unsigned)(D + 1) + 2u + c.slack2;
         const unsigned bmax = best > 0xFFFFFFFFu - slack ? 0xFFFFFFFFu : best + slack;
         if (row[qi] > bmax && !skip) {
@@ -2026,7 +2040,7 @@ int run_sad16_top2(const double* A, int nA, int lda, const double* B, int nB, in
 namespace {
 struct SegLayout {
     size_t PS, PM, rowS, rowM, nrefS, nrefM, Aq, Bq, Sc, sc, nrmS, nrmM, part_idx, part_s, idx, dist, bidx, bdist, cand_q, cand_m, n_cand, n_flag,
-           flag_list, flag2, n_flag2, fpi, fpd, grows, gnorms, qinfo, psum, map, n_slots, more_list, n_more, refpart, total;
+           flag_list, flag2, n_flag2, fpi, fpd, grows, gnorms, qinfo, psum, map, n_slots, more_list, n_more, refpart, rowmin, total;
     int D2p, ldqa, ldqb, splits, chunk;
 };
 SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
@@ -2054,7 +2068,7 @@ SegLayout seg_layout(int Q, int VM, int D, int Dp, int S, int tot, int n_max) {
     L.flag_list = take(ns * q * 4); L.flag2 = take(ns * q * 4); L.n_flag2 = take(ns * 4);
     L.fpi = take(ns * kSegFbSlices * q * 2 * 4); L.fpd = take(ns * kSegFbSlices * q * 2 * 8);
     L.grows = take(ns * q * kNG * sizeof(SegGroupRows)); L.gnorms = take(ns * q * kNG * sizeof(SegGroupNorms)); L.qinfo = take(ns * q * sizeof(SegQueryInfo));
-    L.refpart = take((kRefParts * 4 + 1) * 8);
+    L.refpart = take((kRefParts * 4 + 1) * 8); L.rowmin = take(vm * 4);
     L.psum = take(ns * q * kNG * kNC * 8); L.map = take(ns * q * kNG * 4); L.n_slots = take(ns * 4); L.more_list = take(ns * q * 4); L.n_more = take(ns * 4);
     L.total = b;
     return L;
@@ -2193,8 +2207,10 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
         } else {
             SegGroupRows* grows = (SegGroupRows*)(w + L.grows); SegGroupNorms* gnorms = (SegGroupNorms*)(w + L.gnorms); SegQueryInfo* qinfo = (SegQueryInfo*)(w + L.qinfo);
             double* psum = (double*)(w + L.psum); int32_t *map = (int32_t*)(w + L.map), *n_slots = (int32_t*)(w + L.n_slots);
+            uint32_t* rowmin = (uint32_t*)(w + L.rowmin);
+            hipLaunchKernelGGL(segp_rowmin_kernel, dim3((VM + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, (const uint32_t*)Sc, L.ldqa, Q, VM, rowmin);
             hipLaunchKernelGGL(segp_back_pick_kernel, dim3(std::max(1, std::min((Q + 3) / 4, 128)), 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc,
-                               (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const double*)dist, bidx, bdist,
+                               (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const uint32_t*)rowmin, (const double*)dist, bidx, bdist,
                                flag2, n_flag2, skip_refine, grows, gnorms, qinfo, stats);
             hipLaunchKernelGGL(segp_scan_kernel, dim3(S), dim3(kBlock), 0, st, qinfo, Q, (const int32_t*)n_cand, map, n_slots);
             const int nb = (Q * kNG + kRQ * kRW - 1) / (kRQ * kRW);
