@@ -99,3 +99,23 @@ def test_default_library_reads_no_environment_variable():
     assert L.pcreg_debug_set(b"match_exact", 0) == _lib.PCREG_OK
     assert L.pcreg_debug_set(b"no_such_key", 1) == _lib.PCREG_E_ARG
     assert b"no_such_key" in L.pcreg_last_error()
+
+
+def test_matlab_wrappers_only_use_gateway_commands_that_exist():
+    """No MATLAB here: at least every pcreg_mex('<command>', ...) in matlab/*.m (and in INTEGRATION.md's snippets) must be a command
+    the gateway dispatches, and every command of the gateway must be named in its header comment."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gw = open(os.path.join(root, "mex", "pcreg_mex.cpp")).read()
+    have = set(re.findall(r'strcmp\(cmd, "([A-Za-z_]+)"\)', gw))
+    assert len(have) >= 20
+    used = {}
+    for f in glob.glob(os.path.join(root, "matlab", "*.m")) + [os.path.join(root, "INTEGRATION.md")]:
+        for c in re.findall(r"pcreg_mex\('([A-Za-z_]+)'", open(f).read()):
+            used.setdefault(c, f)
+    missing = {c: f for c, f in used.items() if c not in have}
+    assert not missing, missing
+    head = gw[:gw.index("#if __has_include")]
+    undocumented = [c for c in have if "'" + c + "'" not in head]
+    assert not undocumented, undocumented
