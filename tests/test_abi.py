@@ -119,3 +119,47 @@ def test_matlab_wrappers_only_use_gateway_commands_that_exist():
     head = gw[:gw.index("#if __has_include")]
     undocumented = [c for c in have if "'" + c + "'" not in head]
     assert not undocumented, undocumented
+
+
+def test_matlab_wrappers_pass_the_argument_counts_the_gateway_checks():
+    """The other thing only MATLAB would notice: a wrapper handing the gateway a number of arguments its command refuses.  Every
+    pcreg_mex('<command>', a, b, ...) call in matlab/*.m is parsed (nested brackets, '...' continuations) and its argument count held
+    against the command's own `nrhs != N` / `nrhs < N` test in mex/pcreg_mex.cpp."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gw = open(os.path.join(root, "mex", "pcreg_mex.cpp")).read()
+    rule = {}
+    blocks = re.split(r'strcmp\(cmd, "', gw)[1:]
+    for b in blocks:
+        name = b[:b.index('"')]
+        m = re.search(r"nrhs (!=|<) (\d+)", b)
+        if m:
+            rule[name] = (m.group(1), int(m.group(2)))
+    checked = 0
+    for f in glob.glob(os.path.join(root, "matlab", "*.m")):
+        txt = re.sub(r"\.\.\.[^\n]*\n", " ", open(f).read())                  # join continued lines
+        txt = "\n".join(ln.split("%")[0] if "'" not in ln.split("%")[0][-1:] else ln for ln in txt.split("\n"))
+        for m in re.finditer(r"pcreg_mex\('([A-Za-z_]+)'", txt):
+            i, depth, n_args, in_str = m.end(), 1, 1, False
+            while depth > 0 and i < len(txt):
+                ch = txt[i]
+                if in_str:
+                    in_str = ch != "'"
+                elif ch == "'" and txt[i - 1] in "(,[ {=":
+                    in_str = True
+                elif ch in "([{":
+                    depth += 1
+                elif ch in ")]}":
+                    depth -= 1
+                elif ch == "," and depth == 1:
+                    n_args += 1
+                i += 1
+            assert depth == 0, (f, m.group(1))
+            cmd = m.group(1)
+            if cmd in rule:
+                op, n = rule[cmd]
+                ok = n_args == n if op == "!=" else n_args >= n
+                assert ok, f"{os.path.basename(f)}: pcreg_mex('{cmd}', ...) passes {n_args} arguments, the gateway wants nrhs {'==' if op == '!=' else '>='} {n}"
+                checked += 1
+    assert checked >= 10, checked
