@@ -163,3 +163,25 @@ def test_matlab_wrappers_pass_the_argument_counts_the_gateway_checks():
                 assert ok, f"{os.path.basename(f)}: pcreg_mex('{cmd}', ...) passes {n_args} arguments, the gateway wants nrhs {'==' if op == '!=' else '>='} {n}"
                 checked += 1
     assert checked >= 10, checked
+
+
+def test_matlab_wrappers_ask_for_no_more_outputs_than_the_gateway_returns():
+    """[a, b, c] = pcreg_mex('<command>', ...) in matlab/*.m against the highest plhs[k] the command's block of the gateway assigns."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gw = open(os.path.join(root, "mex", "pcreg_mex.cpp")).read()
+    gives = {}
+    for b in re.split(r'strcmp\(cmd, "', gw)[1:]:
+        name = b[:b.index('"')]
+        ks = [int(k) for k in re.findall(r"plhs\[(\d+)\]", b)] + [int(k) for k in re.findall(r"\bout\((\d+),", b)]
+        gives[name] = (max(ks) + 1) if ks else 0
+    checked = 0
+    for f in glob.glob(os.path.join(root, "matlab", "*.m")):
+        txt = re.sub(r"\.\.\.[^\n]*\n", " ", open(f).read())
+        for m in re.finditer(r"(?:\[([^\]=]*)\]|([A-Za-z_][A-Za-z_0-9.]*))\s*=\s*pcreg_mex\('([A-Za-z_]+)'", txt):
+            n_out = len([x for x in re.split(r"[,\s]+", m.group(1).strip()) if x]) if m.group(1) is not None else 1
+            cmd = m.group(3)
+            assert cmd in gives and n_out <= gives[cmd], f"{os.path.basename(f)}: {n_out} outputs asked of '{cmd}', the gateway returns {gives.get(cmd)}"
+            checked += 1
+    assert checked >= 10, checked
