@@ -17,8 +17,12 @@ function out = sphereSweep(hSurface, hModel, featSurface, featModel, centres, R_
                                                                                  c, nd(:), R_desc, par, putativeThresh, ransacCoef, seed);
     S = size(c, 1);
     out.valid = valid; out.centres = c; out.numDesc = double(nd(:)); out.numPutative = nPairs;
-    out.modelRows = mat2cell(rows, double(nd(:)), 1);
-    out.matches = mat2cell(pairs, nPairs, 2);
+    if S == 0
+        out.modelRows = cell(0, 1); out.matches = cell(0, 1);
+    else
+        out.modelRows = mat2cell(reshape(rows, [], 1), double(nd(:)), 1);
+        out.matches = mat2cell(pairs, nPairs, 2);
+    end
     out.trial = trial;
     out.TForms = cell(numel(trial), 1);
     for t = 1:numel(trial), if ~failed(t), out.TForms{t} = T(:, :, t); end, end
