@@ -1077,12 +1077,15 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
 // chain of D adds per candidate): 4.2 of the sweep's 11.7 ms, half of the vector cycles spent with 60 lanes masked off.  Here
 //   segp_pick_kernel    (a wave per query) reads the query's lists, drops it if no pair can pass the filter, and writes up to
 //                       TWO groups of kNC candidates (the 8 smallest reference scores inside the slack): rows, norms, numbers;
-//   segp_scan_kernel    (a workgroup per segment) numbers the groups that exist: slot -> group;
+//   segp_scan_kernel    (a workgroup per segment) numbers the groups a round sums: slot -> group;
 //   segp_rerank_pairs_kernel (a wave per kRQ = 4 groups = 16 (query, candidate) pairs) forms the a - b terms of a 64-feature tile
 //                       pair by pair -- lane = feature, the norms in scalar registers -- into LDS [pair][feature], then lane p adds
 //                       pair p's 64 |terms| in order: every lane sums;
 //   segp_decide_kernel  (a THREAD per query) takes the exact distances, applies the certificate, writes idx / dist / the unproven
-//                       list -- or, for the few queries with more than 8 candidates inside the slack, lists them for
+//                       list.  TWO rounds of scan / pairs / decide: round 1 sums every query's first group, and the exact second
+//                       distance of those four excludes what it can of the second group through the reference scores (round 3's
+//                       bound); round 2 sums the second groups that keep a candidate.  The few queries with more than 8
+//                       candidates inside the slack are listed for
 //   segp_decide_more_kernel (a wave per such query): the remaining candidates that the exact second distance does not exclude
 //                       are summed by seg_rerank as before.
 // The sums are the same chains of the same terms; the top two of ALL candidates inside the slack equal the top two of
@@ -1091,7 +1094,13 @@ __global__ __launch_bounds__(kBlock) void segp_finalize_kernel(SegSets S, const 
 constexpr int kNG = 2;                                                            // groups per query
 struct alignas(32) SegGroupRows { int32_t arow, fast, row[kNC], pad[2]; };          // the a-side row, the kNC b-side rows (row 0 where there is no candidate); fast: all six divide through rinv
 struct alignas(16) SegGroupNorms { double nrm_a, rinv_a, nrm[kNC], rinv[kNC]; };  // of the surface row and the kNC rows (1, 1 where none)
-struct alignas(16) SegQueryInfo { int32_t j[kNG * kNC]; uint32_t g; int32_t ng, n_need, fast; };   // j < 0: none; g: seg_front's; ng groups
+struct alignas(16) SegQueryInfo {
+    int32_t j[kNG * kNC];          // the candidates' local numbers, < 0: none (or excluded by the first group's exact second distance)
+    uint32_t g;                    // seg_front's
+    int32_t ng, n_need, fast;      // groups that hold candidates
+    uint32_t sc2[kNC];             // reference scores of the second group's candidates
+    int32_t r2, pad[3];            // the second group is to be summed (set by the first decide launch)
+};
 
 struct SegFront { int j[kEPL]; unsigned sq[kEPL]; unsigned a1, a2, g; };
 // a query's candidate lists (entry lane + 64 u), the two smallest reference scores and the smallest KC-th score of a chunk
@@ -1146,6 +1155,7 @@ __global__ __launch_bounds__(kBlock) void segp_pick_kernel(SegSets S, const doub
                                                            SegGroupRows* __restrict__ grows, SegGroupNorms* __restrict__ gnorms,
                                                            SegQueryInfo* __restrict__ qinfo) {
     __shared__ int s_j[kBlock / 64][kNG * kNC];
+    __shared__ unsigned s_s[kBlock / 64][kNG * kNC];
     __shared__ unsigned long long s_key[kBlock / 64][64 * kEPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int z = blockIdx.z, nA = S.Q, D = S.Dp;
@@ -1205,7 +1215,7 @@ __global__ __launch_bounds__(kBlock) void segp_pick_kernel(SegSets S, const doub
             const unsigned long long mine = ((unsigned long long)sk[u] << 32) | (unsigned)(lane + 64 * u);
             int rank = 0;
             for (int k = 0; k < n_need; ++k) rank += s_key[wave][k] < mine ? 1 : 0;
-            if (rank < kNG * kNC) s_j[wave][rank] = jk[u];
+            if (rank < kNG * kNC) { s_j[wave][rank] = jk[u]; s_s[wave][rank] = sk[u]; }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -1217,6 +1227,7 @@ __global__ __launch_bounds__(kBlock) void segp_pick_kernel(SegSets S, const doub
         int row = 0; double nrm = 1.0, rinv = 1.0;              // no candidate: row 0 (readable), nobody looks at its sum
         if (jc >= 0) { row = V.rows[jc]; nrm = V.nrmM[jc]; rinv = V.rinvM[jc]; fast = fast && rinv != 0.0; }
         qinfo[o].j[lane] = jc;
+        if (gq == 1) qinfo[o].sc2[cq] = jc >= 0 ? s_s[wave][lane] : 0xFFFFFFFFu;
         if (gq < ng) {
             grows[o * kNG + gq].row[cq] = row; gnorms[o * kNG + gq].nrm[cq] = nrm; gnorms[o * kNG + gq].rinv[cq] = rinv;
             if (cq == 0) { gnorms[o * kNG + gq].nrm_a = a.nrm; gnorms[o * kNG + gq].rinv_a = a.rinv; }
@@ -1224,11 +1235,12 @@ __global__ __launch_bounds__(kBlock) void segp_pick_kernel(SegSets S, const doub
     }
     fast = __ballot(fast) == ~0ull;                            // lanes >= 8 carry the surface row's flag
     if (lane < ng) { grows[o * kNG + lane].arow = qi; grows[o * kNG + lane].fast = fast ? 1 : 0; }
-    if (lane == 0) { qinfo[o].g = F.g; qinfo[o].ng = ng; qinfo[o].n_need = n_need; qinfo[o].fast = fast ? 1 : 0; }
+    if (lane == 0) { qinfo[o].g = F.g; qinfo[o].ng = ng; qinfo[o].n_need = n_need; qinfo[o].fast = fast ? 1 : 0; qinfo[o].r2 = 0; }
 }
 
 // slot -> group (2 qi + g) for the groups that exist, in ascending order; n_slots[z] = their number.  One workgroup per segment.
-__global__ __launch_bounds__(kBlock) void segp_scan_kernel(const SegQueryInfo* __restrict__ qinfo, int Q, const int32_t* __restrict__ n_items,
+// which: 0 = every group, 1 = the first group of every item that has one, 2 = the second groups marked r2
+__global__ __launch_bounds__(kBlock) void segp_scan_kernel(const SegQueryInfo* __restrict__ qinfo, int Q, const int32_t* __restrict__ n_items, int which,
                                                            int32_t* __restrict__ map, int32_t* __restrict__ n_slots) {
     __shared__ int s_w[kBlock / 64], s_base;
     const int z = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1238,7 +1250,10 @@ __global__ __launch_bounds__(kBlock) void segp_scan_kernel(const SegQueryInfo* _
     __syncthreads();
     for (int q0 = 0; q0 < n; q0 += kBlock) {
         const int qi = q0 + tid;
-        const int ng = qi < n ? qinfo[qi].ng : 0;
+        int ng = qi < n ? qinfo[qi].ng : 0;
+        const int g0 = which == 2 ? 1 : 0;
+        if (which == 1) ng = min(ng, 1);
+        else if (which == 2) ng = (ng == 2 && qinfo[qi].r2) ? 1 : 0;
         int incl = ng;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
@@ -1247,7 +1262,7 @@ __global__ __launch_bounds__(kBlock) void segp_scan_kernel(const SegQueryInfo* _
         int base = s_base;
         for (int w = 0; w < wave; ++w) base += s_w[w];
         const int first = base + incl - ng;
-        for (int g = 0; g < ng; ++g) map[first + g] = qi * kNG + g;
+        for (int g = 0; g < ng; ++g) map[first + g] = qi * kNG + g0 + g;
         __syncthreads();
         if (tid == kBlock - 1) s_base = base + incl;
         __syncthreads();
@@ -1395,21 +1410,45 @@ __device__ __forceinline__ bool seg_certified(const SegConst& c, unsigned g, int
     const double lower = (c.rho * ((double)g - (double)(D + 1)) - (double)c.eunits) * c.inv_scale;
     return t2.i2 >= 0 && lower * (1.0 - 1e-12) > t2.d2;
 }
-__global__ __launch_bounds__(kBlock) void segp_decide_kernel(const SegConst* __restrict__ sc, const SegQueryInfo* __restrict__ qinfo, const double* __restrict__ psum,
-                                                             int Q, int D, int32_t* __restrict__ idx, double* __restrict__ dist,
+// round 1 (after the first groups are summed): a query with one group is decided; a query with two has the exact second distance of
+// its first four candidates bound the other four -- a candidate whose reference score cannot lie below it is dropped (j <- -1) --
+// and, if any is left, waits for round 2 (r2 <- 1: segp_scan_kernel(which = 2) lists its second group).  round 2: the queries with r2.
+__global__ __launch_bounds__(kBlock) void segp_decide_kernel(const SegConst* __restrict__ sc, SegQueryInfo* __restrict__ qinfo, const double* __restrict__ psum,
+                                                             int Q, int D, int round, int32_t* __restrict__ idx, double* __restrict__ dist,
                                                              int32_t* __restrict__ flag_list, int32_t* __restrict__ n_flag,
                                                              int32_t* __restrict__ more_list, int32_t* __restrict__ n_more, int force_unproven,
                                                              unsigned long long* __restrict__ stats) {
     const int z = blockIdx.z, qi = blockIdx.x * kBlock + threadIdx.x;
     if (qi >= Q) return;
     const size_t o = (size_t)z * Q + qi;
-    const SegQueryInfo I = qinfo[o];
+    SegQueryInfo I = qinfo[o];
     if (I.ng == 0) return;                                     // segp_pick_kernel wrote "no pair"
-    if (I.n_need > kNG * kNC) { more_list[(size_t)z * Q + atomicAdd(&n_more[z], 1)] = qi; return; }
+    if (round == 2 && !I.r2) return;                           // decided in round 1
+    const SegConst c = sc[z];
     Top2T<double> t2{INFINITY, INFINITY, -1, -1};
 #pragma unroll
-    for (int r = 0; r < kNG * kNC; ++r) if (r < I.ng * kNC) top2_insert_lex_t(t2, psum[o * kNG * kNC + r], I.j[r]);          // j < 0: no candidate
-    const bool ok = !force_unproven && seg_certified(sc[z], I.g, D, t2);
+    for (int r = 0; r < kNC; ++r) top2_insert_lex_t(t2, psum[o * kNG * kNC + r], I.j[r]);          // j < 0: no candidate
+    if (round == 1 && I.ng == 2) {
+        unsigned smax = 0xFFFFFFFFu;
+        if (t2.i2 >= 0 && t2.d2 < INFINITY) {
+            const double t = (t2.d2 * c.scale * (1.0 + 1e-12) + (double)c.eunits) / c.rho + (double)(D + 1) + 1.0;
+            if (t < 4.0e9) smax = (unsigned)t;
+        }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < kNC; ++r) {
+            const bool keep = I.j[kNC + r] >= 0 && I.sc2[r] <= smax;
+            if (!keep) { I.j[kNC + r] = -1; qinfo[o].j[kNC + r] = -1; }
+            any = any || keep;
+        }
+        if (any) { qinfo[o].r2 = 1; return; }
+    }
+    if (round == 2) {
+#pragma unroll
+        for (int r = kNC; r < kNG * kNC; ++r) top2_insert_lex_t(t2, psum[o * kNG * kNC + r], I.j[r]);
+    }
+    if (I.n_need > kNG * kNC) { more_list[(size_t)z * Q + atomicAdd(&n_more[z], 1)] = qi; return; }
+    const bool ok = !force_unproven && seg_certified(c, I.g, D, t2);
     idx[o * 2] = t2.i1; idx[o * 2 + 1] = t2.i2; dist[o * 2] = t2.d1; dist[o * 2 + 1] = t2.d2;          // unproven: the provisional pair segp_refine_kernel starts from
     if (!ok) flag_list[(size_t)z * Q + atomicAdd(&n_flag[z], 1)] = qi;
     if (stats) { atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)I.n_need); if (!ok) atomicAdd(&stats[2], 1ull); }
@@ -2173,12 +2212,14 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
         PCREG_HIP(hipMemsetAsync(n_more, 0, (size_t)S * sizeof(int32_t), st));
         hipLaunchKernelGGL(segp_pick_kernel, dim3((Q + 3) / 4, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, part_idx, part_s, L.splits, idx, dist, force,
                            (o.matchThreshold * 0.01) * (2.0 * sqrt((double)Dp)), o.maxRatio, grows, gnorms, qinfo);
-        hipLaunchKernelGGL(segp_scan_kernel, dim3(S), dim3(kBlock), 0, st, qinfo, Q, (const int32_t*)nullptr, map, n_slots);
         const int nb = (Q * kNG + kRQ * kRW - 1) / (kRQ * kRW);          // workgroups per segment; segments in groups of 8 (one per XCD)
-        hipLaunchKernelGGL(segp_rerank_pairs_kernel, dim3((unsigned)(((S + 7) / 8) * 8 * nb)), dim3(64 * kRW), 0, st, (const double*)PS, (const double*)PM, Q, D, Dp, sc,
-                           grows, gnorms, map, n_slots, nb, S, psum);
-        hipLaunchKernelGGL(segp_decide_kernel, dim3((Q + kBlock - 1) / kBlock, 1, S), dim3(kBlock), 0, st, sc, qinfo, psum, Q, Dp, idx, dist, flag_list, n_flag, more_list, n_more,
-                           force, stats);
+        for (int round = 1; round <= 2; ++round) {                       // the first groups; then the second groups their exact second distance could not exclude
+            hipLaunchKernelGGL(segp_scan_kernel, dim3(S), dim3(kBlock), 0, st, (const SegQueryInfo*)qinfo, Q, (const int32_t*)nullptr, round, map, n_slots);
+            hipLaunchKernelGGL(segp_rerank_pairs_kernel, dim3((unsigned)(((S + 7) / 8) * 8 * nb)), dim3(64 * kRW), 0, st, (const double*)PS, (const double*)PM, Q, D, Dp, sc,
+                               grows, gnorms, map, n_slots, nb, S, psum);
+            hipLaunchKernelGGL(segp_decide_kernel, dim3((Q + kBlock - 1) / kBlock, 1, S), dim3(kBlock), 0, st, sc, qinfo, psum, Q, Dp, round, idx, dist, flag_list, n_flag,
+                               more_list, n_more, force, stats);
+        }
         hipLaunchKernelGGL(segp_decide_more_kernel, dim3(16, 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc, part_idx, part_s, L.splits, qinfo, psum, more_list, n_more,
                            idx, dist, flag_list, n_flag, force, stats);
     }
@@ -2212,7 +2253,7 @@ static int launch_get_matches_segmented_one(const double* descS, int Q, const do
             hipLaunchKernelGGL(segp_back_pick_kernel, dim3(std::max(1, std::min((Q + 3) / 4, 128)), 1, S), dim3(kBlock), 0, st, sets, nrmS, nrmM, sc,
                                (const int32_t*)cand_q, (const int32_t*)cand_m, (const int32_t*)n_cand, (const uint32_t*)Sc, L.ldqa, (const uint32_t*)rowmin, (const double*)dist, bidx, bdist,
                                flag2, n_flag2, skip_refine, grows, gnorms, qinfo, stats);
-            hipLaunchKernelGGL(segp_scan_kernel, dim3(S), dim3(kBlock), 0, st, qinfo, Q, (const int32_t*)n_cand, map, n_slots);
+            hipLaunchKernelGGL(segp_scan_kernel, dim3(S), dim3(kBlock), 0, st, (const SegQueryInfo*)qinfo, Q, (const int32_t*)n_cand, 0, map, n_slots);
             const int nb = (Q * kNG + kRQ * kRW - 1) / (kRQ * kRW);
             hipLaunchKernelGGL(segp_rerank_pairs_kernel, dim3((unsigned)(((S + 7) / 8) * 8 * nb)), dim3(64 * kRW), 0, st, (const double*)PM, (const double*)PS, Q, D, Dp, sc,
                                grows, gnorms, map, n_slots, nb, S, psum);
