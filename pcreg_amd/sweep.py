@@ -189,8 +189,16 @@ class SphereSweep:
                                                         _p(n_sel), sp))                                                     # :109-125
                 assert np.array_equal(n_sel.cpu().numpy(), num_desc), "sphere_select disagrees with sphere_counts"
                 rows_host = rows_all.cpu().numpy().astype(np.int64)
+                # model rows that lie in NO sphere never meet the surface: the matcher gets the model set restricted to the union of the
+                # spheres' rows (the lists renumbered into it; a pair's model index counts inside its sphere, so nothing else changes)
+                union = np.unique(rows_host)
+                if len(union) < 0.95 * self.VM:
+                    desc_u = self.descM[torch.from_numpy(union).to(dev)].contiguous()
+                    rows_u = torch.from_numpy(np.searchsorted(union, rows_host).astype(np.int32)).to(dev)
+                else:
+                    desc_u, rows_u = self.descM, rows_all
                 sph.update(row_off=row_off, tot=tot, n_max=n_max, seg_off=seg_off, roff_dev=roff_dev, rows_all=rows_all, feat_all=feat_all,
-                           model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)])
+                           model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)], desc_u=desc_u, rows_u=rows_u, n_union=int(len(union)))
             self._spheres[skey] = sph
         centres, num_desc, S = sph["centres"], sph["num_desc"], sph["S"]
         if S == 0:
@@ -201,20 +209,22 @@ class SphereSweep:
         pairs_all = torch.zeros((S, max(VS, 1), 2), dtype=i32, device=dev)
         n_pairs = torch.zeros(S, dtype=i32, device=dev)
         o = _match_opts(par)
-        wsb = L.pcreg_dev_get_matches_segmented_workspace(VS, self.VM, self.D, S, tot, n_max)
+        wsb = L.pcreg_dev_get_matches_segmented_workspace(VS, sph["desc_u"].shape[0], self.D, S, tot, n_max)
         if getattr(self, "_seg_ws", None) is None or self._seg_ws.numel() < wsb:
             self._seg_ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
         # the model is fixed for the life of this object (one model, many surfaces): its powered rows and row scalars -- what the
         # segmented matcher makes of the model set alone -- are prepared once per set of options, not once per sweep
-        key = (int(o.change_metric), float(o.metric_factor) if o.change_metric else 0.0)
+        desc_u, rows_u = sph["desc_u"], sph["rows_u"]
+        VMu = desc_u.shape[0]
+        key = (skey, int(o.change_metric), float(o.metric_factor) if o.change_metric else 0.0)
         if getattr(self, "_seg_prep_key", None) != key:
-            nb = L.pcreg_dev_segmented_model_bytes(self.VM, self.D)
+            nb = L.pcreg_dev_segmented_model_bytes(VMu, self.D)
             if getattr(self, "_seg_prep", None) is None or self._seg_prep.numel() < nb:
                 self._seg_prep = torch.empty(max(nb, 256), dtype=torch.uint8, device=dev)
-            check(L.pcreg_dev_segmented_model_prepare(_p(self.descM), self.VM, self.D, C.byref(o), _p(self._seg_prep), C.c_size_t(self._seg_prep.numel()), sp))
+            check(L.pcreg_dev_segmented_model_prepare(_p(desc_u), VMu, self.D, C.byref(o), _p(self._seg_prep), C.c_size_t(self._seg_prep.numel()), sp))
             self._seg_prep_key = key
-        check(L.pcreg_dev_get_matches_segmented_prepared(_p(self.descS), VS, _p(self.descM), self.VM, self.D, _p(self._seg_prep), key[0], C.c_double(o.metric_factor),
-                                                         _p(rows_all), _p(seg_off), S, tot, n_max, C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws),
+        check(L.pcreg_dev_get_matches_segmented_prepared(_p(self.descS), VS, _p(desc_u), VMu, self.D, _p(self._seg_prep), key[1], C.c_double(o.metric_factor),
+                                                         _p(rows_u), _p(seg_off), S, tot, n_max, C.byref(o), _p(pairs_all), None, _p(n_pairs), _p(self._seg_ws),
                                                          C.c_size_t(self._seg_ws.numel()), sp))                                  # :131-149
         return self._finish_sweep(centres, num_desc, row_off, rows_all, feat_all, None, pairs_all, n_pairs, options, putative_thresh, seed, roff_dev,
                                   model_rows=sph["model_rows"])
