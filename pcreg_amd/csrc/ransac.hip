@@ -1935,6 +1935,7 @@ __device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __r
     // ---- phases 1 + 2, four hypotheses at a time: screened scores (ransac.m:48-50), then the refit sums of those that pass (:53-55)
     int c1 = 0;
     bool onlane = false;                       // this lane's hypothesis has its fifteen sums in MSwave
+    int same_as = -1;                          // ... which are those of this earlier hypothesis of the wave (the same inlier set): its refit is this one's
     const int v1c = (v1 ? 1 : 0) | (cert ? 2 : 0);
     for (int h = 0; h < nh; h += kHB32) {
         int hs[kHB32], cnt[kHB32];
@@ -1951,6 +1952,19 @@ __device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __r
         }
         if (!REFINE) continue;
 #ifndef NO_MOM
+        // Hypotheses of the group that selected the SAME inliers have the same fifteen sums (in a sphere that holds the surface most
+        // good samples do: half of this launch's time on the sweep went into summing them again and again): rep[k] = the first
+        // hypothesis of the group with k's inlier set; only representatives are summed, the others receive the representative's sums.
+        int rep[kHB32];
+#pragma unroll
+        for (int k = 0; k < kHB32; ++k) {
+            rep[k] = k;
+#pragma unroll
+            for (int j = k - 1; j >= 0; --j)
+                if (lp[k] && lp[j] && __builtin_amdgcn_ballot_w64(own[k] != own[j]) == 0ull) rep[k] = j;          // wave-uniform
+        }
+#pragma unroll
+        for (int k = 0; k < kHB32; ++k) if (rep[k] != k) { if (lane == hs[k]) same_as = hs[rep[k]]; lp[k] = false; }          // summed through its representative
 #pragma unroll
         for (int kp = 0; kp < kHB32; kp += 2) {
             if (!(lp[kp] || lp[kp + 1])) continue;                               // wave-uniform
@@ -1968,8 +1982,20 @@ __device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __r
                 if (__builtin_amdgcn_inverse_ballot_w64(wb)) mom15_add(accB, q);
             }
             const int kq = 8 * ((lane >> 5) & 1) + 4 * ((lane >> 4) & 1) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1);
-            if (lp[kp]) { const double r = wave_sum15_scatter(accA); if ((lane & 3) == 0 && kq < 15) MSwave[(size_t)hs[kp] * 16 + kq] = r; }
-            if (lp[kp + 1]) { const double r = wave_sum15_scatter(accB); if ((lane & 3) == 0 && kq < 15) MSwave[(size_t)hs[kp + 1] * 16 + kq] = r; }
+            if (lp[kp]) {
+                const double r = wave_sum15_scatter(accA);
+                if ((lane & 3) == 0 && kq < 15) {
+#pragma unroll
+                    for (int k = kp; k < kHB32; ++k) if (rep[k] == kp) MSwave[(size_t)hs[k] * 16 + kq] = r;          // itself and its copies
+                }
+            }
+            if (lp[kp + 1]) {
+                const double r = wave_sum15_scatter(accB);
+                if ((lane & 3) == 0 && kq < 15) {
+#pragma unroll
+                    for (int k = kp + 1; k < kHB32; ++k) if (rep[k] == kp + 1) MSwave[(size_t)hs[k] * 16 + kq] = r;
+                }
+            }
         }
 #endif
     }
@@ -2039,7 +2065,7 @@ __device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __r
 
     // ---- phase 4: rescore the refined transforms (ransac.m:56-58)
     int c2 = 0;
-    unsigned long long mask = __ballot(v2);
+    unsigned long long mask = __ballot(v2 && same_as < 0);          // a copy has its representative's sums, hence its transform and its count
     while (mask) {
         int hs[kHB32], cnt[kHB32];
         unsigned own[kHB32];
@@ -2051,6 +2077,10 @@ __device__ __forceinline__ void ransac_hyp32_body(const RansacArgs& a, char* __r
         score32_group<false>(a, L, g1, g2, n, lane, T32, TFwave, hs, cnt, own);
 #pragma unroll
         for (int k = 0; k < kHB32; ++k) if (lane == hs[k]) c2 = cnt[k];
+    }
+    {
+        const int c2r = __shfl(c2, max(same_as, 0));
+        if (same_as >= 0) c2 = c2r;
     }
     if (mine) {
         const bool keep = v2 && c2 >= thInlr;                                   // ransac.m:59-61
