@@ -420,6 +420,27 @@ def test_resident_kernel_slot_and_class_edges(n, refine, oracle_c):
     _cmp(pc.ransac(p1, p2, coef, seed=5, return_iter_counts=True), ref, n)
 
 
+@pytest.mark.parametrize("n,noise", [(600, 0.0), (1500, 1e-4), (700, 0.02)])
+def test_resident_kernel_hypotheses_with_identical_inlier_sets_share_their_refit(n, noise, oracle_c):
+    """ransac_hyp32_kernel sums a group's hypotheses with EQUAL inlier bit lists once and hands the sums (and the second-pass count)
+    to the copies.  Noise-free or nearly noise-free matches under a generous threshold make every good sample select the same
+    points -- groups of two, three and four copies, mixed with failing samples -- and every per-hypothesis count (first and
+    refined), numSuccess, the winner and its inliers must still be the oracle's; with noise 0.02 the sets differ again."""
+    import pcreg_amd as pc
+    p1, p2, _ = rigid_case(n, 9100 + n, noise=noise, outlier_frac=0.35)
+    coef = dict(minPtNum=3, iterNum=1024, thDist=0.3, thInlrRatio=0.3, REFINE=True, VERBOSE=0)
+    ref = oracle_c.ransac(p1, p2, coef, seed=17)
+    assert not ref["failed"] and ref["numSuccess"] > 50
+    _cmp(pc.ransac(p1, p2, coef, seed=17, return_iter_counts=True), ref, n)
+    # the batched entry point runs the same kernel per registration: two copies of the problem and a shuffled one
+    perm = np.random.default_rng(1).permutation(n)
+    res = pc.ransac_batched([p1, p1[perm], p1], [p2, p2[perm], p2], coef, seed=17)
+    for b, r in enumerate(res):
+        refb = oracle_c.ransac(p1[perm] if b == 1 else p1, p2[perm] if b == 1 else p2, coef, seed=17 + b)
+        assert (r[2], r[3]) == (refb["numSuccess"], refb["maxInliers"]), b
+        np.testing.assert_array_equal(np.asarray(r[1]).ravel(), refb["inlierIdx"])
+
+
 @pytest.mark.parametrize("case", ["three_inliers", "min4", "planar_pts1", "planar_pts2", "loose_sample"])
 def test_resident_kernel_uncertified_refits(case, oracle_c):
     """The refits ransac_hyp32_kernel cannot run from the fifteen masked sums -- exactly three inliers (estimateTransform's
