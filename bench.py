@@ -582,11 +582,26 @@ def extra_sweep(dev, with_cpu: bool) -> dict:
             th = []
             for _ in range(3):
                 t0 = time.perf_counter(); h = host_sweep(); th.append(time.perf_counter() - t0)
+            # the model side in a handle (pcreg_sphere_model_create: once per model), then one call per surface
+            cnt = pc.sphereCounts(fMf, centres_all, kw["R_desc"]); keep = cnt >= kw["min_pts"]
+            t0 = time.perf_counter(); sm = pc.SphereModel(hM, fMf, centres_all[keep], cnt[keep], kw["R_desc"]); t_model = time.perf_counter() - t0
+            try:
+                hm = pc.sphereSweepOnModel(sm, hS, fSf, par, kw["putative_thresh"], opt, seed=kw["seed"])
+                tm = []
+                for _ in range(3):
+                    t0 = time.perf_counter(); hm = pc.sphereSweepOnModel(sm, hS, fSf, par, kw["putative_thresh"], opt, seed=kw["seed"]); tm.append(time.perf_counter() - t0)
+            finally:
+                sm.close()
+        same_m = (np.array_equal(hm["trial"], out["trial"]) and np.array_equal(hm["num_putative"], out["num_putative"]) and
+                  all(np.array_equal(a, b) for a, b in zip(hm["matches"], out["matches"])) and
+                  all((a is None) == (b is None) and (a is None or np.array_equal(a, b)) for a, b in zip(hm["transforms"], out["transforms"])))
         same = (np.array_equal(h["trial"], out["trial"]) and np.array_equal(h["num_putative"], out["num_putative"]) and
                 all(np.array_equal(a, b) for a, b in zip(h["matches"], out["matches"])) and
                 all((a is None) == (b is None) and (a is None or np.array_equal(a, b)) for a, b in zip(h["transforms"], out["transforms"])))
         res["host_tier"] = {"ms": round(min(th) * 1e3, 2), "same_as_device_driver": bool(same),
-                            "note": "pcreg_sphere_counts + pcreg_sphere_sweep, descriptor sets resident, keypoints + results over PCIe"}
+                            "note": "pcreg_sphere_counts + pcreg_sphere_sweep, descriptor sets resident, keypoints + results over PCIe",
+                            "on_model_ms": round(min(tm) * 1e3, 2), "model_create_ms": round(t_model * 1e3, 2), "on_model_same_as_device_driver": bool(same_m),
+                            "on_model_note": "pcreg_sphere_model_create once per model, then pcreg_sphere_sweep_on_model per surface (matlab/sphereSweepModel.m + sphereSweepOn.m)"}
     except Exception as e:
         res["host_tier"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:
@@ -816,7 +831,7 @@ def summary_of(out: dict) -> dict:
           "cfg4_ms": g(ex, "descriptors_cfg4", "ms"), "cfg4_frac": g(ex, "descriptors_cfg4", "roofline", "frac"),
           "align_ms": g(ex, "align_points_knn_batched", "ms"), "align_frac": g(ex, "align_points_knn_batched", "roofline", "frac"),
           "cfg1_ms": g(ex, "ransac_cfg1", "ms"), "cfg1b_ms": g(ex, "ransac_cfg1_batched", "ms"), "cfg1b_frac": g(ex, "ransac_cfg1_batched", "roofline", "frac"),
-          "sweep_ms": g(ex, "sweep", "ms"), "sweep_host_ms": g(ex, "sweep", "host_tier", "ms"), "sweep_frac": g(ex, "sweep", "roofline", "frac"),
+          "sweep_ms": g(ex, "sweep", "ms"), "sweep_host_ms": g(ex, "sweep", "host_tier", "ms"), "sweep_host_on_model_ms": g(ex, "sweep", "host_tier", "on_model_ms"), "sweep_frac": g(ex, "sweep", "roofline", "frac"),
           "cfg5_regs_per_s": g(out, "cfg5_batch", "registrations_per_s"),
           "step_serial_ms": g(out, "two_in_flight", "model_1M", "one_in_flight_ms"),
           "two_1M_x": g(out, "two_in_flight", "model_1M", "speedup"), "two_125k_x": g(out, "two_in_flight", "rank_of_8_emulated_125k", "speedup"),

@@ -217,6 +217,19 @@ int pcreg_sphere_sweep(const pcreg_desc_set* surface, const pcreg_desc_set* mode
                        const pcreg_ransac_opts* coef, int32_t* model_rows, uint32_t* pairs_all, int32_t* n_pairs, int32_t* trial, int* n_trials,
                        double* T, int32_t* num_success, int32_t* max_inliers, int32_t* failed);
 
+/* The same with ONE model and many surfaces (completeExperimentFast.m runs once per surface crop): what the sweep makes of the model
+ * alone -- the spheres' row lists and gathered keypoints, the model set restricted to the union of those rows, its powered rows per
+ * set of getMatches options -- lives in a handle.  pcreg_sphere_model_create takes pcreg_sphere_sweep's model-side arguments and
+ * returns the row lists (model_rows: sum of num_desc entries, 0-based); pcreg_sphere_sweep_on_model takes the surface-side ones and
+ * returns pcreg_sphere_sweep's other outputs (the same values).  The handle holds copies: the model set may be destroyed first. */
+typedef struct pcreg_sphere_model pcreg_sphere_model;
+int pcreg_sphere_model_create(const pcreg_desc_set* model, const double* featModel, int ldM, const double* centres, int S, int ldC,
+                              const int32_t* num_desc, double R_desc, int32_t* model_rows, pcreg_sphere_model** out);
+int pcreg_sphere_model_destroy(pcreg_sphere_model* m);
+int pcreg_sphere_sweep_on_model(pcreg_sphere_model* m, const pcreg_desc_set* surface, const double* featSurface, int ldS, const pcreg_match_opts* par,
+                                int putative_thresh, const pcreg_ransac_opts* coef, uint32_t* pairs_all, int32_t* n_pairs, int32_t* trial, int* n_trials,
+                                double* T, int32_t* num_success, int32_t* max_inliers, int32_t* failed);
+
 /* AlignPoints_KNN.m:1  [pts_aligned, coeff_unambig, c] = AlignPoints_KNN(pts, C1, C2).
  * aligned: n x 3 (ld n); coeff: column-major 3x3; c: 3. */
 int pcreg_align_points_knn(const double* pts, int n, int ld, int C1, int C2,

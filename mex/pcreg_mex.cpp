@@ -16,6 +16,8 @@
 //   'ransacBatched', pts1, pts2, int32 offsets, coef, sample_idx|[], seed -> T (4x4xB), inlierIdx, nInliers, numSuccess, maxInliers, failed
 //   'sphereCounts', featModel, centres, R -> counts | 'sphereSweep', hSurface, hModel, featSurface, featModel, centres, int32 numDesc,
 //       R_desc, par, putativeThresh, coef, seed -> modelRows, pairs, nPairs, trial, T, numSuccess, maxInliers, failed   (completeExperimentFast.m:52-224)
+//   'sphereModelCreate', hModel, featModel, centres, int32 numDesc, R_desc -> handle, modelRows | 'sphereSweepOnModel', hSphereModel, hSurface,
+//       featSurface, S, par, putativeThresh, coef, seed -> pairs, nPairs, trial, T, numSuccess, maxInliers, failed | 'sphereModelDestroy', handle
 //   'getLocalPoints', pts, R, c, min_points, max_points   -> pts_sphere, dists
 //   'setDevice', ordinal | 'commId' -> id | 'commInit', rank, world, id | 'commDestroy'     (one worker per GPU)
 //   'matchPointsSharded', surface, modelRows, m_lo, M_total, thrAbs, maxRatio, unique     -> pairs (P x 2 uint32, global model rows)
@@ -472,6 +474,94 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
                 mxDestroyArray(rows); mxDestroyArray(buf); mxDestroyArray(np); mxDestroyArray(tr); mxDestroyArray(Tb); mxDestroyArray(ns); mxDestroyArray(mi); mxDestroyArray(fl);
             }
         }
+    } else if (!strcmp(cmd, "sphereModelCreate")) {           // [h, modelRows] = pcreg_mex('sphereModelCreate', hModel, featModel, centres, int32(numDesc), R_desc)
+        // the model side of sphereSweep in a handle (one model, many surfaces); modelRows: the spheres' row lists back to back (1-based)
+        if (nrhs != 6 || !mxIsUint64(prhs[1]) || !mxIsDouble(prhs[2]) || !mxIsDouble(prhs[3]) || !mxIsInt32(prhs[4]) || mxGetN(prhs[2]) != 3)
+            usage = "sphereModelCreate: hModel (uint64), featModel (n x 3 double), centres (S x 3 double), int32 numDesc, R_desc";
+        else {
+            pcreg_desc_set* hM = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]);
+            int VM = 0, D = 0;
+            rc = pcreg_desc_set_size(hM, &VM, &D);
+            const int S = (int)mxGetM(prhs[3]);
+            const int32_t* nd = (const int32_t*)mxGetData(prhs[4]);
+            if (rc == PCREG_OK && ((int)mxGetM(prhs[2]) != VM || (S > 0 && mxGetN(prhs[3]) != 3) || (int)(mxGetM(prhs[4]) * mxGetN(prhs[4])) != S))
+                usage = "sphereModelCreate: featModel must have the rows of the model set, centres S x 3, numDesc S entries";
+            else if (rc == PCREG_OK) {
+                size_t tot = 0; for (int i = 0; i < S; ++i) tot += (size_t)(nd[i] > 0 ? nd[i] : 0);
+                mxArray* rows = mxCreateNumericMatrix(tot > 0 ? tot : 1, 1, mxINT32_CLASS, mxREAL);
+                pcreg_sphere_model* h = nullptr;
+                rc = pcreg_sphere_model_create(hM, mxGetPr(prhs[2]), VM > 0 ? VM : 1, mxGetPr(prhs[3]), S, S > 0 ? S : 1, nd, mxGetScalar(prhs[5]), (int32_t*)mxGetData(rows), &h);
+                if (rc == PCREG_OK) {
+                    plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+                    if (nlhs > 1) {
+                        plhs[1] = mxCreateDoubleMatrix(tot, tot ? 1 : 0, mxREAL);
+                        const int32_t* r = (const int32_t*)mxGetData(rows);
+                        for (size_t k = 0; k < tot; ++k) mxGetPr(plhs[1])[k] = (double)r[k] + 1.0;
+                    }
+                }
+                mxDestroyArray(rows);
+            }
+        }
+    } else if (!strcmp(cmd, "sphereSweepOnModel")) {
+        // [pairs, nPairs, trial, T, numSuccess, maxInliers, failed] = pcreg_mex('sphereSweepOnModel', hSphereModel, hSurface, featSurface, S, par,
+        //     putativeThresh, ransacCoef, seed)            (S = the number of spheres of the model handle; outputs as 'sphereSweep' without the rows)
+        if (nrhs != 9 || !mxIsUint64(prhs[1]) || !mxIsUint64(prhs[2]) || !mxIsDouble(prhs[3]) || mxGetN(prhs[3]) != 3)
+            usage = "sphereSweepOnModel: hSphereModel, hSurface (uint64), featSurface (n x 3 double), S, par, putativeThresh, ransacCoef, seed";
+        else {
+            const mxArray* p = prhs[5];
+            pcreg_match_opts o;
+            o.metric = field_is(p, "Metric", "SAD") ? PCREG_METRIC_SAD : PCREG_METRIC_SSD;
+            o.matchThreshold = field(p, "MatchThreshold", 1.0); o.maxRatio = field(p, "MaxRatio", 0.6);
+            o.unique = (int)field(p, "Unique", 0); o.prenormalized = 0;
+            o.unnormalize = (int)field(p, "UNNORMALIZE", 0); o.norm_factor = field(p, "norm_factor", 0.0);
+            o.change_metric = (int)field(p, "CHANGE_METRIC", 0); o.metric_factor = field(p, "metric_factor", 1.0);
+            const mxArray* c = prhs[7];
+            pcreg_ransac_opts ro;
+            ro.minPtNum = (int)field(c, "minPtNum", 3); ro.iterNum = (int)field(c, "iterNum", 1000);
+            ro.thDist = field(c, "thDist", 0.5); ro.thInlrRatio = field(c, "thInlrRatio", 0.1);
+            ro.REFINE = (int)field(c, "REFINE", 1); ro.VERBOSE = 0;
+            ro.seed = (uint64_t)mxGetScalar(prhs[8]);
+            pcreg_sphere_model* sm = (pcreg_sphere_model*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]);
+            pcreg_desc_set* hS = (pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[2]);
+            int Q = 0, D = 0;
+            rc = pcreg_desc_set_size(hS, &Q, &D);
+            const int S = (int)mxGetScalar(prhs[4]);
+            if (rc == PCREG_OK && ((int)mxGetM(prhs[3]) != Q || S < 0)) usage = "sphereSweepOnModel: featSurface must have the rows of the surface set";
+            else if (rc == PCREG_OK) {
+                const size_t s1 = (size_t)(S > 0 ? S : 1);
+                mxArray* buf = mxCreateNumericMatrix(2, s1 * (Q > 0 ? Q : 1), mxUINT32_CLASS, mxREAL);
+                mxArray* np = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL); mxArray* tr = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* Tb = mxCreateDoubleMatrix(16, s1, mxREAL);
+                mxArray* ns = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL); mxArray* mi = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL);
+                mxArray* fl = mxCreateNumericMatrix(s1, 1, mxINT32_CLASS, mxREAL);
+                int nt = 0;
+                rc = pcreg_sphere_sweep_on_model(sm, hS, mxGetPr(prhs[3]), Q > 0 ? Q : 1, &o, (int)mxGetScalar(prhs[6]), &ro, (uint32_t*)mxGetData(buf), (int32_t*)mxGetData(np),
+                                                 (int32_t*)mxGetData(tr), &nt, mxGetPr(Tb), (int32_t*)mxGetData(ns), (int32_t*)mxGetData(mi), (int32_t*)mxGetData(fl));
+                if (rc == PCREG_OK) {
+                    const int32_t* n = (const int32_t*)mxGetData(np);
+                    size_t P = 0; for (int z = 0; z < S; ++z) P += (size_t)n[z];
+                    plhs[0] = mxCreateNumericMatrix(P, 2, mxUINT32_CLASS, mxREAL);
+                    {
+                        const uint32_t* src = (const uint32_t*)mxGetData(buf); uint32_t* dst = (uint32_t*)mxGetData(plhs[0]);
+                        size_t k = 0;
+                        for (int z = 0; z < S; ++z)
+                            for (int e = 0; e < n[z]; ++e, ++k) { dst[k] = src[((size_t)z * Q + e) * 2]; dst[k + P] = src[((size_t)z * Q + e) * 2 + 1]; }
+                    }
+                    auto out = [&](int k, mxArray* a) { if (nlhs > k) plhs[k] = a; else mxDestroyArray(a); };
+                    auto col = [&](const int32_t* v, int len, double add) { mxArray* a = mxCreateDoubleMatrix(len, len ? 1 : 0, mxREAL); for (int i = 0; i < len; ++i) mxGetPr(a)[i] = (double)v[i] + add; return a; };
+                    out(1, col(n, S, 0.0));
+                    out(2, col((const int32_t*)mxGetData(tr), nt, 1.0));
+                    { mwSize dims[3] = {4, 4, (mwSize)nt}; mxArray* T3 = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL); if (nt) memcpy(mxGetPr(T3), mxGetPr(Tb), (size_t)nt * 128); out(3, T3); }
+                    out(4, col((const int32_t*)mxGetData(ns), nt, 0.0));
+                    out(5, col((const int32_t*)mxGetData(mi), nt, 0.0));
+                    out(6, col((const int32_t*)mxGetData(fl), nt, 0.0));
+                }
+                mxDestroyArray(buf); mxDestroyArray(np); mxDestroyArray(tr); mxDestroyArray(Tb); mxDestroyArray(ns); mxDestroyArray(mi); mxDestroyArray(fl);
+            }
+        }
+    } else if (!strcmp(cmd, "sphereModelDestroy")) {
+        if (nrhs != 2 || !mxIsUint64(prhs[1])) usage = "sphereModelDestroy: handle (uint64)";
+        else rc = pcreg_sphere_model_destroy((pcreg_sphere_model*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]));
     } else if (!strcmp(cmd, "descDestroy")) {
         if (nrhs != 2 || !mxIsUint64(prhs[1])) usage = "descDestroy: handle (uint64)";
         else rc = pcreg_desc_set_destroy((pcreg_desc_set*)(uintptr_t)*(const uint64_t*)mxGetData(prhs[1]));

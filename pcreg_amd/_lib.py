@@ -52,7 +52,7 @@ class DevRansacResult(C.Structure):
 SYMBOLS = [
     "pcreg_last_error", "pcreg_version", "pcreg_device_count", "pcreg_set_device", "pcreg_device_name", "pcreg_debug_set", "pcreg_debug_match_stats",
     "pcreg_estimate_transform", "pcreg_calc_dists", "pcreg_ransac", "pcreg_ransac_batched",
-    "pcreg_knn2_points_f32", "pcreg_match_points_f32", "pcreg_match_features", "pcreg_get_matches", "pcreg_desc_set_create", "pcreg_desc_set_destroy", "pcreg_desc_set_size", "pcreg_get_matches_on_sets", "pcreg_get_matches_segmented_on_sets", "pcreg_sphere_counts", "pcreg_sphere_sweep", "pcreg_get_matches_segmented", "pcreg_get_local_points",
+    "pcreg_knn2_points_f32", "pcreg_match_points_f32", "pcreg_match_features", "pcreg_get_matches", "pcreg_desc_set_create", "pcreg_desc_set_destroy", "pcreg_desc_set_size", "pcreg_get_matches_on_sets", "pcreg_get_matches_segmented_on_sets", "pcreg_sphere_counts", "pcreg_sphere_sweep", "pcreg_sphere_model_create", "pcreg_sphere_model_destroy", "pcreg_sphere_sweep_on_model", "pcreg_get_matches_segmented", "pcreg_get_local_points",
     "pcreg_model_create", "pcreg_model_destroy", "pcreg_model_match_points_f32",
     "pcreg_dev_model_create", "pcreg_dev_model_destroy", "pcreg_dev_model_search_workspace", "pcreg_dev_model_search_f32",
     "pcreg_dev_model_match_f32", "pcreg_dev_model_match_table_f32", "pcreg_dev_match_from_table_f32",

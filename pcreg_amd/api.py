@@ -418,6 +418,66 @@ def sphereSweep(hSurface: DescSet, hModel: DescSet, featSurface, featModel, cent
                 transforms=[None if fl[t] else T[t].reshape(4, 4, order="F").copy() for t in range(n)])
 
 
+class SphereModel:
+    """What the sphere sweep makes of the MODEL alone (pcreg_sphere_model_create): the kept spheres' row lists and keypoints, the model
+    descriptor set restricted to the union of those rows, its powered rows per getMatches options -- one model, many surfaces.
+    centres / num_desc: the spheres kept after sphereCounts.  `with SphereModel(...) as sm:` or call close()."""
+
+    def __init__(self, hModel: DescSet, featModel, centres, num_desc, R_desc: float):
+        fM, c = _fcol(featModel), _fcol(centres)
+        self.S = c.shape[0]
+        self.centres = np.asarray(centres, dtype=np.float64).reshape(self.S, 3)
+        self.num_desc = np.ascontiguousarray(num_desc, dtype=np.int32)
+        tot = int(self.num_desc.sum())
+        rows = np.zeros(max(tot, 1), dtype=np.int32)
+        self._h = C.c_void_p()
+        check(lib().pcreg_sphere_model_create(hModel._h, _ptr(fM, C.c_double), max(fM.shape[0], 1), _ptr(c, C.c_double), self.S, max(self.S, 1),
+                                              _ptr(self.num_desc, C.c_int32), C.c_double(R_desc), _ptr(rows, C.c_int32), C.byref(self._h)))
+        off = np.zeros(self.S + 1, dtype=np.int64); off[1:] = np.cumsum(self.num_desc)
+        self.model_rows = [rows[off[i]:off[i + 1]].astype(np.int64) for i in range(self.S)]
+
+    def close(self) -> None:
+        if self._h:
+            lib().pcreg_sphere_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sphereSweepOnModel(sm: SphereModel, hSurface: DescSet, featSurface, par: dict, putative_thresh: int, ransacCoef: dict, seed: int = 0) -> dict:
+    """sphereSweep for one more surface against a prepared SphereModel (pcreg_sphere_sweep_on_model): the same results, without redoing
+    what belongs to the model."""
+    fS = _fcol(featSurface)
+    S, Q = sm.S, hSurface.n
+    pairs = np.zeros((max(S, 1), max(Q, 1), 2), dtype=np.uint32)
+    n_pairs = np.zeros(max(S, 1), dtype=np.int32)
+    trial = np.zeros(max(S, 1), dtype=np.int32)
+    nt = C.c_int(0)
+    T = np.zeros((max(S, 1), 16)); ns = np.zeros(max(S, 1), dtype=np.int32); mi = np.zeros(max(S, 1), dtype=np.int32); fl = np.zeros(max(S, 1), dtype=np.int32)
+    o, rc = _match_opts(par), _ransac_opts(ransacCoef, seed)
+    check(lib().pcreg_sphere_sweep_on_model(sm._h, hSurface._h, _ptr(fS, C.c_double), max(fS.shape[0], 1), C.byref(o), int(putative_thresh), C.byref(rc),
+                                            _ptr(pairs, C.c_uint32), _ptr(n_pairs, C.c_int32), _ptr(trial, C.c_int32), C.byref(nt), _ptr(T, C.c_double),
+                                            _ptr(ns, C.c_int32), _ptr(mi, C.c_int32), _ptr(fl, C.c_int32)))
+    n = nt.value
+    npr = n_pairs[:S].astype(np.int64)
+    tr = trial[:n].astype(np.int64)
+    return dict(centres=sm.centres, num_desc=sm.num_desc.astype(np.int64), num_putative=npr,
+                matches=[pairs[i, :npr[i]].copy() for i in range(S)], model_rows=sm.model_rows, trial=tr,
+                statsPutative=npr[tr], statsSuccess=ns[:n].astype(np.int64), statsInliers=mi[:n].astype(np.int64),
+                statsRatio=np.array([100.0 * mi[t] / npr[tr[t]] if not fl[t] else 0.0 for t in range(n)], dtype=np.float64),
+                transforms=[None if fl[t] else T[t].reshape(4, 4, order="F").copy() for t in range(n)])
+
+
 def getMatches(descSurface, descModel, par: dict) -> np.ndarray:
     """matches = getMatches(descSurface, descModel, par)  (getMatches.m:1-59):
     P x 2 uint32, 1-based [surfaceIdx, modelIdx], ascending in the first column."""

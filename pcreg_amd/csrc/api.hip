@@ -11,6 +11,7 @@
 #include <cmath>
 #include <map>
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 namespace pcreg {
@@ -811,6 +812,153 @@ int pcreg_sphere_sweep(const pcreg_desc_set* surface, const pcreg_desc_set* mode
     PCREG_HIP(hipStreamSynchronize(g_stream));
     for (int i = 0; i < S; ++i)
         if (h_nsel[i] != num_desc[i]) { set_error("pcreg_sphere_sweep: num_desc[%d] = %d, but the sphere holds %d keypoints (pass pcreg_sphere_counts' values)", i, num_desc[i], h_nsel[i]); return PCREG_E_ARG; }
+    *n_trials = h_nt;
+    for (int t = 0; t < h_nt; ++t) {
+        trial[t] = h_tr[t];
+        const pcreg_dev_ransac_result& r = h_res[t];
+        for (int k = 0; k < 16; ++k) T[(size_t)t * 16 + k] = r.failed ? 0.0 : r.T[k];
+        num_success[t] = r.num_success; max_inliers[t] = r.max_inliers; failed[t] = r.failed;
+    }
+    return PCREG_OK;
+}
+
+// ---- the sphere sweep's model side as a handle: one model, many surfaces ----------------------------------------------------
+// Everything of pcreg_sphere_sweep that does not depend on the surface: the spheres' row lists and gathered keypoints, the model
+// set restricted to the union of those rows (the lists renumbered into it) and, per set of getMatches options, its powered rows.
+struct pcreg_sphere_model {
+    int S, VMu, D, tot, n_max;
+    int32_t *seg_off, *rows_u; int64_t* roff; double *feat_all, *desc_u, *prep;
+    int prep_cm; double prep_factor;
+};
+static void sphere_model_free(pcreg_sphere_model* m) {
+    if (!m) return;
+    void* p[] = {m->seg_off, m->rows_u, m->roff, m->feat_all, m->desc_u, m->prep};
+    for (void* q : p) if (q) (void)hipFree(q);
+    delete m;
+}
+int pcreg_sphere_model_create(const pcreg_desc_set* model, const double* featModel, int ldM, const double* centres, int S, int ldC,
+                              const int32_t* num_desc, double R_desc, int32_t* model_rows, pcreg_sphere_model** out) {
+    PCREG_ARG(model && featModel && out && S >= 0 && S <= 65535 && ldC >= S && ldM >= model->n && (S == 0 || (centres && num_desc && model_rows)));
+    GUARD();
+    *out = nullptr;
+    const int VM = model->n, D = model->D;
+    std::vector<int32_t> off((size_t)S + 1, 0); std::vector<int64_t> roff((size_t)S, 0);
+    int n_max = 0;
+    for (int i = 0; i < S; ++i) {
+        PCREG_ARG(num_desc[i] >= 0 && num_desc[i] <= VM && (long long)off[i] + num_desc[i] < 2147483647LL);
+        off[i + 1] = off[i] + num_desc[i]; roff[i] = off[i]; n_max = std::max(n_max, num_desc[i]);
+    }
+    const int tot = off[S];
+    pcreg_sphere_model* m = new pcreg_sphere_model{S, 0, D, tot, n_max, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, -1, 0.0};
+    auto fail = [&](int rc) { sphere_model_free(m); return rc; };
+    if (S == 0 || tot == 0 || VM == 0) { *out = m; return PCREG_OK; }
+    void *tmp, *fm, *tc, *cen, *nsel, *rows, *nd;
+    int rc = PCREG_OK;
+    if ((rc = scratch().get(0, sizeof(double) * 3 * (size_t)VM, &tmp)) || (rc = scratch().get(1, sizeof(double) * 3 * (size_t)VM, &fm)) ||
+        (rc = scratch().get(3, sizeof(double) * 3 * (size_t)S, &tc)) || (rc = scratch().get(9, sizeof(double) * 3 * (size_t)S, &cen)) ||
+        (rc = scratch().get(12, sizeof(int32_t) * (size_t)S, &nsel)) || (rc = scratch().get(4, sizeof(int32_t) * (size_t)tot, &rows)) ||
+        (rc = scratch().get(5, 256, &nd)))
+        return fail(rc);
+    if (hipMalloc((void**)&m->seg_off, sizeof(int32_t) * ((size_t)S + 1)) != hipSuccess || hipMalloc((void**)&m->roff, sizeof(int64_t) * (size_t)S) != hipSuccess ||
+        hipMalloc((void**)&m->rows_u, sizeof(int32_t) * (size_t)tot) != hipSuccess || hipMalloc((void**)&m->feat_all, sizeof(double) * 3 * (size_t)tot) != hipSuccess) {
+        set_error("pcreg_sphere_model_create: out of device memory"); return fail(PCREG_E_HIP);
+    }
+    if ((rc = upload_points_aos(featModel, VM, ldM, (double*)tmp, (double*)fm, g_stream)) || (rc = upload_points_aos(centres, S, ldC, (double*)tc, (double*)cen, g_stream)))
+        return fail(rc);
+    if (hipMemcpyAsync(m->seg_off, off.data(), sizeof(int32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, g_stream) != hipSuccess ||
+        hipMemcpyAsync(m->roff, roff.data(), sizeof(int64_t) * (size_t)S, hipMemcpyHostToDevice, g_stream) != hipSuccess) { set_error("copy failed"); return fail(PCREG_E_HIP); }
+    if ((rc = launch_sphere_select_batched((const double*)fm, VM, (const double*)cen, S, R_desc, m->seg_off, (int32_t*)rows, m->feat_all, (int32_t*)nsel, g_stream)))
+        return fail(rc);
+    std::vector<int32_t> h_nsel((size_t)S);
+    if (hipMemcpyAsync(h_nsel.data(), nsel, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream) != hipSuccess ||
+        hipMemcpyAsync(model_rows, rows, sizeof(int32_t) * (size_t)tot, hipMemcpyDeviceToHost, g_stream) != hipSuccess ||
+        hipStreamSynchronize(g_stream) != hipSuccess) { set_error("pcreg_sphere_model_create: read-back failed"); return fail(PCREG_E_HIP); }
+    for (int i = 0; i < S; ++i)
+        if (h_nsel[i] != num_desc[i]) { set_error("pcreg_sphere_model_create: num_desc[%d] = %d, but the sphere holds %d keypoints (pass pcreg_sphere_counts' values)", i, num_desc[i], h_nsel[i]); return fail(PCREG_E_ARG); }
+    // the union of the spheres' rows (ascending) and the lists renumbered into it
+    std::vector<int32_t> uni(model_rows, model_rows + tot);
+    std::sort(uni.begin(), uni.end());
+    uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+    std::vector<int32_t> ren((size_t)tot);
+    for (int k = 0; k < tot; ++k) ren[k] = (int32_t)(std::lower_bound(uni.begin(), uni.end(), model_rows[k]) - uni.begin());
+    m->VMu = (int)uni.size();
+    const double* rM;
+    if ((rc = desc_set_rows(model, &rM))) return fail(rc);
+    void* duni;
+    if ((rc = scratch().get(6, sizeof(int32_t) * uni.size(), &duni))) return fail(rc);
+    if (hipMalloc((void**)&m->desc_u, sizeof(double) * uni.size() * (size_t)D) != hipSuccess) { set_error("pcreg_sphere_model_create: out of device memory"); return fail(PCREG_E_HIP); }
+    const int32_t nu = m->VMu;
+    if (hipMemcpyAsync(duni, uni.data(), sizeof(int32_t) * uni.size(), hipMemcpyHostToDevice, g_stream) != hipSuccess ||
+        hipMemcpyAsync(nd, &nu, sizeof(int32_t), hipMemcpyHostToDevice, g_stream) != hipSuccess ||
+        hipMemcpyAsync(m->rows_u, ren.data(), sizeof(int32_t) * (size_t)tot, hipMemcpyHostToDevice, g_stream) != hipSuccess) { set_error("copy failed"); return fail(PCREG_E_HIP); }
+    if ((rc = launch_gather_rows_f64(rM, D, (const int32_t*)duni, (const int32_t*)nd, m->VMu, m->desc_u, g_stream))) return fail(rc);
+    if (hipStreamSynchronize(g_stream) != hipSuccess) { set_error("pcreg_sphere_model_create failed"); return fail(PCREG_E_HIP); }          // the host vectors go out of scope
+    *out = m;
+    return PCREG_OK;
+}
+int pcreg_sphere_model_destroy(pcreg_sphere_model* m) {
+    if (!m) return PCREG_OK;
+    std::lock_guard<std::mutex> lock(g_mu);
+    (void)hipDeviceSynchronize();
+    sphere_model_free(m);
+    return PCREG_OK;
+}
+int pcreg_sphere_sweep_on_model(pcreg_sphere_model* m, const pcreg_desc_set* surface, const double* featSurface, int ldS, const pcreg_match_opts* par,
+                                int putative_thresh, const pcreg_ransac_opts* coef, uint32_t* pairs_all, int32_t* n_pairs, int32_t* trial, int* n_trials,
+                                double* T, int32_t* num_success, int32_t* max_inliers, int32_t* failed) {
+    PCREG_ARG(m && surface && featSurface && par && coef && n_trials && surface->D == m->D && ldS >= surface->n && coef->minPtNum == 3 && coef->iterNum >= 1);
+    PCREG_ARG(m->S == 0 || (pairs_all && n_pairs && trial && T && num_success && max_inliers && failed));
+    if (par->metric != PCREG_METRIC_SAD) { set_error("pcreg_sphere_sweep_on_model: Metric must be SAD"); return PCREG_E_ARG; }
+    GUARD();
+    *n_trials = 0;
+    const int S = m->S, VS = surface->n, D = m->D, tot = m->tot;
+    if (S == 0) return PCREG_OK;
+    if (VS == 0 || tot == 0 || m->VMu == 0) { for (int i = 0; i < S; ++i) n_pairs[i] = 0; return PCREG_OK; }
+    const size_t vs = (size_t)VS, ld = (size_t)S * vs;
+    PCREG_ARG(ld <= 0x7FFFFFFFull);
+    void *tmp, *fs, *dp, *dn, *ws, *tidx, *toff, *nt, *p12, *res, *inl, *rws;
+    TRY(scratch().get(0, sizeof(double) * 3 * vs, &tmp));
+    TRY(scratch().get(2, sizeof(double) * 3 * vs, &fs));
+    TRY(scratch().get(6, sizeof(uint32_t) * (size_t)S * vs * 2, &dp));
+    TRY(scratch().get(7, sizeof(int32_t) * (size_t)S, &dn));
+    const size_t wsb = get_matches_segmented_workspace_bytes(VS, m->VMu, D, S, tot, m->n_max);
+    TRY(scratch().get(8, wsb, &ws));
+    TRY(scratch().get(13, sizeof(int32_t) * (3 * (size_t)S + 2), &tidx));
+    toff = (int32_t*)tidx + S; nt = (int32_t*)tidx + 2 * (size_t)S + 1;
+    TRY(scratch().get(14, sizeof(double) * 6 * ld, &p12));
+    TRY(scratch().get(15, sizeof(pcreg_dev_ransac_result) * (size_t)S, &res));
+    TRY(scratch().get(16, sizeof(int32_t) * ld, &inl));
+    const size_t rwsb = ransac_workspace_bytes(coef->iterNum, S, VS);
+    TRY(scratch().get(17, rwsb, &rws));
+    const double* rS;
+    TRY(desc_set_rows(surface, &rS));
+    if (!(m->prep && m->prep_cm == par->change_metric && (!par->change_metric || m->prep_factor == par->metric_factor))) {
+        if (!m->prep) PCREG_HIP(hipMalloc((void**)&m->prep, segmented_prepared_model_bytes(m->VMu, D)));
+        m->prep_cm = -1;
+        TRY(launch_segmented_prepare_model(m->desc_u, m->VMu, D, *par, m->prep, m->prep + (size_t)m->VMu * D, g_stream));
+        m->prep_cm = par->change_metric; m->prep_factor = par->metric_factor;
+    }
+    const SegPreparedModel prep{m->prep, m->prep + (size_t)m->VMu * D, m->VMu, D, m->prep_cm, m->prep_factor};
+    TRY(upload_points_aos(featSurface, VS, ldS, (double*)tmp, (double*)fs, g_stream));
+    TRY(launch_get_matches_segmented(rS, VS, m->desc_u, m->VMu, D, m->rows_u, m->seg_off, S, tot, m->n_max, *par, (uint32_t*)dp, nullptr, (int32_t*)dn,
+                                     ws, wsb, g_stream, &prep));
+    TRY(launch_sweep_plan((const int32_t*)dn, S, putative_thresh, (int32_t*)tidx, (int32_t*)toff, (int32_t*)nt, g_stream));
+    double *p1 = (double*)p12, *p2 = (double*)p12 + 3 * ld;
+    PCREG_HIP(hipMemsetAsync(p12, 0, sizeof(double) * 6 * ld, g_stream));
+    TRY(launch_sweep_gather((const uint32_t*)dp, VS, (const int32_t*)dn, (const int32_t*)tidx, (const int32_t*)toff, (const int32_t*)nt, S, (const double*)fs,
+                            m->feat_all, m->roff, p1, p2, (int)ld, g_stream));
+    PCREG_HIP(hipMemsetAsync(res, 0, sizeof(pcreg_dev_ransac_result) * (size_t)S, g_stream));
+    TRY(launch_ransac(p1, p2, (int)ld, (const int32_t*)toff, nullptr, VS, S, *coef, nullptr, (pcreg_dev_ransac_result*)res, (int32_t*)inl, nullptr, nullptr,
+                      rws, rwsb, g_stream));
+    std::vector<int32_t> h_tr((size_t)S);
+    std::vector<pcreg_dev_ransac_result> h_res((size_t)S);
+    int32_t h_nt = 0;
+    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * vs * 2, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(h_tr.data(), tidx, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(&h_nt, nt, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipMemcpyAsync(h_res.data(), res, sizeof(pcreg_dev_ransac_result) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipStreamSynchronize(g_stream));
     *n_trials = h_nt;
     for (int t = 0; t < h_nt; ++t) {
         trial[t] = h_tr[t];

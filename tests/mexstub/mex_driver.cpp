@@ -339,6 +339,57 @@ int drv_sphere_sweep(const double* dS, int Q, const double* dM, int VM, int D, c
     return rc;
 }
 
+// matlab/sphereSweepModel.m + sphereSweepOn.m: the model handle made once (and the model set destroyed right after), then n_surf
+// surfaces (rows of dS / fS back to back, Q rows each) swept against it; outputs of surface u at offset u of every buffer
+int drv_sphere_sweep_model(const double* dS, const double* fS, int n_surf, int Q, const double* dM, int VM, int D, const double* fM, const double* kept, int S,
+                           const int32_t* nd, double R, const double* par7, double thresh, const double* coef5, double seed, double* rows1, int* n_rows,
+                           uint32_t* pairs_colmajor, int* P_total, double* n_pairs, double* trial1, int* n_trials, double* T16, double* num_success,
+                           double* max_inl, double* failed, char* err, int errlen) {
+    mxArray* lhs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dM, VM, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+    mxArray* hM = lhs[0]; lhs[0] = nullptr;
+    mxArray* ndm = mxCreateNumericMatrix(S, 1, mxINT32_CLASS, mxREAL);
+    if (S) memcpy(mxGetData(ndm), nd, (size_t)S * 4);
+    { std::vector<mxArray*> rhs{mxCreateString("sphereModelCreate"), mxDuplicateArray(hM), dmat(fM, VM, 3), dmat(kept, S, 3), ndm, mxCreateDoubleScalar(R)};
+      if (call(2, lhs, rhs, err, errlen)) return 1; }
+    mxArray* sm = lhs[0]; lhs[0] = nullptr;
+    *n_rows = (int)(mxGetM(lhs[1]) * mxGetN(lhs[1])); if (*n_rows) memcpy(rows1, mxGetPr(lhs[1]), (size_t)*n_rows * 8);
+    mxDestroyArray(lhs[1]); lhs[1] = nullptr;
+    { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hM}; if (call(0, lhs, rhs, err, errlen)) return 1; }      // the handle owns what it needs
+    int rc = 0;
+    for (int u = 0; u < n_surf && !rc; ++u) {
+        { std::vector<mxArray*> rhs{mxCreateString("descCreate"), dmat(dS + (size_t)u * Q * D, Q, D)}; if (call(1, lhs, rhs, err, errlen)) return 1; }
+        mxArray* hS = lhs[0]; lhs[0] = nullptr;
+        mxArray* p = mxCreateStructMatrix(1, 1, 0, nullptr);
+        mxSetField(p, 0, "Metric", mxCreateString("SAD")); mxSetField(p, 0, "Method", mxCreateString("Approximate"));
+        put(p, "MatchThreshold", par7[0]); put(p, "MaxRatio", par7[1]); put(p, "Unique", par7[2]); put(p, "UNNORMALIZE", par7[3]);
+        put(p, "norm_factor", par7[4]); put(p, "CHANGE_METRIC", par7[5]); put(p, "metric_factor", par7[6]); put(p, "VERBOSE", 0);
+        mxArray* c = mxCreateStructMatrix(1, 1, 0, nullptr);
+        put(c, "minPtNum", coef5[0]); put(c, "iterNum", coef5[1]); put(c, "thDist", coef5[2]); put(c, "thInlrRatio", coef5[3]);
+        put(c, "REFINE", coef5[4]); put(c, "VERBOSE", 0);
+        {
+            std::vector<mxArray*> rhs{mxCreateString("sphereSweepOnModel"), mxDuplicateArray(sm), mxDuplicateArray(hS), dmat(fS + (size_t)u * Q * 3, Q, 3),
+                                      mxCreateDoubleScalar(S), p, mxCreateDoubleScalar(thresh), c, mxCreateDoubleScalar(seed)};
+            rc = call(7, lhs, rhs, err, errlen);
+        }
+        if (!rc) {
+            const size_t us = (size_t)u * S;
+            P_total[u] = (int)mxGetM(lhs[0]); if (P_total[u]) memcpy(pairs_colmajor + (size_t)u * S * Q * 2, mxGetData(lhs[0]), (size_t)P_total[u] * 2 * 4);
+            if (S) memcpy(n_pairs + us, mxGetPr(lhs[1]), (size_t)S * 8);
+            n_trials[u] = (int)(mxGetM(lhs[2]) * mxGetN(lhs[2]));
+            if (n_trials[u]) {
+                memcpy(trial1 + us, mxGetPr(lhs[2]), (size_t)n_trials[u] * 8); memcpy(T16 + us * 16, mxGetPr(lhs[3]), (size_t)n_trials[u] * 128);
+                memcpy(num_success + us, mxGetPr(lhs[4]), (size_t)n_trials[u] * 8); memcpy(max_inl + us, mxGetPr(lhs[5]), (size_t)n_trials[u] * 8);
+                memcpy(failed + us, mxGetPr(lhs[6]), (size_t)n_trials[u] * 8);
+            }
+            for (mxArray*& a : lhs) { mxDestroyArray(a); a = nullptr; }
+        }
+        { std::vector<mxArray*> rhs{mxCreateString("descDestroy"), hS}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    }
+    { std::vector<mxArray*> rhs{mxCreateString("sphereModelDestroy"), sm}; if (call(0, lhs, rhs, err, errlen)) return 1; }
+    return rc;
+}
+
 // one-worker rehearsal of the spmd block of INTEGRATION.md section 3: setDevice, commId, commInit, matchPointsSharded,
 // ransacSharded, commDestroy -- all through the gateway
 int drv_comm_round_trip(const float* surf, int Q, const float* model, int M, float thr, float ratio, uint32_t* pairs_colmajor, int* P,

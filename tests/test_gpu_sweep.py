@@ -80,8 +80,19 @@ def test_host_tier_sphere_sweep_equals_the_device_driver(oracle_py):
         with pytest.raises(Exception):                                       # counts that are not the spheres' counts: refused, not a fault
             pc.sphereSweep(hS, hM, featS, featM, centres[keep], counts[keep] - 1, kw["R_desc"], PAR, kw["putative_thresh"], OPT)
         empty = pc.sphereSweep(hS, hM, featS, featM, centres[:0], counts[:0], kw["R_desc"], PAR, kw["putative_thresh"], OPT)
+        # one model, many surfaces: the model side in a handle (pcreg_sphere_model_create), the model SET destroyed before the sweeps
+        sm = pc.SphereModel(hM, featM, centres[keep], counts[keep], kw["R_desc"])
+    with pc.DescSet(descS) as hS2:
+        on_model = pc.sphereSweepOnModel(sm, hS2, featS, PAR, kw["putative_thresh"], OPT, seed=kw["seed"])
+        on_model2 = pc.sphereSweepOnModel(sm, hS2, featS, dict(PAR, metric_factor=0.8), kw["putative_thresh"], OPT, seed=kw["seed"])
+        on_model3 = pc.sphereSweepOnModel(sm, hS2, featS, PAR, kw["putative_thresh"], OPT, seed=kw["seed"])
+    with pc.DescSet(descS) as hS3, pc.DescSet(descM) as hM3:
+        other_par = pc.sphereSweep(hS3, hM3, featS, featM, centres[keep], counts[keep], kw["R_desc"], dict(PAR, metric_factor=0.8), kw["putative_thresh"], OPT, seed=kw["seed"])
+    sm.close()
+    for k in ("num_putative", "trial", "statsSuccess", "statsInliers"):
+        np.testing.assert_array_equal(on_model2[k], other_par[k], err_msg=k)
     assert len(empty["trial"]) == 0 and empty["matches"] == []
-    for g in (got, again):
+    for g in (got, again, on_model, on_model3):
         for k in ("centres", "num_desc", "num_putative", "trial", "statsPutative", "statsSuccess", "statsInliers", "statsRatio"):
             np.testing.assert_array_equal(g[k], want[k], err_msg=k)
         for k in ("matches", "model_rows"):

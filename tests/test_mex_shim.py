@@ -295,6 +295,56 @@ def test_shim_sphere_sweep(drv, oracle_py):
 
 
 @pytest.mark.gpu
+def test_shim_sphere_sweep_model_handle(drv, oracle_py):
+    """sphereModelCreate (then descDestroy of the model set) + sphereSweepOnModel for two surfaces + sphereModelDestroy through the
+    gateway (matlab/sphereSweepModel.m, sphereSweepOn.m) == sphereSweep on fresh sets, surface for surface."""
+    import pcreg_amd as pc
+    from test_gpu_sweep import _scene, PAR, OPT
+    featM, descM, featS, descS = _scene()
+    R, d_sph, min_pts, thresh, seed = 9.0, 6.0, 500, 60, 5
+    centres = oracle_py.pcUniformSamples(featM, d_sph)
+    counts = pc.sphereCounts(featM, centres, R)
+    keep = counts >= min_pts
+    rng = np.random.default_rng(8)
+    descS2 = np.ascontiguousarray(descS[::-1]) * (1.0 + 0.02 * rng.random(descS.shape))
+    featS2 = np.ascontiguousarray(featS[::-1])
+    surfaces = [(featS, descS), (featS2, descS2)]
+    want = []
+    for f, d in surfaces:
+        with pc.DescSet(d) as hS, pc.DescSet(descM) as hM:
+            want.append(pc.sphereSweep(hS, hM, f, featM, centres[keep], counts[keep], R, PAR, thresh, OPT, seed=seed))
+    S, Q, VM, D = int(keep.sum()), featS.shape[0], featM.shape[0], descM.shape[1]
+    par7 = np.array([PAR["MatchThreshold"], PAR["MaxRatio"], PAR["Unique"], PAR["UNNORMALIZE"], PAR["norm_factor"], PAR["CHANGE_METRIC"], PAR["metric_factor"]], dtype=np.float64)
+    coef5 = np.array([OPT["minPtNum"], OPT["iterNum"], OPT["thDist"], OPT["thInlrRatio"], OPT["REFINE"]], dtype=np.float64)
+    U = len(surfaces)
+    dS_all = np.concatenate([_d(d).ravel(order="K") for _, d in surfaces]); fS_all = np.concatenate([_d(f).ravel(order="K") for f, _ in surfaces])
+    rows1 = np.zeros(int(counts[keep].sum())); nrows = C.c_int()
+    pairs = np.zeros(U * S * Q * 2, dtype=np.uint32); Pt = (C.c_int * U)(); npairs = np.zeros(U * S)
+    trial1 = np.zeros(U * S); nt = (C.c_int * U)(); T = np.zeros(U * S * 16); ns = np.zeros(U * S); mi = np.zeros(U * S); fl = np.zeros(U * S)
+    nd = np.ascontiguousarray(counts[keep], dtype=np.int32)
+    e = _err()
+    rc = drv.drv_sphere_sweep_model(_p(dS_all), _p(fS_all), U, Q, _p(_d(descM)), VM, D, _p(_d(featM)), _p(_d(centres[keep])), S, _p(nd, C.c_int32), C.c_double(R),
+                                    _p(par7), C.c_double(thresh), _p(coef5), C.c_double(seed), _p(rows1), C.byref(nrows), _p(pairs, C.c_uint32), Pt,
+                                    _p(npairs), _p(trial1), nt, _p(T), _p(ns), _p(mi), _p(fl), e, 1024)
+    assert rc == 0, e.value
+    assert nrows.value == len(rows1) and np.array_equal(rows1, np.concatenate(want[0]["model_rows"]) + 1)
+    for u in range(U):
+        w = want[u]
+        assert len(w["trial"]) >= 1
+        assert np.array_equal(npairs[u * S:(u + 1) * S], w["num_putative"])
+        allp = pairs[u * S * Q * 2:][:2 * Pt[u]].reshape(Pt[u], 2, order="F")
+        assert np.array_equal(allp, np.vstack([m for m in w["matches"]]))
+        n, o = nt[u], u * S
+        assert np.array_equal(trial1[o:o + n], w["trial"] + 1) and np.array_equal(ns[o:o + n], w["statsSuccess"]) and np.array_equal(mi[o:o + n], w["statsInliers"])
+        for t in range(n):
+            Tt = w["transforms"][t]
+            assert bool(fl[o + t]) == (Tt is None)
+            if Tt is not None:
+                assert np.array_equal(T[16 * (o + t):16 * (o + t) + 16].reshape(4, 4, order="F"), Tt)
+    assert drv.drv_live_arrays() == 0
+
+
+@pytest.mark.gpu
 def test_shim_get_local_points_keeps_matlabs_classes(drv, oracle_py):
     """getLocalPoints through the gateway: a single cloud with a double centre is evaluated in single arithmetic and comes back
     single (getLocalPoints.m:8-25); [] when a gate fails."""
