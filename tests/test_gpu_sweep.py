@@ -60,6 +60,36 @@ def test_sphere_sweep_equals_oracle_driver(oracle_c, oracle_py):
             assert np.linalg.norm(a - b) < 1e-9
 
 
+def test_sphere_model_handle_edges(oracle_py):
+    """The sphere-model handle at its edges: no spheres at all (an empty sweep, like sphereSweep's), counts that are not the spheres'
+    (refused with the sphere's number), a handle used after close() (refused, not a crash), a surface of another descriptor length."""
+    import pcreg_amd as pc
+    from pcreg_amd._lib import PcregError
+    featM, descM, featS, descS = _scene()
+    R = 9.0
+    centres = oracle_py.pcUniformSamples(featM, 6.0)
+    counts = pc.sphereCounts(featM, centres, R)
+    keep = counts >= 500
+    with pc.DescSet(descS) as hS, pc.DescSet(descM) as hM:
+        with pc.SphereModel(hM, featM, np.zeros((0, 3)), np.zeros(0, dtype=np.int32), R) as sm0:
+            out = pc.sphereSweepOnModel(sm0, hS, featS, PAR, 60, OPT, seed=1)
+            assert len(out["trial"]) == 0 and len(out["matches"]) == 0 and len(out["num_putative"]) == 0
+        wrong = counts[keep].copy(); wrong[1] += 1
+        with pytest.raises(PcregError, match="holds"):
+            pc.SphereModel(hM, featM, centres[keep], wrong, R)
+        sm = pc.SphereModel(hM, featM, centres[keep], counts[keep], R)
+        ref = pc.sphereSweepOnModel(sm, hS, featS, PAR, 60, OPT, seed=1)
+        assert len(ref["trial"]) >= 1
+        with pc.DescSet(descS[:, :-1].copy()) as hShort:
+            with pytest.raises(PcregError):
+                pc.sphereSweepOnModel(sm, hShort, featS, PAR, 60, OPT, seed=1)
+        again = pc.sphereSweepOnModel(sm, hS, featS, PAR, 60, OPT, seed=1)                   # a refused call leaves the handle usable
+        assert np.array_equal(again["trial"], ref["trial"]) and all(np.array_equal(a, b) for a, b in zip(again["matches"], ref["matches"]))
+        sm.close(); sm.close()
+        with pytest.raises(PcregError):
+            pc.sphereSweepOnModel(sm, hS, featS, PAR, 60, OPT, seed=1)
+
+
 def test_host_tier_sphere_sweep_equals_the_device_driver(oracle_py):
     """pcreg_sphere_counts + pcreg_sphere_sweep (what MATLAB reaches through pcreg_mex: host arrays, descriptor sets resident) ==
     SphereSweep.run field for field -- counts, row lists, matches, trial spheres, transforms (the same kernels, the same seeds)."""
