@@ -137,6 +137,11 @@ int pcreg_device_count(int* count) {
     return PCREG_OK;
 }
 
+// page-locked staging of the host tier's result lists (pairs_fetch_*) and the event their counts are waited on
+static void*  g_pin[2] = {nullptr, nullptr};
+static size_t g_pin_bytes[2] = {0, 0};
+static hipEvent_t g_pairs_ev = nullptr;
+
 int pcreg_set_device(int ordinal) {
     std::lock_guard<std::mutex> lock(g_mu);
     int count = 0;
@@ -146,6 +151,8 @@ int pcreg_set_device(int ordinal) {
     for (auto& kv : stream_scratches()) kv.second.release_all();
     stream_scratches().clear();
     if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    if (g_pairs_ev) { (void)hipEventDestroy(g_pairs_ev); g_pairs_ev = nullptr; }
+    for (int k = 0; k < 2; ++k) if (g_pin[k]) { (void)hipHostFree(g_pin[k]); g_pin[k] = nullptr; g_pin_bytes[k] = 0; }
     g_device_ok = -1;
     PCREG_HIP(hipSetDevice(ordinal));
     return ensure_device();
@@ -598,6 +605,60 @@ int pcreg_get_local_points(const double* pts, int N, int ld, double R, const dou
     return PCREG_OK;
 }
 
+// ---- the pair lists of a segmented call on their way back --------------------------------------------------------------------
+// The device holds [S][vs][2] with the first n_pairs[z] pairs of row z valid (vs = the surface's rows: Unique's capacity); a sphere
+// keeps a few hundred of its ~2000 slots, so copying the array as it is moved 5 MB of mostly nothing into pageable memory (~0.5 ms
+// of the 7 ms sweep).  Now: the counts go to a page-locked buffer FIRST (begin: right behind the matcher, in front of whatever the
+// caller launches next), the host waits for them alone (enqueue), packs the columns that hold pairs on the device and fetches that
+// block through page-locked memory; finish() deals it into the caller's array (same layout; slots past n_pairs[z] are not written).
+static int pinned_get(int k, size_t bytes, void** out) {
+    if (g_pin_bytes[k] < bytes) {
+        if (g_pin[k]) { PCREG_HIP(hipHostFree(g_pin[k])); g_pin[k] = nullptr; g_pin_bytes[k] = 0; }
+        const size_t want = align_up(bytes + bytes / 4, 4096);
+        PCREG_HIP(hipHostMalloc(&g_pin[k], want, hipHostMallocDefault));
+        g_pin_bytes[k] = want;
+    }
+    *out = g_pin[k];
+    return PCREG_OK;
+}
+struct PairFetch { int32_t* h_np = nullptr; void* h_packed = nullptr; int m = 0; bool whole = false; };
+static int pairs_fetch_begin(const int32_t* dn, int S, PairFetch& f) {
+    void* h;
+    TRY(pinned_get(0, sizeof(int32_t) * (size_t)S, &h));
+    f.h_np = (int32_t*)h;
+    if (!g_pairs_ev) PCREG_HIP(hipEventCreateWithFlags(&g_pairs_ev, hipEventDisableTiming));
+    PCREG_HIP(hipMemcpyAsync(f.h_np, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PCREG_HIP(hipEventRecord(g_pairs_ev, g_stream));
+    return PCREG_OK;
+}
+static int pairs_fetch_enqueue(PairFetch& f, const uint32_t* dp, size_t vs, int S, int pack_slot, uint32_t* pairs_all) {
+    PCREG_HIP(hipEventSynchronize(g_pairs_ev));
+    int m = 0;
+    for (int z = 0; z < S; ++z) m = std::max(m, (int)f.h_np[z]);
+    f.m = m;
+    if (m == 0) return PCREG_OK;
+    if ((size_t)m * 2 > vs) {                         // most slots hold pairs: the array as it is
+        f.whole = true;
+        PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * vs * 2, hipMemcpyDeviceToHost, g_stream));
+        return PCREG_OK;
+    }
+    void* packed;
+    const size_t row = sizeof(uint32_t) * 2 * (size_t)m;
+    TRY(scratch().get(pack_slot, row * (size_t)S, &packed));
+    TRY(pinned_get(1, row * (size_t)S, &f.h_packed));
+    PCREG_HIP(hipMemcpy2DAsync(packed, row, dp, sizeof(uint32_t) * 2 * vs, row, (size_t)S, hipMemcpyDeviceToDevice, g_stream));
+    PCREG_HIP(hipMemcpyAsync(f.h_packed, packed, row * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    return PCREG_OK;
+}
+// after the stream has been synchronised
+static void pairs_fetch_finish(const PairFetch& f, size_t vs, int S, uint32_t* pairs_all, int32_t* n_pairs) {
+    for (int z = 0; z < S; ++z) {
+        n_pairs[z] = f.h_np[z];
+        if (!f.whole && f.m > 0 && f.h_np[z] > 0)
+            memcpy(pairs_all + (size_t)z * vs * 2, (const char*)f.h_packed + sizeof(uint32_t) * 2 * (size_t)f.m * z, sizeof(uint32_t) * 2 * (size_t)f.h_np[z]);
+    }
+}
+
 // getMatches for S row subsets of one model set, host tier (the parfor of completeExperimentFast.m:131-149 as ONE call)
 int pcreg_get_matches_segmented(const double* descSurface, int Q, int ldS, const double* descModel, int VM, int ldM, int D,
                                 const int32_t* seg_rows, const int32_t* seg_off, int S, const pcreg_match_opts* par,
@@ -634,9 +695,11 @@ int pcreg_get_matches_segmented(const double* descSurface, int Q, int ldS, const
     PCREG_HIP(hipMemcpyAsync(doff, seg_off, sizeof(int32_t) * ((size_t)S + 1), hipMemcpyHostToDevice, g_stream));
     TRY(launch_get_matches_segmented((const double*)rS, Q, (const double*)rM, VM, D, (const int32_t*)dr, (const int32_t*)doff, S, tot, n_max, *par,
                                      (uint32_t*)dp, nullptr, (int32_t*)dn, ws, wsb, g_stream));
-    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * q * 2, hipMemcpyDeviceToHost, g_stream));
-    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PairFetch pf;
+    TRY(pairs_fetch_begin((const int32_t*)dn, S, pf));
+    TRY(pairs_fetch_enqueue(pf, (const uint32_t*)dp, q, S, 20, pairs_all));
     PCREG_HIP(hipStreamSynchronize(g_stream));
+    pairs_fetch_finish(pf, q, S, pairs_all, n_pairs);
     return PCREG_OK;
 }
 
@@ -700,9 +763,11 @@ int pcreg_get_matches_segmented_on_sets(const pcreg_desc_set* surface, const pcr
     TRY(desc_set_prepared(model, *par, &prep));
     TRY(launch_get_matches_segmented(rS, Q, rM, VM, D, (const int32_t*)dr, (const int32_t*)doff, S, tot, n_max, *par,
                                      (uint32_t*)dp, nullptr, (int32_t*)dn, ws, wsb, g_stream, &prep));
-    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * q * 2, hipMemcpyDeviceToHost, g_stream));
-    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    PairFetch pf;
+    TRY(pairs_fetch_begin((const int32_t*)dn, S, pf));
+    TRY(pairs_fetch_enqueue(pf, (const uint32_t*)dp, q, S, 20, pairs_all));
     PCREG_HIP(hipStreamSynchronize(g_stream));
+    pairs_fetch_finish(pf, q, S, pairs_all, n_pairs);
     return PCREG_OK;
 }
 
@@ -796,20 +861,22 @@ int pcreg_sphere_sweep(const pcreg_desc_set* surface, const pcreg_desc_set* mode
     PCREG_HIP(hipMemsetAsync(p12, 0, sizeof(double) * 6 * ld, g_stream));
     TRY(launch_sweep_gather((const uint32_t*)dp, VS, (const int32_t*)dn, (const int32_t*)tidx, (const int32_t*)toff, (const int32_t*)nt, S, (const double*)fs,
                             (const double*)fall, (const int64_t*)droff, p1, p2, (int)ld, g_stream));
+    PairFetch pf;
+    TRY(pairs_fetch_begin((const int32_t*)dn, S, pf));          // the counts leave in front of the RANSAC launch; the lists are packed while it runs
     PCREG_HIP(hipMemsetAsync(res, 0, sizeof(pcreg_dev_ransac_result) * (size_t)S, g_stream));
     TRY(launch_ransac(p1, p2, (int)ld, (const int32_t*)toff, nullptr, VS, S, *coef, nullptr, (pcreg_dev_ransac_result*)res, (int32_t*)inl, nullptr, nullptr,
                       rws, rwsb, g_stream));
     std::vector<int32_t> h_nsel((size_t)S), h_tr((size_t)S);
     std::vector<pcreg_dev_ransac_result> h_res((size_t)S);
     int32_t h_nt = 0;
+    TRY(pairs_fetch_enqueue(pf, (const uint32_t*)dp, vs, S, 20, pairs_all));
     PCREG_HIP(hipMemcpyAsync(h_nsel.data(), nsel, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(model_rows, rows, sizeof(int32_t) * (size_t)tot, hipMemcpyDeviceToHost, g_stream));
-    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * vs * 2, hipMemcpyDeviceToHost, g_stream));
-    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(h_tr.data(), tidx, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(&h_nt, nt, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(h_res.data(), res, sizeof(pcreg_dev_ransac_result) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipStreamSynchronize(g_stream));
+    pairs_fetch_finish(pf, vs, S, pairs_all, n_pairs);
     for (int i = 0; i < S; ++i)
         if (h_nsel[i] != num_desc[i]) { set_error("pcreg_sphere_sweep: num_desc[%d] = %d, but the sphere holds %d keypoints (pass pcreg_sphere_counts' values)", i, num_desc[i], h_nsel[i]); return PCREG_E_ARG; }
     *n_trials = h_nt;
@@ -947,18 +1014,20 @@ int pcreg_sphere_sweep_on_model(pcreg_sphere_model* m, const pcreg_desc_set* sur
     PCREG_HIP(hipMemsetAsync(p12, 0, sizeof(double) * 6 * ld, g_stream));
     TRY(launch_sweep_gather((const uint32_t*)dp, VS, (const int32_t*)dn, (const int32_t*)tidx, (const int32_t*)toff, (const int32_t*)nt, S, (const double*)fs,
                             m->feat_all, m->roff, p1, p2, (int)ld, g_stream));
+    PairFetch pf;
+    TRY(pairs_fetch_begin((const int32_t*)dn, S, pf));          // the counts leave in front of the RANSAC launch; the lists are packed while it runs
     PCREG_HIP(hipMemsetAsync(res, 0, sizeof(pcreg_dev_ransac_result) * (size_t)S, g_stream));
     TRY(launch_ransac(p1, p2, (int)ld, (const int32_t*)toff, nullptr, VS, S, *coef, nullptr, (pcreg_dev_ransac_result*)res, (int32_t*)inl, nullptr, nullptr,
                       rws, rwsb, g_stream));
     std::vector<int32_t> h_tr((size_t)S);
     std::vector<pcreg_dev_ransac_result> h_res((size_t)S);
     int32_t h_nt = 0;
-    PCREG_HIP(hipMemcpyAsync(pairs_all, dp, sizeof(uint32_t) * (size_t)S * vs * 2, hipMemcpyDeviceToHost, g_stream));
-    PCREG_HIP(hipMemcpyAsync(n_pairs, dn, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
+    TRY(pairs_fetch_enqueue(pf, (const uint32_t*)dp, vs, S, 20, pairs_all));
     PCREG_HIP(hipMemcpyAsync(h_tr.data(), tidx, sizeof(int32_t) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(&h_nt, nt, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipMemcpyAsync(h_res.data(), res, sizeof(pcreg_dev_ransac_result) * (size_t)S, hipMemcpyDeviceToHost, g_stream));
     PCREG_HIP(hipStreamSynchronize(g_stream));
+    pairs_fetch_finish(pf, vs, S, pairs_all, n_pairs);
     *n_trials = h_nt;
     for (int t = 0; t < h_nt; ++t) {
         trial[t] = h_tr[t];
