@@ -199,6 +199,9 @@ class SphereSweep:
                     desc_u, rows_u = self.descM, rows_all
                 sph.update(row_off=row_off, tot=tot, n_max=n_max, seg_off=seg_off, roff_dev=roff_dev, rows_all=rows_all, feat_all=feat_all,
                            model_rows=[rows_host[row_off[i]:row_off[i + 1]] for i in range(S)], desc_u=desc_u, rows_u=rows_u, n_union=int(len(union)))
+            # an entry holds the restricted model set (hundreds of MB at the reference's shape): keep the two most recent parameter sets
+            while len(self._spheres) >= 2:
+                self._spheres.pop(next(iter(self._spheres)))
             self._spheres[skey] = sph
         centres, num_desc, S = sph["centres"], sph["num_desc"], sph["S"]
         if S == 0:

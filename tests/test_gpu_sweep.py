@@ -254,6 +254,12 @@ def test_batched_sweep_counts_its_host_syncs(monkeypatch):
         np.testing.assert_array_equal(got2[k], fresh[k])
     for a, b in zip(got2["matches"], fresh["matches"]):
         np.testing.assert_array_equal(a, b)
+    # the kept spheres hold the restricted model set: only the two most recent parameter sets stay, and a dropped one is made anew
+    sw.run(PAR, OPT, R_desc=8.5, d_spheres=6.0, min_pts=300, putative_thresh=50, seed=1)
+    assert len(sw._spheres) == 2 and (9.0, 6.0, 400) not in sw._spheres
+    back = sw.run(PAR, OPT, R_desc=9.0, d_spheres=6.0, min_pts=400, putative_thresh=50, seed=1)
+    for a, b in zip(back["matches"], fresh["matches"]):
+        np.testing.assert_array_equal(a, b)
 
 
 def _segments_direct(descS, descM, rows_list, par, metric=False):
